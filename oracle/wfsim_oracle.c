@@ -1,0 +1,703 @@
+/*
+ * wfsim_oracle.c -- CPU restatement (plain C, scalar, one thread) of WFSim's photon -> raw_records hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product path (wfsim_amd/csrc, HIP) never links or calls it.
+ *
+ * Parity status: PINNED.  Every deterministic stage below is checked bit-for-bit against vectors produced by
+ * running the reference itself (tests/golden/make_golden.py, WFSim v1.2.2 imported from /root/reference in the
+ * build container): add_current currents, pulse bounds, digitised rows, channel masks, ZLE tuples.  The random
+ * stages cannot be stream-compatible with numpy's legacy generator; they follow the reference's arithmetic
+ * (same truncations, term by term) on a counter-based Philox4x32-10 stream (layout in DESIGN.md "RNG streams")
+ * and are pinned statistically against histograms of the reference's own draws (tests/golden/dists.npz).
+ *
+ * Each function names the reference lines it restates (paths relative to /root/reference/wfsim).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef int64_t i64;
+typedef int32_t i32;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+/* ---------------------------------------------------------------- configuration ------------------ */
+typedef struct {
+    /* digitiser / pulse geometry */
+    i32 dt, samples_before, samples_after, store_before, store_after, tlen;
+    i32 trigger_window, baseline, n_rows;           /* n_rows = 801 */
+    i32 n_tpc, n_top, he_first, he_factor, sum_channel, last_bottom, detector_nt;
+    i32 n_spe_channels, noise_len, noise_channels, enable_noise;
+    /* models */
+    i32 s1_simple, s2_time_model /*0 zero_delay, 1 spread around zero*/, n_lum, enable_pmt_ap, n_ap_elements;
+    i32 pad0;
+    double c2a;                                     /* current_2_adc, pulse.py:33-35 */
+    double tts_mean, tts_sigma, p_dpe;
+    double s1_decay_time, s1_decay_spread;
+    double sf_gas, t1_gas, t3_gas, s2_time_spread;
+    double trap_time, gain_spread;
+    double pmt_ap_modifier, pmt_ap_t_modifier;
+    double rext, drift_velocity;
+    u64 seed;
+} orc_config;
+
+typedef struct {
+    i32 n_bins_delay, n_bins_amp, amp_2d, is_uniform;
+    double delay_bin, amp_bin;
+    const double *delay_cdf;   /* [n_ch][n_bins_delay] */
+    const double *amp_cdf;     /* [n_ch][n_bins_amp] or [n_bins_amp] */
+} orc_ap_element;
+
+typedef struct { i64 *p; i64 n, cap; } vec_i64;
+typedef struct { double *p; i64 n, cap; } vec_f64;
+typedef struct { i32 *p; i64 n, cap; } vec_i32;
+typedef struct { int16_t *p; i64 n, cap; } vec_i16;
+typedef struct { uint8_t *p; i64 n, cap; } vec_u8;
+
+#define VEC_PUSH(v, T, x) do { if ((v).n == (v).cap) { (v).cap = (v).cap ? (v).cap * 2 : 1024; \
+    (v).p = (T *)realloc((v).p, (size_t)(v).cap * sizeof(T)); } (v).p[(v).n++] = (x); } while (0)
+#define VEC_RESERVE(v, T, m) do { if ((v).n + (m) > (v).cap) { while ((v).n + (m) > (v).cap) (v).cap = (v).cap ? (v).cap * 2 : 1024; \
+    (v).p = (T *)realloc((v).p, (size_t)(v).cap * sizeof(T)); } } while (0)
+
+typedef struct {
+    orc_config c;
+    const double *templates;     /* [10][tlen]                       pulse.py:146-187 */
+    const double *spe;           /* [n_spe_channels][2001]           pulse.py:189-223 */
+    const double *gains;         /* [n_tpc]                                          */
+    const double *thr_truth;     /* [n_rows] zle/special threshold - 0.5, pulse.py:240-243 */
+    const i64 *thr_zle;          /* [n_rows] baseline - thr - 1, rawdata.py:290-294  */
+    const double *lum_x, *lum_t; /* [n_lum] normalised cdf, emission time, s2.py:333-338 */
+    const int16_t *noise;        /* [noise_len][noise_channels] */
+    orc_ap_element ap[8];
+    double current_max[10];
+
+    /* pulse cache (rawdata.py:180-190) */
+    vec_i32 pl_ch, pl_runset; vec_i64 pl_left, pl_right, pl_cur_off, pl_nph; vec_f64 cur;
+    i64 first_uncommitted_pulse;
+    double last_pulse_end_time;
+    /* all generated photons (channel sorted per pulse call) */
+    vec_i64 ph_t; vec_i16 ph_ch; vec_u8 ph_dpe; vec_f64 ph_gain; vec_i64 call_ph_off; vec_i32 call_kind, call_runset;
+    vec_i64 e_t; vec_i64 call_e_off;
+    /* digitise groups */
+    vec_i64 dg_left, dg_right, dg_first_pulse, dg_n_pulses, dg_ix_rand, dg_row_off;
+    vec_i32 row_ch; vec_i64 row_left, row_right, row_data_off; vec_i32 row_data;
+    /* ZLE intervals */
+    vec_i64 zl_digit, zl_left, zl_right, zl_data_off; vec_i32 zl_ch; vec_i32 zl_data;
+    /* truth accumulators per pulse call (pulse.py:229-271): 12 doubles each */
+    vec_f64 truth;
+    i64 n_pe_total;
+} orc_session;
+
+/* ---------------------------------------------------------------- Philox4x32-10 ------------------ */
+/* Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11); constants of Random123. */
+static inline void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1, u32 out[4])
+{
+    for (int r = 0; r < 10; r++) {
+        u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;
+        u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n1 = (u32)p1, n2 = (u32)(p0 >> 32) ^ c3 ^ k1, n3 = (u32)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_philox(const u32 *ctr, const u32 *key, u32 *out) { philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out); }
+
+/* draw sites (counter word 3); counter = (emitter, instruction gid, item, site) -- DESIGN.md "RNG streams" */
+enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
+       SITE_PH_A = 16, SITE_PH_B = 17, SITE_PH_C = 18, SITE_PH_D = 19, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
+
+static inline void draw(const orc_session *s, u32 emitter, u32 gid, u32 item, u32 site, u32 w[4])
+{
+    philox4x32_10(emitter, gid, item, site, (u32)s->c.seed, (u32)(s->c.seed >> 32), w);
+}
+static inline double u53(u32 a, u32 b) { return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0; }
+static inline u64 bern_threshold(double p)
+{
+    if (!(p > 0)) return 0;
+    if (p >= 1) return 4294967296ull;
+    return (u64)(p * 4294967296.0);
+}
+static inline void box_muller(const u32 w[4], double *z0, double *z1)
+{
+    double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+    double r = sqrt(-2.0 * log(1.0 - u1));
+    double a = 6.283185307179586476925286766559 * u2;
+    *z0 = r * cos(a); *z1 = r * sin(a);
+}
+
+/* Poisson: Hoermann PTRS for lam >= 10, Knuth multiplication below (the two algorithms numpy's legacy
+ * generator uses, s2.py:308 draws np.random.poisson).  Uniform pairs come from SITE_EL_POIS items. */
+static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam)
+{
+    u32 w[4]; u32 it = 0;
+    if (lam <= 0) return 0;
+    if (lam < 10) {
+        double enlam = exp(-lam), prod = 1.0; i64 x = 0;
+        for (;;) {
+            draw(s, emitter, gid, it++, SITE_EL_POIS, w);
+            prod *= u53(w[0], w[1]);
+            if (prod > enlam) x++; else return x;
+            prod *= u53(w[2], w[3]);
+            if (prod > enlam) x++; else return x;
+        }
+    }
+    double slam = sqrt(lam), loglam = log(lam);
+    double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
+    double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2);
+    for (;;) {
+        draw(s, emitter, gid, it++, SITE_EL_POIS, w);
+        double U = u53(w[0], w[1]) - 0.5, V = u53(w[2], w[3]);
+        double us = 0.5 - fabs(U);
+        i64 k = (i64)floor((2 * a / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(a / (us * us) + b) <= -lam + k * loglam - lgamma((double)k + 1)) return k;
+    }
+}
+
+/* ---------------------------------------------------------------- session ------------------------ */
+orc_session *orc_new(const orc_config *c, const double *templates, const double *spe, const double *gains,
+                     const double *thr_truth, const i64 *thr_zle, const double *lum_x, const double *lum_t,
+                     const int16_t *noise)
+{
+    orc_session *s = (orc_session *)calloc(1, sizeof(orc_session));
+    s->c = *c; s->templates = templates; s->spe = spe; s->gains = gains; s->thr_truth = thr_truth; s->thr_zle = thr_zle;
+    s->lum_x = lum_x; s->lum_t = lum_t; s->noise = noise;
+    for (int r = 0; r < 10; r++) {              /* pulse.py:32 current_max */
+        double m = templates[r * c->tlen];
+        for (int k = 1; k < c->tlen; k++) if (templates[r * c->tlen + k] > m) m = templates[r * c->tlen + k];
+        s->current_max[r] = m;
+    }
+    s->last_pulse_end_time = -INFINITY;
+    VEC_PUSH(s->pl_cur_off, i64, 0); VEC_PUSH(s->call_ph_off, i64, 0); VEC_PUSH(s->call_e_off, i64, 0);
+    VEC_PUSH(s->dg_row_off, i64, 0); VEC_PUSH(s->row_data_off, i64, 0); VEC_PUSH(s->zl_data_off, i64, 0);
+    return s;
+}
+
+void orc_set_ap_element(orc_session *s, int e, int n_bins_delay, int n_bins_amp, int amp_2d, int is_uniform,
+                        double delay_bin, double amp_bin, const double *delay_cdf, const double *amp_cdf)
+{
+    orc_ap_element *a = &s->ap[e];
+    a->n_bins_delay = n_bins_delay; a->n_bins_amp = n_bins_amp; a->amp_2d = amp_2d; a->is_uniform = is_uniform;
+    a->delay_bin = delay_bin; a->amp_bin = amp_bin; a->delay_cdf = delay_cdf; a->amp_cdf = amp_cdf;
+}
+
+void orc_free(orc_session *s)
+{
+    void **ptrs[] = { (void **)&s->pl_ch.p, (void **)&s->pl_runset.p, (void **)&s->pl_left.p, (void **)&s->pl_right.p,
+        (void **)&s->pl_cur_off.p, (void **)&s->pl_nph.p, (void **)&s->cur.p, (void **)&s->ph_t.p, (void **)&s->ph_ch.p,
+        (void **)&s->ph_dpe.p, (void **)&s->ph_gain.p, (void **)&s->call_ph_off.p, (void **)&s->call_kind.p,
+        (void **)&s->call_runset.p, (void **)&s->e_t.p, (void **)&s->call_e_off.p, (void **)&s->dg_left.p,
+        (void **)&s->dg_right.p, (void **)&s->dg_first_pulse.p, (void **)&s->dg_n_pulses.p, (void **)&s->dg_ix_rand.p,
+        (void **)&s->dg_row_off.p, (void **)&s->row_ch.p, (void **)&s->row_left.p, (void **)&s->row_right.p,
+        (void **)&s->row_data_off.p, (void **)&s->row_data.p, (void **)&s->zl_digit.p, (void **)&s->zl_left.p,
+        (void **)&s->zl_right.p, (void **)&s->zl_data_off.p, (void **)&s->zl_ch.p, (void **)&s->zl_data.p,
+        (void **)&s->truth.p };
+    for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
+    free(s);
+}
+
+/* ---------------------------------------------------------------- add_current -------------------- */
+static i64 floordiv(i64 a, i64 b) { i64 q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
+static i64 floormod(i64 a, i64 b) { i64 m = a % b; return (m != 0 && ((m < 0) != (b < 0))) ? m + b : m; }
+
+typedef struct { i64 t; i64 i; } tkey;
+static int tkey_cmp(const void *a, const void *b)
+{
+    const tkey *x = (const tkey *)a, *y = (const tkey *)b;
+    if (x->t != y->t) return x->t < y->t ? -1 : 1;
+    return x->i < y->i ? -1 : (x->i > y->i);
+}
+
+/* pulse.py:276-318  Pulse.add_current.  Photons are visited in ascending time; photons of equal ns are merged
+ * (gains summed) and placed once: cur[start : start+tlen] += templates[t % dt] * gain_total, product and sum
+ * rounded separately (numpy does not fuse them).  The reference's argsort is numpy's default introsort, whose
+ * order among equal keys is unspecified; ties are taken here in input order. */
+void orc_add_current(const i64 *t, const double *g, i64 n, i64 pulse_left, i64 dt,
+                     const double *templates, i64 tlen, double *cur)
+{
+    if (n == 0) return;
+    tkey *k = (tkey *)malloc((size_t)n * sizeof(tkey));
+    for (i64 i = 0; i < n; i++) { k[i].t = t[i]; k[i].i = i; }
+    qsort(k, (size_t)n, sizeof(tkey), tkey_cmp);
+    double gain_total = 0;
+    i64 tmp = k[0].t;
+    for (i64 j = 0; j <= n; j++) {
+        if (j == n || k[j].t > tmp) {
+            i64 start = floordiv(tmp, dt) - pulse_left, rem = floormod(tmp, dt);
+            const double *T = templates + rem * tlen;
+            for (i64 q = 0; q < tlen; q++) {
+                volatile double prod = T[q] * gain_total;      /* separate rounding of product and sum */
+                cur[start + q] += prod;
+            }
+            if (j == n) break;
+            gain_total = g[k[j].i]; tmp = k[j].t;
+        } else {
+            gain_total += g[k[j].i];
+        }
+    }
+    free(k);
+}
+
+/* np.sum over a contiguous float64 array: numpy's pairwise summation (blocks of 128, 8 partial sums),
+ * needed to reproduce raw_area of pulse.py:256-257 to the last bit */
+static double np_pairwise_sum(const double *a, i64 n)
+{
+    if (n < 8) { double r = 0.; for (i64 i = 0; i < n; i++) r += a[i]; return r; }
+    if (n <= 128) {
+        double r[8]; i64 i;
+        for (int k = 0; k < 8; k++) r[k] = a[k];
+        for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; k++) r[k] += a[i + k];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    i64 n2 = n / 2; n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* ---------------------------------------------------------------- Pulse.__call__ ----------------- */
+/* pulse.py:81-144 (per-channel loop) + pulse.py:229-271 (add_truth).  Input photons are sorted by channel, times
+ * are post transit-time-spread, gains already drawn (pulse.py:97-107).  n_dpe_ch = number of DPE photons in the
+ * channel slice (only enters the truth quirk pulse.py:255).  Appends pulses to the cache and one truth record. */
+void orc_pulse_call(orc_session *s, int kind, int runset, i64 n, const i64 *t, const int16_t *ch,
+                    const uint8_t *dpe, const double *gain, int gains_preassigned)
+{
+    const orc_config *c = &s->c;
+    double tr[12]; memset(tr, 0, sizeof tr);
+    /* tr: n_photon n_pe n_photon_trigger n_pe_trigger raw_area raw_area_trigger, then the same for bottom */
+    i64 a = 0;
+    while (a < n) {
+        i64 b = a; int channel = ch[a];
+        while (b < n && ch[b] == channel) b++;
+        i64 cnt = b - a;
+        if (channel >= 0 && channel < c->n_tpc && s->gains[channel] == 0) { a = b; continue; }   /* turned off, pulse.py:89 */
+        i64 n_dpe = 0;
+        if (!gains_preassigned) for (i64 i = a; i < b; i++) n_dpe += dpe[i] ? 1 : 0;
+        /* add_truth */
+        double thr = s->thr_truth[channel]; i64 n_trig = 0, n_trig_dpe = 0;
+        double *gtrig = (double *)malloc((size_t)cnt * 8);
+        for (i64 i = a; i < b; i++) {
+            i64 rem = floormod(t[i], c->dt);
+            double amp = gain[i] * s->current_max[rem] * c->c2a;
+            int above = amp > thr;
+            if (above) { gtrig[n_trig++] = gain[i]; if (i - a < n_dpe) n_trig_dpe++; }
+        }
+        double sumg = np_pairwise_sum(gain + a, cnt), sumg_trig = np_pairwise_sum(gtrig, n_trig);
+        free(gtrig);
+        double vals[6] = { (double)cnt, (double)(cnt + n_dpe), (double)n_trig, (double)(n_trig + n_trig_dpe),
+                           sumg / s->gains[channel], sumg_trig / s->gains[channel] };
+        for (int f = 0; f < 6; f++) { tr[f] += vals[f]; if (channel >= c->n_top && channel <= c->last_bottom) tr[6 + f] += vals[f]; }
+        s->n_pe_total += cnt + n_dpe;
+        /* tile bounds pulse.py:118-128 */
+        i64 tmin = t[a], tmax = t[a];
+        for (i64 i = a; i < b; i++) { if (t[i] < tmin) tmin = t[i]; if (t[i] > tmax) tmax = t[i]; }
+        i64 left = floordiv(tmin, c->dt) - c->store_before - c->samples_before;
+        i64 right = floordiv(tmax, c->dt) + c->store_after + c->samples_after;
+        i64 len = right - left + 1;
+        VEC_RESERVE(s->cur, double, len);
+        double *cur = s->cur.p + s->cur.n; memset(cur, 0, (size_t)len * sizeof(double)); s->cur.n += len;
+        orc_add_current(t + a, gain + a, cnt, left, c->dt, s->templates, c->tlen, cur);
+        VEC_PUSH(s->pl_ch, i32, channel); VEC_PUSH(s->pl_runset, i32, runset); VEC_PUSH(s->pl_left, i64, left);
+        VEC_PUSH(s->pl_right, i64, right); VEC_PUSH(s->pl_nph, i64, cnt); VEC_PUSH(s->pl_cur_off, i64, s->cur.n);
+        double end = (double)right * c->dt;                      /* rawdata.py:188-190 */
+        if (end > s->last_pulse_end_time) s->last_pulse_end_time = end;
+        a = b;
+    }
+    for (int f = 0; f < 12; f++) VEC_PUSH(s->truth, double, tr[f]);
+    VEC_RESERVE(s->ph_t, i64, n); VEC_RESERVE(s->ph_ch, int16_t, n); VEC_RESERVE(s->ph_dpe, uint8_t, n); VEC_RESERVE(s->ph_gain, double, n);
+    memcpy(s->ph_t.p + s->ph_t.n, t, (size_t)n * 8); s->ph_t.n += n;
+    memcpy(s->ph_ch.p + s->ph_ch.n, ch, (size_t)n * 2); s->ph_ch.n += n;
+    memcpy(s->ph_dpe.p + s->ph_dpe.n, dpe, (size_t)n); s->ph_dpe.n += n;
+    memcpy(s->ph_gain.p + s->ph_gain.n, gain, (size_t)n * 8); s->ph_gain.n += n;
+    VEC_PUSH(s->call_ph_off, i64, s->ph_t.n); VEC_PUSH(s->call_kind, i32, kind); VEC_PUSH(s->call_runset, i32, runset);
+    VEC_PUSH(s->call_e_off, i64, s->e_t.n);
+}
+
+/* ---------------------------------------------------------------- digitise ----------------------- */
+static double round_half_even(double x) { return nearbyint(x); }   /* np.around, default rounding mode */
+
+/* utils.py:13-58 find_intervals_below_threshold, the sequential state machine as written there */
+i64 orc_find_intervals_below_threshold(const i64 *w, i64 n, i64 threshold, i64 holdoff, i64 *result, i64 result_size)
+{
+    i64 last = n - 1, cur = 0, start = -1, end = -1; int in = 0;
+    for (i64 i = 0; i < n; i++) {
+        i64 x = w[i];
+        if (x < threshold) { if (!in) { in = 1; start = i; } end = i; }
+        if ((i == last && in) || (x >= threshold && i >= end + holdoff && in)) {
+            in = 0; result[cur * 2] = start; result[cur * 2 + 1] = end; cur++;
+            if (cur == result_size) { /* utils.py:54-55 writes past the buffer; never reached with a 50000 buffer */ return cur; }
+        }
+    }
+    return cur;
+}
+
+/* rawdata.py:204-272 digitize_pulse_cache + :398-458 add_noise/add_baseline/digitizer_saturation, then
+ * rawdata.py:274-311 ZLE over the same window.  Consumes all pulses cached since the previous digitise. */
+void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
+{
+    const orc_config *c = &s->c;
+    i64 p0 = s->first_uncommitted_pulse, p1 = s->pl_ch.n;
+    if (p1 == p0) return;
+    i64 tw = c->trigger_window;
+    i64 left = s->pl_left.p[p0], right = s->pl_right.p[p0];
+    for (i64 p = p0; p < p1; p++) { if (s->pl_left.p[p] < left) left = s->pl_left.p[p]; if (s->pl_right.p[p] > right) right = s->pl_right.p[p]; }
+    left -= tw; right += tw;
+    if (floormod(left, 2) != 0) left -= 1;                        /* rawdata.py:221-222 */
+    i64 L = right - left + 1, R = c->n_rows;
+    i64 *raw = (i64 *)calloc((size_t)(R * L), sizeof(i64));       /* rawdata.py:224 */
+    uint8_t *mask = (uint8_t *)calloc((size_t)R, 1);
+    i64 *ml = (i64 *)malloc((size_t)R * 8), *mr = (i64 *)calloc((size_t)R, 8);
+    for (i64 r = 0; r < R; r++) ml[r] = INT64_MAX;
+    for (i64 p = p0; p < p1; p++) {
+        int ch = s->pl_ch.p[p]; if (ch < 0) ch += (int)R;         /* python negative index, SURVEY B.12 */
+        i64 pl = s->pl_left.p[p], pr = s->pl_right.p[p];
+        mask[ch] = 1; if (pl < ml[ch]) ml[ch] = pl; if (pr > mr[ch]) mr[ch] = pr;
+        const double *cur = s->cur.p + s->pl_cur_off.p[p];
+        i64 *row = raw + ch * L + (pl - left);
+        for (i64 i = 0; i <= pr - pl; i++) {
+            i64 adc = -(i64)round_half_even(cur[i] * c->c2a);     /* rawdata.py:236, per pulse rounding */
+            row[i] += adc;
+            if (c->detector_nt) {
+                i64 he = adc * c->he_factor;                      /* int(high_energy_deamplification_factor) */
+                if (ch < c->n_top) raw[(c->he_first + ch) * L + (pl - left) + i] += he;
+                else if (ch <= c->last_bottom) raw[c->sum_channel * L + (pl - left) + i] += he;
+            }
+        }
+        if (c->detector_nt && ch < c->n_top) { int h = c->he_first + ch; mask[h] = 1; ml[h] = ml[ch]; mr[h] = mr[ch]; }
+    }
+    for (i64 r = 0; r < R; r++) if (mask[r]) { ml[r] -= left + tw; mr[r] -= left - tw; }   /* rawdata.py:258-259 */
+    /* add_noise rawdata.py:398-437 */
+    i64 ix_rand = -1;
+    if (c->enable_noise) {
+        i64 nl = INT64_MAX, nr = INT64_MIN; int any = 0;
+        for (i64 r = 0; r < R; r++) if (mask[r]) { any = 1; if (ml[r] < nl) nl = ml[r]; if (mr[r] > nr) nr = mr[r]; }
+        if (any) {
+            i64 N = c->noise_len, high = (N - nr + nl - 1 < 0) ? N - 1 : N - nr + nl - 1;
+            if (high <= 0) ix_rand = 0;
+            else { u32 w[4]; draw(s, 0, noise_gid, 0, SITE_NOISE, w); ix_rand = (i64)(u53(w[0], w[1]) * (double)high); }
+            for (i64 ch = 0; ch < R; ch++) {
+                if (ch >= c->noise_channels || !mask[ch]) continue;
+                for (i64 ix = ml[ch]; ix <= mr[ch]; ix++) {
+                    if (ix >= L) continue;
+                    i64 in = ix_rand + ix - ml[ch];
+                    if (in >= N) in -= N * (in / N);
+                    raw[ch * L + ix] += s->noise[in * c->noise_channels + ch];
+                }
+            }
+        }
+    }
+    i64 dg = s->dg_left.n;
+    VEC_PUSH(s->dg_left, i64, left); VEC_PUSH(s->dg_right, i64, right); VEC_PUSH(s->dg_first_pulse, i64, p0);
+    VEC_PUSH(s->dg_n_pulses, i64, p1 - p0); VEC_PUSH(s->dg_ix_rand, i64, ix_rand);
+    i64 *itv = (i64 *)malloc(50000 * 2 * sizeof(i64));            /* rawdata.py:280 */
+    for (i64 ch = 0; ch < R; ch++) {
+        if (!mask[ch]) continue;
+        i64 cl = ml[ch], cr = mr[ch];
+        i64 *row = raw + ch * L;
+        for (i64 ix = cl; ix <= cr; ix++) { row[ix] += c->baseline; if (row[ix] < 0) row[ix] = 0; }   /* :439-458 */
+        i64 n = cr - cl + 1;
+        VEC_PUSH(s->row_ch, i32, (i32)ch); VEC_PUSH(s->row_left, i64, cl); VEC_PUSH(s->row_right, i64, cr);
+        VEC_RESERVE(s->row_data, i32, n);
+        for (i64 i = 0; i < n; i++) s->row_data.p[s->row_data.n + i] = (i32)row[cl + i];
+        s->row_data.n += n; VEC_PUSH(s->row_data_off, i64, s->row_data.n);
+        /* ZLE rawdata.py:282-311 */
+        i64 holdoff = tw + tw + 1;
+        i64 nit = orc_find_intervals_below_threshold(row + cl, n, s->thr_zle[ch], holdoff, itv, 50000);
+        for (i64 k = 0; k < nit; k++) {
+            i64 a = itv[2 * k] - tw, b = itv[2 * k + 1] + tw;
+            if (a < 0) a = 0; if (a > n - 1) a = n - 1; if (b < 0) b = 0; if (b > n - 1) b = n - 1;   /* np.clip */
+            a = (i64)(ceil((double)a / 2.0) * 2); b = (i64)(floor((double)b / 2.0) * 2);           /* even landing */
+            VEC_PUSH(s->zl_digit, i64, dg); VEC_PUSH(s->zl_ch, i32, (i32)ch);
+            VEC_PUSH(s->zl_left, i64, left + cl + a); VEC_PUSH(s->zl_right, i64, left + cl + b);
+            i64 m = b - a + 1; if (m < 0) m = 0;
+            VEC_RESERVE(s->zl_data, i32, m);
+            for (i64 i = 0; i < m; i++) s->zl_data.p[s->zl_data.n + i] = (i32)row[cl + a + i];
+            s->zl_data.n += m; VEC_PUSH(s->zl_data_off, i64, s->zl_data.n);
+        }
+    }
+    VEC_PUSH(s->dg_row_off, i64, s->row_ch.n);
+    free(itv); free(raw); free(mask); free(ml); free(mr);
+    s->first_uncommitted_pulse = p1;
+}
+
+/* ---------------------------------------------------------------- photon generation -------------- */
+static int cmp_ch_stable(const void *a, const void *b)
+{
+    const i64 *x = (const i64 *)a, *y = (const i64 *)b;     /* key = channel << 40 | index */
+    return *x < *y ? -1 : (*x > *y);
+}
+
+typedef struct { vec_i64 t; vec_i16 ch; vec_u8 dpe; vec_f64 gain; vec_i32 g1, g2; } photon_buf;
+
+/* np.random.choice(channels, p=...) == searchsorted(cdf, u, side='right') on the normalised cumulative sum
+ * (s1.py:154-158, s2.py:673-677); cdf row prepared by the host exactly as numpy does. */
+static int channel_from_cdf(const double *cdf, int n, double u)
+{
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (u < cdf[mid]) hi = mid; else lo = mid + 1; }
+    return lo < n ? lo : n - 1;
+}
+
+static double interp_lum(const orc_session *s, double u)
+{
+    /* np.interp(u, y / y[-1], t), s2.py:338 */
+    const double *xp = s->lum_x, *fp = s->lum_t; int n = s->c.n_lum;
+    if (u <= xp[0]) return fp[0];
+    if (u >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (xp[mid] <= u) lo = mid; else hi = mid; }
+    if (xp[lo] == u) return fp[lo];
+    double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+    return slope * (u - xp[lo]) + fp[lo];
+}
+
+/* One photon: pulse.py:53-56 (TTS), :76-79 (DPE), :97-103 (SPE gain, idx = int(u*2000)+1), plus the timing terms of
+ * s1.py:180-194 (simple) or s2.py:504-557 (luminescence simple + singlet/triplet + spread + electron time).
+ * Every term is truncated to int64 on its own before it is added. */
+static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u32 item, i64 t0,
+                       const double *cdf, i64 *t_out, int *ch_out, int *dpe_out, double *gain_out)
+{
+    const orc_config *c = &s->c;
+    u32 A[4], B[4], C[4], D[4];
+    draw(s, emitter, gid, item, SITE_PH_A, A);
+    draw(s, emitter, gid, item, SITE_PH_B, B);
+    draw(s, emitter, gid, item, SITE_PH_C, C);
+    int ch = channel_from_cdf(cdf, c->n_tpc, u53(A[0], A[1]));
+    int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
+    int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
+    double z_tts, z_spread;
+    box_muller(C, &z_tts, &z_spread);
+    double e1 = -log(1.0 - u53(B[0], B[1]));
+    i64 t = t0;
+    if (!is_s2) {
+        if (c->s1_simple) { t += (i64)(e1 * c->s1_decay_time); t += (i64)(0.0 + c->s1_decay_spread * z_spread); }
+    } else {
+        draw(s, emitter, gid, item, SITE_PH_D, D);
+        t += (i64)interp_lum(s, u53(D[0], D[1]));
+        double delay = ((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas;     /* pulse.py:339-341 */
+        t += (i64)(e1 * delay);
+        if (c->s2_time_model == 1) t += (i64)(0.0 + c->s2_time_spread * z_spread);
+    }
+    t += (i64)(c->tts_mean + c->tts_sigma * z_tts);
+    int sc = c->n_spe_channels > ch ? ch : 0;
+    const double *row = s->spe + (i64)sc * 2001;
+    double G = s->gains[ch], gain = G * row[g1];
+    if (is_dpe) gain += G * row[g2];
+    *t_out = t; *ch_out = ch; *dpe_out = is_dpe; *gain_out = gain;
+}
+
+static void sort_by_channel_and_call(orc_session *s, int kind, int runset, photon_buf *pb, int preassigned)
+{
+    i64 n = pb->t.n;
+    i64 *key = (i64 *)malloc((size_t)(n ? n : 1) * 8);
+    for (i64 i = 0; i < n; i++) key[i] = ((i64)pb->ch.p[i] << 40) | i;
+    qsort(key, (size_t)n, 8, cmp_ch_stable);
+    i64 *t = (i64 *)malloc((size_t)(n ? n : 1) * 8); int16_t *ch = (int16_t *)malloc((size_t)(n ? n : 1) * 2);
+    uint8_t *dpe = (uint8_t *)malloc((size_t)(n ? n : 1)); double *g = (double *)malloc((size_t)(n ? n : 1) * 8);
+    for (i64 i = 0; i < n; i++) { i64 j = key[i] & ((1ll << 40) - 1); t[i] = pb->t.p[j]; ch[i] = pb->ch.p[j]; dpe[i] = pb->dpe.p[j]; g[i] = pb->gain.p[j]; }
+    orc_pulse_call(s, kind, runset, n, t, ch, dpe, g, preassigned);
+    free(key); free(t); free(ch); free(dpe); free(g);
+}
+
+/* afterpulse.py:172-249 PMT_Afterpulse.photon_afterpulse for the photons of the pulse call just made */
+static void pmt_afterpulse_call(orc_session *s, int runset, u32 gid, i64 call_index, const u32 *emitter_of, const u32 *item_of)
+{
+    const orc_config *c = &s->c;
+    i64 a = s->call_ph_off.p[call_index], b = s->call_ph_off.p[call_index + 1];
+    if (b == a) return;                                    /* afterpulse.py:162-164 */
+    photon_buf pb; memset(&pb, 0, sizeof pb);
+    for (int e = 0; e < c->n_ap_elements; e++) {
+        const orc_ap_element *ap = &s->ap[e];
+        for (i64 i = a; i < b; i++) {
+            int ch = s->ph_ch.p[i]; u32 w[4];
+            draw(s, emitter_of[i - a], gid, item_of[i - a], SITE_AP + (u32)e, w);
+            double rU0 = 1.0 - u53(w[0], w[1]), rU1 = 1.0 - u53(w[2], w[3]);
+            const double *dc = ap->delay_cdf + (i64)ch * ap->n_bins_delay;
+            double prob = dc[ap->n_bins_delay - 1];
+            rU0 /= c->pmt_ap_modifier;
+            if (s->ph_dpe.p[i]) rU0 /= 2;
+            if (!(rU0 <= prob)) continue;
+            double delay, amp;
+            if (ap->is_uniform) {
+                u32 x[4]; draw(s, emitter_of[i - a], gid, item_of[i - a], SITE_AP_X + (u32)e, x);
+                double lo = dc[0], hi = dc[1];
+                delay = (lo + (hi - lo) * u53(x[0], x[1])) * ap->delay_bin; amp = 1.0;
+            } else {
+                int best = 0; double bd = fabs(dc[0] - rU0);                  /* np.argmin(|cdf - u|) : first minimum */
+                for (int k = 1; k < ap->n_bins_delay; k++) { double d = fabs(dc[k] - rU0); if (d < bd) { bd = d; best = k; } }
+                delay = best * ap->delay_bin - c->pmt_ap_t_modifier;
+                const double *ac = ap->amp_2d ? ap->amp_cdf + (i64)ch * ap->n_bins_amp : ap->amp_cdf;
+                int ba = 0; double bad = fabs(ac[0] - rU1);
+                for (int k = 1; k < ap->n_bins_amp; k++) { double d = fabs(ac[k] - rU1); if (d < bad) { bad = d; ba = k; } }
+                amp = ba * ap->amp_bin;
+            }
+            /* afterpulse.py:235: int64 timing + float delay; the sum is float and is cast back to int64 in
+             * pulse.py:130 (astype(np.int64)) after the bounds were taken on the float values */
+            double tf = (double)s->ph_t.p[i] + delay;
+            VEC_PUSH(pb.t, i64, (i64)tf); VEC_PUSH(pb.ch, int16_t, (int16_t)ch); VEC_PUSH(pb.dpe, uint8_t, 0);
+            VEC_PUSH(pb.gain, double, s->gains[ch] * amp);
+        }
+    }
+    sort_by_channel_and_call(s, 3, runset, &pb, 1);
+    free(pb.t.p); free(pb.ch.p); free(pb.dpe.p); free(pb.gain.p);
+}
+
+/* s1.py:60-114 S1.__call__ (model 'simple'), one instruction = one run-set.  Returns photons generated. */
+i64 orc_s1(orc_session *s, u32 gid, int runset, i64 time, i64 amp, double p_hit, const double *cdf)
+{
+    u64 T = bern_threshold(p_hit); i64 n_hits = 0; u32 w[4];
+    for (i64 j = 0; j < amp; j++) {                   /* s1.py:133 Binomial(amp, ly) as a sum of Bernoulli trials */
+        if ((j & 3) == 0) draw(s, 0, gid, (u32)(j >> 2), SITE_S1_HIT, w);
+        n_hits += (u64)w[j & 3] < T;
+    }
+    photon_buf pb; memset(&pb, 0, sizeof pb);
+    u32 *em = (u32 *)malloc((size_t)(n_hits ? n_hits : 1) * 4), *it = (u32 *)malloc((size_t)(n_hits ? n_hits : 1) * 4);
+    for (i64 k = 0; k < n_hits; k++) {
+        i64 t; int ch, dpe; double g;
+        one_photon(s, 0, 0, gid, (u32)k, time, cdf, &t, &ch, &dpe, &g);
+        VEC_PUSH(pb.t, i64, t); VEC_PUSH(pb.ch, int16_t, (int16_t)ch); VEC_PUSH(pb.dpe, uint8_t, (uint8_t)dpe); VEC_PUSH(pb.gain, double, g);
+    }
+    /* remember (emitter,item) in channel-sorted order for the afterpulse stage */
+    i64 n = n_hits; i64 *key = (i64 *)malloc((size_t)(n ? n : 1) * 8);
+    for (i64 i = 0; i < n; i++) key[i] = ((i64)pb.ch.p[i] << 40) | i;
+    qsort(key, (size_t)n, 8, cmp_ch_stable);
+    for (i64 i = 0; i < n; i++) { em[i] = 0; it[i] = (u32)(key[i] & ((1ll << 40) - 1)); }
+    i64 call = s->call_kind.n;
+    sort_by_channel_and_call(s, 1, runset, &pb, 0);
+    if (s->c.enable_pmt_ap) pmt_afterpulse_call(s, runset, gid, call, em, it);
+    free(key); free(em); free(it); free(pb.t.p); free(pb.ch.p); free(pb.dpe.p); free(pb.gain.p);
+    return n_hits;
+}
+
+/* s2.py:73-136 S2.__call__ (luminescence 'simple'), one instruction.  Candidate electron j < amp survives with
+ * probability cy (s2.py:254 Binomial as Bernoulli trials); survivors draw s2.py:280-282 arrival time and
+ * s2.py:308-310 photon count; photons as one_photon(). */
+i64 orc_s2(orc_session *s, u32 gid, int runset, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
+           double sc_gain, const double *cdf)
+{
+    const orc_config *c = &s->c;
+    u64 T = bern_threshold(cy); u32 w[4];
+    photon_buf pb; memset(&pb, 0, sizeof pb);
+    vec_i64 em = {0}, it = {0};
+    for (i64 j = 0; j < amp; j++) {
+        if ((j & 3) == 0) draw(s, 0, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);
+        if (!((u64)w[j & 3] < T)) continue;
+        u32 A[4], B[4]; double z_drift, z_gain;
+        draw(s, (u32)j, gid, 0, SITE_EL_A, A);
+        draw(s, (u32)j, gid, 0, SITE_EL_B, B);
+        box_muller(B, &z_drift, &z_gain);
+        double timing = -log(1.0 - u53(A[0], A[1])) * c->trap_time;
+        timing += drift_mean + drift_spread * z_drift;
+        i64 et = time + (i64)timing;
+        i64 nph = poisson_draw(s, (u32)j, gid, sc_gain);
+        nph += (i64)(0.0 + c->gain_spread * z_gain);
+        if (nph < 0) nph = 0;
+        VEC_PUSH(s->e_t, i64, et);
+        for (i64 m = 0; m < nph; m++) {
+            i64 t; int ch, dpe; double g;
+            one_photon(s, 1, (u32)j, gid, (u32)m, et, cdf, &t, &ch, &dpe, &g);
+            VEC_PUSH(pb.t, i64, t); VEC_PUSH(pb.ch, int16_t, (int16_t)ch); VEC_PUSH(pb.dpe, uint8_t, (uint8_t)dpe); VEC_PUSH(pb.gain, double, g);
+            VEC_PUSH(em, i64, j); VEC_PUSH(it, i64, m);
+        }
+    }
+    i64 n = pb.t.n; i64 *key = (i64 *)malloc((size_t)(n ? n : 1) * 8);
+    u32 *em2 = (u32 *)malloc((size_t)(n ? n : 1) * 4), *it2 = (u32 *)malloc((size_t)(n ? n : 1) * 4);
+    for (i64 i = 0; i < n; i++) key[i] = ((i64)pb.ch.p[i] << 40) | i;
+    qsort(key, (size_t)n, 8, cmp_ch_stable);
+    for (i64 i = 0; i < n; i++) { i64 q = key[i] & ((1ll << 40) - 1); em2[i] = (u32)em.p[q]; it2[i] = (u32)it.p[q]; }
+    i64 call = s->call_kind.n;
+    sort_by_channel_and_call(s, 2, runset, &pb, 0);
+    if (c->enable_pmt_ap) pmt_afterpulse_call(s, runset, gid, call, em2, it2);
+    free(key); free(em2); free(it2); free(em.p); free(it.p); free(pb.t.p); free(pb.ch.p); free(pb.dpe.p); free(pb.gain.p);
+    return n;
+}
+
+/* ---------------------------------------------------------------- scheduler ---------------------- */
+/* rawdata.py:38-157 RawData.__call__ with electron afterpulses off: instructions are sorted by
+ * time - z/v*[S2], split where the gap exceeds rext; clusters run in order, S1 run-sets then S2 run-sets (one
+ * instruction per run-set, save_full_truth); the cache is digitised when the next cluster starts more than rext
+ * after the end of the last pulse (rawdata.py:96-98) and at the end (rawdata.py:154-155). */
+void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, const float *z, const i32 *amp,
+                  const u32 *gid, const double *p_hit, const double *drift_mean, const double *drift_spread,
+                  const double *sc_gain, const i32 *cdf_row, const double *cdf_table)
+{
+    const orc_config *c = &s->c;
+    if (n == 0) return;
+    i64 *it = (i64 *)malloc((size_t)n * 8); tkey *ord = (tkey *)malloc((size_t)n * sizeof(tkey));
+    for (i64 i = 0; i < n; i++) {
+        /* rawdata.py:61: time + (z / v * (type % 2 - 1)).astype(int64); z is a float32 array and v a python float,
+         * so numpy evaluates the quotient and the product in float32 */
+        int sgn = ((type[i] % 2 + 2) % 2) - 1;
+        volatile float q = z[i] / (float)c->drift_velocity;
+        volatile float qs = q * (float)sgn;
+        it[i] = time[i] + (i64)qs;
+        ord[i].t = it[i]; ord[i].i = i;
+    }
+    qsort(ord, (size_t)n, sizeof(tkey), tkey_cmp);
+    i64 a = 0, group_start = 0; int runset = 0;
+    while (a < n) {
+        i64 b = a + 1;
+        while (b < n && !((double)(ord[b].t - ord[b - 1].t) > c->rext)) b++;
+        if (!isinf(s->last_pulse_end_time) && (double)ord[a].t - s->last_pulse_end_time > c->rext) {
+            orc_digitize_and_zle(s, gid[ord[group_start].i]);    /* rawdata.py:96-98 */
+            group_start = a;
+        }
+        for (int ptype = 1; ptype <= 2; ptype++)
+            for (i64 k = a; k < b; k++) {
+                i64 i = ord[k].i; if (type[i] != ptype) continue;
+                const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
+                if (ptype == 1) orc_s1(s, gid[i], runset++, time[i], amp[i], p_hit[i], cdf);
+                else orc_s2(s, gid[i], runset++, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+            }
+        a = b;
+    }
+    orc_digitize_and_zle(s, gid[ord[group_start].i]);         /* rawdata.py:154-155 */
+    free(it); free(ord);
+}
+
+/* ---------------------------------------------------------------- record packing ----------------- */
+/* strax_interface.py:391-436: one ZLE interval -> ceil(len/110) raw_records (244-byte packed layout). */
+i64 orc_pack_records(const orc_session *s, i64 samples_per_record, uint8_t *out, i64 capacity)
+{
+    i64 nrec = 0, rec_bytes = 24 + 2 * samples_per_record;
+    for (i64 k = 0; k < s->zl_ch.n; k++) {
+        i64 left = s->zl_left.p[k], plen = s->zl_right.p[k] - left + 1;
+        if (plen <= 0) continue;
+        i64 need = (plen + samples_per_record - 1) / samples_per_record;
+        const i32 *d = s->zl_data.p + s->zl_data_off.p[k];
+        for (i64 i = 0; i < need; i++, nrec++) {
+            if (!out) continue;
+            if (nrec >= capacity) return -1;
+            uint8_t *r = out + nrec * rec_bytes; memset(r, 0, (size_t)rec_bytes);
+            i64 tm = s->c.dt * (left + samples_per_record * i);
+            i32 len = (i32)((plen < samples_per_record * (i + 1) ? plen : samples_per_record * (i + 1)) - samples_per_record * i);
+            int16_t dt16 = (int16_t)s->c.dt, ch16 = (int16_t)s->zl_ch.p[k], ri = (int16_t)i; i32 pl32 = (i32)plen;
+            memcpy(r, &tm, 8); memcpy(r + 8, &len, 4); memcpy(r + 12, &dt16, 2); memcpy(r + 14, &ch16, 2);
+            memcpy(r + 16, &pl32, 4); memcpy(r + 20, &ri, 2);
+            for (i32 q = 0; q < len; q++) { int16_t v = (int16_t)d[samples_per_record * i + q]; memcpy(r + 24 + 2 * q, &v, 2); }
+        }
+    }
+    return nrec;
+}
+
+/* ---------------------------------------------------------------- accessors ---------------------- */
+#define GETTER(name, field, T) T *orc_##name(orc_session *s, i64 *n) { *n = s->field.n; return s->field.p; }
+GETTER(pl_ch, pl_ch, i32) GETTER(pl_runset, pl_runset, i32) GETTER(pl_left, pl_left, i64) GETTER(pl_right, pl_right, i64)
+GETTER(pl_cur_off, pl_cur_off, i64) GETTER(pl_nph, pl_nph, i64) GETTER(cur, cur, double)
+GETTER(ph_t, ph_t, i64) GETTER(ph_ch, ph_ch, int16_t) GETTER(ph_dpe, ph_dpe, uint8_t) GETTER(ph_gain, ph_gain, double)
+GETTER(call_ph_off, call_ph_off, i64) GETTER(call_kind, call_kind, i32) GETTER(call_runset, call_runset, i32)
+GETTER(e_t, e_t, i64) GETTER(call_e_off, call_e_off, i64)
+GETTER(dg_left, dg_left, i64) GETTER(dg_right, dg_right, i64) GETTER(dg_first_pulse, dg_first_pulse, i64)
+GETTER(dg_n_pulses, dg_n_pulses, i64) GETTER(dg_ix_rand, dg_ix_rand, i64) GETTER(dg_row_off, dg_row_off, i64)
+GETTER(row_ch, row_ch, i32) GETTER(row_left, row_left, i64) GETTER(row_right, row_right, i64)
+GETTER(row_data_off, row_data_off, i64) GETTER(row_data, row_data, i32)
+GETTER(zl_digit, zl_digit, i64) GETTER(zl_ch, zl_ch, i32) GETTER(zl_left, zl_left, i64) GETTER(zl_right, zl_right, i64)
+GETTER(zl_data_off, zl_data_off, i64) GETTER(zl_data, zl_data, i32) GETTER(truth, truth, double)
+i64 orc_n_pe(const orc_session *s) { return s->n_pe_total; }
+
+/* stand-alone samplers used by the distribution tests */
+void orc_sample_poisson(orc_session *s, double lam, i64 n, i64 *out) { for (i64 i = 0; i < n; i++) out[i] = poisson_draw(s, (u32)i, 12345u, lam); }

@@ -1,0 +1,505 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING the reference (WFSim v1.2.2).
+
+Run once in the build container (needs /root/reference; the GPU box never runs this):
+
+    python tests/golden/make_golden.py
+
+The reference's hot-path modules are imported under the stubs of ``_ref_stubs.py`` (identity njit, so
+every draw comes from numpy's seeded global generator).  What is written is DATA only: inputs and
+outputs at the stage boundaries of SURVEY.md section 8c (G1..G7), the cleaned bundled fax config and
+the bundled single-channel SPE distribution.  No reference source text is stored.
+
+Stage boundaries captured per chain case (everything downstream of them is deterministic):
+  * per Pulse.__call__   : post-TTS photon times, channels, DPE flags, per-photon gains  -> pulses
+  * per digitize call    : pulse list -> (left, right, channel mask, raw rows in their active range)
+  * per ZLE              : yielded (channel, left, right, data) tuples
+  * truth rows
+"""
+import gzip
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pandas as pd
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from _ref_stubs import import_reference, REFERENCE_ROOT   # noqa: E402
+from wfsim_amd.dtypes import instruction_dtype, truth_extra_dtype   # noqa: E402
+
+TMP = '/tmp/wfsim_golden_tmp'
+os.makedirs(TMP, exist_ok=True)
+N_TPC, N_TOP = 494, 253
+
+
+# ---------------------------------------------------------------------------------------------
+# config / resources
+# ---------------------------------------------------------------------------------------------
+def load_bundled_config():
+    """files/XENONnT_wfsim_config.json with // and # comments and trailing commas removed."""
+    out = []
+    for line in open(REFERENCE_ROOT + '/files/XENONnT_wfsim_config.json'):
+        if line.lstrip().startswith('//'):
+            continue
+        if '"url_base"' in line:
+            continue
+        line = re.sub(r'#.*$', '', line)
+        line = re.sub(r'\s//.*$', '', line)
+        out.append(line)
+    txt = ''.join(out)
+    txt = re.sub(r',\s*([\]}])', r'\1', txt)
+    return json.loads(txt)
+
+
+def spe_distribution():
+    df = pd.read_csv(REFERENCE_ROOT + '/files/XENONnT_spe_distributions_single_channel.csv')
+    charge = df['charge'].values.astype(np.float64)
+    pdf = df['0'].values.astype(np.float64)
+    mean = (charge * pdf).sum() / pdf.sum()
+    return charge / mean, pdf, mean       # normalised so the mean SPE scaling factor is 1
+
+
+def write_spe_csv(path):
+    charge, pdf, _ = spe_distribution()
+    cols = {'charge': charge}
+    for ch in range(N_TPC):
+        cols[str(ch)] = pdf
+    pd.DataFrame(cols).to_csv(path, index=False)
+
+
+def synthetic_pmt_positions():
+    """A made-up PMT layout (rings) used only to get a non-uniform, position dependent pattern."""
+    def rings(n):
+        k = np.arange(n)
+        r = 48.0 * np.sqrt((k + 0.5) / n)
+        phi = k * 2.399963229728653
+        return np.stack([r * np.cos(phi), r * np.sin(phi)], axis=1)
+    return np.concatenate([rings(N_TOP), rings(N_TPC - N_TOP)])
+
+
+PMT_XY = synthetic_pmt_positions()
+
+
+class SyntheticPatternMap:
+    """Host callable standing in for straxen.InterpolatingMap: positions[n, >=2] -> weights[n, 494]."""
+    def __init__(self, scale, width_top, width_bottom, floor):
+        self.scale, self.wt, self.wb, self.floor = scale, width_top, width_bottom, floor
+        self.shape = (N_TPC,)
+
+    def __call__(self, positions, **kw):
+        positions = np.asarray(positions, dtype=np.float64)
+        d2 = ((positions[:, None, :2] - PMT_XY[None, :, :]) ** 2).sum(axis=2)
+        w = np.where(np.arange(N_TPC)[None, :] < N_TOP, self.wt, self.wb)
+        return self.scale * (self.floor + np.exp(-d2 / (2 * w ** 2)))
+
+
+def base_config(**overrides):
+    c = load_bundled_config()
+    spe_csv = TMP + '/spe_494.csv'
+    if not os.path.exists(spe_csv):
+        write_spe_csv(spe_csv)
+    c.update(dict(
+        detector='XENONnT', n_tpc_pmts=N_TPC, n_top_pmts=N_TOP,
+        channel_map=dict(tpc=(0, 493), he=(500, 752), aqmon=(790, 807), sum_signal=800),
+        gains=np.full(N_TPC, 2e6), channels_bottom=np.arange(N_TOP, N_TPC),
+        right_raw_extension=100000, field_distortion_model='none',
+        s1_lce_correction_map=['constant dummy', 1, []], se_gain_map=['constant dummy', 1, []],
+        diffusion_constant_transverse=0, url_base='/nonexistent', photon_area_distribution=spe_csv,
+        seed=1, per_pmt_truth=False, chunk_size=1,
+    ))
+    c.update(overrides)
+    return c
+
+
+def make_instructions(rows):
+    ins = np.zeros(len(rows), dtype=instruction_dtype)
+    for i, r in enumerate(rows):
+        for k, v in r.items():
+            ins[i][k] = v
+        ins[i]['event_number'] = r.get('event_number', i)
+        ins[i]['recoil'] = r.get('recoil', 7)
+    return ins
+
+
+# ---------------------------------------------------------------------------------------------
+# instrumented run of the reference
+# ---------------------------------------------------------------------------------------------
+class Recorder:
+    def __init__(self, ref):
+        self.ref = ref
+        self.calls = []        # Pulse.__call__ records
+        self.digits = []       # digitize records
+        self.zle = []          # (digitize index, ch, left, right, data)
+        self._gain_parts = None
+        self._randint = []
+
+    def install(self):
+        P = self.ref.pulse.Pulse
+        rec = self
+        orig_call = P.__call__
+        orig_add = P.add_current
+
+        def add_current(t, g, pulse_left, dt, templates, cur):
+            rec._gain_parts.append(np.array(g, dtype=np.float64))
+            return orig_add(t, g, pulse_left, dt, templates, cur)
+
+        def call(self_, *a):
+            rec._gain_parts = []
+            orig_call(self_, *a)
+            gains = np.concatenate(rec._gain_parts) if rec._gain_parts else np.zeros(0)
+            rec.calls.append(dict(
+                kind=type(self_).__name__,
+                t=np.array(self_._photon_timings, dtype=np.int64),
+                ch=np.array(self_._photon_channels, dtype=np.int64),
+                dpe=np.array(self_._photon_is_dpe, dtype=bool),
+                gain=gains,
+                has_gains='_photon_gains' in self_.__dict__,
+                e_t=np.array(getattr(self_, '_electron_timings', []), dtype=np.int64),
+                pulses=[dict(p) for p in self_._pulses],
+                truth=dict((k, np.array(v)) for k, v in self_._truth_buffer.items()),
+            ))
+        P.add_current = staticmethod(add_current)
+        P.__call__ = call
+        self._restore = (orig_call, orig_add)
+
+        R = self.ref.rawdata.RawData
+        orig_dig = R.digitize_pulse_cache
+
+        def digitize(self_):
+            n_cached = len(self_._pulses_cache)
+            first_pulse_id = rec.n_pulses_seen() - n_cached
+            old = np.random.randint
+            rec._randint = []
+
+            def randint(*a, **k):
+                v = old(*a, **k)
+                rec._randint.append(int(v))
+                return v
+            np.random.randint = randint
+            try:
+                orig_dig(self_)
+            finally:
+                np.random.randint = old
+            if n_cached == 0:
+                return
+            m = self_._channel_mask
+            chs = np.where(m['mask'])[0]
+            rows = [np.array(self_._raw_data[c, m['left'][c]:m['right'][c] + 1]) for c in chs]
+            rec.digits.append(dict(
+                left=int(self_.left), right=int(self_.right), first_pulse=first_pulse_id, n_pulses=n_cached,
+                ch=chs.astype(np.int64), ch_left=m['left'][chs].astype(np.int64),
+                ch_right=m['right'][chs].astype(np.int64), rows=rows,
+                sum_row=np.array(self_._raw_data[800]), ix_rand=list(rec._randint)))
+        R.digitize_pulse_cache = digitize
+        self._restore_dig = orig_dig
+
+    def uninstall(self):
+        P = self.ref.pulse.Pulse
+        P.__call__, add = self._restore
+        P.add_current = staticmethod(add)
+        self.ref.rawdata.RawData.digitize_pulse_cache = self._restore_dig
+
+    def n_pulses_seen(self):
+        return sum(len(c['pulses']) for c in self.calls)
+
+
+def run_chain(ref, config, instructions, seed, pattern_maps=None, noise=None, ap=None, store_currents=False):
+    """Run reference RawData over instructions; return flat dict of arrays for np.savez."""
+    config = dict(config)
+    # the reference caches Resources keyed on file names only; clear so per-case patches do not leak
+    ref.load_resource._cached_configs.clear()
+    ref.pulse._cached_pmt_current_templates.clear()
+    ref.pulse._cached_uniform_to_pe_arr.clear()
+    if ap is not None:
+        path = TMP + '/pmt_ap.json.gz'
+        with gzip.open(path, 'wt') as f:
+            json.dump({k: {q: (v.tolist() if isinstance(v, np.ndarray) else v) for q, v in d.items()}
+                       for k, d in ap.items()}, f)
+        config['photon_ap_cdfs'] = path
+        config['enable_pmt_afterpulses'] = True
+    if noise is not None:
+        path = TMP + '/noise.npz'
+        np.savez(path, arr_0=noise)
+        config['noise_file'] = path
+        config['enable_noise'] = True
+    rd = ref.rawdata.RawData(config)
+    if pattern_maps is not None:
+        rd.resource.s1_pattern_map = pattern_maps['s1']
+        rd.resource.s2_pattern_map = pattern_maps['s2']
+    truth_dtype = instruction_dtype + truth_extra_dtype + [('fill', bool)]
+    truth = np.zeros(max(len(instructions) * 2, 10), dtype=truth_dtype)
+    rec = Recorder(ref)
+    rec.install()
+    np.random.seed(seed)
+    try:
+        for ch, left, right, data in rd(instructions, truth_buffer=truth, progress_bar=False):
+            rec.zle.append((len(rec.digits) - 1, int(ch), int(left), int(right), np.array(data, dtype=np.int64)))
+    finally:
+        rec.uninstall()
+
+    out = dict(instructions=instructions, seed=np.int64(seed))
+    calls = rec.calls
+    kinds = ['Pulse', 'S1', 'S2', 'PMT_Afterpulse', 'PhotoIonization_Electron', 'PhotoElectric_Electron']
+    out['call_kind'] = np.array([kinds.index(c['kind']) for c in calls], dtype=np.int8)
+    out['call_has_gains'] = np.array([c['has_gains'] for c in calls], dtype=bool)
+    out['call_ph_off'] = np.concatenate([[0], np.cumsum([len(c['t']) for c in calls])]).astype(np.int64)
+    out['ph_t'] = np.concatenate([c['t'] for c in calls] + [np.zeros(0, np.int64)])
+    out['ph_ch'] = np.concatenate([c['ch'] for c in calls] + [np.zeros(0, np.int64)]).astype(np.int16)
+    out['ph_dpe'] = np.concatenate([c['dpe'] for c in calls] + [np.zeros(0, bool)])
+    out['ph_gain'] = np.concatenate([c['gain'] for c in calls] + [np.zeros(0)])
+    assert len(out['ph_gain']) == len(out['ph_t'])
+    out['call_e_off'] = np.concatenate([[0], np.cumsum([len(c['e_t']) for c in calls])]).astype(np.int64)
+    out['e_t'] = np.concatenate([c['e_t'] for c in calls] + [np.zeros(0, np.int64)])
+    tkeys = sorted(calls[0]['truth'].keys()) if calls else []
+    for k in tkeys:
+        out['call_truth_' + k] = np.array([c['truth'][k] for c in calls])
+    pulses = [p for c in calls for p in c['pulses']]
+    out['call_pulse_off'] = np.concatenate([[0], np.cumsum([len(c['pulses']) for c in calls])]).astype(np.int64)
+    out['pl_ch'] = np.array([p['channel'] for p in pulses], dtype=np.int16)
+    out['pl_left'] = np.array([p['left'] for p in pulses], dtype=np.int64)
+    out['pl_right'] = np.array([p['right'] for p in pulses], dtype=np.int64)
+    out['pl_photons'] = np.array([p['photons'] for p in pulses], dtype=np.int64)
+    if store_currents:
+        out['pl_cur_off'] = np.concatenate([[0], np.cumsum([len(p['current']) for p in pulses])]).astype(np.int64)
+        out['pl_current'] = np.concatenate([p['current'] for p in pulses])
+    d = rec.digits
+    out['dg_left'] = np.array([x['left'] for x in d], dtype=np.int64)
+    out['dg_right'] = np.array([x['right'] for x in d], dtype=np.int64)
+    out['dg_first_pulse'] = np.array([x['first_pulse'] for x in d], dtype=np.int64)
+    out['dg_n_pulses'] = np.array([x['n_pulses'] for x in d], dtype=np.int64)
+    out['dg_ix_rand'] = np.array([x['ix_rand'][0] if x['ix_rand'] else -1 for x in d], dtype=np.int64)
+    out['dg_row_off'] = np.concatenate([[0], np.cumsum([len(x['ch']) for x in d])]).astype(np.int64)
+    out['row_ch'] = np.concatenate([x['ch'] for x in d] + [np.zeros(0, np.int64)]).astype(np.int16)
+    out['row_left'] = np.concatenate([x['ch_left'] for x in d] + [np.zeros(0, np.int64)])
+    out['row_right'] = np.concatenate([x['ch_right'] for x in d] + [np.zeros(0, np.int64)])
+    rows = [r for x in d for r in x['rows']]
+    out['row_data_off'] = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int64)
+    out['row_data'] = np.concatenate(rows + [np.zeros(0, np.int64)]).astype(np.int32)
+    out['dg_sum_min'] = np.array([x['sum_row'].min() for x in d], dtype=np.int64)
+    out['dg_sum_total'] = np.array([x['sum_row'].sum() for x in d], dtype=np.int64)
+    z = rec.zle
+    out['zle_digit'] = np.array([x[0] for x in z], dtype=np.int64)
+    out['zle_ch'] = np.array([x[1] for x in z], dtype=np.int16)
+    out['zle_left'] = np.array([x[2] for x in z], dtype=np.int64)
+    out['zle_right'] = np.array([x[3] for x in z], dtype=np.int64)
+    out['zle_data_off'] = np.concatenate([[0], np.cumsum([len(x[4]) for x in z])]).astype(np.int64)
+    out['zle_data'] = np.concatenate([x[4] for x in z] + [np.zeros(0, np.int64)]).astype(np.int32)
+    assert np.all(out['zle_data'] == np.concatenate([x[4] for x in z] + [np.zeros(0, np.int64)]))
+    out['truth'] = truth[truth['fill']]
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# fixtures
+# ---------------------------------------------------------------------------------------------
+def fixture_tables(ref):
+    cfg = base_config()
+    p = ref.pulse.Pulse(cfg)
+    _, pdf, mean = spe_distribution()
+    # the charge axis exactly as the reference parsed it back from the CSV (pandas' default float parser is
+    # not round-trip exact, so this can differ from charge/mean in the last bit)
+    charge = p.resource.photon_area_distribution['charge'].values.astype(np.float64)
+    np.savez_compressed(
+        HERE + '/tables.npz',
+        templates=p._pmt_current_templates, spe_row=p.uniform_to_pe_arr(np.arange(2000) / 2000.0 + 1e-9, 0),
+        spe_table_row_full=p._Pulse__uniform_to_pe_arr[7], current_max=p.current_max,
+        current_2_adc=np.float64(p.current_2_adc), spe_charge=charge, spe_pdf=pdf, spe_mean=np.float64(mean))
+    jcfg = {k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in cfg.items()
+            if k not in ('photon_area_distribution', 'url_base', 'turned_off_pmts')}
+    with open(HERE + '/config_nt.json', 'w') as f:
+        json.dump(jcfg, f, indent=0, sort_keys=True)
+    return p
+
+
+def fixture_add_current(ref, p):
+    """G1: direct calls of the reference's Pulse.add_current."""
+    rng = np.random.default_rng(11)
+    T = p._pmt_current_templates
+    cases = []
+
+    def case(t, g, extra_left=52, extra_right=70):
+        t = np.asarray(t, dtype=np.int64)
+        g = np.asarray(g, dtype=np.float64)
+        left = int(t.min() // 10) - extra_left
+        right = int(t.max() // 10) + extra_right
+        cur = np.zeros(right - left + 1)
+        ref.pulse.Pulse.add_current(t, g, left, 10, T, cur)
+        cases.append((t, g, left, cur))
+    case([1234], [1.0])                                   # single photon
+    case([1234, 1234, 1234], [0.5, 1.5, 2.25])            # duplicate-ns photons are merged
+    case([-37, -31, -5, 0, 3, 9, 10], rng.uniform(1e6, 3e6, 7))     # negative times: floor // and %
+    case(rng.integers(10**9, 10**9 + 300, 40), rng.uniform(1e6, 3e6, 40))         # S1-like
+    case(rng.normal(5 * 10**8, 600, 2000).astype(np.int64), rng.uniform(0, 6e6, 2000))   # S2-like, collisions
+    case(rng.integers(0, 50000, 300), rng.uniform(1e6, 3e6, 300))    # long sparse tile
+    out = dict(n=np.int64(len(cases)))
+    for i, (t, g, left, cur) in enumerate(cases):
+        out[f't{i}'], out[f'g{i}'], out[f'left{i}'], out[f'cur{i}'] = t, g, np.int64(left), cur
+    np.savez_compressed(HERE + '/add_current.npz', **out)
+
+
+def synthetic_afterpulse_tables(rng):
+    """Shape per afterpulse.py:181-186: element -> delaytime_cdf[n_ch, n_bins] (NOT normalised: last value
+    is the AP probability), amplitude_cdf[n_ch, n_bins] or [n_bins], bin sizes."""
+    nb = 200
+    out = {}
+    for name, p_ap, mean_delay, amp2d in [('He', 0.02, 60, True), ('Xe', 0.012, 140, False)]:
+        x = np.arange(nb)
+        shape = np.cumsum(np.exp(-0.5 * ((x - mean_delay) / 15.0) ** 2))
+        shape /= shape[-1]
+        prob = p_ap * rng.uniform(0.5, 1.5, N_TPC)
+        dcdf = shape[None, :] * prob[:, None]
+        a = np.cumsum(np.exp(-0.5 * ((np.arange(100) - 25) / 8.0) ** 2))
+        a /= a[-1]
+        acdf = np.repeat(a[None, :], N_TPC, axis=0) if amp2d else a
+        out[name] = dict(delaytime_cdf=dcdf, amplitude_cdf=acdf, delaytime_bin_size=10.0, amplitude_bin_size=0.04)
+    # 'Uniform' element: delaytime_cdf is [n_ch, 2]; delay ~ U(col0, col1) * bin and the AP probability is col -1
+    out['Uniform'] = dict(delaytime_cdf=np.stack([np.full(N_TPC, 0.004), np.full(N_TPC, 0.008)], axis=1),
+                          amplitude_cdf=np.ones(3), delaytime_bin_size=1000.0, amplitude_bin_size=1.0)
+    return out
+
+
+def fixture_chains(ref):
+    pat = dict(s1=SyntheticPatternMap(14e-5, 30.0, 18.0, 0.15), s2=SyntheticPatternMap(30e-5, 9.0, 25.0, 0.02))
+    np.savez_compressed(HERE + '/pattern.npz', pmt_xy=PMT_XY,
+                        s1_params=np.array([14e-5, 30.0, 18.0, 0.15]), s2_params=np.array([30e-5, 9.0, 25.0, 0.02]))
+    MS = 1_000_000
+
+    # A: S1s -- isolated, plus two overlapping in one cluster (per-pulse rounding, several pulses per row)
+    rows = [dict(type=1, time=MS * (i + 1), x=5.0 * i - 20, y=3.0 * i - 10, z=-10.0 - 8 * i, amp=amp)
+            for i, amp in enumerate([417, 1667, 60, 5000, 1, 900, 25000])]
+    rows += [dict(type=1, time=MS * 9, x=1, y=2, z=-50, amp=1667), dict(type=1, time=MS * 9 + 370, x=-7, y=12, z=-20, amp=1200),
+             dict(type=1, time=MS * 9 + 60_000, x=-7, y=12, z=-20, amp=800)]
+    np.savez_compressed(HERE + '/chain_s1.npz',
+                        **run_chain(ref, base_config(), make_instructions(rows), 101, pat, store_currents=True))
+
+    # B: S2s, S1+S2 pair in one cluster, deep S2
+    rows = [dict(type=2, time=MS * 1, x=3, y=-4, z=-10, amp=120),
+            dict(type=1, time=MS * 2, x=10, y=10, z=-5, amp=3000), dict(type=2, time=MS * 2, x=10, y=10, z=-5, amp=400),
+            dict(type=2, time=MS * 4, x=-30, y=20, z=-95, amp=250),
+            dict(type=2, time=MS * 5, x=0, y=0, z=-1, amp=3)]
+    np.savez_compressed(HERE + '/chain_s2.npz',
+                        **run_chain(ref, base_config(), make_instructions(rows), 202, pat, store_currents=False))
+
+    # C: high-energy channels active (int(factor) = 20), uniform dummy maps
+    rows = [dict(type=1, time=MS, x=0, y=0, z=-40, amp=2500), dict(type=2, time=MS, x=0, y=0, z=-40, amp=150),
+            dict(type=1, time=3 * MS, x=20, y=0, z=-5, amp=700)]
+    np.savez_compressed(HERE + '/chain_he.npz',
+                        **run_chain(ref, base_config(high_energy_deamplification_factor=20),
+                                    make_instructions(rows), 303, None))
+
+    # D: noise on (synthetic noise array, 494 columns -> HE rows get no noise), short noise array wraps
+    rng = np.random.default_rng(5)
+    noise = np.round(rng.normal(0, 2.2, (3000, N_TPC))).astype(np.int16)
+    np.savez_compressed(HERE + '/noise.npz', noise=noise)
+    rows = [dict(type=1, time=MS, x=0, y=0, z=-40, amp=1500), dict(type=2, time=MS, x=0, y=0, z=-40, amp=200),
+            dict(type=1, time=3 * MS, x=20, y=0, z=-5, amp=300), dict(type=2, time=5 * MS, x=20, y=0, z=-60, amp=80)]
+    np.savez_compressed(HERE + '/chain_noise.npz',
+                        **run_chain(ref, base_config(), make_instructions(rows), 404, pat, noise=noise))
+
+    # E: PMT afterpulses on (synthetic CDF tables)
+    ap = synthetic_afterpulse_tables(np.random.default_rng(6))
+    np.savez_compressed(HERE + '/pmt_ap_tables.npz',
+                        **{f'{k}_{q}': np.asarray(v) for k, d in ap.items() for q, v in d.items()})
+    rows = [dict(type=1, time=MS, x=0, y=0, z=-40, amp=6000), dict(type=2, time=MS, x=5, y=5, z=-40, amp=300),
+            dict(type=1, time=4 * MS, x=20, y=0, z=-5, amp=50)]
+    np.savez_compressed(HERE + '/chain_pmt_ap.npz',
+                        **run_chain(ref, base_config(), make_instructions(rows), 505, pat, ap=ap))
+
+
+def hist(x):
+    v, c = np.unique(np.asarray(x, dtype=np.int64), return_counts=True)
+    return v.astype(np.int64), c.astype(np.int64)
+
+
+def fixture_distributions(ref):
+    """G7: integer-valued samples of every random stage, as (value, count) histograms."""
+    cfg = base_config()
+    ref.load_resource._cached_configs.clear()
+    s1, s2 = ref.s1.S1(cfg), ref.s2.S2(cfg)
+    P = ref.pulse.Pulse
+    out = {}
+    n = 2_000_000
+    np.random.seed(9001)
+    t = s1.photon_timings(t=np.array([0]), n_photon_hits=np.array([n]), recoil_type=np.array([7]),
+                          config=cfg, phase='liquid')
+    out['s1_simple_v'], out['s1_simple_c'] = hist(t)
+    tts = np.random.normal(cfg['pmt_transit_time_mean'], cfg['pmt_transit_time_spread'] / 2.35482, n).astype(np.int64)
+    out['tts_v'], out['tts_c'] = hist(tts)
+    out['st_gas_v'], out['st_gas_c'] = hist(P.singlet_triplet_delays(n, cfg['singlet_fraction_gas'], cfg, 'gas'))
+    out['lum_v'], out['lum_c'] = hist(s2.luminescence_timings_simple(np.zeros((1, 2)), np.array([n]), cfg, s2.resource))
+    # electron arrival + photons/electron for two depths
+    for tag, z in [('z10', -10.0), ('z90', -90.0)]:
+        zi, xy = np.array([z]), np.zeros((1, 2))
+        ne = np.array([400_000])
+        sc = s2.get_s2_light_yield(xy, cfg, s2.resource)
+        nxy, npe, et = s2.get_n_photons(np.array([0]), ne, zi, xy, sc, cfg, s2.resource)
+        out[f'etime_{tag}_v'], out[f'etime_{tag}_c'] = hist(et)
+        out[f'nph_e_{tag}_v'], out[f'nph_e_{tag}_c'] = hist(npe)
+        out[f'sc_gain_{tag}'] = sc
+        dm, ds = s2.get_s2_drift_time_params(zi, xy, cfg, s2.resource)
+        out[f'drift_{tag}'] = np.array([dm[0], ds[0]])
+        n_el = s2.get_electron_yield(np.full(200_000, 1000), np.zeros((200_000, 2)), np.full(200_000, z),
+                                     np.zeros((200_000, 2)), cfg, s2.resource)
+        out[f'nel_{tag}_v'], out[f'nel_{tag}_c'] = hist(n_el)
+    nh = s1.get_n_photons(np.full(400_000, 1667), np.zeros((400_000, 3)), s1.resource.s1_lce_correction_map, cfg)
+    out['s1_nhits_v'], out['s1_nhits_c'] = hist(nh)
+    # full S2 photon time relative to instruction time (all terms), z=-10
+    np.random.seed(9002)
+    ins = make_instructions([dict(type=2, time=0, x=0, y=0, z=-10, amp=20000)])
+    s2(ins)
+    out['s2_full_v'], out['s2_full_c'] = hist(s2._photon_timings)
+    out['s2_full_ch_counts'] = np.bincount(s2._photon_channels, minlength=N_TPC).astype(np.int64)
+    # SPE gain factors
+    np.random.seed(9003)
+    p = P(cfg)
+    idx = (np.random.random(n) * 2000).astype(np.int64) + 1
+    out['spe_idx_counts'] = np.bincount(idx, minlength=2001).astype(np.int64)
+    dpe = np.random.binomial(1, cfg['p_double_pe_emision'], n)
+    out['dpe_frac'] = np.array([dpe.mean(), n])
+    np.savez_compressed(HERE + '/dists.npz', **out)
+
+
+def fixture_chain_stats(ref):
+    """Per-instruction summary statistics of full reference runs (statistical end-to-end pins)."""
+    MS = 1_000_000
+    out = {}
+    for tag, rows, seed in [
+        ('s1', [dict(type=1, time=MS * (i + 1), x=0, y=0, z=-50, amp=1667) for i in range(300)], 71),
+        ('s2', [dict(type=2, time=MS * (i + 1), x=0, y=0, z=-10, amp=300) for i in range(60)], 72),
+    ]:
+        r = run_chain(ref, base_config(), make_instructions(rows), seed, None)
+        tr = r['truth']
+        for f in ['n_photon', 'n_pe', 'n_photon_trigger', 'n_pe_trigger', 'raw_area', 'raw_area_trigger',
+                  'n_photon_bottom', 't_mean_photon', 't_sigma_photon', 't_first_photon', 't_last_photon',
+                  'n_electron', 't_mean_electron', 't_sigma_electron', 'endtime', 'time']:
+            out[f'{tag}_{f}'] = tr[f]
+        nz = np.bincount(r['zle_digit'], minlength=len(r['dg_left']))
+        out[f'{tag}_n_zle'] = nz
+        ln = (r['zle_right'] - r['zle_left'] + 1)
+        out[f'{tag}_zle_samples'] = np.bincount(r['zle_digit'], weights=ln, minlength=len(r['dg_left']))
+        area = np.array([(16000 - r['zle_data'][a:b]).sum() for a, b in zip(r['zle_data_off'][:-1], r['zle_data_off'][1:])])
+        out[f'{tag}_zle_area'] = np.bincount(r['zle_digit'], weights=area, minlength=len(r['dg_left']))
+        out[f'{tag}_width'] = r['dg_right'] - r['dg_left']
+    np.savez_compressed(HERE + '/chain_stats.npz', **out)
+
+
+if __name__ == '__main__':
+    ref = import_reference()
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'stats']
+    p = fixture_tables(ref)
+    if 'add_current' in which:
+        fixture_add_current(ref, p)
+    if 'chains' in which:
+        fixture_chains(ref)
+    if 'dists' in which:
+        fixture_distributions(ref)
+    if 'stats' in which:
+        fixture_chain_stats(ref)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(('.npz', '.json')):
+            print(f'{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:9.1f} KiB')

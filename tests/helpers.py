@@ -1,0 +1,54 @@
+"""Shared helpers of the test-suite: build oracle / device sessions from a config, replay golden chains."""
+import os
+
+import numpy as np
+
+from wfsim_amd import tables as T
+from wfsim_amd.config import kernel_params, N_ROWS
+from wfsim_amd.resource import Resource
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def host_tables(config, resource=None):
+    resource = resource or Resource(config)
+    thr_truth, thr_zle = T.thresholds(config, N_ROWS)
+    lum_x, lum_t = T.luminescence_table(config)
+    return dict(templates=T.pmt_current_templates(config), spe=T.spe_scaling_table(resource.spe_charge, resource.spe_pdfs),
+                gains=np.asarray(config['gains'], dtype=np.float64), thr_truth=thr_truth, thr_zle=thr_zle,
+                lum_x=lum_x, lum_t=lum_t, noise=getattr(resource, 'noise_data', None))
+
+
+def ap_tables_from_golden():
+    d = golden('pmt_ap_tables.npz')
+    out = {}
+    for name in ['He', 'Xe', 'Uniform']:
+        out[name] = dict(delaytime_cdf=d[f'{name}_delaytime_cdf'], amplitude_cdf=d[f'{name}_amplitude_cdf'],
+                         delaytime_bin_size=float(d[f'{name}_delaytime_bin_size']),
+                         amplitude_bin_size=float(d[f'{name}_amplitude_bin_size']))
+    return out
+
+
+def make_oracle(config, ap_tables=None):
+    from oracle.oracle import Oracle
+    return Oracle(kernel_params(config), host_tables(config), ap_tables)
+
+
+def replay_chain_on_oracle(orc, d):
+    """Feed the photons the reference generated (per Pulse.__call__) and digitise where the reference did."""
+    first = d['dg_first_pulse']
+    npl = d['dg_n_pulses']
+    boundaries = set((first + npl).tolist())
+    n_pulses = 0
+    for k in range(len(d['call_kind'])):
+        a, b = d['call_ph_off'][k], d['call_ph_off'][k + 1]
+        orc.pulse_call(int(d['call_kind'][k]), k, d['ph_t'][a:b], d['ph_ch'][a:b], d['ph_dpe'][a:b], d['ph_gain'][a:b],
+                       bool(d['call_has_gains'][k]))
+        n_pulses += d['call_pulse_off'][k + 1] - d['call_pulse_off'][k]
+        if n_pulses in boundaries:
+            orc.digitize_and_zle(0)
+    return orc.results()

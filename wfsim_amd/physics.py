@@ -1,0 +1,163 @@
+"""Per-instruction quantities evaluated on the host from (callable) maps before a batch goes to the GPU.
+
+Maps are host callables at the drop-in boundary (straxen.InterpolatingMap in production, DummyMap in tests),
+so everything that touches a map is evaluated here, vectorised over the batch, exactly as the reference does:
+
+* S1 hit probability        -- S1.get_n_photons,  /root/reference/wfsim/core/s1.py:117-135 (the Binomial is drawn on the GPU)
+* S1 channel probabilities  -- S1.photon_channels, s1.py:138-159 (the categorical draw happens on the GPU)
+* S2 drift time mean/spread -- S2.get_s2_drift_time_params, /root/reference/wfsim/core/s2.py:158-179
+* S2 electron survival      -- S2.get_electron_yield, s2.py:212-256 (Binomial drawn on the GPU)
+* S2 secondary gain         -- S2.get_s2_light_yield, s2.py:182-209
+* S2 channel probabilities  -- S2.photon_channels, s2.py:616-682
+"""
+import numpy as np
+
+from .resource import DummyMap
+from .tables import choice_cdf
+
+
+def s1_hit_probability(instructions, config, resource):
+    positions = np.array([instructions['x'], instructions['y'], instructions['z']]).T
+    ly = resource.s1_lce_correction_map(positions)
+    if len(ly.shape) != 1:
+        ly = np.squeeze(ly, axis=-1)
+    ly = ly / (1 + config['p_double_pe_emision'])
+    ly = ly * config['s1_detection_efficiency']
+    return np.asarray(ly, dtype=np.float64)
+
+
+def _turned_off(config):
+    gains = np.asarray(config['gains'])
+    return np.arange(len(gains))[gains == 0]
+
+
+def s1_channel_probabilities(instructions, config, resource):
+    positions = np.array([instructions['x'], instructions['y'], instructions['z']]).T
+    channels = np.arange(config['n_tpc_pmts'])
+    p = np.array(resource.s1_pattern_map(positions), dtype=np.float64)
+    p[:, np.isin(channels, _turned_off(config))] = 0
+    return p / np.sum(p, axis=1)[:, None]
+
+
+def s2_drift_time_params(z, xy, config, resource):
+    efd = config['enable_field_dependencies']
+    if efd.get('drift_speed_map', False):
+        v = resource.field_dependencies_map(z, xy, map_name='drift_speed_map')
+        v = v * 1e-4
+        v = v * resource.drift_velocity_scaling
+    else:
+        v = config['drift_velocity_liquid']
+    if efd.get('diffusion_longitudinal_map', False):
+        dl = resource.diffusion_longitudinal_map(z, xy)
+    else:
+        dl = config['diffusion_constant_longitudinal']
+    mean = - z / v + config['drift_time_gate']
+    mean = np.clip(mean, 0, np.inf)
+    spread = np.sqrt(2 * dl * mean)
+    spread /= v
+    return mean, spread
+
+
+def s2_electron_survival(z, xy, positions, config, resource):
+    mean, _ = s2_drift_time_params(z, xy, config, resource)
+    if config.get('ext_eff_from_map', False):
+        rel = resource.s2_correction_map(positions).flatten()
+        if config.get('se_gain_from_map', False):
+            se = resource.se_gain_map(positions)
+        else:
+            se = rel * config['s2_secondary_sc_gain']
+        cy = config['g2_mean'] * rel / se
+    else:
+        cy = config['electron_extraction_yield']
+    cy = cy * np.exp(- 1 * mean / config['electron_lifetime_liquid'])
+    if config['enable_field_dependencies'].get('survival_probability_map', False):
+        p_surv = resource.field_dependencies_map(z, xy, map_name='survival_probability_map')
+        if np.any(p_surv < 0) or np.any(p_surv > 1):
+            p_surv = np.clip(p_surv, a_min=0, a_max=1)
+        cy = cy * p_surv
+    return np.asarray(cy, dtype=np.float64) * np.ones(len(z))
+
+
+def s2_secondary_gain(positions, config, resource):
+    if config.get('se_gain_from_map', False):
+        sc_gain = np.array(resource.se_gain_map(positions), dtype=np.float64)
+    else:
+        sc_gain = np.array(resource.s2_correction_map(positions), dtype=np.float64)
+        sc_gain *= config['s2_secondary_sc_gain']
+    if len(sc_gain.shape) != 1:
+        sc_gain = np.squeeze(sc_gain, axis=-1)
+    sc_gain /= 1 + config['p_double_pe_emision']
+    sc_gain[np.isnan(sc_gain)] = 0
+    return sc_gain
+
+
+def s2_channel_probabilities(positions, config, resource):
+    if config.get('diffusion_constant_transverse', 0) > 0:
+        raise NotImplementedError('transverse-diffusion averaged S2 patterns (s2.py:560-613) are not on the MI355X path')
+    if config.get('s2_aft_sigma', 0.0) != 0:
+        raise NotImplementedError('s2_aft_sigma smearing (s2.py:660-665) is not on the MI355X path')
+    channels = np.arange(config['n_tpc_pmts']).astype(np.int64)
+    bottom_index = np.array(config['channels_bottom'])
+    pattern = np.array(resource.s2_pattern_map(positions), dtype=np.float64)
+    if pattern.shape[1] - 1 not in bottom_index:
+        pattern = np.pad(pattern, [[0, 0], [0, len(bottom_index)]], 'constant', constant_values=1)
+    pattern[:, np.isin(channels, _turned_off(config))] = 0
+    sum_pat = np.sum(pattern, axis=1).reshape(-1, 1)
+    pattern = np.divide(pattern, sum_pat, out=np.zeros_like(pattern), where=sum_pat != 0)
+    assert pattern.shape[1] == len(channels)
+    return pattern
+
+
+def instruction_time(instructions, config):
+    """Ordering key of the scheduler, /root/reference/wfsim/core/rawdata.py:61 (float32 arithmetic, as numpy does)."""
+    v = config['drift_velocity_liquid']
+    return instructions['time'] + (instructions['z'] / v * (instructions['type'] % 2 - 1)).astype(np.int64)
+
+
+def instruction_params(instructions, config, resource):
+    """Batch arrays for the device: hit/survival probability, drift parameters, secondary gain and the
+    cumulative channel table of every instruction (rows de-duplicated)."""
+    n = len(instructions)
+    is_s1 = instructions['type'] == 1
+    is_s2 = instructions['type'] == 2
+    if not np.all(is_s1 | is_s2):
+        raise NotImplementedError('only primary S1 (type 1) and S2 (type 2) instructions are on the MI355X path')
+    p_hit = np.zeros(n)
+    drift_mean = np.zeros(n)
+    drift_spread = np.zeros(n)
+    sc_gain = np.zeros(n)
+    n_ch = config['n_tpc_pmts']
+    const_rows = {}
+    rows = []
+    cdf_row = np.zeros(n, dtype=np.int32)
+    for sel, kind in ((is_s1, 's1'), (is_s2, 's2')):
+        if not sel.any():
+            continue
+        ins = instructions[sel]
+        if kind == 's1':
+            p_hit[sel] = s1_hit_probability(ins, config, resource)
+            pmap = resource.s1_pattern_map
+            probs = (lambda q: s1_channel_probabilities(q, config, resource))
+        else:
+            x, y, z = ins['x'], ins['y'], ins['z']
+            xy = np.array([x, y]).T
+            if config.get('field_distortion_model', 'none') != 'none':
+                raise NotImplementedError('field distortion models need private maps (SURVEY.md 2.1 row 3)')
+            p_hit[sel] = s2_electron_survival(z, xy, xy, config, resource)
+            m, s = s2_drift_time_params(z, xy, config, resource)
+            drift_mean[sel], drift_spread[sel] = m, s
+            sc_gain[sel] = s2_secondary_gain(xy, config, resource)
+            pmap = resource.s2_pattern_map
+            probs = (lambda q: s2_channel_probabilities(np.array([q['x'], q['y']]).T, config, resource))
+        idx = np.where(sel)[0]
+        if isinstance(pmap, DummyMap):
+            const_rows[kind] = len(rows)
+            rows.append(choice_cdf(probs(ins[:1]))[0])
+            cdf_row[idx] = const_rows[kind]
+        else:
+            cdf = choice_cdf(probs(ins))
+            cdf_row[idx] = len(rows) + np.arange(len(idx))
+            rows.extend(list(cdf))
+    cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.zeros((1, n_ch))
+    return dict(p_hit=p_hit, drift_mean=drift_mean, drift_spread=drift_spread, sc_gain=sc_gain,
+                cdf_row=cdf_row, cdf_table=cdf_table)
