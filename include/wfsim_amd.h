@@ -1,0 +1,173 @@
+/*
+ * wfsim_amd.h -- C ABI of the MI355X-native WFSim hot path (libwfsim_amd.so, HIP, gfx950 only).
+ *
+ * The reference (XENONnT/WFSim v1.2.2) is pure Python and has no FFI; its hot path lives behind
+ * wfsim.RawData / wfsim.ChunkRawRecords.  This header is what a binding for that path binds: every entry point
+ * names the reference routine(s) it replaces (paths relative to the reference's wfsim/ directory).  The Python
+ * host side of this repository (wfsim_amd/engine.py, ctypes) is such a binding; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the ABI.  Every function returns 0 on success or a negative
+ *     WFS_E_* code; wfs_last_error(h) gives the message.
+ *   - a handle owns one GPU (hipSetDevice at creation) and one HIP stream; it is not thread safe.
+ *   - "host" pointers are ordinary CPU memory (numpy buffers), copied by the call; "dev" pointers are HBM
+ *     addresses on the handle's GPU (e.g. torch tensors' data_ptr()).
+ *   - instructions of one batch must be sorted by the scheduler key time - z/v*[S2] (rawdata.py:61) and carry
+ *     their time-cluster id (gap > right_raw_extension, rawdata.py:63); wfsim_amd/scheduler.py does that.
+ */
+#ifndef WFSIM_AMD_H
+#define WFSIM_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFS_OK 0
+#define WFS_E_INVALID (-1)   /* bad argument / shape                                      */
+#define WFS_E_HIP (-2)       /* HIP runtime error (message has the call)                  */
+#define WFS_E_CAPACITY (-3)  /* caller buffer too small, or the 10^6-sample window assert */
+#define WFS_E_STATE (-4)     /* call order (tables / batch not loaded)                    */
+
+typedef struct wfs_handle wfs_handle;
+
+/* Scalars of the hot path.  Filled from the fax config by wfsim_amd.config.kernel_params();
+ * the config keys are listed in SURVEY.md appendix A. */
+typedef struct wfs_config {
+    int32_t dt;                /* sample_duration                                   pulse.py:58      */
+    int32_t samples_before;    /* samples_before_pulse_center                       pulse.py:121-127 */
+    int32_t samples_after;     /* samples_after_pulse_center                                         */
+    int32_t store_before;      /* samples_to_store_before                                            */
+    int32_t store_after;       /* samples_to_store_after                                             */
+    int32_t tlen;              /* template length = before + after (22)             pulse.py:175     */
+    int32_t trigger_window;    /* rawdata.py:215-216, 299-304                                        */
+    int32_t baseline;          /* digitizer_reference_baseline                      rawdata.py:270   */
+    int32_t n_rows;            /* rows of the digitiser array (801)                 rawdata.py:224   */
+    int32_t n_tpc;             /* len(gains)                                                         */
+    int32_t n_top;             /* n_top_pmts                                        rawdata.py:243   */
+    int32_t he_first;          /* channel_map['he'][0]                              rawdata.py:244   */
+    int32_t he_factor;         /* int(high_energy_deamplification_factor)           rawdata.py:242   */
+    int32_t sum_channel;       /* channel_map['sum_signal'] (never emitted)              */
+    int32_t last_bottom;       /* channels_bottom[-1]                               rawdata.py:250   */
+    int32_t detector_nt;       /* detector == 'XENONnT'                             rawdata.py:241   */
+    int32_t enable_noise;      /* rawdata.py:263                                                     */
+    int32_t s1_simple;         /* 'simple' in s1_model_type                         s1.py:191        */
+    int32_t s2_time_model;     /* 0 zero_delay, 1 "s2_time_spread around zero"      s2.py:545-550    */
+    int32_t enable_pmt_ap;     /* enable_pmt_afterpulses                            rawdata.py:176   */
+    double c2a;                /* current_2_adc                                     pulse.py:33-35   */
+    double tts_mean, tts_sigma;/* pmt_transit_time_mean, spread/2.35482             pulse.py:53-56   */
+    double p_dpe;              /* p_double_pe_emision                               pulse.py:76      */
+    double s1_decay_time, s1_decay_spread;                    /*                    s1.py:193-194    */
+    double sf_gas, t1_gas, t3_gas;                            /* singlet/triplet    pulse.py:333-341 */
+    double s2_time_spread;                                    /*                    s2.py:550        */
+    double trap_time;          /* electron_trapping_time                            s2.py:280        */
+    double gain_spread;        /* s2_gain_spread                                    s2.py:309        */
+    double pmt_ap_modifier, pmt_ap_t_modifier;                /*                    afterpulse.py:198,223 */
+    double rext;               /* right_raw_extension                               rawdata.py:47    */
+    double drift_velocity;     /* drift_velocity_liquid                             rawdata.py:46    */
+    uint64_t seed;             /* Philox key (the reference seeds numpy's global generator, strax_interface.py:589) */
+} wfs_config;
+
+/* ---- life cycle: replaces RawData.__init__ / Pulse.__init__ (rawdata.py:27-36, pulse.py:24-37) ---------- */
+int wfs_create(const wfs_config *cfg, int device, wfs_handle **out);
+int wfs_destroy(wfs_handle *h);
+const char *wfs_last_error(const wfs_handle *h);
+int wfs_device_count(int *n);
+
+/* Init-time tables (host pointers, copied to HBM once).
+ *   templates  f64[10][tlen]        Pulse.init_pmt_current_templates            pulse.py:146-187
+ *   spe        f64[n_spe][2001]     Pulse.init_spe_scaling_factor_distributions pulse.py:189-223 (n_spe == 1: shared)
+ *   gains      f64[n_tpc]           config['gains']
+ *   thr_truth  f64[n_rows]          zle/special threshold - 0.5                 pulse.py:240-243
+ *   thr_zle    i64[n_rows]          baseline - threshold - 1                    rawdata.py:290-294
+ *   lum_x/t    f64[n_lum]           inverse-CDF table of the simple luminescence model, s2.py:317-341
+ *   noise      i16[noise_len][noise_channels] or NULL                           load_resource.py:375-376 */
+int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, int32_t n_spe,
+                   const double *gains, const double *thr_truth, const int64_t *thr_zle,
+                   const double *lum_x, const double *lum_t, int32_t n_lum,
+                   const int16_t *noise, int32_t noise_len, int32_t noise_channels);
+
+/* PMT afterpulse element tables (resource.uniform_to_pmt_ap[element], afterpulse.py:181-186), element < 8 */
+int wfs_set_ap_element(wfs_handle *h, int32_t element, int32_t n_bins_delay, int32_t n_bins_amp, int32_t amp_2d,
+                       int32_t is_uniform, double delay_bin, double amp_bin,
+                       const double *delay_cdf, const double *amp_cdf);
+
+/* ---- batch input ------------------------------------------------------------------------------------- */
+/* One batch of primary instructions (host pointers; SoA because instruction_dtype is a packed 70-byte record
+ * with an unaligned int64, strax_interface.py:25-42).  Sorted by the scheduler key; cluster[] non-decreasing.
+ *   type i8, time i64, amp i32               instruction fields
+ *   gid u32                                  run-wide instruction index (RNG stream id; shard independent)
+ *   cluster i32                              time-cluster index within the batch (rawdata.py:61-63)
+ *   tmin i64                                 scheduler key (time - z/v*[S2]) of the instruction
+ *   p_hit f64                                S1: light yield (s1.py:125-131); S2: electron survival (s2.py:241-252)
+ *   drift_mean/drift_spread f64              s2.py:158-179
+ *   sc_gain f64                              s2.py:182-209
+ *   cdf_row i32, cdf_table f64[n_cdf][n_tpc] cumulative channel probabilities (np.random.choice, s1.py:154, s2.py:673) */
+int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const int64_t *time, const int32_t *amp,
+                          const uint32_t *gid, const int32_t *cluster, const int64_t *tmin,
+                          const double *p_hit, const double *drift_mean, const double *drift_spread,
+                          const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf);
+
+/* Parity entry: photons supplied instead of generated -- what RawDataOptical.sim_primary hands to Pulse
+ * (rawdata.py:475-493) and what the golden vectors inject.  One "pulse set" = one Pulse.__call__ (pulse.py:39).
+ *   set_cluster i32[n_sets], set_tmin i64[n_sets]   cluster id and scheduler key of the set's instruction
+ *   set_off i64[n_sets+1]                           photon ranges; inside a set photons are sorted by channel
+ *   t i64 (post transit-time spread), ch i16, gain f64 (pulse.py:97-107), dpe u8 */
+int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, const int64_t *set_tmin,
+                     const int64_t *set_off, const int64_t *t, const int16_t *ch, const double *gain,
+                     const uint8_t *dpe);
+
+/* ---- run: replaces RawData.__call__ for the loaded batch (rawdata.py:38-157) ---------------------------- */
+/* Stages: S1/S2 photon generation (s1.py:60-114, s2.py:73-136) [skipped after wfs_load_photons] ->
+ * Pulse.__call__ + add_current (pulse.py:39-144, 276-318) -> digitize_pulse_cache (rawdata.py:204-272) ->
+ * ZLE (rawdata.py:274-311) -> record packing (strax_interface.py:391-436).  Asynchronous on the handle's
+ * stream except for the size read-backs between stages. */
+int wfs_run(wfs_handle *h);
+
+typedef struct wfs_counts {
+    int64_t n_instructions, n_pulse_sets, n_emitters, n_photons, n_pe, n_tiles, n_groups, n_rows,
+            n_raw_samples, n_intervals, n_records;
+} wfs_counts;
+int wfs_get_counts(wfs_handle *h, wfs_counts *out);
+
+/* ---- results (host copies) ---------------------------------------------------------------------------- */
+/* raw_records, 244-byte packed strax layout, in the order the reference yields them (group, channel, interval,
+ * fragment); dst may be a host or a device pointer (wfs_copy_records_dev). */
+int wfs_copy_records(wfs_handle *h, void *dst_host, int64_t capacity_records);
+int wfs_copy_records_dev(wfs_handle *h, void *dst_dev, int64_t capacity_records);
+const void *wfs_records_dev_ptr(wfs_handle *h);
+/* digitise windows: rawdata.left / rawdata.right and the first record of each window (strax_interface.py:394-399) */
+int wfs_copy_groups(wfs_handle *h, int64_t *left, int64_t *right, int64_t *first_record, int64_t *ix_rand);
+/* ZLE intervals (channel, left, right) and their samples: the tuples RawData.__call__ yields (rawdata.py:311) */
+int wfs_copy_intervals(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right,
+                       int64_t *data_off, int64_t capacity);
+int wfs_copy_interval_data(wfs_handle *h, int16_t *data, int64_t capacity);
+/* pulses (tiles): channel, left, right, photons, and the f64 currents (pulse.py:138-144) -- parity/debug */
+int wfs_copy_pulses(wfs_handle *h, int32_t *set, int32_t *channel, int64_t *left, int64_t *right,
+                    int64_t *n_photons, int64_t *cur_off, int64_t capacity);
+int wfs_copy_currents(wfs_handle *h, double *cur, int64_t capacity);   /* needs wfs_set_debug(h, 1) before wfs_run */
+/* digitised rows in their active range (rawdata.py:258-259) -- parity/debug */
+int wfs_copy_rows(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right,
+                  int64_t *data_off, int64_t capacity);
+int wfs_copy_row_data(wfs_handle *h, int32_t *data, int64_t capacity);
+/* generated photons per pulse set, channel sorted: t i64, ch i16, gain f64, dpe u8 (after wfs_run) */
+int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, double *gain, uint8_t *dpe,
+                     int64_t capacity);
+/* truth accumulators per pulse set: 12 f64 (n_photon n_pe n_photon_trigger n_pe_trigger raw_area raw_area_trigger,
+ * then the same for the bottom array; pulse.py:229-271) + photon time stats (n, mean, min, max, std; rawdata.py:325-332) */
+int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t capacity_sets);
+
+/* ---- instrumentation ---------------------------------------------------------------------------------- */
+int wfs_set_debug(wfs_handle *h, int32_t keep_currents);
+int wfs_set_stream(wfs_handle *h, void *hip_stream);
+int wfs_synchronize(wfs_handle *h);
+/* HIP-event timing of the kernels of the last wfs_run: names (NUL separated) and milliseconds */
+int wfs_kernel_times(wfs_handle *h, char *names, int64_t names_cap, float *ms, int32_t *n_launches, int32_t *n_kernels);
+int wfs_set_profiling(wfs_handle *h, int32_t on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -52,3 +52,45 @@ def replay_chain_on_oracle(orc, d):
         if n_pulses in boundaries:
             orc.digitize_and_zle(0)
     return orc.results()
+
+
+# ------------------------------------------------------------------------------------------------ device side
+def make_engine(config, seed=None, resource=None):
+    from wfsim_amd.engine import Engine
+    return Engine(config, resource or Resource(config), device=0, seed=seed)
+
+
+def chain_sets(d, config):
+    """Pulse sets of a golden chain: (set_cluster, set_tmin) per recorded Pulse.__call__."""
+    from wfsim_amd.scheduler import schedule, processing_order
+    ins = d['instructions']
+    order, key, cluster = schedule(ins, config)
+    proc = processing_order(ins, order, cluster)
+    set_cluster, set_tmin = [], []
+    k = -1
+    for kind in d['call_kind']:
+        if kind != 3:          # a primary Pulse call; kind 3 = PMT afterpulses of the previous primary
+            k += 1
+        set_cluster.append(cluster[proc[k]])
+        set_tmin.append(key[proc[k]])
+    assert k == len(ins) - 1
+    return np.asarray(set_cluster, np.int32), np.asarray(set_tmin, np.int64)
+
+
+def replay_chain_on_engine(eng, d, config, debug=True):
+    set_cluster, set_tmin = chain_sets(d, config)
+    eng.set_debug(debug)
+    dpe = np.array(d['ph_dpe'], dtype=np.uint8)
+    for k in np.where(d['call_has_gains'])[0]:        # pre-assigned gains: n_double_pe = 0 (pulse.py:105-106)
+        dpe[d['call_ph_off'][k]:d['call_ph_off'][k + 1]] = 0
+    eng.load_photons(set_cluster, set_tmin, d['call_ph_off'], d['ph_t'], d['ph_ch'], d['ph_gain'], dpe)
+    return eng.run()
+
+
+def canonical_intervals(group, ch, left, right, data_off, data):
+    """list of (group, ch, left, right, bytes) sorted -- order independent comparison"""
+    out = []
+    for k in range(len(ch)):
+        out.append((int(group[k]), int(ch[k]), int(left[k]), int(right[k]),
+                    np.asarray(data[data_off[k]:data_off[k + 1]], dtype=np.int64).tobytes()))
+    return sorted(out)

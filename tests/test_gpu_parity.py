@@ -1,0 +1,112 @@
+"""HIP path against the golden vectors of the reference and against the CPU oracle (MI355X only).
+
+Everything here goes through the C ABI (wfsim_amd.engine -> libwfsim_amd.so).  Photons are injected at the
+stage boundary Pulse.__call__ so that all results are deterministic:
+  * pulse bounds, photon counts: exact
+  * tile currents (f64): bit-exact (tolerance 4 ulp of the tile maximum only for tiles with >= 3 photons in one ns,
+    whose merge order the reference leaves to numpy's unstable argsort)
+  * digitised rows, ZLE intervals, records: exact (the north-star bar is 1 ADC count; we get 0)
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import (golden, make_engine, make_oracle, replay_chain_on_engine, replay_chain_on_oracle,
+                           canonical_intervals, ap_tables_from_golden)
+from wfsim_amd.config import xenonnt_test_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _nonempty_groups(eng):
+    g = eng.groups()
+    keep = np.where(g['right'] >= g['left'])[0]
+    return g, keep
+
+
+def _check_chain(name, config):
+    d = golden(name)
+    eng = make_engine(config)
+    counts = replay_chain_on_engine(eng, d, config)
+    # ---- pulses
+    p = eng.pulses(currents=True)
+    order = np.lexsort((p['channel'], p['set']))
+    assert np.array_equal(p['channel'][order], d['pl_ch'])
+    assert np.array_equal(p['left'][order], d['pl_left'])
+    assert np.array_equal(p['right'][order], d['pl_right'])
+    assert np.array_equal(p['n_photons'][order], d['pl_photons'])
+    if 'pl_current' in d:
+        for j, k in enumerate(order):
+            cur = p['current'][p['cur_off'][k]:p['cur_off'][k] + p['right'][k] - p['left'][k] + 1]
+            ref = d['pl_current'][d['pl_cur_off'][j]:d['pl_cur_off'][j + 1]]
+            assert np.array_equal(cur, ref), f'tile {j}: max diff {np.abs(cur - ref).max()}'
+    # ---- digitise windows
+    g, keep = _nonempty_groups(eng)
+    assert np.array_equal(g['left'][keep], d['dg_left'])
+    assert np.array_equal(g['right'][keep], d['dg_right'])
+    gmap = {int(gi): j for j, gi in enumerate(keep)}
+    # ---- rows
+    r = eng.rows()
+    rows = sorted((gmap[int(r['group'][k])], int(r['channel'][k]), int(r['left'][k]), int(r['right'][k]),
+                   r['data'][r['data_off'][k]:r['data_off'][k] + r['right'][k] - r['left'][k] + 1].astype(np.int64).tobytes())
+                  for k in range(len(r['group'])))
+    dig_of_row = np.repeat(np.arange(len(d['dg_left'])), np.diff(d['dg_row_off']))
+    ref_rows = sorted((int(dig_of_row[k]), int(d['row_ch'][k]), int(d['row_left'][k]), int(d['row_right'][k]),
+                       d['row_data'][d['row_data_off'][k]:d['row_data_off'][k + 1]].astype(np.int64).tobytes())
+                      for k in range(len(d['row_ch'])))
+    if max(x[1] for x in rows) < 500:
+        # int(high_energy_deamplification_factor) == 0 and no HE noise: the reference keeps flat baseline rows for the
+        # high-energy channels (rawdata.py:242-249) that can never produce a ZLE interval; the HIP path skips them
+        flat = np.full(1, 16000, dtype=np.int64)
+        assert all(np.all(np.frombuffer(x[4], dtype=np.int64) == flat) for x in ref_rows if x[1] >= 500)
+        ref_rows = [x for x in ref_rows if x[1] < 500]
+    assert len(rows) == len(ref_rows)
+    for a, b in zip(rows, ref_rows):
+        assert a[:4] == b[:4]
+        assert a[4] == b[4], f'row {a[:4]} differs'
+    # ---- ZLE
+    z = eng.intervals()
+    got = canonical_intervals([gmap[int(x)] for x in z['group']], z['channel'], z['left'], z['right'], z['data_off'], z['data'])
+    ref = canonical_intervals(d['zle_digit'], d['zle_ch'], d['zle_left'], d['zle_right'], d['zle_data_off'], d['zle_data'])
+    assert len(got) == len(ref)
+    assert got == ref
+    # ---- records: yield order of the reference = (window, channel, interval)
+    rec = eng.records()
+    n_expected = np.ceil((d['zle_right'] - d['zle_left'] + 1) / 110).astype(int)
+    assert len(rec) == n_expected.sum()
+    first = np.concatenate([[0], np.cumsum(n_expected)[:-1]])
+    assert np.array_equal(rec['time'][first], 10 * d['zle_left'])
+    assert np.array_equal(rec['channel'][first], d['zle_ch'])
+    assert np.array_equal(rec['pulse_length'][first], d['zle_right'] - d['zle_left'] + 1)
+    assert np.all(rec['dt'] == 10) and np.all(rec['baseline'] == 0)
+    return d, eng
+
+
+@pytest.mark.parametrize('name', ['chain_s1.npz', 'chain_s2.npz'])
+def test_chain_vs_reference_golden(name):
+    d, eng = _check_chain(name, xenonnt_test_config())
+    # truth accumulators
+    acc, ts = eng.truth()
+    for j, f in enumerate(['n_photon', 'n_pe', 'n_photon_trigger', 'n_pe_trigger']):
+        assert np.array_equal(acc[:, j], d['call_truth_' + f]), f
+        assert np.array_equal(acc[:, 6 + j], d['call_truth_' + f + '_bottom']), f
+    for j, f in [(4, 'raw_area'), (5, 'raw_area_trigger')]:
+        assert np.allclose(acc[:, j], d['call_truth_' + f], rtol=1e-12, atol=0)
+        assert np.allclose(acc[:, 6 + j], d['call_truth_' + f + '_bottom'], rtol=1e-12, atol=0)
+
+
+def test_chain_he_channels():
+    _check_chain('chain_he.npz', xenonnt_test_config(high_energy_deamplification_factor=20))
+
+
+def test_chain_pmt_afterpulse_pulses():
+    _check_chain('chain_pmt_ap.npz', xenonnt_test_config())
+
+
+def test_records_match_oracle_bytes():
+    cfg = xenonnt_test_config()
+    d = golden('chain_s2.npz')
+    eng = make_engine(cfg)
+    replay_chain_on_engine(eng, d, cfg, debug=False)
+    orc = make_oracle(cfg)
+    replay_chain_on_oracle(orc, d)
+    assert eng.records().tobytes() == orc.pack_records().tobytes()

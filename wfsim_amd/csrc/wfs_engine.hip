@@ -1,0 +1,781 @@
+// wfs_engine.hip -- host side of libwfsim_amd.so: the C ABI of include/wfsim_amd.h, device memory arenas,
+// stage orchestration on one HIP stream.  gfx950 (MI355X) only.
+#include "wfs_kernels.h"
+#include "../../include/wfsim_amd.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    template <class T> T *as() const { return (T *)p; }
+};
+
+struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf; };
+
+struct KernelTime { std::string name; hipEvent_t a, b; };
+
+}  // namespace
+
+struct wfs_handle {
+    wfs_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr; bool own_stream = false;
+    std::string err;
+    WfsDev dev;
+    bool tables_set = false, batch_loaded = false, injected = false, ran = false;
+    int keep_currents = 0, profiling = 0;
+    // tables
+    DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise;
+    ApElem ap[WFS_MAX_AP];
+    // instructions
+    i64 n_ins = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
+    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, em_off;
+    DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
+    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax;
+    DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles;
+    DevBuf ph_t, ph_code, ph_gain;
+    DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
+    DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
+    DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
+    DevBuf truth, tminmax, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
+    DevBuf scan_tmp, scal;
+    // host mirrors
+    std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
+    wfs_counts counts{};
+    i64 h_scal[16] = {0};
+    i64 n_active_tiles = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0;
+    i64 cur_total = 0, row_dbg_total = 0;
+    std::vector<KernelTime> times;
+
+    int fail(int code, const std::string &msg) { err = msg; return code; }
+};
+
+namespace {
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    return h->fail(WFS_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+
+int ensure(wfs_handle *h, DevBuf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return WFS_OK;
+    if (b.p) HIPCHK(hipFree(b.p));
+    size_t want = bytes + bytes / 8 + 256;
+    b.p = nullptr; b.cap = 0;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return WFS_OK;
+}
+
+int upload(wfs_handle *h, DevBuf &b, const void *src, size_t bytes)
+{
+    int rc = ensure(h, b, bytes); if (rc) return rc;
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return WFS_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct Timer {
+    wfs_handle *h; bool on;
+    Timer(wfs_handle *h_, const char *name) : h(h_), on(h_->profiling != 0)
+    {
+        if (!on) return;
+        KernelTime kt; kt.name = name;
+        hipEventCreate(&kt.a); hipEventCreate(&kt.b);
+        hipEventRecord(kt.a, h->stream);
+        h->times.push_back(kt);
+    }
+    ~Timer() { if (on) hipEventRecord(h->times.back().b, h->stream); }
+};
+
+inline unsigned nblocks(i64 n, int tpb) { return (unsigned)((n + tpb - 1) / tpb); }
+
+int fill64(wfs_handle *h, DevBuf &b, i64 n, i64 v)
+{
+    TRY(ensure(h, b, (size_t)n * 8));
+    if (n) { Timer t(h, "k_fill_i64"); hipLaunchKernelGGL(k_fill_i64, dim3(nblocks(n, 256)), dim3(256), 0, h->stream, b.as<i64>(), n, v); }
+    return WFS_OK;
+}
+int fill32(wfs_handle *h, DevBuf &b, i64 n, i32 v)
+{
+    TRY(ensure(h, b, (size_t)n * 4));
+    if (n) { Timer t(h, "k_fill_i32"); hipLaunchKernelGGL(k_fill_i32, dim3(nblocks(n, 256)), dim3(256), 0, h->stream, b.as<i32>(), n, v); }
+    return WFS_OK;
+}
+
+// exclusive scan i32[n] -> i64[n+1]; total written to scal[slot]
+int scan(wfs_handle *h, const i32 *in, i64 n, DevBuf &out, int scal_slot)
+{
+    TRY(ensure(h, out, (size_t)(n + 1) * 8));
+    i64 nb = (n + SCAN_TILE - 1) / SCAN_TILE; if (nb < 1) nb = 1;
+    TRY(ensure(h, h->scan_tmp, (size_t)nb * 8));
+    i64 *total = h->scal.as<i64>() + scal_slot;
+    if (n == 0) { HIPCHK(hipMemsetAsync(out.p, 0, 8, h->stream)); HIPCHK(hipMemsetAsync(total, 0, 8, h->stream)); return WFS_OK; }
+    { Timer t(h, "k_scan_reduce"); hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_TPB), 0, h->stream, in, n, h->scan_tmp.as<i64>()); }
+    { Timer t(h, "k_scan_spine"); hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->scan_tmp.as<i64>(), nb, total); }
+    { Timer t(h, "k_scan_down"); hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(SCAN_TPB), 0, h->stream, in, n, h->scan_tmp.as<i64>(), out.as<i64>()); }
+    return WFS_OK;
+}
+
+int read_scal(wfs_handle *h)
+{
+    HIPCHK(hipMemcpyAsync(h->h_scal, h->scal.p, sizeof(h->h_scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return WFS_OK;
+}
+
+void refresh_dev(wfs_handle *h)
+{
+    const wfs_config &c = h->cfg; WfsDev &d = h->dev;
+    d.dt = c.dt; d.samples_before = c.samples_before; d.samples_after = c.samples_after; d.store_before = c.store_before;
+    d.store_after = c.store_after; d.tlen = c.tlen; d.tw = c.trigger_window; d.baseline = c.baseline; d.n_rows = c.n_rows;
+    d.n_tpc = c.n_tpc; d.n_top = c.n_top; d.he_first = c.he_first; d.he_factor = c.he_factor; d.last_bottom = c.last_bottom;
+    d.detector_nt = c.detector_nt; d.s1_simple = c.s1_simple; d.s2_time_model = c.s2_time_model; d.enable_pmt_ap = c.enable_pmt_ap;
+    d.c2a = c.c2a; d.tts_mean = c.tts_mean; d.tts_sigma = c.tts_sigma; d.p_dpe = c.p_dpe; d.s1_decay_time = c.s1_decay_time;
+    d.s1_decay_spread = c.s1_decay_spread; d.sf_gas = c.sf_gas; d.t1_gas = c.t1_gas; d.t3_gas = c.t3_gas;
+    d.s2_time_spread = c.s2_time_spread; d.trap_time = c.trap_time; d.gain_spread = c.gain_spread;
+    d.pmt_ap_modifier = c.pmt_ap_modifier; d.pmt_ap_t_modifier = c.pmt_ap_t_modifier; d.rext = c.rext;
+    d.k0 = (u32)c.seed; d.k1 = (u32)(c.seed >> 32);
+    // HE rows are only materialised when they can differ from a flat baseline: a non-zero int(factor)
+    // (rawdata.py:242) or noise columns for the HE channels
+    d.enable_noise = (c.enable_noise && d.noise != nullptr) ? 1 : 0;
+    bool he_noise = d.enable_noise && d.noise_channels > c.he_first;
+    d.he_rows = (c.detector_nt && c.n_top > 0 && (c.he_factor != 0 || he_noise)) ? 1 : 0;
+    d.row_slots = c.n_tpc + (d.he_rows ? c.n_top : 0);
+}
+
+}  // namespace
+
+extern "C" {
+
+int wfs_device_count(int *n) { return hipGetDeviceCount(n) == hipSuccess ? WFS_OK : WFS_E_HIP; }
+
+int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
+{
+    if (!cfg || !out) return WFS_E_INVALID;
+    if (cfg->n_tpc <= 0 || cfg->n_tpc > WFS_MAX_CH || cfg->dt != 10 || cfg->tlen <= 0 || cfg->tlen > 64) return WFS_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WFS_E_HIP;      // fail loudly: no CPU fallback
+    if (device < 0 || device >= ndev) return WFS_E_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return WFS_E_HIP;
+    wfs_handle *h = new wfs_handle();
+    h->cfg = *cfg; h->device = device;
+    memset(&h->dev, 0, sizeof(h->dev));
+    if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return WFS_E_HIP; }
+    h->own_stream = true;
+    if (hipMalloc(&h->scal.p, 256) != hipSuccess) { delete h; return WFS_E_HIP; }
+    h->scal.cap = 256;
+    refresh_dev(h);
+    *out = h;
+    return WFS_OK;
+}
+
+int wfs_destroy(wfs_handle *h)
+{
+    if (!h) return WFS_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    DevBuf *all[] = {&h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
+        &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
+        &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
+        &h->active_tiles, &h->ph_t, &h->ph_code, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
+        &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
+        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->currents, &h->cur_len, &h->cur_off,
+        &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
+    for (DevBuf *b : all) if (b->p) hipFree(b->p);
+    for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); }
+    for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return WFS_OK;
+}
+
+const char *wfs_last_error(const wfs_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int wfs_set_stream(wfs_handle *h, void *s)
+{
+    if (!h) return WFS_E_INVALID;
+    if (h->own_stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); h->own_stream = false; }
+    h->stream = (hipStream_t)s;
+    return WFS_OK;
+}
+
+int wfs_synchronize(wfs_handle *h) { if (!h) return WFS_E_INVALID; HIPCHK(hipStreamSynchronize(h->stream)); return WFS_OK; }
+int wfs_set_debug(wfs_handle *h, int32_t keep) { if (!h) return WFS_E_INVALID; h->keep_currents = keep; return WFS_OK; }
+int wfs_set_profiling(wfs_handle *h, int32_t on) { if (!h) return WFS_E_INVALID; h->profiling = on; return WFS_OK; }
+
+int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, int32_t n_spe, const double *gains,
+                   const double *thr_truth, const int64_t *thr_zle, const double *lum_x, const double *lum_t, int32_t n_lum,
+                   const int16_t *noise, int32_t noise_len, int32_t noise_channels)
+{
+    if (!h || !templates || !spe || !gains || !thr_truth || !thr_zle || n_spe < 1) return h ? h->fail(WFS_E_INVALID, "wfs_set_tables: null table") : WFS_E_INVALID;
+    if (n_spe != 1 && n_spe < h->cfg.n_tpc) return h->fail(WFS_E_INVALID, "wfs_set_tables: n_spe must be 1 or >= n_tpc");
+    HIPCHK(hipSetDevice(h->device));
+    const wfs_config &c = h->cfg;
+    TRY(upload(h, h->t_templates, templates, sizeof(double) * c.dt * c.tlen));
+    TRY(upload(h, h->t_spe, spe, sizeof(double) * 2001 * (size_t)n_spe));
+    TRY(upload(h, h->t_gains, gains, sizeof(double) * c.n_tpc));
+    TRY(upload(h, h->t_thr_truth, thr_truth, sizeof(double) * c.n_rows));
+    TRY(upload(h, h->t_thr_zle, thr_zle, sizeof(int64_t) * c.n_rows));
+    WfsDev &d = h->dev;
+    d.n_lum = 0;
+    if (lum_x && lum_t && n_lum >= 2) {
+        TRY(upload(h, h->t_lumx, lum_x, sizeof(double) * n_lum)); TRY(upload(h, h->t_lumt, lum_t, sizeof(double) * n_lum));
+        d.n_lum = n_lum;
+    }
+    d.noise = nullptr; d.noise_len = 0; d.noise_channels = 0;
+    if (noise && noise_len > 0 && noise_channels > 0) {
+        TRY(upload(h, h->t_noise, noise, sizeof(int16_t) * (size_t)noise_len * noise_channels));
+        d.noise = h->t_noise.as<int16_t>(); d.noise_len = noise_len; d.noise_channels = noise_channels;
+    }
+    d.templates = h->t_templates.as<double>(); d.spe = h->t_spe.as<double>(); d.n_spe = n_spe; d.gains = h->t_gains.as<double>();
+    d.thr_truth = h->t_thr_truth.as<double>(); d.thr_zle = h->t_thr_zle.as<i64>(); d.lum_x = h->t_lumx.as<double>(); d.lum_t = h->t_lumt.as<double>();
+    for (int r = 0; r < c.dt; r++) {                       // pulse.py:32 current_max
+        double m = templates[r * c.tlen];
+        for (int k = 1; k < c.tlen; k++) m = std::max(m, templates[r * c.tlen + k]);
+        d.current_max[r] = m;
+    }
+    refresh_dev(h);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->tables_set = true;
+    return WFS_OK;
+}
+
+int wfs_set_ap_element(wfs_handle *h, int32_t e, int32_t n_bins_delay, int32_t n_bins_amp, int32_t amp_2d, int32_t is_uniform,
+                       double delay_bin, double amp_bin, const double *delay_cdf, const double *amp_cdf)
+{
+    if (!h || e < 0 || e >= WFS_MAX_AP || !delay_cdf || !amp_cdf) return WFS_E_INVALID;
+    ApElem &a = h->ap[e];
+    a.n_bins_delay = n_bins_delay; a.n_bins_amp = n_bins_amp; a.amp_2d = amp_2d; a.is_uniform = is_uniform; a.delay_bin = delay_bin; a.amp_bin = amp_bin;
+    TRY(upload(h, a.delay_cdf, delay_cdf, sizeof(double) * (size_t)h->cfg.n_tpc * n_bins_delay));
+    TRY(upload(h, a.amp_cdf, amp_cdf, sizeof(double) * (size_t)(amp_2d ? h->cfg.n_tpc : 1) * n_bins_amp));
+    h->dev.n_ap = std::max(h->dev.n_ap, e + 1);
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return WFS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- batch input
+static int load_clusters(wfs_handle *h, i64 n, const int32_t *cluster, const int64_t *tmin, const uint32_t *gid)
+{
+    // clusters are contiguous runs of the (sorted) input; first member gives the key and the noise stream id
+    std::vector<i64> cl_tmin; std::vector<u32> cl_gid;
+    for (i64 i = 0; i < n; i++) {
+        if (cluster[i] < 0 || (i > 0 && (cluster[i] < cluster[i - 1] || cluster[i] > cluster[i - 1] + 1)) || (i == 0 && cluster[0] != 0))
+            return h->fail(WFS_E_INVALID, "cluster ids must start at 0 and be non-decreasing without gaps");
+        if ((i64)cl_tmin.size() <= cluster[i]) { cl_tmin.push_back(tmin[i]); cl_gid.push_back(gid ? gid[i] : (u32)i); }
+        else cl_tmin[cluster[i]] = std::min(cl_tmin[cluster[i]], (i64)tmin[i]);
+    }
+    h->n_clusters = (i64)cl_tmin.size();
+    TRY(upload(h, h->cl_tmin, cl_tmin.data(), cl_tmin.size() * 8));
+    TRY(upload(h, h->cl_gid, cl_gid.data(), cl_gid.size() * 4));
+    HIPCHK(hipStreamSynchronize(h->stream));       // vectors go out of scope
+    return WFS_OK;
+}
+
+int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const int64_t *time, const int32_t *amp, const uint32_t *gid,
+                          const int32_t *cluster, const int64_t *tmin, const double *p_hit, const double *drift_mean,
+                          const double *drift_spread, const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
+    if (n <= 0 || !type || !time || !amp || !gid || !cluster || !tmin || !p_hit || !drift_mean || !drift_spread || !sc_gain || !cdf_row || !cdf_table || n_cdf <= 0)
+        return h->fail(WFS_E_INVALID, "wfs_load_instructions: null or empty input");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<i64> em_off((size_t)n + 1);
+    em_off[0] = 0;
+    for (i64 i = 0; i < n; i++) {
+        if (type[i] != 1 && type[i] != 2) return h->fail(WFS_E_INVALID, "only instruction types 1 (S1) and 2 (S2) are supported");
+        if (amp[i] < 0) return h->fail(WFS_E_INVALID, "negative amp");
+        if (cdf_row[i] < 0 || cdf_row[i] >= n_cdf) return h->fail(WFS_E_INVALID, "cdf_row out of range");
+        if (type[i] == 2 && h->dev.n_lum < 2) return h->fail(WFS_E_STATE, "S2 instructions need the luminescence table");
+        em_off[i + 1] = em_off[i] + (type[i] == 1 ? 1 : (i64)amp[i]);
+    }
+    h->n_ins = n; h->n_sets = n; h->n_emitters = em_off[n]; h->n_tiles = n * h->cfg.n_tpc;
+    if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
+    TRY(upload(h, h->ins_type, type, (size_t)n)); TRY(upload(h, h->ins_time, time, (size_t)n * 8)); TRY(upload(h, h->ins_amp, amp, (size_t)n * 4));
+    TRY(upload(h, h->ins_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_p, p_hit, (size_t)n * 8)); TRY(upload(h, h->ins_dm, drift_mean, (size_t)n * 8));
+    TRY(upload(h, h->ins_ds, drift_spread, (size_t)n * 8)); TRY(upload(h, h->ins_sc, sc_gain, (size_t)n * 8));
+    TRY(upload(h, h->ins_cdfrow, cdf_row, (size_t)n * 4)); TRY(upload(h, h->cdf_table, cdf_table, (size_t)n_cdf * h->cfg.n_tpc * 8));
+    TRY(upload(h, h->em_off, em_off.data(), em_off.size() * 8));
+    TRY(upload(h, h->set_cluster, cluster, (size_t)n * 4)); TRY(upload(h, h->set_t0, time, (size_t)n * 8));
+    TRY(ensure(h, h->set_mode, (size_t)n * 4)); HIPCHK(hipMemsetAsync(h->set_mode.p, 0, (size_t)n * 4, h->stream));
+    TRY(load_clusters(h, n, cluster, tmin, gid));
+    h->injected = false; h->batch_loaded = true; h->ran = false;
+    return WFS_OK;
+}
+
+int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, const int64_t *set_tmin, const int64_t *set_off,
+                     const int64_t *t, const int16_t *ch, const double *gain, const uint8_t *dpe)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
+    if (n_sets <= 0 || !set_cluster || !set_tmin || !set_off) return h->fail(WFS_E_INVALID, "wfs_load_photons: null or empty input");
+    HIPCHK(hipSetDevice(h->device));
+    const i64 P = set_off[n_sets]; const int nch = h->cfg.n_tpc;
+    h->n_ins = 0; h->n_sets = n_sets; h->n_tiles = n_sets * nch; h->n_photons = P; h->n_emitters = 0;
+    if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
+    // host bucketing: the input is already channel sorted inside each set
+    std::vector<i32> count((size_t)h->n_tiles, 0), tmn((size_t)h->n_tiles, 0x7fffffff), tmx((size_t)h->n_tiles, (i32)0x80000000), rel((size_t)P);
+    std::vector<i64> t0((size_t)n_sets, 0);
+    std::vector<i32> mode((size_t)n_sets, 1);
+    for (i64 s = 0; s < n_sets; s++) {
+        i64 a = set_off[s], b = set_off[s + 1];
+        if (b < a) return h->fail(WFS_E_INVALID, "set_off must be non-decreasing");
+        if (b == a) { t0[s] = set_tmin[s]; continue; }
+        i64 mn = t[a];
+        for (i64 p = a; p < b; p++) mn = std::min(mn, (i64)t[p]);
+        t0[s] = mn;
+        for (i64 p = a; p < b; p++) {
+            if (ch[p] < 0 || ch[p] >= nch) return h->fail(WFS_E_INVALID, "photon channel out of range");
+            if (p > a && ch[p] < ch[p - 1]) return h->fail(WFS_E_INVALID, "photons of a set must be sorted by channel");
+            i64 r = t[p] - mn;
+            if (r > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "photon time span of a set exceeds 2^31 ns");
+            rel[p] = (i32)r;
+            size_t tile = (size_t)(s * nch + ch[p]);
+            count[tile]++; tmn[tile] = std::min(tmn[tile], (i32)r); tmx[tile] = std::max(tmx[tile], (i32)r);
+        }
+    }
+    h->h_set_off.assign(set_off, set_off + n_sets + 1);
+    TRY(upload(h, h->set_cluster, set_cluster, (size_t)n_sets * 4)); TRY(upload(h, h->set_t0, t0.data(), (size_t)n_sets * 8));
+    TRY(upload(h, h->set_mode, mode.data(), (size_t)n_sets * 4));
+    TRY(upload(h, h->tile_count, count.data(), count.size() * 4)); TRY(upload(h, h->tile_tmin, tmn.data(), tmn.size() * 4));
+    TRY(upload(h, h->tile_tmax, tmx.data(), tmx.size() * 4));
+    TRY(upload(h, h->ph_t, rel.data(), (size_t)P * 4)); TRY(upload(h, h->ph_gain, gain, (size_t)P * 8));
+    TRY(ensure(h, h->ph_code, (size_t)P * 4));
+    if (dpe) {   // DPE flags ride in the code word (only the truth quirk pulse.py:255 reads them in explicit-gain mode)
+        std::vector<u32> code((size_t)P);
+        for (i64 p = 0; p < P; p++) code[p] = dpe[p] ? (1u << 16) : 0u;
+        TRY(upload(h, h->ph_code, code.data(), (size_t)P * 4));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    } else {
+        HIPCHK(hipMemsetAsync(h->ph_code.p, 0, (size_t)P * 4, h->stream));
+    }
+    TRY(load_clusters(h, n_sets, set_cluster, set_tmin, nullptr));
+    h->injected = true; h->batch_loaded = true; h->ran = false;
+    return WFS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- run
+static int run_generation(wfs_handle *h)
+{
+    const WfsDev &d = h->dev;
+    const i64 N = h->n_ins, E = h->n_emitters, T = h->n_tiles;
+    TRY(ensure(h, h->em_time, (size_t)E * 8)); TRY(ensure(h, h->em_nph, (size_t)E * 4)); TRY(ensure(h, h->em_ins, (size_t)E * 4));
+    TRY(ensure(h, h->el_stat, (size_t)N * 32)); TRY(ensure(h, h->el_minmax, (size_t)N * 16));
+    HIPCHK(hipMemsetAsync(h->el_stat.p, 0, (size_t)N * 32, h->stream));
+    {
+        std::vector<i64> mm((size_t)N * 2);
+        for (i64 i = 0; i < N; i++) { mm[2 * i] = I64_MAX; mm[2 * i + 1] = I64_MIN; }
+        HIPCHK(hipMemcpyAsync(h->el_minmax.p, mm.data(), mm.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    GenArgs g{};
+    g.n_ins = N; g.n_emitters = E;
+    g.ins_type = h->ins_type.as<int8_t>(); g.ins_time = h->ins_time.as<i64>(); g.ins_amp = h->ins_amp.as<i32>(); g.ins_gid = h->ins_gid.as<u32>();
+    g.ins_p = h->ins_p.as<double>(); g.ins_dm = h->ins_dm.as<double>(); g.ins_ds = h->ins_ds.as<double>(); g.ins_sc = h->ins_sc.as<double>();
+    g.ins_cdfrow = h->ins_cdfrow.as<i32>(); g.cdf_table = h->cdf_table.as<double>(); g.em_off = h->em_off.as<i64>();
+    g.em_time = h->em_time.as<i64>(); g.em_nph = h->em_nph.as<i32>(); g.em_ins = h->em_ins.as<i32>();
+    g.el_stat = h->el_stat.as<double>(); g.el_minmax = h->el_minmax.as<i64>(); g.scal = h->scal.as<i64>();
+    { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }
+    { Timer t(h, "k_s2_electrons"); hipLaunchKernelGGL(k_s2_electrons, dim3(nblocks(E, 256)), dim3(256), 0, h->stream, d, g); }
+    TRY(scan(h, h->em_nph.as<i32>(), E, h->em_ph_off, 6));
+    TRY(read_scal(h));
+    const i64 P = h->h_scal[6];
+    h->n_photons = P;
+    g.em_ph_off = h->em_ph_off.as<i64>(); g.n_photons = P;
+    TRY(ensure(h, h->tile_count, (size_t)T * 4)); TRY(ensure(h, h->tile_cursor, (size_t)T * 4));
+    HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (size_t)T * 4, h->stream)); HIPCHK(hipMemsetAsync(h->tile_cursor.p, 0, (size_t)T * 4, h->stream));
+    TRY(fill32(h, h->tile_tmin, T, 0x7fffffff)); TRY(fill32(h, h->tile_tmax, T, (i32)0x80000000));
+    TRY(ensure(h, h->ph_t, (size_t)P * 4)); TRY(ensure(h, h->ph_code, (size_t)P * 4));
+    g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
+    g.tile_tmax = h->tile_tmax.as<i32>(); g.ph_t = h->ph_t.as<i32>(); g.ph_code = h->ph_code.as<u32>();
+    if (P > 0) {
+        const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
+        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true>), dim3(nb), dim3(GEN_TPB), 0, h->stream, d, g); }
+        TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
+        g.tile_off = h->tile_off.as<i64>();
+        { Timer t(h, "k_photons_fill"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false>), dim3(nb), dim3(GEN_TPB), 0, h->stream, d, g); }
+    } else {
+        TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
+    }
+    return WFS_OK;
+}
+
+int wfs_run(wfs_handle *h)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->batch_loaded) return h->fail(WFS_E_STATE, "no batch loaded");
+    HIPCHK(hipSetDevice(h->device));
+    for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    h->times.clear();
+    const WfsDev &d = h->dev;
+    const i64 T = h->n_tiles, S = h->n_sets, C = h->n_clusters;
+    HIPCHK(hipMemsetAsync(h->scal.p, 0, 128, h->stream));
+    if (!h->injected) TRY(run_generation(h));
+    else TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
+
+    // ---- geometry: tiles -> clusters -> groups -> rows
+    TRY(fill64(h, h->cl_end, C, I64_MIN)); TRY(ensure(h, h->cl_group, (size_t)C * 4));
+    TRY(fill64(h, h->grp_lo, C, I64_MAX)); TRY(fill64(h, h->grp_hi, C, I64_MIN));
+    TRY(ensure(h, h->grp_left, (size_t)C * 8)); TRY(ensure(h, h->grp_right, (size_t)C * 8)); TRY(ensure(h, h->grp_ixrand, (size_t)C * 8));
+    TRY(ensure(h, h->grp_gid, (size_t)C * 4)); HIPCHK(hipMemsetAsync(h->grp_gid.p, 0xff, (size_t)C * 4, h->stream));
+    TRY(fill64(h, h->row_lo, C * d.n_tpc, I64_MAX)); TRY(fill64(h, h->row_hi, C * d.n_tpc, I64_MIN));
+    TRY(ensure(h, h->acc_len, (size_t)C * d.n_tpc * 4)); HIPCHK(hipMemsetAsync(h->acc_len.p, 0, (size_t)C * d.n_tpc * 4, h->stream));
+    TRY(ensure(h, h->itv_cap, (size_t)C * d.row_slots * 4)); TRY(ensure(h, h->active_rows, (size_t)C * d.row_slots * 4));
+    TRY(ensure(h, h->active_tiles, (size_t)T * 4));
+    GeomArgs ga{};
+    ga.n_sets = S; ga.n_tiles = T; ga.n_clusters = C;
+    ga.tile_count = h->tile_count.as<i32>(); ga.tile_tmin = h->tile_tmin.as<i32>(); ga.tile_tmax = h->tile_tmax.as<i32>();
+    ga.set_cluster = h->set_cluster.as<i32>(); ga.set_t0 = h->set_t0.as<i64>(); ga.cl_tmin = h->cl_tmin.as<i64>(); ga.cl_gid = h->cl_gid.as<u32>();
+    ga.cl_end = h->cl_end.as<i64>(); ga.cl_group = h->cl_group.as<i32>(); ga.grp_lo = h->grp_lo.as<i64>(); ga.grp_hi = h->grp_hi.as<i64>();
+    ga.grp_left = h->grp_left.as<i64>(); ga.grp_right = h->grp_right.as<i64>(); ga.grp_ixrand = h->grp_ixrand.as<i64>(); ga.grp_gid = h->grp_gid.as<u32>();
+    ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
+    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>();
+    { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
+    { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(64), 0, h->stream, d, ga); }
+    { Timer t(h, "k_tile_rows"); hipLaunchKernelGGL(k_tile_rows, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
+    { Timer t(h, "k_group_final"); hipLaunchKernelGGL(k_group_final, dim3(nblocks(C, 256)), dim3(256), 0, h->stream, d, ga); }
+    { Timer t(h, "k_row_len"); hipLaunchKernelGGL(k_row_len, dim3(nblocks(C * d.row_slots, 256)), dim3(256), 0, h->stream, d, ga); }
+    TRY(scan(h, h->acc_len.as<i32>(), C * d.n_tpc, h->acc_off, 8));
+    TRY(scan(h, h->itv_cap.as<i32>(), C * d.row_slots, h->itv_off, 9));
+    TRY(read_scal(h));
+    if (h->h_scal[1] == 1) return h->fail(WFS_E_CAPACITY, "Pulse cache too long (digitise window of 10^6 samples or more, rawdata.py:219)");
+    if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
+    h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_active_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5];
+    h->s_raw = h->h_scal[8]; h->n_itv_slots = h->h_scal[9];
+    // deterministic processing order of the work lists (they were appended with atomics)
+    // (results do not depend on it; sorting keeps profiles and debug dumps reproducible)
+
+    // ---- pulses
+    TRY(ensure(h, h->raw, (size_t)h->s_raw * 4)); HIPCHK(hipMemsetAsync(h->raw.p, 0, (size_t)h->s_raw * 4, h->stream));
+    TRY(ensure(h, h->truth, (size_t)S * 16 * 8)); HIPCHK(hipMemsetAsync(h->truth.p, 0, (size_t)S * 16 * 8, h->stream));
+    TRY(ensure(h, h->tminmax, (size_t)S * 16));
+    {
+        std::vector<i64> mm((size_t)S * 2);
+        for (i64 i = 0; i < S; i++) { mm[2 * i] = I64_MAX; mm[2 * i + 1] = I64_MIN; }
+        HIPCHK(hipMemcpyAsync(h->tminmax.p, mm.data(), mm.size() * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    PulseArgs pa{};
+    pa.active_tiles = h->active_tiles.as<i32>(); pa.n_active = h->n_active_tiles;
+    pa.tile_count = h->tile_count.as<i32>(); pa.tile_tmin = h->tile_tmin.as<i32>(); pa.tile_tmax = h->tile_tmax.as<i32>(); pa.tile_off = h->tile_off.as<i64>();
+    pa.set_cluster = h->set_cluster.as<i32>(); pa.set_t0 = h->set_t0.as<i64>(); pa.set_mode = h->set_mode.as<i32>();
+    pa.ph_t = h->ph_t.as<i32>(); pa.ph_code = h->ph_code.as<u32>(); pa.ph_gain = h->ph_gain.as<double>();
+    pa.cl_group = h->cl_group.as<i32>(); pa.row_lo = h->row_lo.as<i64>(); pa.acc_off = h->acc_off.as<i64>(); pa.raw = h->raw.as<i32>();
+    pa.truth = h->truth.as<double>(); pa.tminmax = h->tminmax.as<i64>();
+    const int W_MAX = 1024;
+    int W = (int)std::min<i64>(std::max<i64>(h->max_nb, d.tlen + 1), W_MAX);
+    W = (W + 7) / 8 * 8;
+    pa.W = W;
+    h->cur_total = 0;
+    if (h->keep_currents && h->n_active_tiles > 0) {
+        // debug: tile lengths in work-list order -> offsets
+        std::vector<i32> at((size_t)h->n_active_tiles), tmn((size_t)T), tmx((size_t)T);
+        std::vector<i64> t0((size_t)S);
+        HIPCHK(hipMemcpy(at.data(), h->active_tiles.p, at.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tmn.data(), h->tile_tmin.p, tmn.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(tmx.data(), h->tile_tmax.p, tmx.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(t0.data(), h->set_t0.p, t0.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<i64> off(at.size() + 1, 0);
+        for (size_t k = 0; k < at.size(); k++) {
+            i64 set = at[k] / d.n_tpc;
+            i64 b0 = floordiv(t0[set] + tmn[at[k]], (i64)d.dt), b1 = floordiv(t0[set] + tmx[at[k]], (i64)d.dt);
+            off[k + 1] = off[k] + (b1 - b0 + 1) + d.store_before + d.samples_before + d.store_after + d.samples_after;
+        }
+        h->cur_total = off.back();
+        TRY(upload(h, h->cur_off, off.data(), off.size() * 8));
+        TRY(ensure(h, h->currents, (size_t)h->cur_total * 8));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        pa.currents = h->currents.as<double>(); pa.cur_off = h->cur_off.as<i64>();
+    }
+    if (h->n_active_tiles > 0) {
+        size_t lds = ((size_t)d.dt * W + (size_t)d.dt * d.tlen) * 8 + (size_t)W * 4 + 64;
+        lds = (lds + 15) / 16 * 16;
+        Timer t(h, "k_pulse");
+        if (h->max_tile <= 64 && W <= 64)
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<64>), dim3((unsigned)h->n_active_tiles), dim3(64), lds, h->stream, d, pa);
+        else
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256>), dim3((unsigned)h->n_active_tiles), dim3(256), lds, h->stream, d, pa);
+    }
+
+    // ---- ZLE + records
+    const i64 RS = C * d.row_slots;
+    TRY(ensure(h, h->itv_left, (size_t)h->n_itv_slots * 8)); TRY(ensure(h, h->itv_right, (size_t)h->n_itv_slots * 8));
+    TRY(ensure(h, h->itv_n, (size_t)RS * 4)); TRY(ensure(h, h->row_nrec, (size_t)RS * 4));
+    HIPCHK(hipMemsetAsync(h->itv_n.p, 0, (size_t)RS * 4, h->stream)); HIPCHK(hipMemsetAsync(h->row_nrec.p, 0, (size_t)RS * 4, h->stream));
+    ZleArgs za{};
+    za.active_rows = h->active_rows.as<i32>(); za.n_active_rows = h->n_active_rows; za.row_lo = h->row_lo.as<i64>(); za.row_hi = h->row_hi.as<i64>();
+    za.acc_off = h->acc_off.as<i64>(); za.raw = h->raw.as<i32>(); za.grp_left = h->grp_left.as<i64>(); za.grp_ixrand = h->grp_ixrand.as<i64>();
+    za.itv_off = h->itv_off.as<i64>(); za.itv_left = h->itv_left.as<i64>(); za.itv_right = h->itv_right.as<i64>();
+    za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = 110;
+    h->row_dbg_total = 0;
+    if (h->keep_currents && h->n_active_rows > 0) {
+        std::vector<i32> ar((size_t)h->n_active_rows);
+        std::vector<i64> lo((size_t)C * d.n_tpc), hi((size_t)C * d.n_tpc);
+        HIPCHK(hipMemcpy(ar.data(), h->active_rows.p, ar.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(lo.data(), h->row_lo.p, lo.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hi.data(), h->row_hi.p, hi.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<i64> off(ar.size() + 1, 0);
+        for (size_t k = 0; k < ar.size(); k++) {
+            i64 g = ar[k] / d.row_slots; i32 slot = (i32)(ar[k] - g * d.row_slots); i32 c = slot < d.n_tpc ? slot : slot - d.n_tpc;
+            off[k + 1] = off[k] + hi[g * d.n_tpc + c] - lo[g * d.n_tpc + c] + 1 + 2 * d.tw;
+        }
+        h->row_dbg_total = off.back();
+        TRY(upload(h, h->row_dbg_off, off.data(), off.size() * 8));
+        TRY(ensure(h, h->row_dbg, (size_t)h->row_dbg_total * 4));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        za.row_dbg = h->row_dbg.as<i32>(); za.row_dbg_off = h->row_dbg_off.as<i64>();
+    }
+    if (h->n_active_rows > 0) { Timer t(h, "k_zle"); hipLaunchKernelGGL(k_zle, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
+    TRY(scan(h, h->row_nrec.as<i32>(), RS, h->rec_off, 10));
+    TRY(read_scal(h));
+    h->n_records = h->h_scal[10];
+    TRY(ensure(h, h->records, (size_t)h->n_records * 244));
+    za.rec_off = h->rec_off.as<i64>(); za.records = h->records.as<uint8_t>(); za.rec_capacity = h->n_records;
+    if (h->n_active_rows > 0 && h->n_records > 0) { Timer t(h, "k_pack"); hipLaunchKernelGGL(k_pack, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    h->ran = true;
+    return WFS_OK;
+}
+
+int wfs_get_counts(wfs_handle *h, wfs_counts *out)
+{
+    if (!h || !out) return WFS_E_INVALID;
+    if (!h->ran) return h->fail(WFS_E_STATE, "wfs_run has not completed");
+    wfs_counts c{};
+    c.n_instructions = h->n_ins; c.n_pulse_sets = h->n_sets; c.n_emitters = h->n_emitters; c.n_photons = h->n_photons;
+    c.n_tiles = h->n_active_tiles; c.n_groups = h->n_groups; c.n_rows = h->n_active_rows; c.n_raw_samples = h->s_raw;
+    c.n_records = h->n_records;
+    // n_pe and n_intervals need device reductions: sum the per-set truth (cheap)
+    std::vector<double> tr((size_t)h->n_sets * 16);
+    HIPCHK(hipMemcpy(tr.data(), h->truth.p, tr.size() * 8, hipMemcpyDeviceToHost));
+    double npe = 0; for (i64 s = 0; s < h->n_sets; s++) npe += tr[s * 16 + 1];
+    c.n_pe = (i64)(npe + 0.5);
+    std::vector<i32> n((size_t)h->n_clusters * h->dev.row_slots);
+    HIPCHK(hipMemcpy(n.data(), h->itv_n.p, n.size() * 4, hipMemcpyDeviceToHost));
+    i64 ni = 0; for (i32 v : n) ni += v;
+    c.n_intervals = ni;
+    *out = c; h->counts = c;
+    return WFS_OK;
+}
+
+const void *wfs_records_dev_ptr(wfs_handle *h) { return h ? h->records.p : nullptr; }
+
+int wfs_copy_records(wfs_handle *h, void *dst, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (cap < h->n_records) return h->fail(WFS_E_CAPACITY, "record buffer too small");
+    if (h->n_records) HIPCHK(hipMemcpy(dst, h->records.p, (size_t)h->n_records * 244, hipMemcpyDeviceToHost));
+    return WFS_OK;
+}
+
+int wfs_copy_records_dev(wfs_handle *h, void *dst, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (cap < h->n_records) return h->fail(WFS_E_CAPACITY, "record buffer too small");
+    if (h->n_records) { HIPCHK(hipMemcpyAsync(dst, h->records.p, (size_t)h->n_records * 244, hipMemcpyDeviceToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    return WFS_OK;
+}
+
+int wfs_copy_groups(wfs_handle *h, int64_t *left, int64_t *right, int64_t *first_record, int64_t *ix_rand)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    const i64 G = h->n_groups;
+    if (left) HIPCHK(hipMemcpy(left, h->grp_left.p, (size_t)G * 8, hipMemcpyDeviceToHost));
+    if (right) HIPCHK(hipMemcpy(right, h->grp_right.p, (size_t)G * 8, hipMemcpyDeviceToHost));
+    if (ix_rand) HIPCHK(hipMemcpy(ix_rand, h->grp_ixrand.p, (size_t)G * 8, hipMemcpyDeviceToHost));
+    if (first_record) {
+        std::vector<i64> ro((size_t)h->n_clusters * h->dev.row_slots + 1);
+        HIPCHK(hipMemcpy(ro.data(), h->rec_off.p, ro.size() * 8, hipMemcpyDeviceToHost));
+        for (i64 g = 0; g < G; g++) first_record[g] = ro[(size_t)g * h->dev.row_slots];
+    }
+    return WFS_OK;
+}
+
+int wfs_copy_intervals(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right, int64_t *data_off, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    const WfsDev &d = h->dev;
+    const i64 RS = h->n_clusters * d.row_slots;
+    std::vector<i32> n((size_t)RS); std::vector<i64> off((size_t)RS + 1), L((size_t)h->n_itv_slots), R((size_t)h->n_itv_slots);
+    HIPCHK(hipMemcpy(n.data(), h->itv_n.p, n.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(off.data(), h->itv_off.p, off.size() * 8, hipMemcpyDeviceToHost));
+    if (h->n_itv_slots) {
+        HIPCHK(hipMemcpy(L.data(), h->itv_left.p, L.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(R.data(), h->itv_right.p, R.size() * 8, hipMemcpyDeviceToHost));
+    }
+    i64 k = 0, doff = 0;
+    for (i64 idx = 0; idx < RS; idx++) {
+        i64 g = idx / d.row_slots; i32 slot = (i32)(idx - g * d.row_slots);
+        i32 chn = slot < d.n_tpc ? slot : d.he_first + slot - d.n_tpc;
+        for (i32 q = 0; q < n[idx]; q++) {
+            if (k >= cap) return h->fail(WFS_E_CAPACITY, "interval buffer too small");
+            i64 l = L[off[idx] + q], r = R[off[idx] + q];
+            group[k] = (i32)g; channel[k] = chn; left[k] = l; right[k] = r; data_off[k] = doff;
+            doff += (r - l + 1 > 0) ? r - l + 1 : 0; k++;
+        }
+    }
+    if (k < cap) data_off[k] = doff;
+    return WFS_OK;
+}
+
+int wfs_copy_interval_data(wfs_handle *h, int16_t *data, int64_t cap)
+{
+    // unpack the records: fragments of one interval are consecutive
+    if (!h || !h->ran) return WFS_E_STATE;
+    std::vector<uint8_t> rec((size_t)h->n_records * 244);
+    if (h->n_records) HIPCHK(hipMemcpy(rec.data(), h->records.p, rec.size(), hipMemcpyDeviceToHost));
+    i64 k = 0;
+    for (i64 r = 0; r < h->n_records; r++) {
+        i32 len; memcpy(&len, &rec[(size_t)r * 244 + 8], 4);
+        if (k + len > cap) return h->fail(WFS_E_CAPACITY, "interval data buffer too small");
+        memcpy(data + k, &rec[(size_t)r * 244 + 24], (size_t)len * 2);
+        k += len;
+    }
+    return WFS_OK;
+}
+
+int wfs_copy_pulses(wfs_handle *h, int32_t *set, int32_t *channel, int64_t *left, int64_t *right, int64_t *nph, int64_t *cur_off, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    const WfsDev &d = h->dev;
+    const i64 A = h->n_active_tiles;
+    if (cap < A) return h->fail(WFS_E_CAPACITY, "pulse buffer too small");
+    std::vector<i32> at((size_t)A), cnt((size_t)h->n_tiles), tmn((size_t)h->n_tiles), tmx((size_t)h->n_tiles);
+    std::vector<i64> t0((size_t)h->n_sets);
+    if (A) HIPCHK(hipMemcpy(at.data(), h->active_tiles.p, at.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt.data(), h->tile_count.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tmn.data(), h->tile_tmin.p, tmn.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tmx.data(), h->tile_tmax.p, tmx.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t0.data(), h->set_t0.p, t0.size() * 8, hipMemcpyDeviceToHost));
+    i64 off = 0;
+    for (i64 k = 0; k < A; k++) {
+        i64 tile = at[k], s = tile / d.n_tpc;
+        i64 b0 = floordiv(t0[s] + tmn[tile], (i64)d.dt), b1 = floordiv(t0[s] + tmx[tile], (i64)d.dt);
+        set[k] = (i32)s; channel[k] = (i32)(tile - s * d.n_tpc);
+        left[k] = b0 - d.store_before - d.samples_before; right[k] = b1 + d.store_after + d.samples_after;
+        nph[k] = cnt[tile]; cur_off[k] = off; off += right[k] - left[k] + 1;
+    }
+    return WFS_OK;
+}
+
+int wfs_copy_currents(wfs_handle *h, double *cur, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (!h->keep_currents) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
+    if (cap < h->cur_total) return h->fail(WFS_E_CAPACITY, "current buffer too small");
+    if (h->cur_total) HIPCHK(hipMemcpy(cur, h->currents.p, (size_t)h->cur_total * 8, hipMemcpyDeviceToHost));
+    return WFS_OK;
+}
+
+int wfs_copy_rows(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right, int64_t *data_off, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (!h->keep_currents) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
+    const WfsDev &d = h->dev;
+    const i64 A = h->n_active_rows;
+    if (cap < A) return h->fail(WFS_E_CAPACITY, "row buffer too small");
+    std::vector<i32> ar((size_t)A); std::vector<i64> lo((size_t)h->n_clusters * d.n_tpc), hi(lo.size()), gl((size_t)h->n_groups);
+    if (A) HIPCHK(hipMemcpy(ar.data(), h->active_rows.p, ar.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(lo.data(), h->row_lo.p, lo.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(hi.data(), h->row_hi.p, hi.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gl.data(), h->grp_left.p, gl.size() * 8, hipMemcpyDeviceToHost));
+    i64 off = 0;
+    for (i64 k = 0; k < A; k++) {
+        i64 g = ar[k] / d.row_slots; i32 slot = (i32)(ar[k] - g * d.row_slots); i32 c = slot < d.n_tpc ? slot : slot - d.n_tpc;
+        group[k] = (i32)g; channel[k] = slot < d.n_tpc ? slot : d.he_first + c;
+        // relative to the window like the reference's channel mask (rawdata.py:258-259)
+        left[k] = lo[g * d.n_tpc + c] - gl[g] - d.tw; right[k] = hi[g * d.n_tpc + c] - gl[g] + d.tw;
+        data_off[k] = off; off += right[k] - left[k] + 1;
+    }
+    return WFS_OK;
+}
+
+int wfs_copy_row_data(wfs_handle *h, int32_t *data, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (cap < h->row_dbg_total) return h->fail(WFS_E_CAPACITY, "row data buffer too small");
+    if (h->row_dbg_total) HIPCHK(hipMemcpy(data, h->row_dbg.p, (size_t)h->row_dbg_total * 4, hipMemcpyDeviceToHost));
+    return WFS_OK;
+}
+
+int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, double *gain, uint8_t *dpe, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    const WfsDev &d = h->dev;
+    const i64 P = h->n_photons, T = h->n_tiles;
+    if (cap < P) return h->fail(WFS_E_CAPACITY, "photon buffer too small");
+    std::vector<i64> off((size_t)T + 1), t0((size_t)h->n_sets);
+    std::vector<i32> rel((size_t)P); std::vector<u32> code((size_t)P);
+    HIPCHK(hipMemcpy(off.data(), h->tile_off.p, off.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t0.data(), h->set_t0.p, t0.size() * 8, hipMemcpyDeviceToHost));
+    if (P) { HIPCHK(hipMemcpy(rel.data(), h->ph_t.p, rel.size() * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(code.data(), h->ph_code.p, code.size() * 4, hipMemcpyDeviceToHost)); }
+    std::vector<double> gains((size_t)d.n_tpc), spe((size_t)2001 * d.n_spe), pg;
+    HIPCHK(hipMemcpy(gains.data(), h->t_gains.p, gains.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(spe.data(), h->t_spe.p, spe.size() * 8, hipMemcpyDeviceToHost));
+    if (h->injected && P) { pg.resize((size_t)P); HIPCHK(hipMemcpy(pg.data(), h->ph_gain.p, pg.size() * 8, hipMemcpyDeviceToHost)); }
+    for (i64 s = 0; s <= h->n_sets; s++) set_off[s] = off[(size_t)s * d.n_tpc];
+    for (i64 tile = 0; tile < T; tile++) {
+        i64 s = tile / d.n_tpc; int c = (int)(tile - s * d.n_tpc);
+        const double *row = &spe[(size_t)(d.n_spe > 1 ? c : 0) * 2001];
+        for (i64 p = off[tile]; p < off[tile + 1]; p++) {
+            t[p] = t0[s] + rel[p]; ch[p] = (int16_t)c;
+            u32 g1 = code[p] & 0xffffu, g2 = code[p] >> 16;
+            if (h->injected) { gain[p] = pg[p]; dpe[p] = g2 != 0; }
+            else { double g = gains[c] * row[g1]; if (g2) g += gains[c] * row[g2]; gain[p] = g; dpe[p] = g2 != 0; }
+        }
+    }
+    return WFS_OK;
+}
+
+int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    const i64 S = h->n_sets;
+    if (cap < S) return h->fail(WFS_E_CAPACITY, "truth buffer too small");
+    std::vector<double> tr((size_t)S * 16); std::vector<i64> mm((size_t)S * 2), t0((size_t)S);
+    HIPCHK(hipMemcpy(tr.data(), h->truth.p, tr.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mm.data(), h->tminmax.p, mm.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t0.data(), h->set_t0.p, t0.size() * 8, hipMemcpyDeviceToHost));
+    for (i64 s = 0; s < S; s++) {
+        for (int f = 0; f < 12; f++) acc12[s * 12 + f] = tr[s * 16 + f];
+        double n = tr[s * 16 + 12], st = tr[s * 16 + 13], st2 = tr[s * 16 + 14];
+        double mean = n > 0 ? st / n : 0, var = n > 0 ? st2 / n - mean * mean : 0;
+        tstat5[s * 5 + 0] = n; tstat5[s * 5 + 1] = n > 0 ? (double)t0[s] + mean : NAN;
+        tstat5[s * 5 + 2] = n > 0 ? (double)mm[2 * s] : NAN; tstat5[s * 5 + 3] = n > 0 ? (double)mm[2 * s + 1] : NAN;
+        tstat5[s * 5 + 4] = n > 0 ? sqrt(var > 0 ? var : 0) : NAN;
+    }
+    return WFS_OK;
+}
+
+int wfs_kernel_times(wfs_handle *h, char *names, int64_t names_cap, float *ms, int32_t *n_launches, int32_t *n_kernels)
+{
+    if (!h) return WFS_E_INVALID;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<std::string> uniq; std::vector<float> tot; std::vector<int> cnt;
+    for (auto &t : h->times) {
+        float m = 0; hipEventElapsedTime(&m, t.a, t.b);
+        size_t k = 0; for (; k < uniq.size(); k++) if (uniq[k] == t.name) break;
+        if (k == uniq.size()) { uniq.push_back(t.name); tot.push_back(0); cnt.push_back(0); }
+        tot[k] += m; cnt[k]++;
+    }
+    i64 pos = 0;
+    for (size_t k = 0; k < uniq.size(); k++) {
+        if (pos + (i64)uniq[k].size() + 1 > names_cap) return h->fail(WFS_E_CAPACITY, "names buffer too small");
+        memcpy(names + pos, uniq[k].c_str(), uniq[k].size() + 1); pos += (i64)uniq[k].size() + 1;
+        ms[k] = tot[k]; n_launches[k] = cnt[k];
+    }
+    *n_kernels = (int32_t)uniq.size();
+    return WFS_OK;
+}
+
+}  // extern "C"

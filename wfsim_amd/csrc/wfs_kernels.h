@@ -1,0 +1,748 @@
+// wfs_kernels.h -- HIP kernels of the MI355X WFSim hot path (gfx950).  Included once by wfs_engine.hip.
+//
+// Data layout in HBM (one batch):
+//   pulse set   = one Pulse.__call__ of the reference (one S1 or S2 instruction, or its PMT afterpulses)
+//   tile        = (pulse set, channel): the photons of one pulse in one PMT; tile id = set * n_tpc + channel
+//   photons     = SoA bucketed by tile: ph_t i32 (ns relative to the set's t0), ph_code u32 (SPE table indices
+//                 g1 | g2 << 16, g2 = 0: no double-PE) or ph_gain f64 (pre-assigned gains)
+//   group       = digitise window (one digitize_pulse_cache call): clusters merged by the rule of rawdata.py:96-98
+//   row         = (group, channel) active range [row_lo - tw, row_hi + tw]; int32 accumulators in one arena
+//   intervals   = ZLE output per row, reserved slots; records = 244-byte strax raw_records
+#pragma once
+#include "wfs_device.h"
+
+#define I64_MAX 0x7fffffffffffffffLL
+#define I64_MIN (-I64_MAX - 1)
+
+// ------------------------------------------------------------------------------------------------ fills
+__global__ void k_fill_i64(i64 *p, i64 n, i64 v) { i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_fill_i32(i32 *p, i64 n, i32 v) { i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+
+// ------------------------------------------------------------------------------------------------ scan
+// exclusive scan i32[n] -> i64[n+1] in three launches (reduce / spine / down-sweep); 4096 items per block
+#define SCAN_TPB 256
+#define SCAN_IPT 16
+#define SCAN_TILE (SCAN_TPB * SCAN_IPT)
+
+__device__ __forceinline__ i64 block_reduce_sum(i64 v, i64 *sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    i64 r = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) r += sh[i];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(SCAN_TPB) void k_scan_reduce(const i32 *__restrict__ in, i64 n, i64 *__restrict__ block_sums)
+{
+    __shared__ i64 sh[SCAN_TPB / 64];
+    i64 base = (i64)blockIdx.x * SCAN_TILE;
+    i64 s = 0;
+    for (int k = 0; k < SCAN_IPT; k++) { i64 i = base + (i64)k * SCAN_TPB + threadIdx.x; if (i < n) s += in[i]; }
+    s = block_reduce_sum(s, sh);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_spine(i64 *__restrict__ block_sums, i64 nb, i64 *__restrict__ total)
+{
+    __shared__ i64 sh[1024];
+    __shared__ i64 carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (i64 base = 0; base < nb; base += 1024) {
+        i64 i = base + threadIdx.x;
+        i64 v = i < nb ? block_sums[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            i64 t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+            __syncthreads();
+            sh[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < nb) block_sums[i] = carry + sh[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += sh[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(SCAN_TPB) void k_scan_down(const i32 *__restrict__ in, i64 n, const i64 *__restrict__ block_sums,
+                                                        i64 *__restrict__ out)
+{
+    __shared__ i64 sh[SCAN_TPB];
+    i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;
+    i64 v[SCAN_IPT], s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { i64 i = base + k; v[k] = i < n ? in[i] : 0; s += v[k]; }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 1; o < SCAN_TPB; o <<= 1) {
+        i64 t = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    i64 run = block_sums[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { i64 i = base + k; if (i < n) out[i] = run; run += v[k]; if (i == n - 1) out[n] = run; }
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+struct GeomArgs {
+    i64 n_sets, n_tiles, n_clusters;
+    const i32 *tile_count, *tile_tmin, *tile_tmax;
+    const i32 *set_cluster; const i64 *set_t0;
+    const i64 *cl_tmin; const u32 *cl_gid;
+    i64 *cl_end; i32 *cl_group;
+    i64 *grp_lo, *grp_hi, *grp_left, *grp_right, *grp_ixrand; u32 *grp_gid;
+    i64 *row_lo, *row_hi;
+    i32 *acc_len, *itv_cap; i32 *active_rows;
+    i64 *scal;           // [0] n_groups [1] error flag [2] n_active_rows [3] n_active_tiles [4] max start bins [5] max tile photons
+    i32 *active_tiles;
+};
+
+__device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i32 tmax, i64 &left, i64 &right, i64 &bin0, i64 &nb)
+{
+    // pulse.py:118-127
+    bin0 = floordiv(t0 + tmin, (i64)d.dt);
+    i64 bin1 = floordiv(t0 + tmax, (i64)d.dt);
+    nb = bin1 - bin0 + 1;
+    left = bin0 - d.store_before - d.samples_before;
+    right = bin1 + d.store_after + d.samples_after;
+}
+
+// per tile: end time of its pulse -> cluster (rawdata.py:188-190); list of non-empty tiles
+__global__ void k_tile_geom(WfsDev d, GeomArgs a)
+{
+    i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= a.n_tiles || a.tile_count[tile] <= 0) return;
+    i64 set = tile / d.n_tpc;
+    i64 left, right, bin0, nb;
+    tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+    atomicMax(&a.cl_end[a.set_cluster[set]], right * d.dt);
+    i64 k = atomicAdd((u64 *)&a.scal[3], 1ull);
+    a.active_tiles[k] = (i32)tile;
+    atomicMax(&a.scal[4], nb);
+    atomicMax(&a.scal[5], (i64)a.tile_count[tile]);
+}
+
+// one thread: digitise groups.  The cache is digitised before cluster k when
+// min(instruction key of k) - last_pulse_end_time > rext and a pulse exists (rawdata.py:96-98); last_pulse_end_time
+// is a running maximum over everything simulated so far (rawdata.py:188-190).
+__global__ void k_groups(WfsDev d, GeomArgs a)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool has = false; i64 runmax = 0; i32 g = 0;
+    for (i64 k = 0; k < a.n_clusters; k++) {
+        if (has && (double)(a.cl_tmin[k] - runmax) > d.rext) g++;
+        a.cl_group[k] = g;
+        if (a.grp_gid[g] == 0xffffffffu) a.grp_gid[g] = a.cl_gid[k];
+        i64 e = a.cl_end[k];
+        if (e != I64_MIN) { runmax = has ? (e > runmax ? e : runmax) : e; has = true; }
+    }
+    a.scal[0] = g + 1;
+}
+
+__global__ void k_tile_rows(WfsDev d, GeomArgs a)
+{
+    i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= a.n_tiles || a.tile_count[tile] <= 0) return;
+    i64 set = tile / d.n_tpc; i32 ch = (i32)(tile - set * d.n_tpc);
+    i64 left, right, bin0, nb;
+    tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+    i64 g = a.cl_group[a.set_cluster[set]];
+    atomicMin(&a.row_lo[g * d.n_tpc + ch], left); atomicMax(&a.row_hi[g * d.n_tpc + ch], right);
+    atomicMin(&a.grp_lo[g], left); atomicMax(&a.grp_hi[g], right);
+}
+
+// per group: window (rawdata.py:215-224) and the noise offset (rawdata.py:407-417)
+__global__ void k_group_final(WfsDev d, GeomArgs a)
+{
+    i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.scal[0]) return;
+    if (a.grp_lo[g] == I64_MAX) { a.grp_left[g] = 0; a.grp_right[g] = -1; a.grp_ixrand[g] = -1; return; }
+    i64 left = a.grp_lo[g] - d.tw, right = a.grp_hi[g] + d.tw;
+    if (!(right - left < 1000000)) atomicMax(&a.scal[1], (i64)1);           // "Pulse cache too long", rawdata.py:219
+    if (floormod(left, 2) != 0) left -= 1;
+    a.grp_left[g] = left; a.grp_right[g] = right;
+    i64 ix = -1;
+    if (d.enable_noise) {
+        i64 nl = a.grp_lo[g] - left - d.tw, nr = a.grp_hi[g] - left + d.tw;
+        i64 N = d.noise_len, high = (N - nr + nl - 1 < 0) ? N - 1 : N - nr + nl - 1;
+        if (high <= 0) ix = 0;
+        else { u32x4 w = philox4x32_10(0, a.grp_gid[g], 0, SITE_NOISE, d.k0, d.k1); ix = (i64)(u53(w.x, w.y) * (double)high); }
+    }
+    a.grp_ixrand[g] = ix;
+}
+
+// per (group, row slot): accumulator length and reserved ZLE interval slots
+__global__ void k_row_len(WfsDev d, GeomArgs a)
+{
+    i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 n = a.scal[0] * d.row_slots;
+    if (idx >= a.n_clusters * d.row_slots) return;
+    i32 cap = 0;
+    if (idx < n) {
+        i64 g = idx / d.row_slots; i32 slot = (i32)(idx - g * d.row_slots);
+        i32 ch = slot < d.n_tpc ? slot : slot - d.n_tpc;         // HE slot -> its top channel
+        i64 lo = a.row_lo[g * d.n_tpc + ch];
+        if (lo != I64_MAX) {
+            i64 len = a.row_hi[g * d.n_tpc + ch] - lo + 1 + 2 * (i64)d.tw;
+            i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
+            cap = (i32)((len + hold) / (hold + 1));
+            if (slot < d.n_tpc) a.acc_len[g * d.n_tpc + ch] = (i32)len;
+            i64 k = atomicAdd((u64 *)&a.scal[2], 1ull);
+            a.active_rows[k] = (i32)idx;
+        }
+    }
+    a.itv_cap[idx] = cap;
+}
+
+// ------------------------------------------------------------------------------------------------ pulse kernel
+// Pulse.__call__ per-channel body + add_current (pulse.py:82-144, 276-318) + the per-pulse rounding and
+// accumulation of digitize_pulse_cache (rawdata.py:231-239), one workgroup per tile.
+//
+// add_current visits photons in ascending time, merges photons of equal ns and adds templates[t % dt] * gain_total
+// at sample t // dt - pulse_left.  Here the merged gains are built first in LDS, H[r][j] = sum of gains of photons
+// with t % dt = r in start bin j (one LDS float atomic per photon), then every sample gathers its 22 x 10 possible
+// contributions in ascending (j, r) = ascending time order with a separate multiply and add.  Adding a zero
+// contribution does not change a float sum, so the result equals the reference's current bit for bit (except for
+// the order in which three or more photons of the SAME ns are merged, which numpy's unstable argsort leaves open).
+struct PulseArgs {
+    const i32 *active_tiles; i64 n_active;
+    const i32 *tile_count, *tile_tmin, *tile_tmax; const i64 *tile_off;
+    const i32 *set_cluster; const i64 *set_t0; const i32 *set_mode;       // mode 0: SPE codes, 1: explicit gains
+    const i32 *ph_t; const u32 *ph_code; const double *ph_gain;
+    const i32 *cl_group; const i64 *row_lo; const i64 *acc_off;
+    i32 *raw;
+    double *truth;        // [n_sets][16]: 12 accumulators (pulse.py:259-271) + n, sum t, sum t^2, (min,max kept separately)
+    i64 *tminmax;         // [n_sets][2] absolute min / max photon time
+    double *currents; const i64 *cur_off;     // debug: f64 tile currents
+    i32 W;                // start bins per LDS window
+};
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int W = a.W, tlen = d.tlen, dt = d.dt;
+    double *H = (double *)smem;                 // [dt][W]
+    double *T = H + (size_t)dt * W;             // [dt][tlen] templates
+    u32 *occ = (u32 *)(T + dt * tlen);          // [W] photons per start bin
+    double *red = (double *)(occ + W);          // [8] block reduction scratch
+    const int tid = threadIdx.x;
+
+    const i64 tile = a.active_tiles[blockIdx.x];
+    const i32 n = a.tile_count[tile];
+    const i64 off = a.tile_off[tile];
+    const i64 set = tile / d.n_tpc; const i32 ch = (i32)(tile - set * d.n_tpc);
+    const i64 t0 = a.set_t0[set];
+    i64 left, right, bin0, nb;
+    tile_bounds(d, t0, a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+    const i64 L = right - left + 1;
+    const int lead = d.store_before + d.samples_before;
+    const i64 g = a.cl_group[a.set_cluster[set]];
+    const i64 ridx = g * d.n_tpc + ch;
+    i32 *dst = a.raw + a.acc_off[ridx] + (left - (a.row_lo[ridx] - d.tw));
+    const int mode = a.set_mode[set];
+    const double G = d.gains[ch];
+    const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? ch : 0) * 2001;
+
+    for (int i = tid; i < dt * tlen; i += TPB) T[i] = d.templates[i];
+
+    // truth (pulse.py:229-271)
+    double acc_n = 0, acc_dpe = 0, acc_trig = 0, acc_trig_dpe = 0, acc_g = 0, acc_gtrig = 0, acc_t = 0, acc_t2 = 0;
+    i32 n_dpe_tile = 0;
+    {                         // number of DPE photons of the tile (needed by the truth quirk pulse.py:255)
+        i32 c = 0;
+        for (i32 p = tid; p < n; p += TPB) c += (a.ph_code[off + p] >> 16) != 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        i32 *sdpe = (i32 *)red;
+        if ((tid & 63) == 0) sdpe[tid >> 6] = c;
+        __syncthreads();
+        for (int w = 0; w < TPB / 64; w++) n_dpe_tile += sdpe[w];
+        __syncthreads();
+    }
+    const double thr = d.thr_truth[ch];
+
+    for (i64 w0 = 0; w0 < nb; w0 += W - (tlen - 1)) {
+        const int Wc = (int)((nb - w0 < W) ? nb - w0 : W);
+        const bool first = (w0 == 0), last = (w0 + Wc >= nb);
+        for (int i = tid; i < dt * W; i += TPB) H[i] = 0.0;
+        for (int i = tid; i < W; i += TPB) occ[i] = 0;
+        __syncthreads();
+        for (i32 p = tid; p < n; p += TPB) {
+            i64 tabs = t0 + a.ph_t[off + p];
+            i64 bin = floordiv(tabs, (i64)dt) - bin0;
+            int r = (int)floormod(tabs, (i64)dt);
+            double gain;
+            bool is_dpe = false;
+            if (mode == 0) {
+                u32 code = a.ph_code[off + p];
+                u32 g1 = code & 0xffffu, g2 = code >> 16;
+                gain = G * spe_row[g1];                       // pulse.py:97-98
+                if (g2) { gain += G * spe_row[g2]; is_dpe = true; }   // pulse.py:101-103
+            } else {
+                gain = a.ph_gain[off + p];                    // pulse.py:107
+                is_dpe = (a.ph_code[off + p] >> 16) != 0;     // injected photons carry their DPE flag here
+            }
+            if (bin >= w0 && bin < w0 + Wc) {
+                atomicAdd(&H[r * W + (int)(bin - w0)], gain);
+                atomicAdd(&occ[(int)(bin - w0)], 1u);
+            }
+            if (first) {
+                bool above = gain * d.current_max[r] * d.c2a > thr;
+                acc_n += 1; acc_dpe += is_dpe; acc_g += gain;
+                if (above) { acc_trig += 1; acc_gtrig += gain; if (p < n_dpe_tile) acc_trig_dpe += 1; }
+                double tr = (double)a.ph_t[off + p];
+                acc_t += tr; acc_t2 += tr * tr;
+            }
+        }
+        __syncthreads();
+        const i64 s_lo = first ? 0 : w0 + lead + (tlen - 1);
+        const i64 s_hi = last ? L : w0 + Wc + lead;
+        for (i64 s = s_lo + tid; s < s_hi; s += TPB) {
+            double cur = 0.0;
+            for (int k = tlen - 1; k >= 0; k--) {
+                i64 j = s - lead - k;
+                if (j < w0 || j >= w0 + Wc) continue;
+                int jj = (int)(j - w0);
+                if (occ[jj] == 0) continue;
+#pragma unroll
+                for (int r = 0; r < 10; r++) {
+                    double prod = T[r * tlen + k] * H[r * W + jj];
+                    cur = cur + prod;
+                }
+            }
+            if (a.currents) a.currents[a.cur_off[blockIdx.x] + s] = cur;
+            i64 adc = -(i64)rint(cur * d.c2a);                 // rawdata.py:236, np.around = round half to even
+            if (adc != 0) atomicAdd(&dst[s], (i32)adc);
+        }
+        if (last) break;            // wave-uniform
+        __syncthreads();
+    }
+
+    if (a.truth) {
+        double v[8] = {acc_n, acc_dpe, acc_trig, acc_trig_dpe, acc_g, acc_gtrig, acc_t, acc_t2};
+        for (int q = 0; q < 8; q++) {
+            double x = v[q];
+            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+            if ((tid & 63) == 0) red[tid >> 6] = x;
+            __syncthreads();
+            if (tid == 0) { double s = 0; for (int w = 0; w < TPB / 64; w++) s += red[w]; v[q] = s; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            double *tr = a.truth + set * 16;
+            double vals[6] = {v[0], v[0] + v[1], v[2], v[2] + v[3], v[4] / G, v[5] / G};
+            bool bottom = ch >= d.n_top && ch <= d.last_bottom;
+            for (int f = 0; f < 6; f++) {
+                if (vals[f] != 0) { atomicAdd(&tr[f], vals[f]); if (bottom) atomicAdd(&tr[6 + f], vals[f]); }
+            }
+            atomicAdd(&tr[12], v[0]); atomicAdd(&tr[13], v[6]); atomicAdd(&tr[14], v[7]);
+            atomicMin(&a.tminmax[set * 2], t0 + a.tile_tmin[tile]); atomicMax(&a.tminmax[set * 2 + 1], t0 + a.tile_tmax[tile]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ ZLE + records
+struct ZleArgs {
+    const i32 *active_rows; i64 n_active_rows;
+    const i64 *row_lo, *row_hi, *acc_off; const i32 *raw;
+    const i64 *grp_left, *grp_ixrand;
+    const i64 *itv_off;
+    i64 *itv_left, *itv_right; i32 *itv_n, *row_nrec;
+    const i64 *rec_off;          // per row slot: first record
+    uint8_t *records; i64 rec_capacity;
+    i32 *row_dbg; const i64 *row_dbg_off;   // debug: finished rows
+    i32 spr;                     // samples per record
+};
+
+// finished sample of a row: accumulated ADC + noise + baseline, clamped at 0
+// (rawdata.py:398-458 add_noise / add_baseline / digitizer_saturation, fused into the read)
+__device__ __forceinline__ i32 finish_sample(const WfsDev &d, const i32 *acc, i64 i, i32 slot_ch, bool he, i64 ix_rand)
+{
+    i64 v = acc[i];
+    if (he) v *= d.he_factor;                                   // rawdata.py:242-246
+    if (d.enable_noise && slot_ch < d.noise_channels) {
+        i64 in = ix_rand + i;
+        if (in >= d.noise_len) in -= (i64)d.noise_len * (in / d.noise_len);
+        v += d.noise[in * d.noise_channels + slot_ch];
+    }
+    v += d.baseline;
+    return v < 0 ? 0 : (i32)v;
+}
+
+__device__ __forceinline__ void row_of_slot(const WfsDev &d, i64 idx, i64 &g, i32 &channel, i32 &acc_ch, bool &he)
+{
+    g = idx / d.row_slots; i32 slot = (i32)(idx - g * d.row_slots);
+    he = slot >= d.n_tpc; acc_ch = he ? slot - d.n_tpc : slot; channel = he ? d.he_first + acc_ch : slot;
+}
+
+// one wave per row: find_intervals_below_threshold (utils.py:13-58) in its parallel form: consecutive
+// hit samples a < b belong to one interval iff b - a <= max(holdoff, 1); then the window of rawdata.py:302-308.
+__global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.n_active_rows) return;
+    const i64 idx = a.active_rows[r];
+    i64 g; i32 channel, acc_ch; bool he;
+    row_of_slot(d, idx, g, channel, acc_ch, he);
+    const i64 ridx = g * d.n_tpc + acc_ch;
+    const i64 len = a.row_hi[ridx] - a.row_lo[ridx] + 1 + 2 * (i64)d.tw;
+    const i32 *acc = a.raw + a.acc_off[ridx];
+    const i64 thr = d.thr_zle[channel];
+    const i64 ixr = a.grp_ixrand[g];
+    i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
+    const i64 base = a.itv_off[idx];
+    const i64 row_abs = a.row_lo[ridx] - d.tw;
+    // close interval k = [rawl, rawr] (first / last hit): window, clip, even landing (rawdata.py:302-308),
+    // absolute sample indices (rawdata.py:311); returns the number of records it needs
+    auto close_interval = [&](i32 k, i64 rawl, i64 rawr) -> i32 {
+        i64 l = rawl - d.tw, rr = rawr + d.tw;
+        l = l < 0 ? 0 : (l > len - 1 ? len - 1 : l); rr = rr < 0 ? 0 : (rr > len - 1 ? len - 1 : rr);
+        l = (l + 1) / 2 * 2; rr = rr / 2 * 2;                  // ceil(l/2)*2, floor(r/2)*2 for non-negative ints
+        a.itv_left[base + k] = row_abs + l; a.itv_right[base + k] = row_abs + rr;
+        i64 plen = rr - l + 1;
+        return plen > 0 ? (i32)((plen + a.spr - 1) / a.spr) : 0;
+    };
+    i64 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;
+    for (i64 c0 = 0; c0 < len; c0 += 64) {
+        i64 i = c0 + lane;
+        i32 v = i < len ? finish_sample(d, acc, i, channel, he, ixr) : 0x7fffffff;
+        if (a.row_dbg && i < len) a.row_dbg[a.row_dbg_off[r] + i] = v;
+        bool hit = i < len && (i64)v < thr;
+        u64 mask = __ballot(hit);
+        u64 lt = (1ull << lane) - 1ull;
+        u64 below = mask & lt;
+        i64 prev = below ? c0 + 63 - __clzll(below) : carry_last;       // last hit before this sample
+        bool start = hit && (prev < 0 || i - prev > hold);
+        u64 smask = __ballot(start);
+        if (start) {
+            u64 sbelow = smask & lt;
+            i32 k = count + __popcll(sbelow);
+            i64 prev_left = sbelow ? c0 + 63 - __clzll(sbelow) : open_left;
+            if (k > 0) nrec += close_interval(k - 1, prev_left, prev);
+        }
+        count += __popcll(smask);
+        if (smask) open_left = c0 + 63 - __clzll(smask);
+        if (mask) carry_last = c0 + 63 - __clzll(mask);
+    }
+    if (lane == 0 && count > 0) nrec += close_interval(count - 1, open_left, carry_last);
+    for (int o = 32; o > 0; o >>= 1) nrec += __shfl_down(nrec, o, 64);
+    if (lane == 0) { a.itv_n[idx] = count; a.row_nrec[idx] = nrec; }
+}
+
+// one wave per row: write its intervals as strax raw_records (strax_interface.py:425-435); a record is 61 dwords
+__global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.n_active_rows) return;
+    const i64 idx = a.active_rows[r];
+    const i32 count = a.itv_n[idx];
+    if (count == 0) return;
+    i64 g; i32 channel, acc_ch; bool he;
+    row_of_slot(d, idx, g, channel, acc_ch, he);
+    const i64 ridx = g * d.n_tpc + acc_ch;
+    const i32 *acc = a.raw + a.acc_off[ridx];
+    const i64 row_abs = a.row_lo[ridx] - d.tw;
+    const i64 ixr = a.grp_ixrand[g];
+    const i64 base = a.itv_off[idx];
+    const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
+    i64 rec = a.rec_off[idx];
+    for (i32 k = 0; k < count; k++) {
+        const i64 left = a.itv_left[base + k], plen = a.itv_right[base + k] - left + 1;
+        if (plen <= 0) continue;
+        const i64 need = (plen + spr - 1) / spr;
+        for (i64 f = 0; f < need; f++, rec++) {
+            if (rec >= a.rec_capacity) return;
+            u32 *out = (u32 *)(a.records + rec * (24 + 2 * (i64)spr));
+            const i64 time = (i64)d.dt * (left + spr * f);
+            const i32 length = (i32)((plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f);
+            for (int q = lane; q < rec_dwords; q += 64) {
+                u32 w;
+                if (q == 0) w = (u32)(u64)time;
+                else if (q == 1) w = (u32)((u64)time >> 32);
+                else if (q == 2) w = (u32)length;
+                else if (q == 3) w = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
+                else if (q == 4) w = (u32)plen;
+                else if (q == 5) w = (u32)(uint16_t)f;           // record_i, baseline = 0
+                else {
+                    int s0 = (q - 6) * 2;
+                    i64 i0 = (left - row_abs) + spr * f + s0;
+                    u32 lo = s0 < length ? (u32)(uint16_t)finish_sample(d, acc, i0, channel, he, ixr) : 0u;
+                    u32 hi = s0 + 1 < length ? (u32)(uint16_t)finish_sample(d, acc, i0 + 1, channel, he, ixr) : 0u;
+                    w = lo | (hi << 16);
+                }
+                out[q] = w;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ generation
+struct GenArgs {
+    i64 n_ins, n_emitters, n_photons;
+    const int8_t *ins_type; const i64 *ins_time; const i32 *ins_amp; const u32 *ins_gid;
+    const double *ins_p, *ins_dm, *ins_ds, *ins_sc; const i32 *ins_cdfrow; const double *cdf_table;
+    const i64 *em_off;            // [n_ins + 1] first emitter of each instruction
+    i64 *em_time; i32 *em_nph; i32 *em_ins; const i64 *em_ph_off;
+    i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
+    i32 *ph_t; u32 *ph_code;
+    double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
+    i64 *el_minmax;
+    i64 *scal;
+};
+
+// Poisson: PTRS (Hoermann 1993) for lam >= 10, multiplication method below; same algorithm and uniforms as the oracle
+__device__ i64 poisson_draw(const WfsDev &d, u32 emitter, u32 gid, double lam)
+{
+    u32 it = 0;
+    if (lam <= 0) return 0;
+    if (lam < 10) {
+        double enlam = exp(-lam), prod = 1.0; i64 x = 0;
+        for (;;) {
+            u32x4 w = philox4x32_10(emitter, gid, it++, SITE_EL_POIS, d.k0, d.k1);
+            prod *= u53(w.x, w.y);
+            if (prod > enlam) x++; else return x;
+            prod *= u53(w.z, w.w);
+            if (prod > enlam) x++; else return x;
+        }
+    }
+    double slam = sqrt(lam), loglam = log(lam);
+    double b = 0.931 + 2.53 * slam, aa = -0.059 + 0.02483 * b;
+    double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2);
+    for (;;) {
+        u32x4 w = philox4x32_10(emitter, gid, it++, SITE_EL_POIS, d.k0, d.k1);
+        double U = u53(w.x, w.y) - 0.5, V = u53(w.z, w.w);
+        double us = 0.5 - fabs(U);
+        i64 k = (i64)floor((2 * aa / us + b) * U + lam + 0.43);
+        if (us >= 0.07 && V <= vr) return k;
+        if (k < 0 || (us < 0.013 && V > us)) continue;
+        if (log(V) + log(invalpha) - log(aa / (us * us) + b) <= -lam + k * loglam - lgamma((double)k + 1)) return k;
+    }
+}
+
+// S1: n_hits = Binomial(amp, ly) as a sum of Bernoulli trials (s1.py:133), one wave per instruction
+__global__ __launch_bounds__(256) void k_s1_hits(WfsDev d, GenArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    i64 i = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n_ins || a.ins_type[i] != 1) return;
+    const u64 T = bern_threshold(a.ins_p[i]);
+    const i64 amp = a.ins_amp[i]; const u32 gid = a.ins_gid[i];
+    i32 hits = 0;
+    for (i64 q = lane; q * 4 < amp; q += 64) {
+        u32x4 w = philox4x32_10(0, gid, (u32)q, SITE_S1_HIT, d.k0, d.k1);
+        i64 j = q * 4;
+        hits += (u64)w.x < T;
+        if (j + 1 < amp) hits += (u64)w.y < T;
+        if (j + 2 < amp) hits += (u64)w.z < T;
+        if (j + 3 < amp) hits += (u64)w.w < T;
+    }
+    for (int o = 32; o > 0; o >>= 1) hits += __shfl_down(hits, o, 64);
+    if (lane == 0) { i64 e = a.em_off[i]; a.em_nph[e] = hits; a.em_time[e] = a.ins_time[i]; a.em_ins[e] = (i32)i; }
+}
+
+// S2: one thread per candidate electron (s2.py:254, 258-286, 308-310)
+__global__ __launch_bounds__(256) void k_s2_electrons(WfsDev d, GenArgs a)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 i = -1; bool is_s2 = false;
+    if (e < a.n_emitters) {
+        i64 lo = 0, hi = a.n_ins;                   // instruction of emitter e: em_off[lo] <= e < em_off[lo+1]
+        while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_off[mid] <= e) lo = mid; else hi = mid; }
+        i = lo; is_s2 = a.ins_type[i] == 2;
+    }
+    double st_n = 0, st_t = 0, st_t2 = 0; i64 st_min = I64_MAX, st_max = I64_MIN;
+    if (is_s2) {
+        const u32 j = (u32)(e - a.em_off[i]); const u32 gid = a.ins_gid[i];
+        a.em_ins[e] = (i32)i;
+        u32x4 sv = philox4x32_10(0, gid, j >> 2, SITE_S2_SURVIVE, d.k0, d.k1);
+        u32 word = (j & 3) == 0 ? sv.x : (j & 3) == 1 ? sv.y : (j & 3) == 2 ? sv.z : sv.w;
+        if (!((u64)word < bern_threshold(a.ins_p[i]))) { a.em_nph[e] = 0; a.em_time[e] = I64_MIN; }
+        else {
+            u32x4 A = philox4x32_10(j, gid, 0, SITE_EL_A, d.k0, d.k1);
+            u32x4 B = philox4x32_10(j, gid, 0, SITE_EL_B, d.k0, d.k1);
+            double z_drift, z_gain;
+            box_muller(B, z_drift, z_gain);
+            double timing = -log(1.0 - u53(A.x, A.y)) * d.trap_time;
+            timing += a.ins_dm[i] + a.ins_ds[i] * z_drift;
+            i64 et = a.ins_time[i] + (i64)timing;                         // s2.py:282
+            i64 nph = poisson_draw(d, j, gid, a.ins_sc[i]);
+            nph += (i64)(0.0 + d.gain_spread * z_gain);                   // s2.py:309
+            if (nph < 0) nph = 0;
+            a.em_nph[e] = (i32)nph; a.em_time[e] = et;
+            double tr = (double)(et - a.ins_time[i]);
+            st_n = 1; st_t = tr; st_t2 = tr * tr; st_min = et; st_max = et;
+        }
+    }
+    // electron time statistics of the truth row (rawdata.py:325-332): one set of atomics per wave when the
+    // whole wave works on one instruction, else one per lane
+    const i64 i_first = __shfl(i, 0, 64);
+    bool leader = true;
+    if (__all(i == i_first)) {
+        for (int o = 32; o > 0; o >>= 1) {
+            st_n += __shfl_down(st_n, o, 64); st_t += __shfl_down(st_t, o, 64); st_t2 += __shfl_down(st_t2, o, 64);
+            i64 mn = __shfl_down(st_min, o, 64), mx = __shfl_down(st_max, o, 64);
+            st_min = mn < st_min ? mn : st_min; st_max = mx > st_max ? mx : st_max;
+        }
+        leader = (threadIdx.x & 63) == 0;
+    }
+    if (leader && st_n > 0) {
+        atomicAdd(&a.el_stat[i * 4 + 0], st_n); atomicAdd(&a.el_stat[i * 4 + 1], st_t); atomicAdd(&a.el_stat[i * 4 + 2], st_t2);
+        atomicMin(&a.el_minmax[i * 2], st_min); atomicMax(&a.el_minmax[i * 2 + 1], st_max);
+    }
+}
+
+__device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double u)
+{
+    int lo = 0, hi = n;                             // searchsorted(cdf, u, side='right')
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (u < cdf[mid]) hi = mid; else lo = mid + 1; }
+    return lo < n ? lo : n - 1;
+}
+
+__device__ __forceinline__ double interp_lum(const WfsDev &d, double u)
+{
+    const double *xp = d.lum_x, *fp = d.lum_t; const int n = d.n_lum;      // np.interp, s2.py:338
+    if (u <= xp[0]) return fp[0];
+    if (u >= xp[n - 1]) return fp[n - 1];
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (xp[mid] <= u) lo = mid; else hi = mid; }
+    if (xp[lo] == u) return fp[lo];
+    double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
+    return slope * (u - xp[lo]) + fp[lo];
+}
+
+#define GEN_TPB 256
+#define GEN_PPT 8
+#define GEN_BLOCK (GEN_TPB * GEN_PPT)
+#define GEN_WIN 2304               // emitter offsets staged in LDS per block
+
+struct PhotonId { i64 e; i32 ins; u32 j, m; };
+
+// Photon -> (emitter, instruction, item).  The block's emitter window is staged in LDS when it fits.
+__device__ __forceinline__ PhotonId photon_identify(const GenArgs &a, i64 p, const i64 *win, i64 e_lo, int nwin)
+{
+    PhotonId id;
+    i64 e;
+    if (nwin > 0) {
+        int lo = 0, hi = nwin;                       // win[k] = em_ph_off[e_lo + k]; find last k with win[k] <= p
+        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win[mid] <= p) lo = mid; else hi = mid; }
+        e = e_lo + lo;
+        id.m = (u32)(p - win[lo]);
+    } else {
+        i64 lo = 0, hi = a.n_emitters;
+        while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
+        e = lo;
+        id.m = (u32)(p - a.em_ph_off[lo]);
+    }
+    id.e = e; id.ins = a.em_ins[e]; id.j = (u32)(e - a.em_off[id.ins]);
+    return id;
+}
+
+// Pass A (COUNT = true): channel of every photon -> photons per tile.
+// Pass B (COUNT = false): the whole photon (s1.py:180-194 / s2.py:504-557 timing terms, pulse.py:53-56 transit time,
+// pulse.py:76-79 double-PE, pulse.py:97-103 SPE gain indices) written straight into its tile's bucket.
+template <bool COUNT>
+__global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
+{
+    __shared__ i64 win[GEN_WIN];
+    __shared__ i32 hist[WFS_MAX_CH];
+    __shared__ i32 hbase[WFS_MAX_CH];
+    __shared__ i32 hmin[WFS_MAX_CH], hmax[WFS_MAX_CH];
+    __shared__ i64 s_elo, s_ehi;
+    const int tid = threadIdx.x;
+    const i64 p0 = (i64)blockIdx.x * GEN_BLOCK;
+    const i64 p1 = (p0 + GEN_BLOCK < a.n_photons) ? p0 + GEN_BLOCK : a.n_photons;
+    if (tid < 2) {
+        i64 p = tid == 0 ? p0 : p1 - 1;
+        i64 lo = 0, hi = a.n_emitters;
+        while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
+        if (tid == 0) s_elo = lo; else s_ehi = lo;
+    }
+    for (int c = tid; c < d.n_tpc; c += GEN_TPB) { hist[c] = 0; hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; }
+    __syncthreads();
+    const i64 e_lo = s_elo, e_hi = s_ehi;
+    const int nwin = (e_hi - e_lo + 2 <= GEN_WIN) ? (int)(e_hi - e_lo + 2) : 0;
+    for (int k = tid; k < nwin; k += GEN_TPB) win[k] = a.em_ph_off[e_lo + k];
+    const bool single = a.em_ins[e_lo] == a.em_ins[e_hi];       // all photons of the block in one pulse set
+    __syncthreads();
+
+    i32 my_ch[GEN_PPT], my_rank[GEN_PPT], my_t[GEN_PPT]; u32 my_code[GEN_PPT]; i32 my_ins[GEN_PPT];
+#pragma unroll
+    for (int q = 0; q < GEN_PPT; q++) {
+        const i64 p = p0 + (i64)q * GEN_TPB + tid;
+        my_ch[q] = -1;
+        if (p >= p1) continue;
+        const PhotonId id = photon_identify(a, p, win, e_lo, nwin);
+        const i32 ins = id.ins; const u32 gid = a.ins_gid[ins];
+        const double *cdf = a.cdf_table + (size_t)a.ins_cdfrow[ins] * d.n_tpc;
+        const u32x4 A = philox4x32_10(id.j, gid, id.m, SITE_PH_A, d.k0, d.k1);
+        const int ch = channel_from_cdf(cdf, d.n_tpc, u53(A.x, A.y));
+        my_ch[q] = ch; my_ins[q] = ins;
+        if (COUNT) {
+            if (single) atomicAdd(&hist[ch], 1);
+            else atomicAdd(&a.tile_count[(i64)ins * d.n_tpc + ch], 1);
+            continue;
+        }
+        const bool is_s2 = a.ins_type[ins] == 2;
+        const u32x4 B = philox4x32_10(id.j, gid, id.m, SITE_PH_B, d.k0, d.k1);
+        const u32x4 C = philox4x32_10(id.j, gid, id.m, SITE_PH_C, d.k0, d.k1);
+        const bool is_dpe = (u64)A.z < bern_threshold(d.p_dpe);
+        const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
+        double z_tts, z_spread;
+        box_muller(C, z_tts, z_spread);
+        const double e1 = -log(1.0 - u53(B.x, B.y));
+        i64 t = a.em_time[id.e] - a.ins_time[ins];          // relative to the instruction time
+        if (!is_s2) {
+            if (d.s1_simple) { t += (i64)(e1 * d.s1_decay_time); t += (i64)(0.0 + d.s1_decay_spread * z_spread); }
+        } else {
+            const u32x4 D = philox4x32_10(id.j, gid, id.m, SITE_PH_D, d.k0, d.k1);
+            t += (i64)interp_lum(d, u53(D.x, D.y));
+            const double delay = ((u64)B.w < bern_threshold(d.sf_gas)) ? d.t1_gas : d.t3_gas;
+            t += (i64)(e1 * delay);
+            if (d.s2_time_model == 1) t += (i64)(0.0 + d.s2_time_spread * z_spread);
+        }
+        t += (i64)(d.tts_mean + d.tts_sigma * z_tts);
+        if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
+        my_t[q] = (i32)t; my_code[q] = g1 | (is_dpe ? (g2 << 16) : 0u);
+        if (single) {
+            my_rank[q] = atomicAdd(&hist[ch], 1);
+            atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
+        } else {
+            const i64 tile = (i64)ins * d.n_tpc + ch;
+            my_rank[q] = atomicAdd(&a.tile_cursor[tile], 1);
+            atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
+        }
+    }
+    __syncthreads();
+    if (single) {
+        const i64 tbase = (i64)a.em_ins[e_lo] * d.n_tpc;
+        for (int c = tid; c < d.n_tpc; c += GEN_TPB) {
+            const i32 h = hist[c];
+            if (h == 0) continue;
+            if (COUNT) atomicAdd(&a.tile_count[tbase + c], h);
+            else {
+                hbase[c] = atomicAdd(&a.tile_cursor[tbase + c], h);
+                atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
+            }
+        }
+    }
+    if (COUNT) return;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < GEN_PPT; q++) {
+        if (my_ch[q] < 0) continue;
+        const i64 tile = (i64)my_ins[q] * d.n_tpc + my_ch[q];
+        const i64 pos = a.tile_off[tile] + (single ? hbase[my_ch[q]] : 0) + my_rank[q];
+        a.ph_t[pos] = my_t[q]; a.ph_code[pos] = my_code[q];
+    }
+}

@@ -1,0 +1,234 @@
+"""ctypes binding of libwfsim_amd.so (include/wfsim_amd.h) -- the only way the Python host side reaches the GPU.
+
+There is no CPU fallback: if the HIP library is missing, fails to load, or no MI355X is visible, constructing an
+``Engine`` raises.  Nothing in this module (or anywhere under wfsim_amd/) imports the test oracle.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .config import kernel_params, N_ROWS
+from .dtypes import raw_record_dtype
+from . import tables as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libwfsim_amd.so')
+
+_I32 = ['dt', 'samples_before', 'samples_after', 'store_before', 'store_after', 'tlen', 'trigger_window', 'baseline',
+        'n_rows', 'n_tpc', 'n_top', 'he_first', 'he_factor', 'sum_channel', 'last_bottom', 'detector_nt', 'enable_noise',
+        's1_simple', 's2_time_model', 'enable_pmt_ap']
+_F64 = ['c2a', 'tts_mean', 'tts_sigma', 'p_dpe', 's1_decay_time', 's1_decay_spread', 'sf_gas', 't1_gas', 't3_gas',
+        's2_time_spread', 'trap_time', 'gain_spread', 'pmt_ap_modifier', 'pmt_ap_t_modifier', 'rext', 'drift_velocity']
+
+
+class WfsConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in _I32] + [(n, C.c_double) for n in _F64] + [('seed', C.c_uint64)]
+
+
+class WfsCounts(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ['n_instructions', 'n_pulse_sets', 'n_emitters', 'n_photons', 'n_pe', 'n_tiles',
+                                         'n_groups', 'n_rows', 'n_raw_samples', 'n_intervals', 'n_records']]
+
+
+class WfsError(RuntimeError):
+    pass
+
+
+_lib = None
+EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'wfs_set_tables', 'wfs_set_ap_element',
+           'wfs_load_instructions', 'wfs_load_photons', 'wfs_run', 'wfs_get_counts', 'wfs_copy_records',
+           'wfs_copy_records_dev', 'wfs_records_dev_ptr', 'wfs_copy_groups', 'wfs_copy_intervals',
+           'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
+           'wfs_copy_photons', 'wfs_copy_truth', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
+           'wfs_kernel_times', 'wfs_set_profiling']
+
+
+def load_library():
+    """Loads libwfsim_amd.so; raises if it is missing (build it with ``python -c "import __graft_entry__ as g; g.build()"``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise WfsError(f'{LIB_PATH} not found: the HIP extension is not built; there is no CPU fallback')
+        lib = C.CDLL(LIB_PATH)
+        for name in EXPORTS:
+            getattr(lib, name)          # AttributeError if a declared symbol is missing
+        lib.wfs_last_error.restype = C.c_char_p
+        lib.wfs_last_error.argtypes = [C.c_void_p]
+        lib.wfs_records_dev_ptr.restype = C.c_void_p
+        lib.wfs_records_dev_ptr.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def device_count():
+    n = C.c_int(0)
+    rc = load_library().wfs_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class Engine:
+    """One GPU, one stream, one fax configuration."""
+
+    def __init__(self, config, resource, device=0, seed=None):
+        self.lib = load_library()
+        self.config = config
+        params = kernel_params(config)
+        if seed is not None:
+            params['seed'] = int(seed)
+        self.params = params
+        cfg = WfsConfig()
+        for n, _ in WfsConfig._fields_:
+            setattr(cfg, n, params[n])
+        self._h = C.c_void_p(0)
+        rc = self.lib.wfs_create(C.byref(cfg), C.c_int(device), C.byref(self._h))
+        if rc != 0:
+            raise WfsError(f'wfs_create failed with code {rc}: no usable MI355X / HIP runtime (device {device})')
+        thr_truth, thr_zle = T.thresholds(config, N_ROWS)
+        lum_x, lum_t = T.luminescence_table(config)
+        self.tables = dict(
+            templates=T.pmt_current_templates(config), spe=T.spe_scaling_table(resource.spe_charge, resource.spe_pdfs),
+            gains=_arr(config['gains'], np.float64), thr_truth=_arr(thr_truth, np.float64), thr_zle=_arr(thr_zle, np.int64),
+            lum_x=_arr(lum_x, np.float64), lum_t=_arr(lum_t, np.float64),
+            noise=_arr(resource.noise_data, np.int16) if (params['enable_noise'] and hasattr(resource, 'noise_data')) else None)
+        t = self.tables
+        assert t['templates'].shape == (params['dt'], params['tlen'])
+        nl, nc = t['noise'].shape if t['noise'] is not None else (0, 0)
+        self._check(self.lib.wfs_set_tables(
+            self._h, _p(t['templates']), _p(t['spe']), C.c_int32(t['spe'].shape[0]), _p(t['gains']), _p(t['thr_truth']),
+            _p(t['thr_zle']), _p(t['lum_x']), _p(t['lum_t']), C.c_int32(len(t['lum_x'])), _p(t['noise']), C.c_int32(nl), C.c_int32(nc)))
+        if params['enable_pmt_ap'] and hasattr(resource, 'uniform_to_pmt_ap'):
+            for e, (name, d) in enumerate(resource.uniform_to_pmt_ap.items()):
+                dc, ac = _arr(d['delaytime_cdf'], np.float64), _arr(d['amplitude_cdf'], np.float64)
+                self._check(self.lib.wfs_set_ap_element(
+                    self._h, C.c_int32(e), C.c_int32(dc.shape[1]), C.c_int32(ac.shape[-1]), C.c_int32(ac.ndim == 2),
+                    C.c_int32('Uniform' in name), C.c_double(d['delaytime_bin_size']), C.c_double(d['amplitude_bin_size']), _p(dc), _p(ac)))
+
+    # ------------------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.lib.wfs_last_error(self._h)
+            raise WfsError(f'libwfsim_amd error {rc}: {msg.decode() if msg else ""}')
+
+    def close(self):
+        if self._h:
+            self.lib.wfs_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def load_instructions(self, ins, gid, cluster, tmin, ip):
+        """ins: instruction array sorted by the scheduler key; ip: dict from physics.instruction_params."""
+        n = len(ins)
+        a = [_arr(ins['type'], np.int8), _arr(ins['time'], np.int64), _arr(ins['amp'], np.int32), _arr(gid, np.uint32),
+             _arr(cluster, np.int32), _arr(tmin, np.int64), _arr(ip['p_hit'], np.float64), _arr(ip['drift_mean'], np.float64),
+             _arr(ip['drift_spread'], np.float64), _arr(ip['sc_gain'], np.float64), _arr(ip['cdf_row'], np.int32),
+             _arr(ip['cdf_table'], np.float64)]
+        self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0])))
+
+    def load_photons(self, set_cluster, set_tmin, set_off, t, ch, gain, dpe=None):
+        a = [_arr(set_cluster, np.int32), _arr(set_tmin, np.int64), _arr(set_off, np.int64), _arr(t, np.int64),
+             _arr(ch, np.int16), _arr(gain, np.float64), _arr(dpe, np.uint8) if dpe is not None else None]
+        self._check(self.lib.wfs_load_photons(self._h, C.c_int64(len(a[0])), *[_p(x) for x in a]))
+
+    def run(self):
+        self._check(self.lib.wfs_run(self._h))
+        c = WfsCounts()
+        self._check(self.lib.wfs_get_counts(self._h, C.byref(c)))
+        self.counts = {n: getattr(c, n) for n, _ in WfsCounts._fields_}
+        return self.counts
+
+    def set_debug(self, on=True):
+        self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(on))))
+
+    def set_profiling(self, on=True):
+        self._check(self.lib.wfs_set_profiling(self._h, C.c_int32(int(on))))
+
+    def set_stream(self, stream_ptr):
+        self._check(self.lib.wfs_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # ---- results ---------------------------------------------------------------------------------
+    def records(self):
+        n = self.counts['n_records']
+        out = np.zeros(n, dtype=raw_record_dtype())
+        self._check(self.lib.wfs_copy_records(self._h, _p(out), C.c_int64(n)))
+        return out
+
+    def records_dev_ptr(self):
+        return self.lib.wfs_records_dev_ptr(self._h)
+
+    def copy_records_to_device(self, dev_ptr, capacity):
+        self._check(self.lib.wfs_copy_records_dev(self._h, C.c_void_p(dev_ptr), C.c_int64(capacity)))
+
+    def groups(self):
+        g = self.counts['n_groups']
+        left, right, first, ix = (np.zeros(g, dtype=np.int64) for _ in range(4))
+        self._check(self.lib.wfs_copy_groups(self._h, _p(left), _p(right), _p(first), _p(ix)))
+        return dict(left=left, right=right, first_record=first, ix_rand=ix)
+
+    def intervals(self):
+        n = self.counts['n_intervals']
+        group, ch = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        left, right, off = np.zeros(n, np.int64), np.zeros(n, np.int64), np.zeros(n + 1, np.int64)
+        self._check(self.lib.wfs_copy_intervals(self._h, _p(group), _p(ch), _p(left), _p(right), _p(off), C.c_int64(n + 1)))
+        data = np.zeros(int(off[n]), dtype=np.int16)
+        self._check(self.lib.wfs_copy_interval_data(self._h, _p(data), C.c_int64(len(data))))
+        return dict(group=group, channel=ch, left=left, right=right, data_off=off, data=data)
+
+    def pulses(self, currents=False):
+        n = self.counts['n_tiles']
+        s, ch = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        left, right, nph, off = (np.zeros(n, np.int64) for _ in range(4))
+        self._check(self.lib.wfs_copy_pulses(self._h, _p(s), _p(ch), _p(left), _p(right), _p(nph), _p(off), C.c_int64(n)))
+        out = dict(set=s, channel=ch, left=left, right=right, n_photons=nph, cur_off=off)
+        if currents:
+            total = int((right - left + 1).sum())
+            cur = np.zeros(total, dtype=np.float64)
+            self._check(self.lib.wfs_copy_currents(self._h, _p(cur), C.c_int64(total)))
+            out['current'] = cur
+        return out
+
+    def rows(self):
+        n = self.counts['n_rows']
+        g, ch = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        left, right, off = (np.zeros(n, np.int64) for _ in range(3))
+        self._check(self.lib.wfs_copy_rows(self._h, _p(g), _p(ch), _p(left), _p(right), _p(off), C.c_int64(n)))
+        total = int((right - left + 1).sum())
+        data = np.zeros(total, dtype=np.int32)
+        self._check(self.lib.wfs_copy_row_data(self._h, _p(data), C.c_int64(total)))
+        return dict(group=g, channel=ch, left=left, right=right, data_off=off, data=data)
+
+    def photons(self):
+        n, s = self.counts['n_photons'], self.counts['n_pulse_sets']
+        off = np.zeros(s + 1, np.int64)
+        t, ch, gain, dpe = np.zeros(n, np.int64), np.zeros(n, np.int16), np.zeros(n, np.float64), np.zeros(n, np.uint8)
+        self._check(self.lib.wfs_copy_photons(self._h, _p(off), _p(t), _p(ch), _p(gain), _p(dpe), C.c_int64(n)))
+        return dict(set_off=off, t=t, ch=ch, gain=gain, dpe=dpe)
+
+    def truth(self):
+        s = self.counts['n_pulse_sets']
+        acc, ts = np.zeros((s, 12)), np.zeros((s, 5))
+        self._check(self.lib.wfs_copy_truth(self._h, _p(acc), _p(ts), C.c_int64(s)))
+        return acc, ts
+
+    def kernel_times(self):
+        names = C.create_string_buffer(4096)
+        ms = (C.c_float * 64)()
+        nl = (C.c_int32 * 64)()
+        nk = C.c_int32(0)
+        self._check(self.lib.wfs_kernel_times(self._h, names, C.c_int64(4096), ms, nl, C.byref(nk)))
+        parts = names.raw.split(b'\0')[:nk.value]
+        return {parts[k].decode(): (float(ms[k]), int(nl[k])) for k in range(nk.value)}
