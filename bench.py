@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: photoelectrons/s (+ raw_records MB/s) of the photon -> raw_records hot path on a batch of
+10^6-PE S2 instructions (BASELINE.json config[2]), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--instructions M]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the whole hot path (S2 electron/photon Monte Carlo, SPE gains, template scatter-add,
+digitisation, ZLE, record packing) over one batch of synthetic instructions that is already resident in HBM,
+followed -- for N > 1 -- by the RCCL gather of the packed raw_records on rank 0 (weak scaling: every rank
+simulates its own M instructions; event clusters are independent).
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from wfsim_amd.config import xenonnt_test_config   # noqa: E402
+from wfsim_amd.dtypes import instruction_dtype     # noqa: E402
+from wfsim_amd.physics import instruction_params   # noqa: E402
+from wfsim_amd.resource import Resource            # noqa: E402
+from wfsim_amd.scheduler import schedule           # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def s2_batch(n, first_gid, t0=0):
+    """BASELINE config[2]: n S2 instructions, 10^4 electrons each, 1 ms apart, z = -10 cm, centre of the TPC."""
+    ins = np.zeros(n, dtype=instruction_dtype)
+    ins['type'] = 2
+    ins['time'] = t0 + 1_000_000 * (1 + np.arange(n))
+    ins['z'] = -10.0
+    ins['amp'] = 10_000
+    ins['recoil'] = 7
+    ins['event_number'] = first_gid + np.arange(n)
+    return ins
+
+
+def bench_config(seed):
+    # E[PE] = 10^4 e- * survival * sc_gain 100 = ~10^6 PE per instruction
+    return xenonnt_test_config(s2_secondary_sc_gain=100.0, seed=seed)
+
+
+def algorithmic_bytes(counts):
+    """B_alg = 21 P + 4 S_raw + 244 R + 70 N_inst"""
+    return 21 * counts['n_photons'] + 4 * counts['n_raw_samples'] + 244 * counts['n_records'] + 70 * counts['n_instructions']
+
+
+def cpu_baseline(cfg, n_sample):
+    """The C oracle (CPU restatement, one thread) on a bounded sample of the same workload."""
+    from tests.helpers import make_oracle
+    res = Resource(cfg)
+    ins = s2_batch(n_sample, 0)
+    order, key, cluster = schedule(ins, cfg)
+    ip = instruction_params(ins[order], cfg, res)
+    orc = make_oracle(cfg)
+    t0 = time.perf_counter()
+    orc.simulate(ins[order], order.astype(np.uint32), ip)
+    rec = orc.pack_records()
+    dt = time.perf_counter() - t0
+    return dict(value=orc.n_pe / dt, unit='photoelectrons/s', cores=1, kind='port',
+                sample=f'{n_sample} S2 instructions of the bench batch (10^4 e-, ~10^6 PE each), {dt:.1f} s, '
+                       f'{len(rec) // 244} records, C oracle single thread'), dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--instructions', type=int, default=1000, help='S2 instructions per GPU per step')
+    ap.add_argument('--cpu-sample', type=int, default=12, help='S2 instructions timed on the CPU oracle (0: skip)')
+    ap.add_argument('--no-gather', action='store_true', help='skip the RCCL gather of records (N > 1)')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    from wfsim_amd.engine import Engine
+    cfg = bench_config(seed=3)
+    res = Resource(cfg)
+    M = args.instructions
+    ins = s2_batch(M, first_gid=rank * M)
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    gid = (rank * M + order).astype(np.uint32)          # run-wide instruction ids: streams do not depend on the sharding
+    ip = instruction_params(s_ins, cfg, res)
+    eng = Engine(cfg, res, device=local_rank)
+    eng.load_instructions(s_ins, gid, cluster, key, ip)   # inputs resident in HBM before the timed region
+
+    gather_buf = None
+
+    def step(profile=False):
+        eng.set_profiling(profile)
+        counts = eng.run()
+        if world > 1 and not args.no_gather:
+            # variable-length gather of the packed records on rank 0 (RCCL over xGMI)
+            n = torch.tensor([counts['n_records']], device='cuda', dtype=torch.int64)
+            ns = [torch.zeros_like(n) for _ in range(world)] if rank == 0 else None
+            dist.gather(n, ns, dst=0)
+            nonlocal gather_buf
+            mine = torch.empty(counts['n_records'] * 244, dtype=torch.uint8, device='cuda')
+            eng.copy_records_to_device(mine.data_ptr(), counts['n_records'])
+            if rank == 0:
+                sizes = [int(x.item()) * 244 for x in ns]
+                bufs = [torch.empty(s, dtype=torch.uint8, device='cuda') for s in sizes]
+                reqs = [dist.irecv(bufs[r], src=r) for r in range(1, world)]
+                bufs[0] = mine
+                for q in reqs:
+                    q.wait()
+                gather_buf = bufs
+            else:
+                dist.send(mine, dst=0)
+        return counts
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([counts['n_pe'], counts['n_records'], counts['n_photons']], device='cuda', dtype=torch.int64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_pe, total_rec, total_ph = (int(x) for x in tot.tolist())
+    else:
+        total_pe, total_rec, total_ph = counts['n_pe'], counts['n_records'], counts['n_photons']
+
+    # one extra (untimed) profiled step: HIP-event duration of every kernel on the engine's stream
+    counts = step(profile=True)
+    ktimes = eng.kernel_times()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms_per_step = 1e3 * elapsed / args.steps
+    dom = max(ktimes, key=lambda k: ktimes[k][0])
+    dom_ms, dom_launches = ktimes[dom]
+    b_alg = algorithmic_bytes(counts)
+    achieved = b_alg / (dom_ms / dom_launches * 1e-3) / 1e9
+    out = dict(
+        metric='photoelectrons/sec + raw_records MB/s, 10^6-PE S2 batch', value=total_pe * args.steps / elapsed,
+        unit='photoelectrons/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+        higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
+        raw_records_MB_per_s=total_rec * 244 * args.steps / elapsed / 1e6,
+        config=dict(workload=f'{M} S2 instructions per GPU, 1e4 electrons each (~1e6 PE), 494 PMTs, z=-10 cm, '
+                             f's2_secondary_sc_gain=100, noise/afterpulses off (BASELINE configs[2])',
+                    instructions_per_gpu=M, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
+                    gather='none' if (world == 1 or args.no_gather) else 'rccl send/recv to rank 0'),
+        roofline=dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
+                      traffic=None, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,
+                      pipeline_frac=b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      kernels_ms={k: round(v[0], 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}),
+    )
+    if args.cpu_sample > 0:
+        out['cpu_baseline'], _ = cpu_baseline(cfg, args.cpu_sample)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

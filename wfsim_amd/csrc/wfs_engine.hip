@@ -173,6 +173,9 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     if (hipMalloc(&h->scal.p, 256) != hipSuccess) { delete h; return WFS_E_HIP; }
     h->scal.cap = 256;
     refresh_dev(h);
+    // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
+    hipFuncSetAttribute((const void *)k_pulse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
     return WFS_OK;
 }
