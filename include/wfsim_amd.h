@@ -160,7 +160,9 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
 int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t capacity_sets);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
-int wfs_set_debug(wfs_handle *h, int32_t keep_currents);
+/* flags: bit 0 keep f64 tile currents and finished rows for wfs_copy_currents / wfs_copy_rows; bit 1 send every tile
+ * to the dense pulse kernel (both kernels give the same bits; used by the parity tests) */
+int wfs_set_debug(wfs_handle *h, int32_t flags);
 int wfs_set_stream(wfs_handle *h, void *hip_stream);
 int wfs_synchronize(wfs_handle *h);
 /* HIP-event timing of the kernels of the last wfs_run: names (NUL separated) and milliseconds */

@@ -77,9 +77,9 @@ def chain_sets(d, config):
     return np.asarray(set_cluster, np.int32), np.asarray(set_tmin, np.int64)
 
 
-def replay_chain_on_engine(eng, d, config, debug=True):
+def replay_chain_on_engine(eng, d, config, debug=True, force_dense=False):
     set_cluster, set_tmin = chain_sets(d, config)
-    eng.set_debug(debug)
+    eng.set_debug(debug, force_dense)
     dpe = np.array(d['ph_dpe'], dtype=np.uint8)
     for k in np.where(d['call_has_gains'])[0]:        # pre-assigned gains: n_double_pe = 0 (pulse.py:105-106)
         dpe[d['call_ph_off'][k]:d['call_ph_off'][k + 1]] = 0

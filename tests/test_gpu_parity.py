@@ -23,10 +23,10 @@ def _nonempty_groups(eng):
     return g, keep
 
 
-def _check_chain(name, config):
+def _check_chain(name, config, force_dense=False):
     d = golden(name)
     eng = make_engine(config)
-    counts = replay_chain_on_engine(eng, d, config)
+    counts = replay_chain_on_engine(eng, d, config, force_dense=force_dense)
     # ---- pulses
     p = eng.pulses(currents=True)
     order = np.lexsort((p['channel'], p['set']))
@@ -81,9 +81,10 @@ def _check_chain(name, config):
     return d, eng
 
 
+@pytest.mark.parametrize('force_dense', [False, True])
 @pytest.mark.parametrize('name', ['chain_s1.npz', 'chain_s2.npz'])
-def test_chain_vs_reference_golden(name):
-    d, eng = _check_chain(name, xenonnt_test_config())
+def test_chain_vs_reference_golden(name, force_dense):
+    d, eng = _check_chain(name, xenonnt_test_config(), force_dense)
     # truth accumulators
     acc, ts = eng.truth()
     for j, f in enumerate(['n_photon', 'n_pe', 'n_photon_trigger', 'n_pe_trigger']):

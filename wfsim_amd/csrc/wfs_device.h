@@ -14,6 +14,7 @@ typedef unsigned int u32;
 
 #define WFS_MAX_CH 1024          // channels that fit the LDS histograms of the bucketing kernels
 #define WFS_MAX_AP 8
+#define WFS_DT 10                // sample_duration [ns]; wfs_create rejects anything else
 
 enum WfsSite : u32 {
     SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,

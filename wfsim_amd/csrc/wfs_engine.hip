@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -38,7 +39,7 @@ struct wfs_handle {
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, em_off;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax;
-    DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles;
+    DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, dense_tiles;
     DevBuf ph_t, ph_code, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
@@ -49,9 +50,10 @@ struct wfs_handle {
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
     i64 h_scal[16] = {0};
-    i64 n_active_tiles = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0;
+    i64 n_active_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0;
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
+    double h_templates[WFS_DT * 22] = {0};
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
@@ -160,7 +162,7 @@ int wfs_device_count(int *n) { return hipGetDeviceCount(n) == hipSuccess ? WFS_O
 int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
 {
     if (!cfg || !out) return WFS_E_INVALID;
-    if (cfg->n_tpc <= 0 || cfg->n_tpc > WFS_MAX_CH || cfg->dt != 10 || cfg->tlen <= 0 || cfg->tlen > 64) return WFS_E_INVALID;
+    if (cfg->n_tpc <= 0 || cfg->n_tpc > WFS_MAX_CH || cfg->dt != WFS_DT || cfg->tlen != 22) return WFS_E_INVALID;   // kernels are specialised for 10 ns samples and 22-tap templates
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WFS_E_HIP;      // fail loudly: no CPU fallback
     if (device < 0 || device >= ndev) return WFS_E_INVALID;
@@ -174,8 +176,10 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     h->scal.cap = 256;
     refresh_dev(h);
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
-    hipFuncSetAttribute((const void *)k_pulse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
     return WFS_OK;
 }
@@ -189,7 +193,7 @@ int wfs_destroy(wfs_handle *h)
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
-        &h->active_tiles, &h->ph_t, &h->ph_code, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
+        &h->active_tiles, &h->dense_tiles, &h->ph_t, &h->ph_code, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
@@ -241,6 +245,7 @@ int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, in
     }
     d.templates = h->t_templates.as<double>(); d.spe = h->t_spe.as<double>(); d.n_spe = n_spe; d.gains = h->t_gains.as<double>();
     d.thr_truth = h->t_thr_truth.as<double>(); d.thr_zle = h->t_thr_zle.as<i64>(); d.lum_x = h->t_lumx.as<double>(); d.lum_t = h->t_lumt.as<double>();
+    memcpy(h->h_templates, templates, sizeof(h->h_templates));
     for (int r = 0; r < c.dt; r++) {                       // pulse.py:32 current_max
         double m = templates[r * c.tlen];
         for (int k = 1; k < c.tlen; k++) m = std::max(m, templates[r * c.tlen + k]);
@@ -402,6 +407,11 @@ static int run_generation(wfs_handle *h)
     g.tile_tmax = h->tile_tmax.as<i32>(); g.ph_t = h->ph_t.as<i32>(); g.ph_code = h->ph_code.as<u32>();
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
+        // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart
+        auto gcd = [](u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } return x; };
+        u64 stride = std::max<u64>(1, nb / 1021) | 1;
+        while (gcd(stride, nb) != 1) stride += 2;
+        g.n_blocks = nb; g.block_stride = (i64)stride;
         { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true>), dim3(nb), dim3(GEN_TPB), 0, h->stream, d, g); }
         TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
         g.tile_off = h->tile_off.as<i64>();
@@ -433,7 +443,7 @@ int wfs_run(wfs_handle *h)
     TRY(fill64(h, h->row_lo, C * d.n_tpc, I64_MAX)); TRY(fill64(h, h->row_hi, C * d.n_tpc, I64_MIN));
     TRY(ensure(h, h->acc_len, (size_t)C * d.n_tpc * 4)); HIPCHK(hipMemsetAsync(h->acc_len.p, 0, (size_t)C * d.n_tpc * 4, h->stream));
     TRY(ensure(h, h->itv_cap, (size_t)C * d.row_slots * 4)); TRY(ensure(h, h->active_rows, (size_t)C * d.row_slots * 4));
-    TRY(ensure(h, h->active_tiles, (size_t)T * 4));
+    TRY(ensure(h, h->active_tiles, (size_t)T * 4)); TRY(ensure(h, h->dense_tiles, (size_t)T * 4));
     GeomArgs ga{};
     ga.n_sets = S; ga.n_tiles = T; ga.n_clusters = C;
     ga.tile_count = h->tile_count.as<i32>(); ga.tile_tmin = h->tile_tmin.as<i32>(); ga.tile_tmax = h->tile_tmax.as<i32>();
@@ -441,7 +451,7 @@ int wfs_run(wfs_handle *h)
     ga.cl_end = h->cl_end.as<i64>(); ga.cl_group = h->cl_group.as<i32>(); ga.grp_lo = h->grp_lo.as<i64>(); ga.grp_hi = h->grp_hi.as<i64>();
     ga.grp_left = h->grp_left.as<i64>(); ga.grp_right = h->grp_right.as<i64>(); ga.grp_ixrand = h->grp_ixrand.as<i64>(); ga.grp_gid = h->grp_gid.as<u32>();
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
-    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>();
+    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0;
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
     { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(64), 0, h->stream, d, ga); }
     { Timer t(h, "k_tile_rows"); hipLaunchKernelGGL(k_tile_rows, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
@@ -452,7 +462,10 @@ int wfs_run(wfs_handle *h)
     TRY(read_scal(h));
     if (h->h_scal[1] == 1) return h->fail(WFS_E_CAPACITY, "Pulse cache too long (digitise window of 10^6 samples or more, rawdata.py:219)");
     if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
-    h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_active_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5];
+    h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5];
+    h->n_dense_tiles = h->h_scal[11]; h->max_nb_dense = h->h_scal[12]; h->n_active_tiles = h->n_sparse_tiles + h->n_dense_tiles;
+    if (h->n_dense_tiles > 0)       // one work list: sparse tiles first, dense tiles behind them
+        HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_sparse_tiles, h->dense_tiles.p, (size_t)h->n_dense_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
     h->s_raw = h->h_scal[8]; h->n_itv_slots = h->h_scal[9];
     // deterministic processing order of the work lists (they were appended with atomics)
     // (results do not depend on it; sorting keeps profiles and debug dumps reproducible)
@@ -474,15 +487,13 @@ int wfs_run(wfs_handle *h)
     pa.ph_t = h->ph_t.as<i32>(); pa.ph_code = h->ph_code.as<u32>(); pa.ph_gain = h->ph_gain.as<double>();
     pa.cl_group = h->cl_group.as<i32>(); pa.row_lo = h->row_lo.as<i64>(); pa.acc_off = h->acc_off.as<i64>(); pa.raw = h->raw.as<i32>();
     pa.truth = h->truth.as<double>(); pa.tminmax = h->tminmax.as<i64>();
-    const int W_MAX = 1024;
-    int W = (int)std::min<i64>(std::max<i64>(h->max_nb, d.tlen + 1), W_MAX);
-    W = (W + 7) / 8 * 8;
-    pa.W = W;
+    { const char *ab = getenv("WFS_ABLATE"); pa.ablate = ab ? atoi(ab) : 0; }
     h->cur_total = 0;
-    if (h->keep_currents && h->n_active_tiles > 0) {
+    if ((h->keep_currents & 1) && h->n_active_tiles > 0) {
         // debug: tile lengths in work-list order -> offsets
         std::vector<i32> at((size_t)h->n_active_tiles), tmn((size_t)T), tmx((size_t)T);
         std::vector<i64> t0((size_t)S);
+        HIPCHK(hipStreamSynchronize(h->stream));
         HIPCHK(hipMemcpy(at.data(), h->active_tiles.p, at.size() * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tmn.data(), h->tile_tmin.p, tmn.size() * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(tmx.data(), h->tile_tmax.p, tmx.size() * 4, hipMemcpyDeviceToHost));
@@ -499,14 +510,34 @@ int wfs_run(wfs_handle *h)
         HIPCHK(hipStreamSynchronize(h->stream));
         pa.currents = h->currents.as<double>(); pa.cur_off = h->cur_off.as<i64>();
     }
-    if (h->n_active_tiles > 0) {
-        size_t lds = ((size_t)d.dt * W + (size_t)d.dt * d.tlen) * 8 + (size_t)W * 4 + 64;
+    if (h->n_sparse_tiles > 0) {
+        PulseArgs ps = pa;
+        ps.W = (int)((h->max_nb + 7) / 8 * 8); ps.NP = (int)((h->max_tile + 7) / 8 * 8);
+        const bool small = h->max_tile <= 256 && h->max_nb <= 256;
+        const int tpb = small ? 64 : 256;
+        size_t lds = (size_t)ps.NP * 12 + (size_t)8 * (tpb / 64) * 8 + ((size_t)d.dt * ps.W + 8) * 2 + 8 * 4 + std::max((size_t)d.dt * ps.W * 2, (size_t)8 * 260 * 8) + 16;
         lds = (lds + 15) / 16 * 16;
-        Timer t(h, "k_pulse");
-        if (h->max_tile <= 64 && W <= 64)
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<64>), dim3((unsigned)h->n_active_tiles), dim3(64), lds, h->stream, d, pa);
-        else
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256>), dim3((unsigned)h->n_active_tiles), dim3(256), lds, h->stream, d, pa);
+        Timer t(h, "k_pulse_sparse");
+        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_sparse<64>), dim3((unsigned)h->n_sparse_tiles), dim3(64), lds, h->stream, d, ps);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_sparse<256>), dim3((unsigned)h->n_sparse_tiles), dim3(256), lds, h->stream, d, ps);
+    }
+    if (h->n_dense_tiles > 0) {
+        PulseArgs pd = pa;
+        pd.active_tiles = h->active_tiles.as<i32>() + h->n_sparse_tiles;
+        if (pd.cur_off) pd.cur_off += h->n_sparse_tiles;
+        const int W_MAX = 1024;
+        int W = (int)std::min<i64>(std::max<i64>(h->max_nb_dense, d.tlen + 1), W_MAX);
+        W = (W + 7) / 8 * 8;
+        pd.W = W;
+        TemplateArg tp;
+        memcpy(tp.t, h->h_templates, sizeof(tp.t));
+        const bool small = W <= 128;
+        const int tpb = small ? 128 : 256;
+        size_t lds = (size_t)(W + 2 * DENSE_PAD) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
+        lds = (lds + 15) / 16 * 16;
+        Timer t(h, "k_pulse_dense");
+        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128>), dim3((unsigned)h->n_dense_tiles), dim3(128), lds, h->stream, d, pd, tp);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256>), dim3((unsigned)h->n_dense_tiles), dim3(256), lds, h->stream, d, pd, tp);
     }
 
     // ---- ZLE + records
@@ -520,7 +551,7 @@ int wfs_run(wfs_handle *h)
     za.itv_off = h->itv_off.as<i64>(); za.itv_left = h->itv_left.as<i64>(); za.itv_right = h->itv_right.as<i64>();
     za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = 110;
     h->row_dbg_total = 0;
-    if (h->keep_currents && h->n_active_rows > 0) {
+    if ((h->keep_currents & 1) && h->n_active_rows > 0) {
         std::vector<i32> ar((size_t)h->n_active_rows);
         std::vector<i64> lo((size_t)C * d.n_tpc), hi((size_t)C * d.n_tpc);
         HIPCHK(hipMemcpy(ar.data(), h->active_rows.p, ar.size() * 4, hipMemcpyDeviceToHost));
@@ -674,7 +705,7 @@ int wfs_copy_pulses(wfs_handle *h, int32_t *set, int32_t *channel, int64_t *left
 int wfs_copy_currents(wfs_handle *h, double *cur, int64_t cap)
 {
     if (!h || !h->ran) return WFS_E_STATE;
-    if (!h->keep_currents) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
+    if (!(h->keep_currents & 1)) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
     if (cap < h->cur_total) return h->fail(WFS_E_CAPACITY, "current buffer too small");
     if (h->cur_total) HIPCHK(hipMemcpy(cur, h->currents.p, (size_t)h->cur_total * 8, hipMemcpyDeviceToHost));
     return WFS_OK;
@@ -683,7 +714,7 @@ int wfs_copy_currents(wfs_handle *h, double *cur, int64_t cap)
 int wfs_copy_rows(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right, int64_t *data_off, int64_t cap)
 {
     if (!h || !h->ran) return WFS_E_STATE;
-    if (!h->keep_currents) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
+    if (!(h->keep_currents & 1)) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
     const WfsDev &d = h->dev;
     const i64 A = h->n_active_rows;
     if (cap < A) return h->fail(WFS_E_CAPACITY, "row buffer too small");

@@ -102,9 +102,15 @@ struct GeomArgs {
     i64 *grp_lo, *grp_hi, *grp_left, *grp_right, *grp_ixrand; u32 *grp_gid;
     i64 *row_lo, *row_hi;
     i32 *acc_len, *itv_cap; i32 *active_rows;
-    i64 *scal;           // [0] n_groups [1] error flag [2] n_active_rows [3] n_active_tiles [4] max start bins [5] max tile photons
-    i32 *active_tiles;
+    i64 *scal;           // [0] n_groups [1] error flag [2] n_active_rows [3] n sparse tiles [4] their max start bins
+                         // [5] their max photons [11] n dense tiles [12] their max start bins
+    i32 *active_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
+    i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
+    i32 force_dense;     // debug: send every tile to the dense kernel
 };
+
+#define SPARSE_MAX_PHOTONS 32      // tiles with a handful of photons (S1-like) go to the sorted-list kernel
+#define SPARSE_MAX_BINS 64
 
 __device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i32 tmax, i64 &left, i64 &right, i64 &bin0, i64 &nb)
 {
@@ -125,10 +131,16 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     i64 left, right, bin0, nb;
     tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
     atomicMax(&a.cl_end[a.set_cluster[set]], right * d.dt);
-    i64 k = atomicAdd((u64 *)&a.scal[3], 1ull);
-    a.active_tiles[k] = (i32)tile;
-    atomicMax(&a.scal[4], nb);
-    atomicMax(&a.scal[5], (i64)a.tile_count[tile]);
+    if (!a.force_dense && a.tile_count[tile] <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) {
+        i64 k = atomicAdd((u64 *)&a.scal[3], 1ull);
+        a.active_tiles[k] = (i32)tile;
+        atomicMax(&a.scal[4], nb);
+        atomicMax(&a.scal[5], (i64)a.tile_count[tile]);
+    } else {
+        i64 k = atomicAdd((u64 *)&a.scal[11], 1ull);
+        a.dense_tiles[k] = (i32)tile;
+        atomicMax(&a.scal[12], nb);
+    }
 }
 
 // one thread: digitise groups.  The cache is digitised before cluster k when
@@ -223,19 +235,27 @@ struct PulseArgs {
     double *truth;        // [n_sets][16]: 12 accumulators (pulse.py:259-271) + n, sum t, sum t^2, (min,max kept separately)
     i64 *tminmax;         // [n_sets][2] absolute min / max photon time
     double *currents; const i64 *cur_off;     // debug: f64 tile currents
-    i32 W;                // start bins per LDS window
+    i32 W;                // start bins per LDS window (dense) / bins capacity (sparse)
+    i32 NP;               // photon capacity of the sparse kernel's LDS list
+    i32 ablate;           // profiling only: bit0 no truth, bit1 no gather, bit2 no pass1, bit3 no place/merge, bit4 no raw atomics
 };
 
+#define DENSE_PPT 8        // photons per thread per batch held in registers
+#define DENSE_SPT 4        // samples per thread carried through the tap loop
+#define DENSE_PAD 21       // zero start bins on either side of the window: no bounds checks in the tap loop
+
+struct TemplateArg { double t[WFS_DT * 22]; };    // kernarg segment -> scalar loads, the taps live in SGPRs
+
 template <int TPB>
-__global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a)
+__global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateArg tp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int W = a.W, tlen = d.tlen, dt = d.dt;
-    double *H = (double *)smem;                 // [dt][W]
-    double *T = H + (size_t)dt * W;             // [dt][tlen] templates
-    u32 *occ = (u32 *)(T + dt * tlen);          // [W] photons per start bin
-    double *red = (double *)(occ + W);          // [8] block reduction scratch
-    const int tid = threadIdx.x;
+    constexpr int dt = WFS_DT, tlen = 22;
+    const int W = a.W;
+    double *H = (double *)smem;                           // [W + 2 * DENSE_PAD][dt]: merged gain per (start bin, ns remainder)
+    double *red = H + (size_t)(W + 2 * DENSE_PAD) * dt;   // [TPB / 64][8]
+    u32 *wsum = (u32 *)(red + 8 * (TPB / 64));
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
     const i64 tile = a.active_tiles[blockIdx.x];
     const i32 n = a.tile_count[tile];
@@ -252,100 +272,319 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a)
     const int mode = a.set_mode[set];
     const double G = d.gains[ch];
     const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? ch : 0) * 2001;
+    const double thr = d.thr_truth[ch];
+    const i64 rel0 = bin0 * dt - t0;                      // ns of the tile's first start bin relative to t0
 
-    for (int i = tid; i < dt * tlen; i += TPB) T[i] = d.templates[i];
-
-    // truth (pulse.py:229-271)
-    double acc_n = 0, acc_dpe = 0, acc_trig = 0, acc_trig_dpe = 0, acc_g = 0, acc_gtrig = 0, acc_t = 0, acc_t2 = 0;
     i32 n_dpe_tile = 0;
-    {                         // number of DPE photons of the tile (needed by the truth quirk pulse.py:255)
+    {                         // number of DPE photons of the tile (truth quirk pulse.py:255)
         i32 c = 0;
         for (i32 p = tid; p < n; p += TPB) c += (a.ph_code[off + p] >> 16) != 0;
         for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
-        i32 *sdpe = (i32 *)red;
-        if ((tid & 63) == 0) sdpe[tid >> 6] = c;
+        if (lane == 0) wsum[wid] = (u32)c;
         __syncthreads();
-        for (int w = 0; w < TPB / 64; w++) n_dpe_tile += sdpe[w];
-        __syncthreads();
+        for (int w = 0; w < TPB / 64; w++) n_dpe_tile += (i32)wsum[w];
     }
-    const double thr = d.thr_truth[ch];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2
 
     for (i64 w0 = 0; w0 < nb; w0 += W - (tlen - 1)) {
         const int Wc = (int)((nb - w0 < W) ? nb - w0 : W);
         const bool first = (w0 == 0), last = (w0 + Wc >= nb);
-        for (int i = tid; i < dt * W; i += TPB) H[i] = 0.0;
-        for (int i = tid; i < W; i += TPB) occ[i] = 0;
         __syncthreads();
-        for (i32 p = tid; p < n; p += TPB) {
-            i64 tabs = t0 + a.ph_t[off + p];
-            i64 bin = floordiv(tabs, (i64)dt) - bin0;
-            int r = (int)floormod(tabs, (i64)dt);
-            double gain;
-            bool is_dpe = false;
-            if (mode == 0) {
-                u32 code = a.ph_code[off + p];
-                u32 g1 = code & 0xffffu, g2 = code >> 16;
-                gain = G * spe_row[g1];                       // pulse.py:97-98
-                if (g2) { gain += G * spe_row[g2]; is_dpe = true; }   // pulse.py:101-103
-            } else {
-                gain = a.ph_gain[off + p];                    // pulse.py:107
-                is_dpe = (a.ph_code[off + p] >> 16) != 0;     // injected photons carry their DPE flag here
-            }
-            if (bin >= w0 && bin < w0 + Wc) {
-                atomicAdd(&H[r * W + (int)(bin - w0)], gain);
-                atomicAdd(&occ[(int)(bin - w0)], 1u);
-            }
-            if (first) {
-                bool above = gain * d.current_max[r] * d.c2a > thr;
-                acc_n += 1; acc_dpe += is_dpe; acc_g += gain;
-                if (above) { acc_trig += 1; acc_gtrig += gain; if (p < n_dpe_tile) acc_trig_dpe += 1; }
-                double tr = (double)a.ph_t[off + p];
-                acc_t += tr; acc_t2 += tr * tr;
-            }
-        }
+        for (int i = tid; i < (W + 2 * DENSE_PAD) * dt; i += TPB) H[i] = 0.0;
         __syncthreads();
-        const i64 s_lo = first ? 0 : w0 + lead + (tlen - 1);
-        const i64 s_hi = last ? L : w0 + Wc + lead;
-        for (i64 s = s_lo + tid; s < s_hi; s += TPB) {
-            double cur = 0.0;
-            for (int k = tlen - 1; k >= 0; k--) {
-                i64 j = s - lead - k;
-                if (j < w0 || j >= w0 + Wc) continue;
-                int jj = (int)(j - w0);
-                if (occ[jj] == 0) continue;
+        // ---- photons -> H, in register batches so that the global loads of a batch are all in flight together
+        for (i32 base = 0; base < n; base += TPB * DENSE_PPT) {
+            i32 ns[DENSE_PPT]; u32 code[DENSE_PPT]; double gain[DENSE_PPT];
 #pragma unroll
-                for (int r = 0; r < 10; r++) {
-                    double prod = T[r * tlen + k] * H[r * W + jj];
-                    cur = cur + prod;
+            for (int k = 0; k < DENSE_PPT; k++) {
+                const i32 p = base + tid + k * TPB;
+                const bool v = p < n;
+                ns[k] = v ? (i32)(a.ph_t[off + p] - rel0) : -1;
+                code[k] = v ? a.ph_code[off + p] : 0u;
+                gain[k] = (v && mode != 0) ? a.ph_gain[off + p] : 0.0;
+            }
+            if (mode == 0) {
+                double s1[DENSE_PPT], s2[DENSE_PPT];
+#pragma unroll
+                for (int k = 0; k < DENSE_PPT; k++) {
+                    s1[k] = 0; s2[k] = 0;
+                    if (base + k * TPB < n) { s1[k] = spe_row[code[k] & 0xffffu]; if (__any((code[k] >> 16) != 0)) s2[k] = spe_row[code[k] >> 16]; }
+                }
+#pragma unroll
+                for (int k = 0; k < DENSE_PPT; k++) {
+                    double gk = G * s1[k];                              // pulse.py:97-98
+                    if (code[k] >> 16) gk += G * s2[k];                 // pulse.py:101-103
+                    gain[k] = gk;
                 }
             }
-            if (a.currents) a.currents[a.cur_off[blockIdx.x] + s] = cur;
-            i64 adc = -(i64)rint(cur * d.c2a);                 // rawdata.py:236, np.around = round half to even
-            if (adc != 0) atomicAdd(&dst[s], (i32)adc);
+#pragma unroll
+            for (int k = 0; k < DENSE_PPT; k++) {
+                if (ns[k] < 0) continue;
+                const int bin = ns[k] / dt, r = ns[k] - bin * dt;
+                const i64 jw = bin - w0;
+                if (jw >= 0 && jw < Wc) atomicAdd(&H[((int)jw + DENSE_PAD) * dt + r], gain[k]);
+                if (first) {
+                    const bool above = gain[k] * d.current_max[r] * d.c2a > thr;
+                    const bool is_dpe = (code[k] >> 16) != 0;
+                    acc[0] += 1; acc[1] += is_dpe; acc[4] += gain[k];
+                    if (above) { acc[2] += 1; acc[5] += gain[k]; if (base + tid + k * TPB < n_dpe_tile) acc[3] += 1; }
+                    const double tr = (double)(ns[k] + rel0);
+                    acc[6] += tr; acc[7] += tr * tr;
+                }
+            }
         }
-        if (last) break;            // wave-uniform
         __syncthreads();
+        // ---- every sample gathers its tlen x dt possible contributions in ascending time (pulse.py:303-318)
+        const i64 s_lo = first ? 0 : w0 + lead + (tlen - 1);
+        const i64 s_hi = last ? L : w0 + Wc + lead;
+        // Tap loop outermost so that only the dt taps of one k are live in SGPRs; each thread carries DENSE_SPT samples
+        for (i64 sb = s_lo; sb < s_hi; sb += (i64)TPB * DENSE_SPT) {
+            double cur[DENSE_SPT]; const double *Hs[DENSE_SPT]; bool act[DENSE_SPT];
+#pragma unroll
+            for (int q = 0; q < DENSE_SPT; q++) {
+                const i64 s = sb + tid + (i64)q * TPB;
+                const i64 jhi = s - lead - w0;             // window-relative start bin of tap k = 0
+                act[q] = s < s_hi && jhi >= 0 && jhi - (tlen - 1) < Wc;
+                Hs[q] = H + ((act[q] ? (int)jhi : 0) + DENSE_PAD) * dt;
+                cur[q] = 0.0;
+            }
+#pragma unroll 1
+            for (int k = tlen - 1; k >= 0; k--) {
+                const double T0 = tp.t[0 * tlen + k], T1 = tp.t[1 * tlen + k], T2 = tp.t[2 * tlen + k], T3 = tp.t[3 * tlen + k],
+                             T4 = tp.t[4 * tlen + k], T5 = tp.t[5 * tlen + k], T6 = tp.t[6 * tlen + k], T7 = tp.t[7 * tlen + k],
+                             T8 = tp.t[8 * tlen + k], T9 = tp.t[9 * tlen + k];
+#pragma unroll
+                for (int q = 0; q < DENSE_SPT; q++) {
+                    const double2 *hp = (const double2 *)(Hs[q] - k * dt);
+                    const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
+                    double c = cur[q], prod;
+                    prod = T0 * h0.x; c = c + prod;  prod = T1 * h0.y; c = c + prod;
+                    prod = T2 * h1.x; c = c + prod;  prod = T3 * h1.y; c = c + prod;
+                    prod = T4 * h2.x; c = c + prod;  prod = T5 * h2.y; c = c + prod;
+                    prod = T6 * h3.x; c = c + prod;  prod = T7 * h3.y; c = c + prod;
+                    prod = T8 * h4.x; c = c + prod;  prod = T9 * h4.y; c = c + prod;
+                    cur[q] = c;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < DENSE_SPT; q++) {
+                const i64 s = sb + tid + (i64)q * TPB;
+                if (s >= s_hi) continue;
+                const double c = act[q] ? cur[q] : 0.0;
+                if (a.currents) a.currents[a.cur_off[blockIdx.x] + s] = c;
+                const i64 adc = -(i64)rint(c * d.c2a);             // rawdata.py:236, np.around = round half to even
+                if (adc != 0) atomicAdd(&dst[s], (i32)adc);
+            }
+        }
+        if (last) break;            // block-uniform
     }
 
     if (a.truth) {
-        double v[8] = {acc_n, acc_dpe, acc_trig, acc_trig_dpe, acc_g, acc_gtrig, acc_t, acc_t2};
-        for (int q = 0; q < 8; q++) {
-            double x = v[q];
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-            if ((tid & 63) == 0) red[tid >> 6] = x;
-            __syncthreads();
-            if (tid == 0) { double s = 0; for (int w = 0; w < TPB / 64; w++) s += red[w]; v[q] = s; }
-            __syncthreads();
-        }
-        if (tid == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+        __syncthreads();
+        if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
+        __syncthreads();
+        if (tid < 15) {
+            double v[8];
+            for (int q = 0; q < 8; q++) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + q]; v[q] = sum; }
             double *tr = a.truth + set * 16;
-            double vals[6] = {v[0], v[0] + v[1], v[2], v[2] + v[3], v[4] / G, v[5] / G};
-            bool bottom = ch >= d.n_top && ch <= d.last_bottom;
-            for (int f = 0; f < 6; f++) {
-                if (vals[f] != 0) { atomicAdd(&tr[f], vals[f]); if (bottom) atomicAdd(&tr[6 + f], vals[f]); }
+            const double vals[6] = {v[0], v[0] + v[1], v[2], v[2] + v[3], v[4] / G, v[5] / G};
+            const bool bottom = ch >= d.n_top && ch <= d.last_bottom;
+            if (tid < 6) { if (vals[tid] != 0) atomicAdd(&tr[tid], vals[tid]); }
+            else if (tid < 12) { if (bottom && vals[tid - 6] != 0) atomicAdd(&tr[tid], vals[tid - 6]); }
+            else if (tid == 12) { atomicAdd(&tr[12], v[0]); atomicMin(&a.tminmax[set * 2], t0 + a.tile_tmin[tile]); }
+            else if (tid == 13) { atomicAdd(&tr[13], v[6]); atomicMax(&a.tminmax[set * 2 + 1], t0 + a.tile_tmax[tile]); }
+            else atomicAdd(&tr[14], v[7]);
+        }
+    }
+}
+
+// Sparse form of the same computation, for tiles with few photons per start bin (every S1, S2s up to ~10^6 PE):
+// the photons are counting-sorted by their ns in LDS (one counter per ns of the tile, two u16 counters per dword),
+// photons of equal ns are merged (first of the run gets the summed gain, the others 0.0, which add nothing) --
+// i.e. the sorted, merged photon list add_current walks (pulse.py:297-318) -- and every sample gathers its
+// contributions from the contiguous slice of that list in ascending time.  Same bits as the dense kernel.
+#define SPARSE_PPT 16      // photons per thread held in registers: tile photons <= TPB * SPARSE_PPT
+
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tlen = d.tlen; constexpr int dt = WFS_DT;      // sample_duration is 10 ns (checked by wfs_create)
+    // T replicas: 8 copies of the templates, rows padded to tlen + 2 with a zero tap on either side, copies offset by
+    // 4 bank pairs so that the 64 lanes' data-dependent template reads spread over the LDS banks
+    constexpr int TROW = 24, TREP = 260, NREP = 8;       // requires tlen == 22
+    double *cg = (double *)smem;                         // [NP] merged gain of the sorted photons
+    double *red = cg + a.NP;                             // [TPB / 64][8]
+    i32 *ctoff = (i32 *)(red + 8 * (TPB / 64));          // [NP] r * TROW - start bin
+    unsigned short *boff = (unsigned short *)(ctoff + a.NP);           // [dt * W + 2] exclusive offsets
+    u32 *wsum = (u32 *)(boff + ((dt * a.W + 2 + 3) & ~3));             // [TPB / 64]
+    u32 *cnt = wsum + 8;                                 // [dt * W / 2] packed u16 pairs: photons per ns ...
+    double *Trep = (double *)cnt;                        // ... later reused for [NREP][TREP] template copies
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+
+    const i64 tile = a.active_tiles[blockIdx.x];
+    const i32 n = a.tile_count[tile];
+    const i64 off = a.tile_off[tile];
+    const i64 set = tile / d.n_tpc; const i32 ch = (i32)(tile - set * d.n_tpc);
+    const i64 t0 = a.set_t0[set];
+    i64 left, right, bin0, nb64;
+    tile_bounds(d, t0, a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb64);
+    const int nb = (int)nb64, nns = nb * dt;
+    const int L = (int)(right - left + 1);
+    const int lead = d.store_before + d.samples_before;
+    const int mode = a.set_mode[set];
+    const double G = d.gains[ch];
+    const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? ch : 0) * 2001;
+    const double thr = d.thr_truth[ch];
+    const i32 rel0 = (i32)(bin0 * dt - t0);              // ns of the tile's first start bin relative to t0
+
+    // ---- all photons of the tile into registers: independent loads, all in flight together
+    i32 ns[SPARSE_PPT]; u32 code[SPARSE_PPT]; double gain[SPARSE_PPT];
+    const int kmax = (n + TPB - 1) / TPB;                // block-uniform: registers beyond it stay empty
+#pragma unroll
+    for (int k = 0; k < SPARSE_PPT; k++) {
+        const i32 p = tid + k * TPB;
+        const bool v = p < n;
+        ns[k] = v ? a.ph_t[off + p] - rel0 : -1;
+        code[k] = v ? a.ph_code[off + p] : 0u;
+        gain[k] = (v && mode != 0) ? a.ph_gain[off + p] : 0.0;
+    }
+    if (mode == 0) {
+        double s1[SPARSE_PPT], s2[SPARSE_PPT];
+#pragma unroll
+        for (int k = 0; k < SPARSE_PPT; k++) {
+            s1[k] = 0; s2[k] = 0;
+            if (k < kmax) { s1[k] = spe_row[code[k] & 0xffffu]; if (__any((code[k] >> 16) != 0)) s2[k] = spe_row[code[k] >> 16]; }
+        }
+#pragma unroll
+        for (int k = 0; k < SPARSE_PPT; k++) {
+            double gk = G * s1[k];                                  // pulse.py:97-98
+            if (code[k] >> 16) gk += G * s2[k];                     // pulse.py:101-103
+            gain[k] = gk;
+        }
+    }
+    for (int i = tid; i < (nns + 1) / 2; i += TPB) cnt[i] = 0;
+    i32 n_dpe_tile = 0;
+    {                         // number of DPE photons of the tile (truth quirk pulse.py:255)
+        i32 c = 0;
+#pragma unroll
+        for (int k = 0; k < SPARSE_PPT; k++) c += (code[k] >> 16) != 0;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (lane == 0) wsum[wid] = (u32)c;
+        __syncthreads();
+        for (int w = 0; w < TPB / 64; w++) n_dpe_tile += (i32)wsum[w];
+    }
+    __syncthreads();
+
+    // ---- pass 1: photons per ns, truth accumulators (pulse.py:229-271)
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2
+#pragma unroll
+    for (int k = 0; k < SPARSE_PPT; k++) {
+        if (ns[k] < 0) continue;
+        atomicAdd(&cnt[ns[k] >> 1], 1u << ((ns[k] & 1) * 16));
+        const int r = ns[k] % dt;
+        const bool above = gain[k] * d.current_max[r] * d.c2a > thr;
+        const bool is_dpe = (code[k] >> 16) != 0;
+        acc[0] += 1; acc[1] += is_dpe; acc[4] += gain[k];
+        if (above) { acc[2] += 1; acc[5] += gain[k]; if (tid + k * TPB < n_dpe_tile) acc[3] += 1; }
+        const double tr = (double)(ns[k] + rel0);
+        acc[6] += tr; acc[7] += tr * tr;
+    }
+    __syncthreads();
+
+    // ---- exclusive scan of the per-ns counts -> boff[0, nns]
+    {
+        const int C = (nns + TPB - 1) / TPB;
+        const int j0 = tid * C;
+        u32 sum = 0;
+        for (int k = 0; k < C; k++) { int j = j0 + k; if (j < nns) sum += (cnt[j >> 1] >> ((j & 1) * 16)) & 0xffffu; }
+        u32 incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        u32 run = incl - sum;
+        for (int w = 0; w < wid; w++) run += wsum[w];
+        for (int k = 0; k < C; k++) { int j = j0 + k; if (j < nns) { boff[j] = (unsigned short)run; run += (cnt[j >> 1] >> ((j & 1) * 16)) & 0xffffu; } }
+        if (tid == TPB - 1) boff[nns] = (unsigned short)n;
+        __syncthreads();
+        for (int i = tid; i < (nns + 1) / 2; i += TPB) cnt[i] = 0;
+        __syncthreads();
+    }
+
+    // ---- pass 2: place in time order
+#pragma unroll
+    for (int k = 0; k < SPARSE_PPT; k++) {
+        if (ns[k] < 0) continue;
+        const u32 old = atomicAdd(&cnt[ns[k] >> 1], 1u << ((ns[k] & 1) * 16));
+        const u32 pos = boff[ns[k]] + ((old >> ((ns[k] & 1) * 16)) & 0xffffu);
+        cg[pos] = gain[k]; ctoff[pos] = (ns[k] % dt) * TROW - ns[k] / dt;
+    }
+    __syncthreads();
+
+    // ---- merge photons of equal ns (pulse.py:303-313)
+    for (int j = tid; j < nns; j += TPB) {
+        const int q0 = boff[j], m = (int)boff[j + 1] - q0;
+        if (m >= 2) {
+            double tot = cg[q0];
+            for (int q = 1; q < m; q++) { tot += cg[q0 + q]; cg[q0 + q] = 0.0; }
+            cg[q0] = tot;
+        }
+    }
+    __syncthreads();
+
+    // ---- templates into LDS (the counters are dead now)
+    for (int i = tid; i < NREP * TREP; i += TPB) {
+        const int c = i / TREP, x = i - c * TREP, r = x / TROW, kk = x - r * TROW;
+        Trep[i] = (x < dt * TROW && kk >= 1 && kk <= tlen) ? d.templates[r * tlen + kk - 1] : 0.0;
+    }
+    __syncthreads();
+
+    // ---- gather: two samples per lane; sample s <- photons of start bins [s - lead - (tlen-1), s - lead], ascending time
+    const i64 g = a.cl_group[a.set_cluster[set]];
+    const i64 ridx = g * d.n_tpc + ch;
+    i32 *dst = a.raw + a.acc_off[ridx] + (left - (a.row_lo[ridx] - d.tw));
+    for (int sa = 2 * tid; sa < L; sa += 2 * TPB) {
+        int jlo = sa - lead - (tlen - 1), jhi = sa + 1 - lead;
+        if (jlo < 0) jlo = 0;
+        if (jhi > nb - 1) jhi = nb - 1;
+        double cur0 = 0.0, cur1 = 0.0;
+        if (jhi >= jlo) {
+            const int q1 = boff[(jhi + 1) * dt];
+            // k + 1 of sample sa for a photon in start bin j is (sa - lead - j) + 1 in [0, tlen]; sample sa + 1 reads the next tap
+            const double *Ts = Trep + (lane & (NREP - 1)) * TREP + (sa - lead + 1);
+            int q = boff[jlo * dt];
+            for (; q + 2 <= q1; q += 2) {
+                const i32 o0 = ctoff[q], o1 = ctoff[q + 1];
+                const double g0 = cg[q], g1 = cg[q + 1];
+                const double a0 = Ts[o0] * g0, b0 = Ts[o0 + 1] * g0, a1 = Ts[o1] * g1, b1 = Ts[o1 + 1] * g1;
+                cur0 = cur0 + a0; cur1 = cur1 + b0; cur0 = cur0 + a1; cur1 = cur1 + b1;
             }
-            atomicAdd(&tr[12], v[0]); atomicAdd(&tr[13], v[6]); atomicAdd(&tr[14], v[7]);
-            atomicMin(&a.tminmax[set * 2], t0 + a.tile_tmin[tile]); atomicMax(&a.tminmax[set * 2 + 1], t0 + a.tile_tmax[tile]);
+            if (q < q1) { const i32 o0 = ctoff[q]; const double g0 = cg[q]; const double a0 = Ts[o0] * g0, b0 = Ts[o0 + 1] * g0; cur0 = cur0 + a0; cur1 = cur1 + b0; }
+        }
+        if (a.currents) { a.currents[a.cur_off[blockIdx.x] + sa] = cur0; if (sa + 1 < L) a.currents[a.cur_off[blockIdx.x] + sa + 1] = cur1; }
+        const i64 adc0 = -(i64)rint(cur0 * d.c2a), adc1 = -(i64)rint(cur1 * d.c2a);      // rawdata.py:236
+        if (adc0 != 0) atomicAdd(&dst[sa], (i32)adc0);
+        if (adc1 != 0 && sa + 1 < L) atomicAdd(&dst[sa + 1], (i32)adc1);
+    }
+
+    if (a.truth) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+        if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
+        __syncthreads();
+        if (tid < 15) {
+            double v[8];
+            for (int q = 0; q < 8; q++) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + q]; v[q] = sum; }
+            double *tr = a.truth + set * 16;
+            const double vals[6] = {v[0], v[0] + v[1], v[2], v[2] + v[3], v[4] / G, v[5] / G};
+            const bool bottom = ch >= d.n_top && ch <= d.last_bottom;
+            if (tid < 6) { if (vals[tid] != 0) atomicAdd(&tr[tid], vals[tid]); }
+            else if (tid < 12) { if (bottom && vals[tid - 6] != 0) atomicAdd(&tr[tid], vals[tid - 6]); }
+            else if (tid == 12) { atomicAdd(&tr[12], v[0]); atomicMin(&a.tminmax[set * 2], t0 + a.tile_tmin[tile]); }
+            else if (tid == 13) { atomicAdd(&tr[13], v[6]); atomicMax(&a.tminmax[set * 2 + 1], t0 + a.tile_tmax[tile]); }
+            else atomicAdd(&tr[14], v[7]);
         }
     }
 }
@@ -496,6 +735,7 @@ struct GenArgs {
     i64 *em_time; i32 *em_nph; i32 *em_ins; const i64 *em_ph_off;
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
     i32 *ph_t; u32 *ph_code;
+    i64 n_blocks, block_stride;   // photon blocks are visited in a strided order: see k_photons
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
     i64 *scal;
@@ -660,7 +900,10 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
     __shared__ i32 hmin[WFS_MAX_CH], hmax[WFS_MAX_CH];
     __shared__ i64 s_elo, s_ehi;
     const int tid = threadIdx.x;
-    const i64 p0 = (i64)blockIdx.x * GEN_BLOCK;
+    // Blocks that run at the same time should work on different instructions: consecutive photon blocks belong to
+    // the same instruction and would all add into the same n_tpc tile counters (same-address atomic contention).
+    const i64 vb = (i64)(((u64)blockIdx.x * (u64)a.block_stride) % (u64)a.n_blocks);
+    const i64 p0 = vb * GEN_BLOCK;
     const i64 p1 = (p0 + GEN_BLOCK < a.n_photons) ? p0 + GEN_BLOCK : a.n_photons;
     if (tid < 2) {
         i64 p = tid == 0 ? p0 : p1 - 1;

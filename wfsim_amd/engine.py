@@ -151,8 +151,8 @@ class Engine:
         self.counts = {n: getattr(c, n) for n, _ in WfsCounts._fields_}
         return self.counts
 
-    def set_debug(self, on=True):
-        self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(on))))
+    def set_debug(self, on=True, force_dense=False):
+        self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(bool(on)) | (2 if force_dense else 0))))
 
     def set_profiling(self, on=True):
         self._check(self.lib.wfs_set_profiling(self._h, C.c_int32(int(on))))
