@@ -27,10 +27,9 @@ __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        u32 hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        u32 hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        u32 n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
-        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        const u64 p0 = (u64)0xD2511F53u * c0, p1 = (u64)0xCD9E8D57u * c2;     // one v_mad_u64_u32 each
+        const u32 n0 = (u32)(p1 >> 32) ^ c1 ^ k0, n2 = (u32)(p0 >> 32) ^ c3 ^ k1;
+        c0 = n0; c1 = (u32)p1; c2 = n2; c3 = (u32)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return u32x4{c0, c1, c2, c3};
@@ -46,6 +45,14 @@ __device__ __forceinline__ u64 bern_threshold(double p)
     if (!(p > 0)) return 0;
     if (p >= 1) return 4294967296ull;
     return (u64)(p * 4294967296.0);
+}
+
+// first variate only (the second one is not needed when its spread is zero: (i64)(0.0 + 0 * z) == 0)
+__device__ __forceinline__ double box_muller_z0(u32x4 w)
+{
+    double u1 = u53(w.x, w.y), u2 = u53(w.z, w.w);
+    double r = sqrt(-2.0 * log(1.0 - u1));
+    return r * cos(6.283185307179586476925286766559 * u2);
 }
 
 __device__ __forceinline__ void box_muller(u32x4 w, double &z0, double &z1)
@@ -72,6 +79,8 @@ struct WfsDev {
     double trap_time, gain_spread, pmt_ap_modifier, pmt_ap_t_modifier, rext;
     u32 k0, k1;
     double current_max[10];
+    double lum_x0, lum_xl, lum_f0, lum_fl;     // first / last point of the luminescence table
+    i32 need_z1_s1, need_z1_s2;                // second Box-Muller variate needed (non-zero spread)
     // tables
     const double *templates, *spe, *gains, *thr_truth, *lum_x, *lum_t;
     const i64 *thr_zle;

@@ -32,13 +32,13 @@ struct wfs_handle {
     bool tables_set = false, batch_loaded = false, injected = false, ran = false;
     int keep_currents = 0, profiling = 0;
     // tables
-    DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise;
+    DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise, t_lumtab, t_lumguide;
     ApElem ap[WFS_MAX_AP];
     // instructions
     i64 n_ins = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, em_off;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
-    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax;
+    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, dense_tiles;
     DevBuf ph_t, ph_code, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
@@ -145,6 +145,8 @@ void refresh_dev(wfs_handle *h)
     d.s2_time_spread = c.s2_time_spread; d.trap_time = c.trap_time; d.gain_spread = c.gain_spread;
     d.pmt_ap_modifier = c.pmt_ap_modifier; d.pmt_ap_t_modifier = c.pmt_ap_t_modifier; d.rext = c.rext;
     d.k0 = (u32)c.seed; d.k1 = (u32)(c.seed >> 32);
+    d.need_z1_s1 = (c.s1_simple && c.s1_decay_spread != 0.0) ? 1 : 0;
+    d.need_z1_s2 = (c.s2_time_model == 1 && c.s2_time_spread != 0.0) ? 1 : 0;
     // HE rows are only materialised when they can differ from a flat baseline: a non-zero int(factor)
     // (rawdata.py:242) or noise columns for the HE channels
     d.enable_noise = (c.enable_noise && d.noise != nullptr) ? 1 : 0;
@@ -178,6 +180,8 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
     hipFuncSetAttribute((const void *)k_pulse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photons<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photons<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
@@ -189,7 +193,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -237,6 +241,24 @@ int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, in
     if (lum_x && lum_t && n_lum >= 2) {
         TRY(upload(h, h->t_lumx, lum_x, sizeof(double) * n_lum)); TRY(upload(h, h->t_lumt, lum_t, sizeof(double) * n_lum));
         d.n_lum = n_lum;
+        // segment table + guide for interp_lum_guided
+        std::vector<LumEntry> tab((size_t)n_lum - 1);
+        for (int i = 0; i + 1 < n_lum; i++) {
+            if (!(lum_x[i + 1] >= lum_x[i])) return h->fail(WFS_E_INVALID, "luminescence table abscissa must be non-decreasing");
+            tab[i] = LumEntry{lum_x[i], lum_x[i + 1], lum_t[i], (lum_t[i + 1] - lum_t[i]) / (lum_x[i + 1] - lum_x[i])};
+        }
+        std::vector<unsigned short> guide(LUM_G + 2);
+        if (n_lum - 1 > 65535) return h->fail(WFS_E_CAPACITY, "luminescence table too long");
+        int lo = 0;
+        for (int c = 0; c <= LUM_G + 1; c++) {                 // largest lo with x[lo] <= c / LUM_G
+            const double x = (double)c / LUM_G;
+            while (lo + 1 < n_lum - 1 && lum_x[lo + 1] <= x) lo++;
+            guide[c] = (unsigned short)lo;
+        }
+        TRY(upload(h, h->t_lumtab, tab.data(), tab.size() * sizeof(LumEntry)));
+        TRY(upload(h, h->t_lumguide, guide.data(), guide.size() * 2));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        d.lum_x0 = lum_x[0]; d.lum_xl = lum_x[n_lum - 1]; d.lum_f0 = lum_t[0]; d.lum_fl = lum_t[n_lum - 1];
     }
     d.noise = nullptr; d.noise_len = 0; d.noise_channels = 0;
     if (noise && noise_len > 0 && noise_channels > 0) {
@@ -405,6 +427,9 @@ static int run_generation(wfs_handle *h)
     TRY(ensure(h, h->ph_t, (size_t)P * 4)); TRY(ensure(h, h->ph_code, (size_t)P * 4));
     g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
     g.tile_tmax = h->tile_tmax.as<i32>(); g.ph_t = h->ph_t.as<i32>(); g.ph_code = h->ph_code.as<u32>();
+    g.lum_tab = h->t_lumtab.as<LumEntry>(); g.lum_guide = h->t_lumguide.as<unsigned short>();
+    const size_t gen_lds_count = (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 32;
+    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + (size_t)3 * GEN_BLOCK * 4 + 32;
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart
@@ -412,10 +437,13 @@ static int run_generation(wfs_handle *h)
         u64 stride = std::max<u64>(1, nb / 1021) | 1;
         while (gcd(stride, nb) != 1) stride += 2;
         g.n_blocks = nb; g.block_stride = (i64)stride;
-        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true>), dim3(nb), dim3(GEN_TPB), 0, h->stream, d, g); }
+        TRY(ensure(h, h->blk_e, (size_t)nb * 16));
+        g.blk_e = h->blk_e.as<i64>();
+        { Timer t(h, "k_block_emitters"); hipLaunchKernelGGL(k_block_emitters, dim3(nblocks(nb, 256)), dim3(256), 0, h->stream, g); }
+        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true>), dim3(nb), dim3(GEN_TPB), gen_lds_count, h->stream, d, g); }
         TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
         g.tile_off = h->tile_off.as<i64>();
-        { Timer t(h, "k_photons_fill"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false>), dim3(nb), dim3(GEN_TPB), 0, h->stream, d, g); }
+        { Timer t(h, "k_photons_fill"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false>), dim3(nb), dim3(GEN_TPB), gen_lds, h->stream, d, g); }
     } else {
         TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
     }

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         // Tap loop outermost so that only the dt taps of one k are live in SGPRs; each thread carries DENSE_SPT samples
         for (i64 sb = s_lo; sb < s_hi; sb += (i64)TPB * DENSE_SPT) {
             double cur[DENSE_SPT]; const double *Hs[DENSE_SPT]; bool act[DENSE_SPT];
+            const int nq = (int)((s_hi - sb + TPB - 1) / TPB);      // block-uniform number of live sample slots
 #pragma unroll
             for (int q = 0; q < DENSE_SPT; q++) {
                 const i64 s = sb + tid + (i64)q * TPB;
@@ -348,6 +349,9 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 Hs[q] = H + ((act[q] ? (int)jhi : 0) + DENSE_PAD) * dt;
                 cur[q] = 0.0;
             }
+            bool wact[DENSE_SPT];
+#pragma unroll
+            for (int q = 0; q < DENSE_SPT; q++) wact[q] = __any(act[q]);
 #pragma unroll 1
             for (int k = tlen - 1; k >= 0; k--) {
                 const double T0 = tp.t[0 * tlen + k], T1 = tp.t[1 * tlen + k], T2 = tp.t[2 * tlen + k], T3 = tp.t[3 * tlen + k],
@@ -355,6 +359,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                              T8 = tp.t[8 * tlen + k], T9 = tp.t[9 * tlen + k];
 #pragma unroll
                 for (int q = 0; q < DENSE_SPT; q++) {
+                    if (q >= nq || !wact[q]) continue;       // wave-uniform
                     const double2 *hp = (const double2 *)(Hs[q] - k * dt);
                     const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
                     double c = cur[q], prod;
@@ -736,6 +741,8 @@ struct GenArgs {
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
     i32 *ph_t; u32 *ph_code;
     i64 n_blocks, block_stride;   // photon blocks are visited in a strided order: see k_photons
+    const struct LumEntry *lum_tab; const unsigned short *lum_guide;
+    i64 *blk_e;                   // [n_blocks][2] first / last emitter of every photon block
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
     i64 *scal;
@@ -864,128 +871,181 @@ __device__ __forceinline__ double interp_lum(const WfsDev &d, double u)
 #define GEN_TPB 256
 #define GEN_PPT 8
 #define GEN_BLOCK (GEN_TPB * GEN_PPT)
-#define GEN_WIN 2304               // emitter offsets staged in LDS per block
+#define GEN_WIN 512                // emitter offsets staged in LDS per block
+#define CDF_G 512                  // guide cells of the per-block channel search
+#define LUM_G 4096                 // guide cells of the luminescence table
 
-struct PhotonId { i64 e; i32 ins; u32 j, m; };
+struct LumEntry { double x0, x1, f0, slope; };     // np.interp segment [x0, x1): f0 + slope * (u - x0)
 
-// Photon -> (emitter, instruction, item).  The block's emitter window is staged in LDS when it fits.
-__device__ __forceinline__ PhotonId photon_identify(const GenArgs &a, i64 p, const i64 *win, i64 e_lo, int nwin)
+// np.interp(u, xp, fp) of s2.py:338 with the segment found through a guide table instead of a bisection:
+// same segment, same arithmetic (slope = (fp[i+1] - fp[i]) / (xp[i+1] - xp[i]), slope * (u - xp[i]) + fp[i])
+__device__ __forceinline__ double interp_lum_guided(const WfsDev &d, const LumEntry *tab, const unsigned short *guide, double u)
 {
-    PhotonId id;
-    i64 e;
-    if (nwin > 0) {
-        int lo = 0, hi = nwin;                       // win[k] = em_ph_off[e_lo + k]; find last k with win[k] <= p
-        while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win[mid] <= p) lo = mid; else hi = mid; }
-        e = e_lo + lo;
-        id.m = (u32)(p - win[lo]);
-    } else {
+    if (u <= d.lum_x0) return d.lum_f0;
+    if (u >= d.lum_xl) return d.lum_fl;
+    int lo = guide[(int)(u * LUM_G)];
+    LumEntry e = tab[lo];
+    while (u >= e.x1) { lo++; e = tab[lo]; }
+    if (e.x0 == u) return e.f0;
+    return e.slope * (u - e.x0) + e.f0;
+}
+
+// first and last emitter of every photon block: one bisection per thread, all in flight together (a block doing
+// its own two bisections serially costs ~20 us of dependent HBM latency before its 2048 photons can start)
+__global__ void k_block_emitters(GenArgs a)
+{
+    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.n_blocks) return;
+    const i64 p0 = b * GEN_BLOCK;
+    const i64 p1 = (p0 + GEN_BLOCK < a.n_photons) ? p0 + GEN_BLOCK : a.n_photons;
+    for (int w = 0; w < 2; w++) {
+        const i64 p = w == 0 ? p0 : p1 - 1;
         i64 lo = 0, hi = a.n_emitters;
         while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
-        e = lo;
-        id.m = (u32)(p - a.em_ph_off[lo]);
+        a.blk_e[2 * b + w] = lo;
     }
-    id.e = e; id.ins = a.em_ins[e]; id.j = (u32)(e - a.em_off[id.ins]);
-    return id;
 }
 
 // Pass A (COUNT = true): channel of every photon -> photons per tile.
 // Pass B (COUNT = false): the whole photon (s1.py:180-194 / s2.py:504-557 timing terms, pulse.py:53-56 transit time,
 // pulse.py:76-79 double-PE, pulse.py:97-103 SPE gain indices) written straight into its tile's bucket.
+// A block works on GEN_BLOCK consecutive photons.  When they all belong to one instruction (the normal case for an
+// S2) the instruction's scalars, its channel CDF (+ a guide table), the emitter window and the tile offsets are
+// staged in LDS once and the per-tile ranks are taken from an LDS histogram; photons are staged in LDS and written
+// out after the block has reserved its ranges with one global atomic per non-empty tile.
 template <bool COUNT>
 __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
 {
-    __shared__ i64 win[GEN_WIN];
-    __shared__ i32 hist[WFS_MAX_CH];
-    __shared__ i32 hbase[WFS_MAX_CH];
-    __shared__ i32 hmin[WFS_MAX_CH], hmax[WFS_MAX_CH];
-    __shared__ i64 s_elo, s_ehi;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nch = d.n_tpc;
+    // arrays used by both passes first; the count pass launches with only that much LDS
+    i64 *win = (i64 *)smem;                                  // [GEN_WIN] em_ph_off of the block's emitters
+    double *cdf = (double *)(win + GEN_WIN);                 // [nch]
+    i32 *hist = (i32 *)(cdf + nch);                          // [nch]
+    unsigned short *cguide = (unsigned short *)(hist + nch);           // [CDF_G + 8]
+    i64 *wtime = (i64 *)(cguide + CDF_G + 8);                // [GEN_WIN] emitter times
+    i64 *hbase = wtime + GEN_WIN;                            // [nch] tile_off + reserved range
+    i32 *hmin = (i32 *)(hbase + nch), *hmax = hmin + nch;    // [nch] each
+    i32 *st_t = hmax + nch;                                  // [GEN_BLOCK] staged photons
+    u32 *st_code = (u32 *)(st_t + GEN_BLOCK);                // [GEN_BLOCK]
+    u32 *st_cr = st_code + GEN_BLOCK;                        // [GEN_BLOCK] channel << 16 | rank
     const int tid = threadIdx.x;
-    // Blocks that run at the same time should work on different instructions: consecutive photon blocks belong to
-    // the same instruction and would all add into the same n_tpc tile counters (same-address atomic contention).
+    // Blocks that run at the same time work on different instructions (strided order): consecutive photon blocks
+    // belong to one instruction and would otherwise all add into the same n_tpc tile counters.
     const i64 vb = (i64)(((u64)blockIdx.x * (u64)a.block_stride) % (u64)a.n_blocks);
     const i64 p0 = vb * GEN_BLOCK;
     const i64 p1 = (p0 + GEN_BLOCK < a.n_photons) ? p0 + GEN_BLOCK : a.n_photons;
-    if (tid < 2) {
-        i64 p = tid == 0 ? p0 : p1 - 1;
-        i64 lo = 0, hi = a.n_emitters;
-        while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
-        if (tid == 0) s_elo = lo; else s_ehi = lo;
-    }
-    for (int c = tid; c < d.n_tpc; c += GEN_TPB) { hist[c] = 0; hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; }
-    __syncthreads();
-    const i64 e_lo = s_elo, e_hi = s_ehi;
+    for (int c = tid; c < nch; c += GEN_TPB) { hist[c] = 0; if (!COUNT) { hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; } }
+    const i64 e_lo = a.blk_e[2 * vb], e_hi = a.blk_e[2 * vb + 1];
     const int nwin = (e_hi - e_lo + 2 <= GEN_WIN) ? (int)(e_hi - e_lo + 2) : 0;
-    for (int k = tid; k < nwin; k += GEN_TPB) win[k] = a.em_ph_off[e_lo + k];
-    const bool single = a.em_ins[e_lo] == a.em_ins[e_hi];       // all photons of the block in one pulse set
+    for (int k = tid; k < nwin; k += GEN_TPB) {
+        win[k] = a.em_ph_off[e_lo + k];
+        if (!COUNT) wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] : 0;
+    }
+    const i32 ins_lo = a.em_ins[e_lo];
+    const bool single = nwin > 0 && ins_lo == a.em_ins[e_hi];      // all photons of the block in one pulse set
+    // block-uniform instruction data (used when single)
+    const u32 u_gid = a.ins_gid[ins_lo]; const i64 u_emoff = a.em_off[ins_lo]; const i64 u_time = a.ins_time[ins_lo];
+    const bool u_s2 = a.ins_type[ins_lo] == 2;
+    const i64 tbase = (i64)ins_lo * nch;
+    if (single) {
+        const double *row = a.cdf_table + (size_t)a.ins_cdfrow[ins_lo] * nch;
+        for (int c = tid; c < nch; c += GEN_TPB) cdf[c] = row[c];
+    }
     __syncthreads();
+    if (single) {
+        // guide[c] = first channel whose cumulative probability exceeds c / CDF_G (searchsorted side='right')
+        for (int c = tid; c <= CDF_G; c += GEN_TPB) {
+            const double x = (double)c / CDF_G;
+            int lo = 0, hi = nch;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (x < cdf[mid]) hi = mid; else lo = mid + 1; }
+            cguide[c] = (unsigned short)(lo < nch ? lo : nch - 1);
+        }
+        __syncthreads();
+    }
 
-    i32 my_ch[GEN_PPT], my_rank[GEN_PPT], my_t[GEN_PPT]; u32 my_code[GEN_PPT]; i32 my_ins[GEN_PPT];
-#pragma unroll
+#pragma unroll 2
     for (int q = 0; q < GEN_PPT; q++) {
         const i64 p = p0 + (i64)q * GEN_TPB + tid;
-        my_ch[q] = -1;
-        if (p >= p1) continue;
-        const PhotonId id = photon_identify(a, p, win, e_lo, nwin);
-        const i32 ins = id.ins; const u32 gid = a.ins_gid[ins];
-        const double *cdf = a.cdf_table + (size_t)a.ins_cdfrow[ins] * d.n_tpc;
-        const u32x4 A = philox4x32_10(id.j, gid, id.m, SITE_PH_A, d.k0, d.k1);
-        const int ch = channel_from_cdf(cdf, d.n_tpc, u53(A.x, A.y));
-        my_ch[q] = ch; my_ins[q] = ins;
+        if (p >= p1) break;
+        // ---- photon -> (emitter e, instruction, emitter index j in the instruction, item m)
+        i64 e; u32 m; i64 etime = 0;
+        if (nwin > 0) {
+            int lo = 0, hi = nwin;                           // last k with win[k] <= p
+            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win[mid] <= p) lo = mid; else hi = mid; }
+            e = e_lo + lo; m = (u32)(p - win[lo]);
+            if (!COUNT) etime = wtime[lo];
+        } else {
+            i64 lo = 0, hi = a.n_emitters;
+            while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
+            e = lo; m = (u32)(p - a.em_ph_off[lo]);
+            if (!COUNT) etime = a.em_time[lo];
+        }
+        i32 ins; u32 gid, j; i64 itime; bool is_s2; int ch;
+        if (single) { ins = ins_lo; gid = u_gid; j = (u32)(e - u_emoff); itime = u_time; is_s2 = u_s2; }
+        else { ins = a.em_ins[e]; gid = a.ins_gid[ins]; j = (u32)(e - a.em_off[ins]); itime = a.ins_time[ins]; is_s2 = a.ins_type[ins] == 2; }
+        const u32x4 A = philox4x32_10(j, gid, m, SITE_PH_A, d.k0, d.k1);
+        const double uc = u53(A.x, A.y);
+        if (single) {
+            ch = cguide[(int)(uc * CDF_G)];
+            while (ch < nch - 1 && uc >= cdf[ch]) ch++;
+        } else {
+            ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * nch, nch, uc);
+        }
         if (COUNT) {
             if (single) atomicAdd(&hist[ch], 1);
-            else atomicAdd(&a.tile_count[(i64)ins * d.n_tpc + ch], 1);
+            else atomicAdd(&a.tile_count[(i64)ins * nch + ch], 1);
             continue;
         }
-        const bool is_s2 = a.ins_type[ins] == 2;
-        const u32x4 B = philox4x32_10(id.j, gid, id.m, SITE_PH_B, d.k0, d.k1);
-        const u32x4 C = philox4x32_10(id.j, gid, id.m, SITE_PH_C, d.k0, d.k1);
+        const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
+        const u32x4 C = philox4x32_10(j, gid, m, SITE_PH_C, d.k0, d.k1);
         const bool is_dpe = (u64)A.z < bern_threshold(d.p_dpe);
         const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-        double z_tts, z_spread;
-        box_muller(C, z_tts, z_spread);
+        double z_tts, z_spread = 0.0;
+        if (is_s2 ? d.need_z1_s2 : d.need_z1_s1) box_muller(C, z_tts, z_spread);
+        else z_tts = box_muller_z0(C);
         const double e1 = -log(1.0 - u53(B.x, B.y));
-        i64 t = a.em_time[id.e] - a.ins_time[ins];          // relative to the instruction time
+        i64 t = etime - itime;                              // relative to the instruction time
         if (!is_s2) {
             if (d.s1_simple) { t += (i64)(e1 * d.s1_decay_time); t += (i64)(0.0 + d.s1_decay_spread * z_spread); }
         } else {
-            const u32x4 D = philox4x32_10(id.j, gid, id.m, SITE_PH_D, d.k0, d.k1);
-            t += (i64)interp_lum(d, u53(D.x, D.y));
+            const u32x4 D = philox4x32_10(j, gid, m, SITE_PH_D, d.k0, d.k1);
+            t += (i64)interp_lum_guided(d, a.lum_tab, a.lum_guide, u53(D.x, D.y));
             const double delay = ((u64)B.w < bern_threshold(d.sf_gas)) ? d.t1_gas : d.t3_gas;
             t += (i64)(e1 * delay);
             if (d.s2_time_model == 1) t += (i64)(0.0 + d.s2_time_spread * z_spread);
         }
         t += (i64)(d.tts_mean + d.tts_sigma * z_tts);
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-        my_t[q] = (i32)t; my_code[q] = g1 | (is_dpe ? (g2 << 16) : 0u);
+        const u32 code = g1 | (is_dpe ? (g2 << 16) : 0u);
         if (single) {
-            my_rank[q] = atomicAdd(&hist[ch], 1);
+            const u32 rank = (u32)atomicAdd(&hist[ch], 1);
             atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
+            const int slot = q * GEN_TPB + tid;
+            st_t[slot] = (i32)t; st_code[slot] = code; st_cr[slot] = ((u32)ch << 16) | rank;
         } else {
-            const i64 tile = (i64)ins * d.n_tpc + ch;
-            my_rank[q] = atomicAdd(&a.tile_cursor[tile], 1);
+            const i64 tile = (i64)ins * nch + ch;
+            const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
+            a.ph_t[pos] = (i32)t; a.ph_code[pos] = code;
         }
     }
+    if (!single) return;
     __syncthreads();
-    if (single) {
-        const i64 tbase = (i64)a.em_ins[e_lo] * d.n_tpc;
-        for (int c = tid; c < d.n_tpc; c += GEN_TPB) {
-            const i32 h = hist[c];
-            if (h == 0) continue;
-            if (COUNT) atomicAdd(&a.tile_count[tbase + c], h);
-            else {
-                hbase[c] = atomicAdd(&a.tile_cursor[tbase + c], h);
-                atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
-            }
+    for (int c = tid; c < nch; c += GEN_TPB) {
+        const i32 hc = hist[c];
+        if (hc == 0) continue;
+        if (COUNT) atomicAdd(&a.tile_count[tbase + c], hc);
+        else {
+            hbase[c] = a.tile_off[tbase + c] + atomicAdd(&a.tile_cursor[tbase + c], hc);
+            atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
         }
     }
     if (COUNT) return;
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < GEN_PPT; q++) {
-        if (my_ch[q] < 0) continue;
-        const i64 tile = (i64)my_ins[q] * d.n_tpc + my_ch[q];
-        const i64 pos = a.tile_off[tile] + (single ? hbase[my_ch[q]] : 0) + my_rank[q];
-        a.ph_t[pos] = my_t[q]; a.ph_code[pos] = my_code[q];
+    for (int slot = tid; slot < (int)(p1 - p0); slot += GEN_TPB) {
+        const u32 cr = st_cr[slot];
+        const i64 pos = hbase[cr >> 16] + (cr & 0xffffu);
+        a.ph_t[pos] = st_t[slot]; a.ph_code[pos] = st_code[slot];
     }
 }
