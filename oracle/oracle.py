@@ -169,6 +169,11 @@ class Oracle:
         lib().orc_pack_records(self._s, C.c_int64(samples_per_record), _p(out), C.c_int64(n))
         return out
 
+    def sample_term(self, kind, n, p0=0.0, p1=0.0):
+        out = np.zeros(n, dtype=np.int64)
+        lib().orc_sample_term(self._s, C.c_int(kind), C.c_int64(n), C.c_double(p0), C.c_double(p1), _p(out))
+        return out
+
     def sample_poisson(self, lam, n):
         out = np.zeros(n, dtype=np.int64)
         lib().orc_sample_poisson(self._s, C.c_double(lam), C.c_int64(n), _p(out))

@@ -699,5 +699,30 @@ GETTER(zl_digit, zl_digit, i64) GETTER(zl_ch, zl_ch, i32) GETTER(zl_left, zl_lef
 GETTER(zl_data_off, zl_data_off, i64) GETTER(zl_data, zl_data, i32) GETTER(truth, truth, double)
 i64 orc_n_pe(const orc_session *s) { return s->n_pe_total; }
 
-/* stand-alone samplers used by the distribution tests */
+/* stand-alone samplers used by the distribution tests: the individual random terms exactly as one_photon() and
+ * orc_s2() compute them (same draw sites), so each can be compared with a histogram of the reference's own draws.
+ * kind: 0 luminescence delay (s2.py:338), 1 gas singlet/triplet delay (pulse.py:339-341), 2 transit time (pulse.py:54-56),
+ *       3 S1 'simple' delay (s1.py:193-194), 4 electron arrival (s2.py:280-282, p0 = drift mean, p1 = drift spread) */
+void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 *out)
+{
+    const orc_config *c = &s->c;
+    for (i64 i = 0; i < n; i++) {
+        u32 A[4], B[4], C[4], D[4]; u32 em = (u32)(i >> 20), item = (u32)(i & 0xfffff), gid = 777u;
+        draw(s, em, gid, item, SITE_PH_B, B); draw(s, em, gid, item, SITE_PH_C, C); draw(s, em, gid, item, SITE_PH_D, D);
+        double z0, z1; box_muller(C, &z0, &z1);
+        double e1 = -log(1.0 - u53(B[0], B[1]));
+        if (kind == 0) out[i] = (i64)interp_lum(s, u53(D[0], D[1]));
+        else if (kind == 1) out[i] = (i64)(e1 * (((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas));
+        else if (kind == 2) out[i] = (i64)(c->tts_mean + c->tts_sigma * z0);
+        else if (kind == 3) out[i] = (i64)(e1 * c->s1_decay_time) + (i64)(0.0 + c->s1_decay_spread * z1);
+        else {
+            draw(s, (u32)i, gid, 0, SITE_EL_A, A); draw(s, (u32)i, gid, 0, SITE_EL_B, B);
+            box_muller(B, &z0, &z1);
+            double timing = -log(1.0 - u53(A[0], A[1])) * c->trap_time;
+            timing += p0 + p1 * z0;
+            out[i] = (i64)timing;
+        }
+    }
+}
+
 void orc_sample_poisson(orc_session *s, double lam, i64 n, i64 *out) { for (i64 i = 0; i < n; i++) out[i] = poisson_draw(s, (u32)i, 12345u, lam); }
