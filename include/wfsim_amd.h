@@ -119,6 +119,10 @@ int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, 
                      const int64_t *set_off, const int64_t *t, const int16_t *ch, const double *gain,
                      const uint8_t *dpe);
 
+/* State carried across batches: RawData.last_pulse_end_time (rawdata.py:55, 188-190), the running maximum of the end of
+ * every pulse simulated so far, which decides whether the first clusters of this batch open a new digitise window. */
+int wfs_set_window_carry(wfs_handle *h, int32_t has_pulse, int64_t last_pulse_end_time);
+
 /* ---- run: replaces RawData.__call__ for the loaded batch (rawdata.py:38-157) ---------------------------- */
 /* Stages: S1/S2 photon generation (s1.py:60-114, s2.py:73-136) [skipped after wfs_load_photons] ->
  * Pulse.__call__ + add_current (pulse.py:39-144, 276-318) -> digitize_pulse_cache (rawdata.py:204-272) ->
@@ -140,6 +144,8 @@ int wfs_copy_records_dev(wfs_handle *h, void *dst_dev, int64_t capacity_records)
 const void *wfs_records_dev_ptr(wfs_handle *h);
 /* digitise windows: rawdata.left / rawdata.right and the first record of each window (strax_interface.py:394-399) */
 int wfs_copy_groups(wfs_handle *h, int64_t *left, int64_t *right, int64_t *first_record, int64_t *ix_rand);
+/* digitise window of every time-cluster of the batch (rawdata.py:96-98 decided on the GPU) */
+int wfs_copy_cluster_groups(wfs_handle *h, int32_t *group, int64_t capacity_clusters);
 /* ZLE intervals (channel, left, right) and their samples: the tuples RawData.__call__ yields (rawdata.py:311) */
 int wfs_copy_intervals(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right,
                        int64_t *data_off, int64_t capacity);
@@ -158,6 +164,8 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
 /* truth accumulators per pulse set: 12 f64 (n_photon n_pe n_photon_trigger n_pe_trigger raw_area raw_area_trigger,
  * then the same for the bottom array; pulse.py:229-271) + photon time stats (n, mean, min, max, std; rawdata.py:325-332) */
 int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t capacity_sets);
+/* electron arrival-time statistics per instruction (n, mean, min, max, std; rawdata.py:325-332; NaN when there are none) */
+int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t capacity_instructions);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 /* flags: bit 0 keep f64 tile currents and finished rows for wfs_copy_currents / wfs_copy_rows; bit 1 send every tile

@@ -1,0 +1,122 @@
+"""ChunkRawRecords host logic with a stand-in generator (the reference's own injection point
+``rawdata_generator=``, strax_interface.py:355-359).  CPU only: no GPU, no oracle."""
+import numpy as np
+import pytest
+
+from wfsim_amd.config import xenonnt_test_config
+from wfsim_amd.dtypes import instruction_dtype, raw_record_dtype
+from wfsim_amd.strax_interface import ChunkRawRecords
+
+
+class FakeRawData:
+    """Yields deterministic pulses: one digitise window per instruction, a few channels each."""
+
+    def __init__(self, config, with_windows=False):
+        self.config = config
+        self.source_finished = False
+        self.left = self.right = 0
+        if with_windows:
+            self.iter_windows = self._iter_windows
+
+    def _windows(self, instructions):
+        rng = np.random.default_rng(0)
+        for k, t in enumerate(np.sort(instructions['time'])):
+            left = int(t // 10) - 50
+            left -= left % 2
+            pulses = []
+            for ch in sorted(rng.choice(494, size=rng.integers(1, 6), replace=False)):
+                a = left + 2 * int(rng.integers(0, 20))
+                n = 2 * int(rng.integers(30, 200)) + 1
+                pulses.append((int(ch), a, a + n - 1, rng.integers(15000, 16000, n)))
+            right = max(p[2] for p in pulses) + 50
+            yield k, left, right, pulses
+
+    def __call__(self, instructions, truth_buffer=None, **kw):
+        ws = list(self._windows(instructions))
+        for k, left, right, pulses in ws:
+            self.left, self.right = left, right
+            if k == len(ws) - 1:
+                self.source_finished = True
+            for p in pulses:
+                yield p
+        self.source_finished = True
+
+    def _iter_windows(self, instructions, truth_buffer=None, **kw):
+        dtype = np.dtype(raw_record_dtype())
+        ws = list(self._windows(instructions))
+        for k, left, right, pulses in ws:
+            recs = []
+            for ch, a, b, data in pulses:
+                n = b - a + 1
+                need = -(-n // 110)
+                r = np.zeros(need, dtype=dtype)
+                r['channel'], r['dt'], r['pulse_length'] = ch, 10, n
+                r['record_i'] = np.arange(need)
+                r['time'] = 10 * (a + 110 * np.arange(need))
+                r['length'] = [min(n, 110 * (i + 1)) - 110 * i for i in range(need)]
+                r['data'] = np.pad(data, (0, need * 110 - n)).reshape(-1, 110)
+                recs.append(r)
+            self.left, self.right = left, right
+            if k == len(ws) - 1:
+                self.source_finished = True
+            yield dict(left=left, right=right, records=np.concatenate(recs))
+        self.source_finished = True
+
+
+def _instructions(times):
+    ins = np.zeros(len(times), dtype=instruction_dtype)
+    ins['time'] = times
+    ins['type'] = 1
+    ins['amp'] = 100
+    return ins
+
+
+def _run(times, chunk_size, with_windows):
+    cfg = xenonnt_test_config(chunk_size=chunk_size)
+    ChunkRawRecords.record_buffer_length = 20000
+    sim = ChunkRawRecords(cfg, rawdata_generator=FakeRawData, with_windows=with_windows)
+    chunks = []
+    for res in sim(_instructions(times)):
+        chunks.append((sim.chunk_time_pre, sim.chunk_time, res['raw_records'].copy()))
+    assert sim.source_finished()
+    return chunks
+
+
+TIMES = [np.array([1_000_000 * (i + 1) for i in range(40)], dtype=np.int64),
+         np.array([5_000_000, 5_300_000, 2_000_000_000, 2_000_400_000, 9_000_000_000], dtype=np.int64)]
+
+
+@pytest.mark.parametrize('times', TIMES)
+@pytest.mark.parametrize('chunk_size', [0.005, 1])
+def test_window_path_equals_pulse_path(times, chunk_size):
+    a = _run(times, chunk_size, False)
+    b = _run(times, chunk_size, True)
+    assert len(a) == len(b)
+    for (p0, t0, r0), (p1, t1, r1) in zip(a, b):
+        assert (p0, t0) == (p1, t1)
+        assert r0.tobytes() == r1.tobytes()
+
+
+@pytest.mark.parametrize('times', TIMES)
+def test_chunks_are_sorted_complete_and_disjoint(times):
+    chunks = _run(times, 0.005, True)
+    allrec = np.concatenate([c[2] for c in chunks])
+    one = _run(times, 1000, True)
+    ref = np.concatenate([c[2] for c in one])
+    assert len(allrec) == len(ref)
+    assert np.array_equal(np.sort(allrec, order=['time', 'channel']), np.sort(ref, order=['time', 'channel']))
+    last_end = None
+    for pre, end, rec in chunks:
+        if len(rec):
+            assert np.all(np.diff(rec['time']) >= 0)
+            assert rec['time'].min() >= pre and rec['time'].max() <= end
+        if last_end is not None:
+            assert pre == last_end
+        last_end = end
+
+
+def test_empty_instructions():
+    cfg = xenonnt_test_config()
+    sim = ChunkRawRecords(cfg, rawdata_generator=FakeRawData)
+    assert list(sim(_instructions([]))) == []
+    assert sim.source_finished()

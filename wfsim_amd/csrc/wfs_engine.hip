@@ -31,6 +31,7 @@ struct wfs_handle {
     WfsDev dev;
     bool tables_set = false, batch_loaded = false, injected = false, ran = false;
     int keep_currents = 0, profiling = 0;
+    int carry_has = 0; i64 carry_runmax = 0;
     // tables
     DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise, t_lumtab, t_lumguide;
     ApElem ap[WFS_MAX_AP];
@@ -220,6 +221,14 @@ int wfs_set_stream(wfs_handle *h, void *s)
 }
 
 int wfs_synchronize(wfs_handle *h) { if (!h) return WFS_E_INVALID; HIPCHK(hipStreamSynchronize(h->stream)); return WFS_OK; }
+int wfs_set_window_carry(wfs_handle *h, int32_t has, int64_t t) { if (!h) return WFS_E_INVALID; h->carry_has = has; h->carry_runmax = t; return WFS_OK; }
+int wfs_copy_cluster_groups(wfs_handle *h, int32_t *group, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (cap < h->n_clusters) return h->fail(WFS_E_CAPACITY, "cluster buffer too small");
+    HIPCHK(hipMemcpy(group, h->cl_group.p, (size_t)h->n_clusters * 4, hipMemcpyDeviceToHost));
+    return WFS_OK;
+}
 int wfs_set_debug(wfs_handle *h, int32_t keep) { if (!h) return WFS_E_INVALID; h->keep_currents = keep; return WFS_OK; }
 int wfs_set_profiling(wfs_handle *h, int32_t on) { if (!h) return WFS_E_INVALID; h->profiling = on; return WFS_OK; }
 
@@ -464,29 +473,30 @@ int wfs_run(wfs_handle *h)
     else TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
 
     // ---- geometry: tiles -> clusters -> groups -> rows
+    const i64 CG = C + 1;         // group slots
     TRY(fill64(h, h->cl_end, C, I64_MIN)); TRY(ensure(h, h->cl_group, (size_t)C * 4));
-    TRY(fill64(h, h->grp_lo, C, I64_MAX)); TRY(fill64(h, h->grp_hi, C, I64_MIN));
-    TRY(ensure(h, h->grp_left, (size_t)C * 8)); TRY(ensure(h, h->grp_right, (size_t)C * 8)); TRY(ensure(h, h->grp_ixrand, (size_t)C * 8));
-    TRY(ensure(h, h->grp_gid, (size_t)C * 4)); HIPCHK(hipMemsetAsync(h->grp_gid.p, 0xff, (size_t)C * 4, h->stream));
-    TRY(fill64(h, h->row_lo, C * d.n_tpc, I64_MAX)); TRY(fill64(h, h->row_hi, C * d.n_tpc, I64_MIN));
-    TRY(ensure(h, h->acc_len, (size_t)C * d.n_tpc * 4)); HIPCHK(hipMemsetAsync(h->acc_len.p, 0, (size_t)C * d.n_tpc * 4, h->stream));
-    TRY(ensure(h, h->itv_cap, (size_t)C * d.row_slots * 4)); TRY(ensure(h, h->active_rows, (size_t)C * d.row_slots * 4));
+    TRY(fill64(h, h->grp_lo, CG, I64_MAX)); TRY(fill64(h, h->grp_hi, CG, I64_MIN));
+    TRY(ensure(h, h->grp_left, (size_t)CG * 8)); TRY(ensure(h, h->grp_right, (size_t)CG * 8)); TRY(ensure(h, h->grp_ixrand, (size_t)CG * 8));
+    TRY(ensure(h, h->grp_gid, (size_t)CG * 4)); HIPCHK(hipMemsetAsync(h->grp_gid.p, 0xff, (size_t)CG * 4, h->stream));
+    TRY(fill64(h, h->row_lo, CG * d.n_tpc, I64_MAX)); TRY(fill64(h, h->row_hi, CG * d.n_tpc, I64_MIN));
+    TRY(ensure(h, h->acc_len, (size_t)CG * d.n_tpc * 4)); HIPCHK(hipMemsetAsync(h->acc_len.p, 0, (size_t)CG * d.n_tpc * 4, h->stream));
+    TRY(ensure(h, h->itv_cap, (size_t)CG * d.row_slots * 4)); TRY(ensure(h, h->active_rows, (size_t)CG * d.row_slots * 4));
     TRY(ensure(h, h->active_tiles, (size_t)T * 4)); TRY(ensure(h, h->dense_tiles, (size_t)T * 4));
     GeomArgs ga{};
-    ga.n_sets = S; ga.n_tiles = T; ga.n_clusters = C;
+    ga.n_sets = S; ga.n_tiles = T; ga.n_clusters = C; ga.n_gslots = CG;
     ga.tile_count = h->tile_count.as<i32>(); ga.tile_tmin = h->tile_tmin.as<i32>(); ga.tile_tmax = h->tile_tmax.as<i32>();
     ga.set_cluster = h->set_cluster.as<i32>(); ga.set_t0 = h->set_t0.as<i64>(); ga.cl_tmin = h->cl_tmin.as<i64>(); ga.cl_gid = h->cl_gid.as<u32>();
     ga.cl_end = h->cl_end.as<i64>(); ga.cl_group = h->cl_group.as<i32>(); ga.grp_lo = h->grp_lo.as<i64>(); ga.grp_hi = h->grp_hi.as<i64>();
     ga.grp_left = h->grp_left.as<i64>(); ga.grp_right = h->grp_right.as<i64>(); ga.grp_ixrand = h->grp_ixrand.as<i64>(); ga.grp_gid = h->grp_gid.as<u32>();
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
-    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0;
+    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
     { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(64), 0, h->stream, d, ga); }
     { Timer t(h, "k_tile_rows"); hipLaunchKernelGGL(k_tile_rows, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
-    { Timer t(h, "k_group_final"); hipLaunchKernelGGL(k_group_final, dim3(nblocks(C, 256)), dim3(256), 0, h->stream, d, ga); }
-    { Timer t(h, "k_row_len"); hipLaunchKernelGGL(k_row_len, dim3(nblocks(C * d.row_slots, 256)), dim3(256), 0, h->stream, d, ga); }
-    TRY(scan(h, h->acc_len.as<i32>(), C * d.n_tpc, h->acc_off, 8));
-    TRY(scan(h, h->itv_cap.as<i32>(), C * d.row_slots, h->itv_off, 9));
+    { Timer t(h, "k_group_final"); hipLaunchKernelGGL(k_group_final, dim3(nblocks(CG, 256)), dim3(256), 0, h->stream, d, ga); }
+    { Timer t(h, "k_row_len"); hipLaunchKernelGGL(k_row_len, dim3(nblocks(CG * d.row_slots, 256)), dim3(256), 0, h->stream, d, ga); }
+    TRY(scan(h, h->acc_len.as<i32>(), CG * d.n_tpc, h->acc_off, 8));
+    TRY(scan(h, h->itv_cap.as<i32>(), CG * d.row_slots, h->itv_off, 9));
     TRY(read_scal(h));
     if (h->h_scal[1] == 1) return h->fail(WFS_E_CAPACITY, "Pulse cache too long (digitise window of 10^6 samples or more, rawdata.py:219)");
     if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
@@ -569,7 +579,7 @@ int wfs_run(wfs_handle *h)
     }
 
     // ---- ZLE + records
-    const i64 RS = C * d.row_slots;
+    const i64 RS = CG * d.row_slots;
     TRY(ensure(h, h->itv_left, (size_t)h->n_itv_slots * 8)); TRY(ensure(h, h->itv_right, (size_t)h->n_itv_slots * 8));
     TRY(ensure(h, h->itv_n, (size_t)RS * 4)); TRY(ensure(h, h->row_nrec, (size_t)RS * 4));
     HIPCHK(hipMemsetAsync(h->itv_n.p, 0, (size_t)RS * 4, h->stream)); HIPCHK(hipMemsetAsync(h->row_nrec.p, 0, (size_t)RS * 4, h->stream));
@@ -581,7 +591,7 @@ int wfs_run(wfs_handle *h)
     h->row_dbg_total = 0;
     if ((h->keep_currents & 1) && h->n_active_rows > 0) {
         std::vector<i32> ar((size_t)h->n_active_rows);
-        std::vector<i64> lo((size_t)C * d.n_tpc), hi((size_t)C * d.n_tpc);
+        std::vector<i64> lo((size_t)CG * d.n_tpc), hi((size_t)CG * d.n_tpc);
         HIPCHK(hipMemcpy(ar.data(), h->active_rows.p, ar.size() * 4, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(lo.data(), h->row_lo.p, lo.size() * 8, hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(hi.data(), h->row_hi.p, hi.size() * 8, hipMemcpyDeviceToHost));
@@ -622,7 +632,7 @@ int wfs_get_counts(wfs_handle *h, wfs_counts *out)
     HIPCHK(hipMemcpy(tr.data(), h->truth.p, tr.size() * 8, hipMemcpyDeviceToHost));
     double npe = 0; for (i64 s = 0; s < h->n_sets; s++) npe += tr[s * 16 + 1];
     c.n_pe = (i64)(npe + 0.5);
-    std::vector<i32> n((size_t)h->n_clusters * h->dev.row_slots);
+    std::vector<i32> n((size_t)(h->n_clusters + 1) * h->dev.row_slots);
     HIPCHK(hipMemcpy(n.data(), h->itv_n.p, n.size() * 4, hipMemcpyDeviceToHost));
     i64 ni = 0; for (i32 v : n) ni += v;
     c.n_intervals = ni;
@@ -656,7 +666,7 @@ int wfs_copy_groups(wfs_handle *h, int64_t *left, int64_t *right, int64_t *first
     if (right) HIPCHK(hipMemcpy(right, h->grp_right.p, (size_t)G * 8, hipMemcpyDeviceToHost));
     if (ix_rand) HIPCHK(hipMemcpy(ix_rand, h->grp_ixrand.p, (size_t)G * 8, hipMemcpyDeviceToHost));
     if (first_record) {
-        std::vector<i64> ro((size_t)h->n_clusters * h->dev.row_slots + 1);
+        std::vector<i64> ro((size_t)(h->n_clusters + 1) * h->dev.row_slots + 1);
         HIPCHK(hipMemcpy(ro.data(), h->rec_off.p, ro.size() * 8, hipMemcpyDeviceToHost));
         for (i64 g = 0; g < G; g++) first_record[g] = ro[(size_t)g * h->dev.row_slots];
     }
@@ -667,7 +677,7 @@ int wfs_copy_intervals(wfs_handle *h, int32_t *group, int32_t *channel, int64_t 
 {
     if (!h || !h->ran) return WFS_E_STATE;
     const WfsDev &d = h->dev;
-    const i64 RS = h->n_clusters * d.row_slots;
+    const i64 RS = (h->n_clusters + 1) * d.row_slots;
     std::vector<i32> n((size_t)RS); std::vector<i64> off((size_t)RS + 1), L((size_t)h->n_itv_slots), R((size_t)h->n_itv_slots);
     HIPCHK(hipMemcpy(n.data(), h->itv_n.p, n.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(off.data(), h->itv_off.p, off.size() * 8, hipMemcpyDeviceToHost));
@@ -746,7 +756,7 @@ int wfs_copy_rows(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left
     const WfsDev &d = h->dev;
     const i64 A = h->n_active_rows;
     if (cap < A) return h->fail(WFS_E_CAPACITY, "row buffer too small");
-    std::vector<i32> ar((size_t)A); std::vector<i64> lo((size_t)h->n_clusters * d.n_tpc), hi(lo.size()), gl((size_t)h->n_groups);
+    std::vector<i32> ar((size_t)A); std::vector<i64> lo((size_t)(h->n_clusters + 1) * d.n_tpc), hi(lo.size()), gl((size_t)h->n_groups);
     if (A) HIPCHK(hipMemcpy(ar.data(), h->active_rows.p, ar.size() * 4, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(lo.data(), h->row_lo.p, lo.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(hi.data(), h->row_hi.p, hi.size() * 8, hipMemcpyDeviceToHost));
@@ -815,6 +825,26 @@ int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t cap)
         tstat5[s * 5 + 0] = n; tstat5[s * 5 + 1] = n > 0 ? (double)t0[s] + mean : NAN;
         tstat5[s * 5 + 2] = n > 0 ? (double)mm[2 * s] : NAN; tstat5[s * 5 + 3] = n > 0 ? (double)mm[2 * s + 1] : NAN;
         tstat5[s * 5 + 4] = n > 0 ? sqrt(var > 0 ? var : 0) : NAN;
+    }
+    return WFS_OK;
+}
+
+int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    const i64 N = h->n_ins;
+    if (cap < N) return h->fail(WFS_E_CAPACITY, "electron stats buffer too small");
+    if (N == 0) return WFS_OK;
+    std::vector<double> st((size_t)N * 4); std::vector<i64> mm((size_t)N * 2), t0((size_t)N);
+    HIPCHK(hipMemcpy(st.data(), h->el_stat.p, st.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(mm.data(), h->el_minmax.p, mm.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(t0.data(), h->ins_time.p, t0.size() * 8, hipMemcpyDeviceToHost));
+    for (i64 i = 0; i < N; i++) {
+        double n = st[i * 4], s1 = st[i * 4 + 1], s2 = st[i * 4 + 2];
+        double mean = n > 0 ? s1 / n : 0, var = n > 0 ? s2 / n - mean * mean : 0;
+        estat5[i * 5 + 0] = n; estat5[i * 5 + 1] = n > 0 ? (double)t0[i] + mean : NAN;
+        estat5[i * 5 + 2] = n > 0 ? (double)mm[2 * i] : NAN; estat5[i * 5 + 3] = n > 0 ? (double)mm[2 * i + 1] : NAN;
+        estat5[i * 5 + 4] = n > 0 ? sqrt(var > 0 ? var : 0) : NAN;
     }
     return WFS_OK;
 }

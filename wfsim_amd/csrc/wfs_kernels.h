@@ -95,6 +95,7 @@ __global__ __launch_bounds__(SCAN_TPB) void k_scan_down(const i32 *__restrict__ 
 // ------------------------------------------------------------------------------------------------ geometry
 struct GeomArgs {
     i64 n_sets, n_tiles, n_clusters;
+    i64 n_gslots;        // capacity of the per-group arrays: n_clusters + 1 (a carried-in window can open group 1 at cluster 0)
     const i32 *tile_count, *tile_tmin, *tile_tmax;
     const i32 *set_cluster; const i64 *set_t0;
     const i64 *cl_tmin; const u32 *cl_gid;
@@ -107,6 +108,7 @@ struct GeomArgs {
     i32 *active_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
     i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
     i32 force_dense;     // debug: send every tile to the dense kernel
+    i32 init_has; i64 init_runmax;      // last_pulse_end_time carried in from earlier batches
 };
 
 #define SPARSE_MAX_PHOTONS 32      // tiles with a handful of photons (S1-like) go to the sorted-list kernel
@@ -149,7 +151,7 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
 __global__ void k_groups(WfsDev d, GeomArgs a)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    bool has = false; i64 runmax = 0; i32 g = 0;
+    bool has = a.init_has != 0; i64 runmax = a.init_runmax; i32 g = 0;
     for (i64 k = 0; k < a.n_clusters; k++) {
         if (has && (double)(a.cl_tmin[k] - runmax) > d.rext) g++;
         a.cl_group[k] = g;
@@ -197,7 +199,7 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
 {
     i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 n = a.scal[0] * d.row_slots;
-    if (idx >= a.n_clusters * d.row_slots) return;
+    if (idx >= a.n_gslots * d.row_slots) return;
     i32 cap = 0;
     if (idx < n) {
         i64 g = idx / d.row_slots; i32 slot = (i32)(idx - g * d.row_slots);

@@ -1,0 +1,204 @@
+"""GPU-backed ``RawData``: same call protocol as the reference's event scheduler + digitiser.
+
+Reference: /root/reference/wfsim/core/rawdata.py:24-157 (``RawData.__call__``), :313-375 (``get_truth``).
+
+    rd = RawData(config)
+    for channel, left, right, data in rd(instructions, truth_buffer=tb):
+        rd.left, rd.right            # sample bounds of the digitise window being emitted
+    rd.source_finished
+
+The reference simulates one time-cluster at a time in Python; here whole batches of clusters go through the HIP
+pipeline (photon generation -> Pulse -> digitise -> ZLE -> record packing, wfsim_amd/csrc) and the generator
+replays the results window by window, so a consumer written against the reference (``ChunkRawRecords``) cannot tell
+the difference.  ``iter_windows`` is the same stream at window granularity with the records already packed on the
+GPU (what the in-repo ``ChunkRawRecords`` uses).
+"""
+import logging
+
+import numpy as np
+
+from .dtypes import raw_record_dtype
+from .engine import Engine
+from .physics import instruction_params
+from .resource import Resource
+from .scheduler import schedule, processing_order
+
+log = logging.getLogger('wfsim_amd.core')
+
+PULSE_TYPE_NAMES = ('RESERVED', 's1', 's2', 'unknown', 'pi_el', 'pmt_ap', 'pe_el')
+
+
+class RawData:
+    #: upper bound on the expected photons of one GPU batch (sizes the HBM arenas; 288 GB HBM3E leaves room for ~10^10)
+    max_batch_quanta = 2_000_000_000
+
+    def __init__(self, config, device=0, resource=None, seed=None):
+        self.config = config
+        if config.get('enable_electron_afterpulses', False) or config.get('enable_gate_afterpulses', False):
+            raise NotImplementedError('electron afterpulses (secondary instructions, afterpulse.py:14-139) are not on '
+                                      'the MI355X path yet (SURVEY.md 8f.1)')
+        self.resource = resource if resource is not None else Resource(config)
+        self.engine = Engine(config, self.resource, device=device, seed=seed)
+        self.source_finished = False
+        self.left = self.right = 0
+
+    @staticmethod
+    def symtype(ptype):
+        return PULSE_TYPE_NAMES[ptype]
+
+    # ------------------------------------------------------------------------------------------
+    def _batch_end(self, start, est_csum, cluster, scale=1):
+        """End of the batch starting at sorted index ``start``: whole clusters, bounded by expected quanta."""
+        n = len(cluster)
+        limit = (est_csum[start - 1] if start else 0) + self.max_batch_quanta * scale
+        stop = int(np.searchsorted(est_csum, limit, side='right'))
+        stop = max(stop, start + 1)
+        while stop < n and cluster[stop] == cluster[stop - 1]:      # never cut a cluster
+            stop += 1
+        return stop
+
+    def iter_windows(self, instructions, truth_buffer=None, **kwargs):
+        """Yields dict(left, right, records) per digitise window, in time order.  ``records`` are packed strax
+        raw_records in the order the reference yields pulses (channel ascending, interval ascending)."""
+        if truth_buffer is None:
+            truth_buffer = []
+        self.source_finished = False
+        if len(instructions) == 0:
+            self.source_finished = True
+            return
+        cfg = self.config
+        dt, tw, rext = cfg['sample_duration'], cfg['trigger_window'], cfg['right_raw_extension']
+        order, key, cluster = schedule(instructions, cfg)
+        s_ins = instructions[order]
+        n = len(s_ins)
+        self.instruction_event_number = np.min(instructions['event_number'])
+        # crude photon estimate per instruction: only used to bound a batch
+        est_csum = np.cumsum(np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15,
+                                      s_ins['amp'] * float(cfg.get('s2_secondary_sc_gain', 30))))
+        a, scale = 0, 1
+        has_pulse, runmax = False, 0         # RawData.last_pulse_end_time over everything emitted so far
+        while a < n:
+            b = self._batch_end(a, est_csum, cluster, scale)
+            ins = s_ins[a:b]
+            gid = order[a:b].astype(np.uint32)
+            cl = (cluster[a:b] - cluster[a]).astype(np.int32)
+            ip = instruction_params(ins, cfg, self.resource)
+            self.engine.set_window_carry(has_pulse, runmax)
+            self.engine.load_instructions(ins, gid, cl, key[a:b], ip)
+            self.engine.run()
+            groups = self.engine.groups()
+            records = self.engine.records()
+            first = np.append(groups['first_record'], len(records))
+            cl_group = self.engine.cluster_groups(int(cl[-1]) + 1)
+            ins_group = cl_group[cl]
+            n_groups = len(groups['left'])
+            nonempty = groups['right'] >= groups['left']
+            ends = np.where(nonempty, (groups['right'] - tw) * dt, np.iinfo(np.int64).min)   # max(pulse right) * dt per window
+            n_emit = n_groups
+            if b < n and nonempty.any():
+                # would the next cluster have been simulated before this batch's last window was digitised
+                # (rawdata.py:96-98)?  then that window is not complete: simulate it again with the next batch
+                run_all = max(int(ends.max()), runmax) if has_pulse else int(ends.max())
+                if not (key[b] - run_all > rext):
+                    g_last = int(np.where(nonempty)[0][-1])
+                    restart = a + int(np.argmax(ins_group >= g_last))
+                    if restart == a:            # the whole batch is one open window: take a bigger batch
+                        scale *= 2
+                        continue
+                    n_emit, b = g_last, restart
+            proc = processing_order(ins, np.arange(len(ins)), cl)
+            truth_rows = self._truth_rows(ins) if len(truth_buffer) else None
+            for g in range(n_emit):
+                if truth_rows is not None:
+                    for i in proc[ins_group[proc] == g]:
+                        self._write_truth(truth_rows[i], truth_buffer)
+                if not nonempty[g]:
+                    continue
+                has_pulse, runmax = True, (max(runmax, int(ends[g])) if has_pulse else int(ends[g]))
+                self.left, self.right = int(groups['left'][g]), int(groups['right'][g])
+                if b >= n and g == n_groups - 1:
+                    self.source_finished = True
+                yield dict(left=self.left, right=self.right, records=records[first[g]:first[g + 1]])
+            a, scale = b, 1
+        self.source_finished = True
+
+    # ---- truth (rawdata.py:313-375) ----------------------------------------------------------------
+    def _truth_rows(self, ins):
+        acc, ts = self.engine.truth()
+        es = self.engine.electron_stats()
+        cfg = self.config
+        rows = []
+        names = ['n_photon', 'n_pe', 'n_photon_trigger', 'n_pe_trigger', 'raw_area', 'raw_area_trigger']
+        for i in range(len(ins)):
+            r = {}
+            n_ph = ts[i, 0]
+            r['n_photon_t'] = (n_ph, ts[i, 1], ts[i, 2], ts[i, 3], ts[i, 4])
+            r['electron'] = tuple(es[i]) if ins['type'][i] == 2 else (0, np.nan, np.nan, np.nan, np.nan)
+            for j, f in enumerate(names):
+                r[f] = acc[i, j]
+                r[f + '_bottom'] = acc[i, 6 + j]
+            r['instruction'] = ins[i]
+            rows.append(r)
+        return rows
+
+    def _write_truth(self, r, truth_buffer):
+        ix = np.argmin(truth_buffer['fill'])
+        tb = truth_buffer[ix]
+        n, mean, tmin, tmax, std = r['n_photon_t']
+        if n > 0:
+            tb['n_photon'], tb['t_mean_photon'], tb['t_first_photon'] = n, mean, tmin
+            tb['t_last_photon'], tb['t_sigma_photon'] = tmax, std
+        else:
+            tb['n_photon'] = 0
+            tb['t_mean_photon'] = tb['t_first_photon'] = tb['t_last_photon'] = tb['t_sigma_photon'] = np.nan
+        n, mean, tmin, tmax, std = r['electron']
+        if n > 0:
+            tb['n_electron'], tb['t_mean_electron'], tb['t_first_electron'] = n, mean, tmin
+            tb['t_last_electron'], tb['t_sigma_electron'] = tmax, std
+        else:
+            tb['n_electron'] = 0
+            tb['t_mean_electron'] = tb['t_first_electron'] = tb['t_last_electron'] = tb['t_sigma_electron'] = np.nan
+        tb['x_mean_electron'] = tb['y_mean_electron'] = np.nan          # field distortion models are off the path
+        ins = r['instruction']
+        cfg = self.config
+        if np.isnan(tb['t_last_photon']):
+            tb['endtime'] = ins['time']
+        else:
+            tb['endtime'] = tb['t_last_photon'] + (cfg['samples_before_pulse_center'] + cfg['samples_after_pulse_center']
+                                                   + 1) * cfg['sample_duration']
+        for f in ['n_pe', 'n_pe_trigger', 'n_photon', 'n_photon_trigger', 'raw_area', 'raw_area_trigger']:
+            for suffix in ['', '_bottom']:
+                if f + suffix in truth_buffer.dtype.names:
+                    tb[f + suffix] = r[f + suffix]
+        for f in ins.dtype.names:
+            if f in truth_buffer.dtype.names:
+                tb[f] = ins[f]
+        tb['fill'] = True
+
+    # ---- reference protocol ------------------------------------------------------------------------
+    def __call__(self, instructions, truth_buffer=None, progress_bar=True, **kwargs):
+        rec_dtype = np.dtype(raw_record_dtype())
+        spr = rec_dtype['data'].shape[0]
+        for w in self.iter_windows(instructions, truth_buffer, **kwargs):
+            rec = w['records']
+            k = 0
+            while k < len(rec):
+                # the fragments of one ZLE interval are consecutive: record_i = 0 .. ceil(pulse_length / spr) - 1
+                plen = int(rec['pulse_length'][k])
+                nfrag = -(-plen // spr)
+                data = rec['data'][k:k + nfrag].reshape(-1)[:plen].astype(np.int64)
+                left = int(rec['time'][k]) // int(rec['dt'][k])
+                yield int(rec['channel'][k]), left, left + plen - 1, data
+                k += nfrag
+
+
+class RawDataOptical(RawData):
+    """Photon channels / timings supplied up front (nVeto, optical Geant4 input): rawdata.py:461-495."""
+
+    def __init__(self, config, channels=tuple(), timings=tuple(), device=0, resource=None, seed=None):
+        super().__init__(config, device=device, resource=resource, seed=seed)
+        self.channels = np.asarray(channels)
+        self.timings = np.asarray(timings)
+
+    def iter_windows(self, instructions, truth_buffer=None, **kwargs):
+        raise NotImplementedError('optical instruction input lands with the nVeto path (SURVEY.md 8, config 5)')

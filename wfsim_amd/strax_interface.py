@@ -1,0 +1,336 @@
+"""The strax-facing surface of the hot path: ``ChunkRawRecords`` and the ``RawRecordsFromFax*`` plugins.
+
+Drop-in for /root/reference/wfsim/strax_interface.py:353-504 (ChunkRawRecords) and :536-733, :1008-1011 (plugins):
+same constructor, same generator protocol, same ``chunk_time_pre`` / ``chunk_time`` / ``source_finished()``
+attributes, same record layout and chunk boundaries.  The instruction readers that need nestpy / epix / uproot
+(rand_instructions, epix, read_optical) are out of scope; CSV input is kept.
+"""
+import logging
+
+import numpy as np
+
+from .dtypes import (instruction_dtype, optical_extra_dtype, truth_extra_dtype, extra_truth_dtype_per_pmt,
+                     raw_record_dtype, DEFAULT_RECORD_LENGTH)
+from .rawdata import RawData, RawDataOptical
+
+try:                                    # the real strax when it is installed, the in-repo stand-ins otherwise
+    import strax as _strax
+    _Plugin, sort_by_time = _strax.Plugin, _strax.sort_by_time
+    HAVE_STRAX = True
+except ImportError:                     # pragma: no cover - depends on the environment
+    from . import ministrax as _strax
+    _Plugin, sort_by_time = _strax.Plugin, _strax.sort_by_time
+    HAVE_STRAX = False
+
+log = logging.getLogger('wfsim_amd.interface')
+
+
+def instruction_from_csv(filename):
+    """strax_interface.py:336-350"""
+    import pandas as pd
+    df = pd.read_csv(filename)
+    recs = np.zeros(len(df), dtype=instruction_dtype)
+    for column in df.columns:
+        recs[column] = df[column]
+    return recs
+
+
+class ChunkRawRecords(object):
+    record_buffer_length = 5000000          # strax_interface.py:360
+
+    def __init__(self, config, rawdata_generator=RawData, **kwargs):
+        self.config = config
+        self.rawdata = rawdata_generator(self.config, **kwargs)
+        self.record_buffer = np.zeros(self.record_buffer_length,
+                                      dtype=raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH))
+        truth_per_n_pmts = self._n_channels if config.get('per_pmt_truth') else False
+        self.truth_dtype = extra_truth_dtype_per_pmt(truth_per_n_pmts)
+        self.truth_buffer = np.zeros(10000, dtype=instruction_dtype + self.truth_dtype + [('fill', bool)])
+        self.blevel = 0
+
+    @property
+    def _n_channels(self):
+        return len(self.config.get('gains', []))
+
+    # ------------------------------------------------------------------------------------------
+    def __call__(self, instructions, time_zero=None, **kwargs):
+        samples_per_record = DEFAULT_RECORD_LENGTH
+        if len(instructions) == 0:
+            yield from np.array([], dtype=raw_record_dtype(samples_per_record=samples_per_record))
+            self.rawdata.source_finished = True
+            return
+        self._dt = dt = self.config['sample_duration']
+        self._rext = int(self.config['right_raw_extension'])
+        self._cksz = int(self.config['chunk_size'] * 1e9)
+        self.blevel = 0
+        self.chunk_time_pre = time_zero - self._rext if time_zero else np.min(instructions['time']) - self._rext
+        self.chunk_time = self.chunk_time_pre + self._cksz
+        self.current_digitized_right = self.last_digitized_right = 0
+        if hasattr(self.rawdata, 'iter_windows'):
+            yield from self._run_windows(instructions, **kwargs)
+        else:
+            yield from self._run_pulses(instructions, **kwargs)
+        self.last_digitized_right = self.current_digitized_right
+        self.chunk_time = max((self.last_digitized_right + 1) * dt, self.chunk_time_pre + dt)
+        yield from self.final_results()
+
+    def _maybe_close_chunk(self):
+        """strax_interface.py:398-407: the window being emitted starts beyond the current chunk."""
+        dt = self._dt
+        if self.rawdata.left * dt > self.chunk_time + self._rext:
+            if (self.last_digitized_right + 1) * dt > self.chunk_time:
+                self.chunk_time += (self.last_digitized_right + 1) * dt - self.chunk_time
+            yield from self.final_results()
+            self.chunk_time_pre = self.chunk_time
+            self.chunk_time += self._cksz
+            return
+        return
+
+    def _buffer_full_flush(self):
+        """strax_interface.py:409-418"""
+        log.warning('Chunck size too large, insufficient record buffer \n'
+                    'No longer in sync if simulating nVeto with TPC \n'
+                    'Consider reducing the chunk size')
+        self.chunk_time = (self.last_digitized_right + 1) * self._dt
+        yield from self.final_results()
+        self.chunk_time_pre = self.chunk_time
+        self.chunk_time += self._cksz
+
+    def _track_window(self):
+        if self.rawdata.right != self.current_digitized_right:        # strax_interface.py:394-396
+            self.last_digitized_right = self.current_digitized_right
+            self.current_digitized_right = self.rawdata.right
+
+    # ---- window granularity: records arrive packed from the GPU ------------------------------------
+    def _run_windows(self, instructions, **kwargs):
+        buffer_length = len(self.record_buffer)
+        for w in self.rawdata.iter_windows(instructions, truth_buffer=self.truth_buffer, **kwargs):
+            rec = w['records']
+            n_pulses = int(np.count_nonzero(rec['record_i'] == 0))
+            self._track_window()
+            # every pulse of the window re-tests the chunk condition and can close one chunk (strax_interface.py:398)
+            closed = 0
+            while closed < n_pulses and self.rawdata.left * self._dt > self.chunk_time + self._rext:
+                yield from self._maybe_close_chunk()
+                closed += 1
+            if self.blevel + len(rec) > buffer_length:
+                yield from self._buffer_full_flush()
+            if self.blevel + len(rec) > buffer_length:
+                # the reference skips pulses one at a time here; keep whole pulses that fit
+                keep = 0
+                starts = np.where(rec['record_i'] == 0)[0]
+                for s, e in zip(starts, np.append(starts[1:], len(rec))):
+                    if self.blevel + e > buffer_length:
+                        break
+                    keep = e
+                log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
+                rec = rec[:keep]
+            self.record_buffer[self.blevel:self.blevel + len(rec)] = rec
+            self.blevel += len(rec)
+
+    # ---- pulse granularity: any generator with the RawData protocol (strax_interface.py:388-436) ---
+    def _run_pulses(self, instructions, **kwargs):
+        samples_per_record = DEFAULT_RECORD_LENGTH
+        dt = self._dt
+        buffer_length = len(self.record_buffer)
+        for channel, left, right, data in self.rawdata(instructions=instructions, truth_buffer=self.truth_buffer, **kwargs):
+            pulse_length = right - left + 1
+            records_needed = int(np.ceil(pulse_length / samples_per_record))
+            self._track_window()
+            yield from self._maybe_close_chunk()
+            if self.blevel + records_needed > buffer_length:
+                yield from self._buffer_full_flush()
+            if self.blevel + records_needed > buffer_length:
+                log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
+                continue
+            s = slice(self.blevel, self.blevel + records_needed)
+            self.record_buffer[s]['channel'] = channel
+            self.record_buffer[s]['dt'] = dt
+            self.record_buffer[s]['time'] = dt * (left + samples_per_record * np.arange(records_needed))
+            self.record_buffer[s]['length'] = [min(pulse_length, samples_per_record * (i + 1))
+                                               - samples_per_record * i for i in range(records_needed)]
+            self.record_buffer[s]['pulse_length'] = pulse_length
+            self.record_buffer[s]['record_i'] = np.arange(records_needed)
+            self.record_buffer[s]['data'] = np.pad(data, (0, records_needed * samples_per_record - pulse_length),
+                                                   'constant').reshape((-1, samples_per_record))
+            self.blevel += records_needed
+
+    # ------------------------------------------------------------------------------------------
+    def final_results(self):
+        """strax_interface.py:442-497"""
+        records = self.record_buffer[:self.blevel]
+        maska = records['time'] <= self.chunk_time
+        records = records[maska]
+        records = sort_by_time(records)
+
+        tb = self.truth_buffer
+        maskb = (tb['fill'] & ((tb['t_first_photon'] <= self.chunk_time)
+                               | (np.isnan(tb['t_first_photon']) & (tb['time'] <= self.chunk_time))))
+        truth = tb[maskb]
+        tb['fill'][maskb] = False
+        truth.sort(order='time')
+        _truth = np.zeros(len(truth), dtype=self._truth_out_dtype())
+        for name in _truth.dtype.names:
+            _truth[name] = truth[name]
+        ok = ~np.isnan(_truth['t_first_photon'])
+        _truth['time'][ok] = _truth['t_first_photon'][ok].astype(int)
+        _truth.sort(order='time')
+
+        det = self.config['detector']
+        if det == 'XENON1T' or det == 'XENONnT_neutron_veto':
+            yield dict(raw_records=records, truth=_truth)
+        elif det == 'XENONnT':
+            he = self.config['channel_map']['he']
+            yield dict(raw_records=records[records['channel'] < he[0]],
+                       raw_records_he=records[(records['channel'] >= he[0]) & (records['channel'] <= he[-1])],
+                       raw_records_aqmon=records[records['channel'] == 800],
+                       truth=_truth)
+        n_left = int(np.sum(~maska))
+        self.record_buffer[:n_left] = self.record_buffer[:self.blevel][~maska]
+        self.blevel = n_left
+
+    def _truth_out_dtype(self):
+        """the truth buffer's dtype without the 'fill' flag (strax_interface.py:478)"""
+        return [d for d in self.truth_buffer.dtype.descr if (d[0][1] if isinstance(d[0], tuple) else d[0]) != 'fill']
+
+    def source_finished(self):
+        return self.rawdata.source_finished
+
+
+# ---------------------------------------------------------------------------------------------------------------
+class SimulatorPlugin(_Plugin):
+    """strax_interface.py:536-663: stateful source plugin around a ChunkRawRecords iterator."""
+    compressor = 'zstd'
+    depends_on = tuple()
+    rechunk_on_save = False
+    parallel = False
+    last_chunk_time = -999999999999999
+    input_timeout = 3600
+
+    #: config defaults of the strax Options of the reference (strax_interface.py:506-535)
+    option_defaults = dict(detector='XENONnT', event_rate=1000, chunk_size=100, n_chunk=10, per_pmt_truth=False,
+                           fax_file=None, fax_config_override=None, right_raw_extension=100000, seed=False)
+
+    def __init__(self, config=None, run_id=None, device=0):
+        if HAVE_STRAX:          # pragma: no cover
+            super().__init__()
+            self.config = dict(config or {})
+        else:
+            super().__init__(config, run_id)
+        for k, v in self.option_defaults.items():
+            self.config.setdefault(k, v)
+        self.device = device
+
+    def setup(self):
+        self.set_config()
+        self.get_instructions()
+        self.check_instructions()
+        self._setup()
+
+    def set_config(self):
+        """strax_interface.py:566-608 without the CMT / straxen look-ups: gains must be in the config (or to_pe)."""
+        c = self.config
+        overrides = c.get('fax_config_override')
+        if overrides is not None:
+            c.update(overrides)
+        if 'field_distortion_on' in c and 'field_distortion_model' not in c:
+            c['field_distortion_model'] = 'inverse_fdc' if c['field_distortion_on'] else 'none'
+        if 'gains' not in c:
+            to_pe = np.asarray(c['to_pe'], dtype=np.float64)
+            adc_2_current = c['digitizer_voltage_range'] / 2 ** (c['digitizer_bits']) / c['pmt_circuit_load_resistor']
+            c['gains'] = np.divide(adc_2_current, to_pe, out=np.zeros_like(to_pe), where=to_pe != 0)
+        c['channel_map'] = dict(c['channel_map'])
+        c['channel_map']['sum_signal'] = 800
+        c['channels_bottom'] = np.arange(c['n_top_pmts'], c['n_tpc_pmts'])
+
+    def _setup(self):
+        pass
+
+    def get_instructions(self):
+        pass
+
+    def check_instructions(self):
+        pass
+
+    def _sort_check(self, results):
+        """strax_interface.py:622-640"""
+        if not isinstance(results, list):
+            results = [results]
+        last_chunk_time = self.last_chunk_time
+        for result in results:
+            if len(result) == 0:
+                continue
+            if result['time'][0] < self.last_chunk_time + 1000:
+                raise RuntimeError("Simulator returned chunks with insufficient spacing. "
+                                   f"Last chunk's max time was {self.last_chunk_time}, "
+                                   f"this chunk's first time is {result['time'][0]}.")
+            if len(result) == 1:
+                continue
+            if np.diff(result['time']).min() < 0:
+                raise RuntimeError("Simulator returned non-sorted records!")
+            last_chunk_time = max(result['time'].max(), self.last_chunk_time)
+        self.last_chunk_time = last_chunk_time
+
+    def is_ready(self, chunk_i):
+        if 'ready' not in self.__dict__:
+            self.ready = False
+        self.ready ^= True
+        return self.ready
+
+    def source_finished(self):
+        return self.sim.source_finished()
+
+    @property
+    def _n_channels(self):
+        return len(self.config.get('gains', []))
+
+    @property
+    def _truth_dtype(self):
+        return extra_truth_dtype_per_pmt(self._n_channels if self.config.get('per_pmt_truth') else False)
+
+
+class RawRecordsFromFaxNT(SimulatorPlugin):
+    """strax_interface.py:665-714"""
+    provides = ('raw_records', 'raw_records_he', 'raw_records_aqmon', 'truth')
+
+    def _setup(self):
+        self.sim = ChunkRawRecords(self.config, device=self.device)
+        self.sim_iter = self.sim(self.instructions)
+
+    def get_instructions(self):
+        if self.config.get('instructions') is not None:           # in-memory instructions (tests, benchmarks)
+            self.instructions = np.asarray(self.config['instructions'])
+        elif self.config['fax_file']:
+            assert self.config['fax_file'].endswith('csv'), 'Only csv input is supported'
+            self.instructions = instruction_from_csv(self.config['fax_file'])
+        else:
+            raise NotImplementedError('rand_instructions needs nestpy (SURVEY.md 2.1 row 7): pass instructions or a csv')
+
+    def check_instructions(self):
+        c = self.config
+        m = (self.instructions['z'] < - c['tpc_length']) & (self.instructions['type'] == 2)
+        self.instructions = self.instructions[~m]
+        r_instr = np.sqrt(self.instructions['x'] ** 2 + self.instructions['y'] ** 2)
+        assert np.all((r_instr < c['tpc_radius']) | np.isclose(r_instr, c['tpc_radius'])), \
+            "Interaction is outside the TPC (radius)"
+        assert np.all(self.instructions['z'] < 0.25), "Interaction is outside the TPC (in Z)"
+        assert np.all(self.instructions['amp'] > 0), "Interaction has zero size"
+
+    def infer_dtype(self):
+        dtype = {data_type: raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH)
+                 for data_type in self.provides if data_type != 'truth'}
+        dtype['truth'] = instruction_dtype + self._truth_dtype
+        return dtype
+
+    def compute(self):
+        try:
+            result = next(self.sim_iter)
+        except StopIteration:
+            raise RuntimeError("Bug in chunk count computation")
+        self._sort_check(result[self.provides[0]])
+        return {data_type: self.chunk(start=self.sim.chunk_time_pre, end=self.sim.chunk_time,
+                                      data=result[data_type], data_type=data_type) for data_type in self.provides}
+
+
+class RawRecordsFromFax1T(RawRecordsFromFaxNT):
+    provides = ('raw_records', 'truth')
