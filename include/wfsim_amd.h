@@ -131,7 +131,7 @@ int wfs_set_window_carry(wfs_handle *h, int32_t has_pulse, int64_t last_pulse_en
 int wfs_run(wfs_handle *h);
 
 typedef struct wfs_counts {
-    int64_t n_instructions, n_pulse_sets, n_emitters, n_photons, n_pe, n_tiles, n_groups, n_rows,
+    int64_t n_instructions, n_pulse_sets, n_emitters, n_photons /* primary + PMT afterpulse */, n_pe, n_tiles, n_groups, n_rows,
             n_raw_samples, n_intervals, n_records;
 } wfs_counts;
 int wfs_get_counts(wfs_handle *h, wfs_counts *out);
@@ -171,6 +171,9 @@ int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t capacity_inst
 /* flags: bit 0 keep f64 tile currents and finished rows for wfs_copy_currents / wfs_copy_rows; bit 1 send every tile
  * to the dense pulse kernel (both kernels give the same bits; used by the parity tests) */
 int wfs_set_debug(wfs_handle *h, int32_t flags);
+/* parity tests: noise start index per digitise window (rawdata.py:417) instead of the Philox draw; entries < 0 keep the draw.
+ * Indexed by the window number of wfs_copy_groups (host pointer, copied). n = 0 clears the override. */
+int wfs_set_noise_offsets(wfs_handle *h, const int64_t *ix_rand, int64_t n);
 int wfs_set_stream(wfs_handle *h, void *hip_stream);
 int wfs_synchronize(wfs_handle *h);
 /* HIP-event timing of the kernels of the last wfs_run: names (NUL separated) and milliseconds */

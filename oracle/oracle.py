@@ -148,6 +148,10 @@ class Oracle:
         lib().orc_pulse_call(self._s, C.c_int(kind), C.c_int(runset), C.c_int64(len(t)), _p(t), _p(ch), _p(dpe), _p(gain),
                              C.c_int(int(gains_preassigned)))
 
+    def set_noise_override(self, ix_rand):
+        self._noise_override = _arr(ix_rand, np.int64)
+        lib().orc_set_noise_override(self._s, _p(self._noise_override), C.c_int64(len(self._noise_override)))
+
     def digitize_and_zle(self, noise_gid=0):
         lib().orc_digitize_and_zle(self._s, C.c_uint32(noise_gid))
 

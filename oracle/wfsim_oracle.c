@@ -88,6 +88,7 @@ typedef struct {
     /* truth accumulators per pulse call (pulse.py:229-271): 12 doubles each */
     vec_f64 truth;
     i64 n_pe_total;
+    const i64 *noise_override; i64 n_noise_override;    /* tests: ix_rand per digitise call instead of the Philox draw */
 } orc_session;
 
 /* ---------------------------------------------------------------- Philox4x32-10 ------------------ */
@@ -184,6 +185,8 @@ void orc_set_ap_element(orc_session *s, int e, int n_bins_delay, int n_bins_amp,
     a->n_bins_delay = n_bins_delay; a->n_bins_amp = n_bins_amp; a->amp_2d = amp_2d; a->is_uniform = is_uniform;
     a->delay_bin = delay_bin; a->amp_bin = amp_bin; a->delay_cdf = delay_cdf; a->amp_cdf = amp_cdf;
 }
+
+void orc_set_noise_override(orc_session *s, const i64 *ix, i64 n) { s->noise_override = ix; s->n_noise_override = n; }
 
 void orc_free(orc_session *s)
 {
@@ -291,7 +294,7 @@ void orc_pulse_call(orc_session *s, int kind, int runset, i64 n, const i64 *t, c
         double vals[6] = { (double)cnt, (double)(cnt + n_dpe), (double)n_trig, (double)(n_trig + n_trig_dpe),
                            sumg / s->gains[channel], sumg_trig / s->gains[channel] };
         for (int f = 0; f < 6; f++) { tr[f] += vals[f]; if (channel >= c->n_top && channel <= c->last_bottom) tr[6 + f] += vals[f]; }
-        s->n_pe_total += cnt + n_dpe;
+        if (!gains_preassigned) s->n_pe_total += cnt + n_dpe;
         /* tile bounds pulse.py:118-128 */
         i64 tmin = t[a], tmax = t[a];
         for (i64 i = a; i < b; i++) { if (t[i] < tmin) tmin = t[i]; if (t[i] > tmax) tmax = t[i]; }
@@ -379,6 +382,7 @@ void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
             i64 N = c->noise_len, high = (N - nr + nl - 1 < 0) ? N - 1 : N - nr + nl - 1;
             if (high <= 0) ix_rand = 0;
             else { u32 w[4]; draw(s, 0, noise_gid, 0, SITE_NOISE, w); ix_rand = (i64)(u53(w[0], w[1]) * (double)high); }
+            if (s->noise_override && s->dg_left.n < s->n_noise_override && s->noise_override[s->dg_left.n] >= 0) ix_rand = s->noise_override[s->dg_left.n];
             for (i64 ch = 0; ch < R; ch++) {
                 if (ch >= c->noise_channels || !mask[ch]) continue;
                 for (i64 ix = ml[ch]; ix <= mr[ch]; ix++) {

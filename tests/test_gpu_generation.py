@@ -29,14 +29,16 @@ def _instructions(rows):
     return ins
 
 
-def _run_both(cfg, ins, seed=7):
+def _run_both(cfg, ins, seed=7, ap=None):
+    if ap is not None:
+        cfg = dict(cfg, enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap)
     res = Resource(cfg)
     order, key, cluster = schedule(ins, cfg)
     s_ins = ins[order]
     gid = order.astype(np.uint32)
     ip = instruction_params(s_ins, cfg, res)
     cfg = dict(cfg, seed=seed)
-    orc = make_oracle(cfg)
+    orc = make_oracle(cfg, ap)
     orc.simulate(s_ins, gid, ip)
     o = orc.results()
     eng = make_engine(cfg)
@@ -54,8 +56,20 @@ def _compare(orc, o, eng, counts, s_ins):
     # the oracle received sorted instructions, so 'order' is the identity
     cluster = schedule(s_ins, eng.config)[2]
     proc = processing_order(s_ins, np.arange(len(s_ins)), cluster)
-    assert len(proc) == len(o['call_kind'])
-    for k, i in enumerate(proc):
+    n_ins = len(s_ins)
+    # oracle calls: per instruction its primary call, then (PMT afterpulses on and photons present) a kind-3 call;
+    # device sets: instruction i and, for its afterpulses, n_ins + i
+    sets, it = [], iter(proc)
+    for kind in o['call_kind']:
+        if kind != 3:
+            cur = next(it)
+            sets.append(cur)
+        else:
+            sets.append(n_ins + cur)
+    assert len(sets) == len(o['call_kind'])
+    if 3 in o['call_kind']:
+        assert counts['n_pulse_sets'] == 2 * n_ins and (o['call_kind'] == 3).sum() > 0
+    for k, i in enumerate(sets):
         a, b = o['call_ph_off'][k], o['call_ph_off'][k + 1]
         c, e = ph['set_off'][i], ph['set_off'][i + 1]
         assert b - a == e - c, f'instruction {i}: {b - a} vs {e - c} photons'
@@ -103,3 +117,27 @@ def test_small_poisson_mean_and_gain_spread():
     rows = [dict(type=2, time=MS * (i + 1), x=0, y=0, z=-20, amp=300) for i in range(5)]
     _compare(*_run_both(xenonnt_test_config(s2_secondary_sc_gain=7.0, s2_gain_spread=2.5, s2_time_spread=30.0),
                         _instructions(rows)))
+
+
+def test_pmt_afterpulses_generated_on_device():
+    from tests.helpers import ap_tables_from_golden
+    rows = [dict(type=1, time=MS * (i + 1), x=2 * i, y=-i, z=-10 - 3 * i, amp=3000 + 500 * i) for i in range(8)]
+    rows += [dict(type=2, time=MS * (i + 20), x=i, y=2 * i, z=-8 - 4 * i, amp=150 + 30 * i) for i in range(8)]
+    rows += [dict(type=1, time=40 * MS, x=0, y=0, z=-30, amp=1)]
+    orc, o, eng, counts, s_ins = _run_both(xenonnt_test_config(), _instructions(rows), seed=21, ap=ap_tables_from_golden())
+    n_ap = sum(o['call_ph_off'][k + 1] - o['call_ph_off'][k] for k in range(len(o['call_kind'])) if o['call_kind'][k] == 3)
+    assert n_ap > 200
+    _compare(orc, o, eng, counts, s_ins)
+
+
+def test_noise_on_generated_path():
+    from tests.helpers import golden
+    noise = golden('noise.npz')['noise']
+    rows = [dict(type=1, time=MS * (i + 1), x=2 * i, y=-i, z=-10 - 3 * i, amp=300 + 200 * i) for i in range(10)]
+    rows += [dict(type=2, time=MS * (i + 20), x=i, y=2 * i, z=-8 - 4 * i, amp=50 + 30 * i) for i in range(6)]
+    cfg = xenonnt_test_config(enable_noise=True, noise_data=noise)
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows), seed=22)
+    g = eng.groups()
+    keep = g['right'] >= g['left']
+    assert np.array_equal(g['ix_rand'][keep], o['dg_ix_rand']) and np.all(o['dg_ix_rand'] >= 0)
+    _compare(orc, o, eng, counts, s_ins)

@@ -23,10 +23,17 @@ def _nonempty_groups(eng):
     return g, keep
 
 
-def _check_chain(name, config, force_dense=False):
+def _check_chain(name, config, force_dense=False, noise_offsets=False):
     d = golden(name)
     eng = make_engine(config)
     counts = replay_chain_on_engine(eng, d, config, force_dense=force_dense)
+    if noise_offsets:
+        # the reference drew its noise start index from numpy's stream: inject it per digitise window
+        g = eng.groups()
+        ix = np.full(len(g['left']), -1, dtype=np.int64)
+        ix[g['right'] >= g['left']] = d['dg_ix_rand']
+        eng.set_noise_offsets(ix)
+        counts = replay_chain_on_engine(eng, d, config, force_dense=force_dense)
     # ---- pulses
     p = eng.pulses(currents=True)
     order = np.lexsort((p['channel'], p['set']))
@@ -101,6 +108,11 @@ def test_chain_he_channels():
 
 def test_chain_pmt_afterpulse_pulses():
     _check_chain('chain_pmt_ap.npz', xenonnt_test_config())
+
+
+def test_chain_noise():
+    cfg = xenonnt_test_config(enable_noise=True, noise_data=golden('noise.npz')['noise'])
+    _check_chain('chain_noise.npz', cfg, noise_offsets=True)
 
 
 def test_records_match_oracle_bytes():

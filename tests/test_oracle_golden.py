@@ -108,3 +108,14 @@ def test_record_packing_layout():
     got = np.concatenate([rec['data'][i][:rec['length'][i]] for i in range(n_expected[k])])
     assert np.array_equal(got, d['zle_data'][:n])
     assert rec['length'][n_expected[0] - 1] == n - 110 * (n_expected[0] - 1)
+
+
+def test_chain_noise():
+    d = golden('chain_noise.npz')
+    cfg = xenonnt_test_config(enable_noise=True, noise_data=golden('noise.npz')['noise'])
+    orc = make_oracle(cfg)
+    orc.set_noise_override(d['dg_ix_rand'])
+    r = replay_chain_on_oracle(orc, d)
+    assert np.array_equal(r['row_data'], d['row_data'])
+    for k in ['ch', 'left', 'right', 'data']:
+        assert np.array_equal(r['zl_' + k], d['zle_' + k]), k

@@ -46,7 +46,7 @@ struct wfs_handle {
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
     DevBuf truth, tminmax, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
-    DevBuf scan_tmp, scal;
+    DevBuf scan_tmp, scal, noise_override; i64 n_noise_override = 0;
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
@@ -55,6 +55,8 @@ struct wfs_handle {
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
     double h_templates[WFS_DT * 22] = {0};
+    i64 zero64 = 0;
+    DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
@@ -114,16 +116,24 @@ int fill32(wfs_handle *h, DevBuf &b, i64 n, i32 v)
 }
 
 // exclusive scan i32[n] -> i64[n+1]; total written to scal[slot]
+int scan_into(wfs_handle *h, const i32 *in, i64 n, i64 *outp, int scal_slot, i64 offset);
+
 int scan(wfs_handle *h, const i32 *in, i64 n, DevBuf &out, int scal_slot)
 {
     TRY(ensure(h, out, (size_t)(n + 1) * 8));
+    return scan_into(h, in, n, out.as<i64>(), scal_slot, 0);
+}
+
+// exclusive scan into a caller-provided range, every output shifted by offset
+int scan_into(wfs_handle *h, const i32 *in, i64 n, i64 *outp, int scal_slot, i64 offset)
+{
     i64 nb = (n + SCAN_TILE - 1) / SCAN_TILE; if (nb < 1) nb = 1;
     TRY(ensure(h, h->scan_tmp, (size_t)nb * 8));
     i64 *total = h->scal.as<i64>() + scal_slot;
-    if (n == 0) { HIPCHK(hipMemsetAsync(out.p, 0, 8, h->stream)); HIPCHK(hipMemsetAsync(total, 0, 8, h->stream)); return WFS_OK; }
+    if (n == 0) { h->zero64 = offset; HIPCHK(hipMemcpyAsync(outp, &h->zero64, 8, hipMemcpyHostToDevice, h->stream)); HIPCHK(hipMemsetAsync(total, 0, 8, h->stream)); return WFS_OK; }
     { Timer t(h, "k_scan_reduce"); hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_TPB), 0, h->stream, in, n, h->scan_tmp.as<i64>()); }
     { Timer t(h, "k_scan_spine"); hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(1024), 0, h->stream, h->scan_tmp.as<i64>(), nb, total); }
-    { Timer t(h, "k_scan_down"); hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(SCAN_TPB), 0, h->stream, in, n, h->scan_tmp.as<i64>(), out.as<i64>()); }
+    { Timer t(h, "k_scan_down"); hipLaunchKernelGGL(k_scan_down, dim3((unsigned)nb), dim3(SCAN_TPB), 0, h->stream, in, n, h->scan_tmp.as<i64>(), outp, offset); }
     return WFS_OK;
 }
 
@@ -181,8 +191,9 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
     hipFuncSetAttribute((const void *)k_pulse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_photons<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_photons<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photons<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photons<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photons<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
@@ -194,7 +205,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -221,6 +232,13 @@ int wfs_set_stream(wfs_handle *h, void *s)
 }
 
 int wfs_synchronize(wfs_handle *h) { if (!h) return WFS_E_INVALID; HIPCHK(hipStreamSynchronize(h->stream)); return WFS_OK; }
+int wfs_set_noise_offsets(wfs_handle *h, const int64_t *ix, int64_t n)
+{
+    if (!h || n < 0 || (n > 0 && !ix)) return WFS_E_INVALID;
+    h->n_noise_override = n;
+    if (n) { TRY(upload(h, h->noise_override, ix, (size_t)n * 8)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    return WFS_OK;
+}
 int wfs_set_window_carry(wfs_handle *h, int32_t has, int64_t t) { if (!h) return WFS_E_INVALID; h->carry_has = has; h->carry_runmax = t; return WFS_OK; }
 int wfs_copy_cluster_groups(wfs_handle *h, int32_t *group, int64_t cap)
 {
@@ -337,15 +355,23 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         if (type[i] == 2 && h->dev.n_lum < 2) return h->fail(WFS_E_STATE, "S2 instructions need the luminescence table");
         em_off[i + 1] = em_off[i] + (type[i] == 1 ? 1 : (i64)amp[i]);
     }
-    h->n_ins = n; h->n_sets = n; h->n_emitters = em_off[n]; h->n_tiles = n * h->cfg.n_tpc;
+    // PMT afterpulses are a second pulse set per instruction (rawdata.py:176-178): set n + i belongs to instruction i
+    h->ap_active = h->cfg.enable_pmt_ap && h->dev.n_ap > 0;
+    const i64 S = h->ap_active ? 2 * n : n;
+    h->n_ins = n; h->n_sets = S; h->n_emitters = em_off[n]; h->n_tiles = S * h->cfg.n_tpc;
     if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
     TRY(upload(h, h->ins_type, type, (size_t)n)); TRY(upload(h, h->ins_time, time, (size_t)n * 8)); TRY(upload(h, h->ins_amp, amp, (size_t)n * 4));
     TRY(upload(h, h->ins_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_p, p_hit, (size_t)n * 8)); TRY(upload(h, h->ins_dm, drift_mean, (size_t)n * 8));
     TRY(upload(h, h->ins_ds, drift_spread, (size_t)n * 8)); TRY(upload(h, h->ins_sc, sc_gain, (size_t)n * 8));
     TRY(upload(h, h->ins_cdfrow, cdf_row, (size_t)n * 4)); TRY(upload(h, h->cdf_table, cdf_table, (size_t)n_cdf * h->cfg.n_tpc * 8));
     TRY(upload(h, h->em_off, em_off.data(), em_off.size() * 8));
-    TRY(upload(h, h->set_cluster, cluster, (size_t)n * 4)); TRY(upload(h, h->set_t0, time, (size_t)n * 8));
-    TRY(ensure(h, h->set_mode, (size_t)n * 4)); HIPCHK(hipMemsetAsync(h->set_mode.p, 0, (size_t)n * 4, h->stream));
+    {
+        std::vector<i32> sc((size_t)S), sm((size_t)S, 0); std::vector<i64> st((size_t)S);
+        for (i64 i = 0; i < S; i++) { sc[i] = cluster[i % n]; st[i] = time[i % n]; sm[i] = i >= n ? 1 : 0; }
+        TRY(upload(h, h->set_cluster, sc.data(), (size_t)S * 4)); TRY(upload(h, h->set_t0, st.data(), (size_t)S * 8));
+        TRY(upload(h, h->set_mode, sm.data(), (size_t)S * 4));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     TRY(load_clusters(h, n, cluster, tmin, gid));
     h->injected = false; h->batch_loaded = true; h->ran = false;
     return WFS_OK;
@@ -428,17 +454,34 @@ static int run_generation(wfs_handle *h)
     TRY(scan(h, h->em_nph.as<i32>(), E, h->em_ph_off, 6));
     TRY(read_scal(h));
     const i64 P = h->h_scal[6];
-    h->n_photons = P;
+    h->n_photons = P; h->n_ap_photons = 0;
     g.em_ph_off = h->em_ph_off.as<i64>(); g.n_photons = P;
+    const i64 TP = N * d.n_tpc;                 // primary tiles; afterpulse tiles follow
+    const bool ap_on = h->ap_active;
+    const i64 ap_cap = ap_on ? P / 8 + 65536 : 0;
     TRY(ensure(h, h->tile_count, (size_t)T * 4)); TRY(ensure(h, h->tile_cursor, (size_t)T * 4));
     HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (size_t)T * 4, h->stream)); HIPCHK(hipMemsetAsync(h->tile_cursor.p, 0, (size_t)T * 4, h->stream));
     TRY(fill32(h, h->tile_tmin, T, 0x7fffffff)); TRY(fill32(h, h->tile_tmax, T, (i32)0x80000000));
-    TRY(ensure(h, h->ph_t, (size_t)P * 4)); TRY(ensure(h, h->ph_code, (size_t)P * 4));
+    TRY(ensure(h, h->ph_t, (size_t)(P + ap_cap) * 4)); TRY(ensure(h, h->ph_code, (size_t)(P + ap_cap) * 4));
+    TRY(ensure(h, h->tile_off, (size_t)(T + 1) * 8));
     g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
     g.tile_tmax = h->tile_tmax.as<i32>(); g.ph_t = h->ph_t.as<i32>(); g.ph_code = h->ph_code.as<u32>();
+    g.tile_off = h->tile_off.as<i64>();
     g.lum_tab = h->t_lumtab.as<LumEntry>(); g.lum_guide = h->t_lumguide.as<unsigned short>();
+    ApArgs ap{};
+    if (ap_on) {
+        ap.n = d.n_ap;
+        for (int e = 0; e < d.n_ap; e++) {
+            const ApElem &s = h->ap[e];
+            ap.el[e] = ApElemDev{s.n_bins_delay, s.n_bins_amp, s.amp_2d, s.is_uniform, s.delay_bin, s.amp_bin, s.delay_cdf.as<double>(), s.amp_cdf.as<double>()};
+        }
+        TRY(ensure(h, h->ap_ins, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_ch, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_t, (size_t)ap_cap * 4));
+        TRY(ensure(h, h->ap_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ph_gain, (size_t)ap_cap * 8));
+        ap.cap = ap_cap; ap.ap_ins = h->ap_ins.as<i32>(); ap.ap_ch = h->ap_ch.as<i32>(); ap.ap_t = h->ap_t.as<i32>(); ap.ap_gain = h->ap_gain.as<double>();
+        ap.count = h->scal.as<i64>() + 13;
+    }
     const size_t gen_lds_count = (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 32;
-    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + (size_t)3 * GEN_BLOCK * 4 + 32;
+    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + (size_t)3 * GEN_BLOCK * 4 + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 32;
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart
@@ -449,12 +492,22 @@ static int run_generation(wfs_handle *h)
         TRY(ensure(h, h->blk_e, (size_t)nb * 16));
         g.blk_e = h->blk_e.as<i64>();
         { Timer t(h, "k_block_emitters"); hipLaunchKernelGGL(k_block_emitters, dim3(nblocks(nb, 256)), dim3(256), 0, h->stream, g); }
-        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true>), dim3(nb), dim3(GEN_TPB), gen_lds_count, h->stream, d, g); }
-        TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
-        g.tile_off = h->tile_off.as<i64>();
-        { Timer t(h, "k_photons_fill"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false>), dim3(nb), dim3(GEN_TPB), gen_lds, h->stream, d, g); }
+        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true, false>), dim3(nb), dim3(GEN_TPB), gen_lds_count, h->stream, d, g, ap); }
+        TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
+        { Timer t(h, "k_photons_fill");
+          if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true>), dim3(nb), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, false>), dim3(nb), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap); }
     } else {
-        TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
+        TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
+    }
+    if (ap_on) {
+        // afterpulse photons: count per tile of the afterpulse sets, offsets behind the primary photons, place
+        { Timer t(h, "k_ap_count"); hipLaunchKernelGGL(k_ap_count, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
+        TRY(scan_into(h, h->tile_count.as<i32>() + TP, TP, h->tile_off.as<i64>() + TP, 14, P));
+        { Timer t(h, "k_ap_place"); hipLaunchKernelGGL(k_ap_place, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - P); }
+        TRY(read_scal(h));
+        if (h->h_scal[13] > ap_cap) return h->fail(WFS_E_CAPACITY, "more PMT afterpulse photons than 1/8 of the primary photons: afterpulse probability unreasonably high");
+        h->n_ap_photons = h->h_scal[13];
     }
     return WFS_OK;
 }
@@ -470,7 +523,7 @@ int wfs_run(wfs_handle *h)
     const i64 T = h->n_tiles, S = h->n_sets, C = h->n_clusters;
     HIPCHK(hipMemsetAsync(h->scal.p, 0, 128, h->stream));
     if (!h->injected) TRY(run_generation(h));
-    else TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7));
+    else { h->ap_active = false; TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7)); }
 
     // ---- geometry: tiles -> clusters -> groups -> rows
     const i64 CG = C + 1;         // group slots
@@ -490,6 +543,7 @@ int wfs_run(wfs_handle *h)
     ga.grp_left = h->grp_left.as<i64>(); ga.grp_right = h->grp_right.as<i64>(); ga.grp_ixrand = h->grp_ixrand.as<i64>(); ga.grp_gid = h->grp_gid.as<u32>();
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
     ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
+    ga.noise_override = h->n_noise_override ? h->noise_override.as<i64>() : nullptr; ga.n_noise_override = h->n_noise_override;
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
     { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(64), 0, h->stream, d, ga); }
     { Timer t(h, "k_tile_rows"); hipLaunchKernelGGL(k_tile_rows, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
@@ -522,7 +576,8 @@ int wfs_run(wfs_handle *h)
     pa.active_tiles = h->active_tiles.as<i32>(); pa.n_active = h->n_active_tiles;
     pa.tile_count = h->tile_count.as<i32>(); pa.tile_tmin = h->tile_tmin.as<i32>(); pa.tile_tmax = h->tile_tmax.as<i32>(); pa.tile_off = h->tile_off.as<i64>();
     pa.set_cluster = h->set_cluster.as<i32>(); pa.set_t0 = h->set_t0.as<i64>(); pa.set_mode = h->set_mode.as<i32>();
-    pa.ph_t = h->ph_t.as<i32>(); pa.ph_code = h->ph_code.as<u32>(); pa.ph_gain = h->ph_gain.as<double>();
+    pa.ph_t = h->ph_t.as<i32>(); pa.ph_code = h->ph_code.as<u32>();
+    pa.ph_gain = (!h->injected && h->ap_active) ? h->ph_gain.as<double>() - h->n_photons : h->ph_gain.as<double>();
     pa.cl_group = h->cl_group.as<i32>(); pa.row_lo = h->row_lo.as<i64>(); pa.acc_off = h->acc_off.as<i64>(); pa.raw = h->raw.as<i32>();
     pa.truth = h->truth.as<double>(); pa.tminmax = h->tminmax.as<i64>();
     { const char *ab = getenv("WFS_ABLATE"); pa.ablate = ab ? atoi(ab) : 0; }
@@ -624,13 +679,14 @@ int wfs_get_counts(wfs_handle *h, wfs_counts *out)
     if (!h || !out) return WFS_E_INVALID;
     if (!h->ran) return h->fail(WFS_E_STATE, "wfs_run has not completed");
     wfs_counts c{};
-    c.n_instructions = h->n_ins; c.n_pulse_sets = h->n_sets; c.n_emitters = h->n_emitters; c.n_photons = h->n_photons;
+    c.n_instructions = h->n_ins; c.n_pulse_sets = h->n_sets; c.n_emitters = h->n_emitters; c.n_photons = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0);
     c.n_tiles = h->n_active_tiles; c.n_groups = h->n_groups; c.n_rows = h->n_active_rows; c.n_raw_samples = h->s_raw;
     c.n_records = h->n_records;
     // n_pe and n_intervals need device reductions: sum the per-set truth (cheap)
     std::vector<double> tr((size_t)h->n_sets * 16);
     HIPCHK(hipMemcpy(tr.data(), h->truth.p, tr.size() * 8, hipMemcpyDeviceToHost));
-    double npe = 0; for (i64 s = 0; s < h->n_sets; s++) npe += tr[s * 16 + 1];
+    const i64 n_prim = (!h->injected && h->ap_active) ? h->n_ins : h->n_sets;       // afterpulse sets carry no truth (rawdata.py:322-323)
+    double npe = 0; for (i64 s = 0; s < n_prim; s++) npe += tr[s * 16 + 1];
     c.n_pe = (i64)(npe + 0.5);
     std::vector<i32> n((size_t)(h->n_clusters + 1) * h->dev.row_slots);
     HIPCHK(hipMemcpy(n.data(), h->itv_n.p, n.size() * 4, hipMemcpyDeviceToHost));
@@ -784,7 +840,7 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
 {
     if (!h || !h->ran) return WFS_E_STATE;
     const WfsDev &d = h->dev;
-    const i64 P = h->n_photons, T = h->n_tiles;
+    const i64 P = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0), T = h->n_tiles;
     if (cap < P) return h->fail(WFS_E_CAPACITY, "photon buffer too small");
     std::vector<i64> off((size_t)T + 1), t0((size_t)h->n_sets);
     std::vector<i32> rel((size_t)P); std::vector<u32> code((size_t)P);
@@ -794,7 +850,8 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
     std::vector<double> gains((size_t)d.n_tpc), spe((size_t)2001 * d.n_spe), pg;
     HIPCHK(hipMemcpy(gains.data(), h->t_gains.p, gains.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(spe.data(), h->t_spe.p, spe.size() * 8, hipMemcpyDeviceToHost));
-    if (h->injected && P) { pg.resize((size_t)P); HIPCHK(hipMemcpy(pg.data(), h->ph_gain.p, pg.size() * 8, hipMemcpyDeviceToHost)); }
+    const i64 gain_first = h->injected ? 0 : h->n_photons;         // ph_gain covers the explicit-gain photons only
+    if (P - gain_first > 0 && (h->injected || h->ap_active)) { pg.resize((size_t)(P - gain_first)); HIPCHK(hipMemcpy(pg.data(), h->ph_gain.p, pg.size() * 8, hipMemcpyDeviceToHost)); }
     for (i64 s = 0; s <= h->n_sets; s++) set_off[s] = off[(size_t)s * d.n_tpc];
     for (i64 tile = 0; tile < T; tile++) {
         i64 s = tile / d.n_tpc; int c = (int)(tile - s * d.n_tpc);
@@ -802,7 +859,7 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
         for (i64 p = off[tile]; p < off[tile + 1]; p++) {
             t[p] = t0[s] + rel[p]; ch[p] = (int16_t)c;
             u32 g1 = code[p] & 0xffffu, g2 = code[p] >> 16;
-            if (h->injected) { gain[p] = pg[p]; dpe[p] = g2 != 0; }
+            if (h->injected || p >= h->n_photons) { gain[p] = pg[(size_t)(p - gain_first)]; dpe[p] = g2 != 0; }
             else { double g = gains[c] * row[g1]; if (g2) g += gains[c] * row[g2]; gain[p] = g; dpe[p] = g2 != 0; }
         }
     }

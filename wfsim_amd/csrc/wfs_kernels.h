@@ -72,7 +72,7 @@ __global__ __launch_bounds__(1024) void k_scan_spine(i64 *__restrict__ block_sum
 }
 
 __global__ __launch_bounds__(SCAN_TPB) void k_scan_down(const i32 *__restrict__ in, i64 n, const i64 *__restrict__ block_sums,
-                                                        i64 *__restrict__ out)
+                                                        i64 *__restrict__ out, i64 offset)
 {
     __shared__ i64 sh[SCAN_TPB];
     i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(SCAN_TPB) void k_scan_down(const i32 *__restrict__ 
         sh[threadIdx.x] += t;
         __syncthreads();
     }
-    i64 run = block_sums[blockIdx.x] + sh[threadIdx.x] - s;
+    i64 run = offset + block_sums[blockIdx.x] + sh[threadIdx.x] - s;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++) { i64 i = base + k; if (i < n) out[i] = run; run += v[k]; if (i == n - 1) out[n] = run; }
 }
@@ -109,6 +109,7 @@ struct GeomArgs {
     i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
     i32 force_dense;     // debug: send every tile to the dense kernel
     i32 init_has; i64 init_runmax;      // last_pulse_end_time carried in from earlier batches
+    const i64 *noise_override; i64 n_noise_override;
 };
 
 #define SPARSE_MAX_PHOTONS 32      // tiles with a handful of photons (S1-like) go to the sorted-list kernel
@@ -190,6 +191,7 @@ __global__ void k_group_final(WfsDev d, GeomArgs a)
         i64 N = d.noise_len, high = (N - nr + nl - 1 < 0) ? N - 1 : N - nr + nl - 1;
         if (high <= 0) ix = 0;
         else { u32x4 w = philox4x32_10(0, a.grp_gid[g], 0, SITE_NOISE, d.k0, d.k1); ix = (i64)(u53(w.x, w.y) * (double)high); }
+        if (a.noise_override && g < a.n_noise_override && a.noise_override[g] >= 0) ix = a.noise_override[g];
     }
     a.grp_ixrand[g] = ix;
 }
@@ -877,7 +879,18 @@ __device__ __forceinline__ double interp_lum(const WfsDev &d, double u)
 #define CDF_G 512                  // guide cells of the per-block channel search
 #define LUM_G 4096                 // guide cells of the luminescence table
 
-struct LumEntry { double x0, x1, f0, slope; };     // np.interp segment [x0, x1): f0 + slope * (u - x0)
+struct LumEntry { double x0, x1, f0, slope; };
+
+// PMT afterpulse element tables (afterpulse.py:181-186) and the staging list of generated afterpulse photons
+struct ApElemDev { i32 n_bins_delay, n_bins_amp, amp_2d, is_uniform; double delay_bin, amp_bin; const double *delay_cdf, *amp_cdf; };
+struct ApArgs {
+    i32 n; i32 pad;
+    ApElemDev el[WFS_MAX_AP];
+    i64 cap;                        // capacity of the staging list
+    i32 *ap_ins; i32 *ap_ch; i32 *ap_t; double *ap_gain;     // [cap] instruction, channel, ns relative to the instruction, gain
+    i64 *count;                     // number of staged afterpulse photons (device scalar)
+};
+#define AP_STAGE 384               // afterpulse photons a block stages in LDS before it reserves space in the global list     // np.interp segment [x0, x1): f0 + slope * (u - x0)
 
 // np.interp(u, xp, fp) of s2.py:338 with the segment found through a guide table instead of a bisection:
 // same segment, same arithmetic (slope = (fp[i+1] - fp[i]) / (xp[i+1] - xp[i]), slope * (u - xp[i]) + fp[i])
@@ -915,8 +928,8 @@ __global__ void k_block_emitters(GenArgs a)
 // S2) the instruction's scalars, its channel CDF (+ a guide table), the emitter window and the tile offsets are
 // staged in LDS once and the per-tile ranks are taken from an LDS histogram; photons are staged in LDS and written
 // out after the block has reserved its ranges with one global atomic per non-empty tile.
-template <bool COUNT>
-__global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
+template <bool COUNT, bool AP>
+__global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs ap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nch = d.n_tpc;
@@ -931,7 +944,11 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
     i32 *st_t = hmax + nch;                                  // [GEN_BLOCK] staged photons
     u32 *st_code = (u32 *)(st_t + GEN_BLOCK);                // [GEN_BLOCK]
     u32 *st_cr = st_code + GEN_BLOCK;                        // [GEN_BLOCK] channel << 16 | rank
+    double *aps_gain = (double *)(st_cr + GEN_BLOCK);        // [AP_STAGE] staged afterpulse photons (AP only)
+    i32 *aps_ins = (i32 *)(aps_gain + AP_STAGE), *aps_ch = aps_ins + AP_STAGE, *aps_t = aps_ch + AP_STAGE;
+    __shared__ i32 s_apn; __shared__ i64 s_apbase;
     const int tid = threadIdx.x;
+    if (AP && tid == 0) s_apn = 0;
     // Blocks that run at the same time work on different instructions (strided order): consecutive photon blocks
     // belong to one instruction and would otherwise all add into the same n_tpc tile counters.
     const i64 vb = (i64)(((u64)blockIdx.x * (u64)a.block_stride) % (u64)a.n_blocks);
@@ -1020,6 +1037,43 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
         t += (i64)(d.tts_mean + d.tts_sigma * z_tts);
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
         const u32 code = g1 | (is_dpe ? (g2 << 16) : 0u);
+        if (AP) {
+            // PMT afterpulses of this photon (afterpulse.py:172-249): one uniform pair per element
+            for (int e = 0; e < ap.n; e++) {
+                const ApElemDev &el = ap.el[e];
+                const u32x4 w = philox4x32_10(j, gid, m, SITE_AP + (u32)e, d.k0, d.k1);
+                double rU0 = 1.0 - u53(w.x, w.y);
+                const double rU1 = 1.0 - u53(w.z, w.w);
+                const double *dc = el.delay_cdf + (size_t)ch * el.n_bins_delay;
+                const double prob = dc[el.n_bins_delay - 1];
+                rU0 /= d.pmt_ap_modifier;
+                if (is_dpe) rU0 /= 2;
+                if (!(rU0 <= prob)) continue;
+                double delay, amp;
+                if (el.is_uniform) {
+                    const u32x4 x = philox4x32_10(j, gid, m, SITE_AP_X + (u32)e, d.k0, d.k1);
+                    delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
+                } else {
+                    int best = 0; double bd = fabs(dc[0] - rU0);            // np.argmin(|cdf - u|): first minimum
+                    for (int k = 1; k < el.n_bins_delay; k++) { const double dd = fabs(dc[k] - rU0); if (dd < bd) { bd = dd; best = k; } }
+                    delay = best * el.delay_bin - d.pmt_ap_t_modifier;
+                    const double *ac = el.amp_2d ? el.amp_cdf + (size_t)ch * el.n_bins_amp : el.amp_cdf;
+                    int ba = 0; double bad = fabs(ac[0] - rU1);
+                    for (int k = 1; k < el.n_bins_amp; k++) { const double dd = fabs(ac[k] - rU1); if (dd < bad) { bad = dd; ba = k; } }
+                    amp = ba * el.amp_bin;
+                }
+                const double tf = (double)(itime + t) + delay;              // afterpulse.py:235, int64 + float
+                i64 tap = (i64)tf - itime;
+                if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
+                const double gap = d.gains[ch] * amp;
+                const i32 k = atomicAdd(&s_apn, 1);
+                if (k < AP_STAGE) { aps_ins[k] = ins; aps_ch[k] = ch; aps_t[k] = (i32)tap; aps_gain[k] = gap; }
+                else {
+                    const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull);
+                    if (gk < ap.cap) { ap.ap_ins[gk] = ins; ap.ap_ch[gk] = ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = gap; }
+                }
+            }
+        }
         if (single) {
             const u32 rank = (u32)atomicAdd(&hist[ch], 1);
             atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
@@ -1030,6 +1084,16 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
             const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
             a.ph_t[pos] = (i32)t; a.ph_code[pos] = code;
+        }
+    }
+    if (AP && !COUNT) {
+        __syncthreads();
+        const int nst = s_apn < AP_STAGE ? s_apn : AP_STAGE;
+        if (tid == 0 && nst > 0) s_apbase = (i64)atomicAdd((u64 *)ap.count, (u64)nst);
+        __syncthreads();
+        for (int k = tid; k < nst; k += GEN_TPB) {
+            const i64 gk = s_apbase + k;
+            if (gk < ap.cap) { ap.ap_ins[gk] = aps_ins[k]; ap.ap_ch[gk] = aps_ch[k]; ap.ap_t[gk] = aps_t[k]; ap.ap_gain[gk] = aps_gain[k]; }
         }
     }
     if (!single) return;
@@ -1051,3 +1115,24 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a)
         a.ph_t[pos] = st_t[slot]; a.ph_code[pos] = st_code[slot];
     }
 }
+
+// afterpulse photons -> tiles of the afterpulse pulse set of their instruction (set n_ins + ins): count, then place
+__global__ void k_ap_count(WfsDev d, GenArgs a, ApArgs ap)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
+    if (i >= n) return;
+    atomicAdd(&a.tile_count[((i64)a.n_ins + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i]], 1);
+}
+
+__global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
+    if (i >= n) return;
+    const i64 tile = ((i64)a.n_ins + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i];
+    const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
+    a.ph_t[pos] = ap.ap_t[i]; a.ph_code[pos] = 0u; ph_gain_base[pos] = ap.ap_gain[i];
+    atomicMin(&a.tile_tmin[tile], ap.ap_t[i]); atomicMax(&a.tile_tmax[tile], ap.ap_t[i]);
+}
+

@@ -40,7 +40,7 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_load_instructions', 'wfs_load_photons', 'wfs_run', 'wfs_get_counts', 'wfs_copy_records',
            'wfs_copy_records_dev', 'wfs_records_dev_ptr', 'wfs_copy_groups', 'wfs_copy_intervals',
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
-           'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
+           'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
            'wfs_kernel_times', 'wfs_set_profiling']
 
 
@@ -223,6 +223,10 @@ class Engine:
         acc, ts = np.zeros((s, 12)), np.zeros((s, 5))
         self._check(self.lib.wfs_copy_truth(self._h, _p(acc), _p(ts), C.c_int64(s)))
         return acc, ts
+
+    def set_noise_offsets(self, ix_rand):
+        a = _arr(ix_rand, np.int64)
+        self._check(self.lib.wfs_set_noise_offsets(self._h, _p(a), C.c_int64(len(a))))
 
     def set_window_carry(self, has_pulse, last_pulse_end_time):
         self._check(self.lib.wfs_set_window_carry(self._h, C.c_int32(int(has_pulse)), C.c_int64(int(last_pulse_end_time))))
