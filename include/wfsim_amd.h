@@ -119,6 +119,13 @@ int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, 
                      const int64_t *set_off, const int64_t *t, const int16_t *ch, const double *gain,
                      const uint8_t *dpe);
 
+/* Optical input: replaces RawDataOptical.sim_primary (rawdata.py:475-493).  One pulse set per instruction; its photons
+ * are channels[first[i]:last[i]] / timings[...] (ns relative to the instruction), cut to 0 <= t < time_cutoff
+ * (nveto_time_max_cutoff).  Transit time spread, double-PE and SPE gains are drawn on the GPU (Pulse.__call__). */
+int wfs_load_optical(wfs_handle *h, int64_t n, const int64_t *time, const uint32_t *gid, const int32_t *cluster,
+                     const int64_t *tmin, const int32_t *first, const int32_t *last,
+                     const int32_t *channels, const int64_t *timings, int64_t n_photons, int64_t time_cutoff);
+
 /* State carried across batches: RawData.last_pulse_end_time (rawdata.py:55, 188-190), the running maximum of the end of
  * every pulse simulated so far, which decides whether the first clusters of this batch open a new digitise window. */
 int wfs_set_window_carry(wfs_handle *h, int32_t has_pulse, int64_t last_pulse_end_time);

@@ -167,6 +167,12 @@ class Oracle:
                            ['type', 'time', 'z', 'amp', 'gid', 'p_hit', 'drift_mean', 'drift_spread', 'sc_gain',
                             'cdf_row', 'cdf_table']])
 
+    def simulate_optical(self, instructions, gid, channels, timings, cutoff):
+        a = dict(time=_arr(instructions['time'], np.int64), gid=_arr(gid, np.uint32), first=_arr(instructions['_first'], np.int32),
+                 last=_arr(instructions['_last'], np.int32), channels=_arr(channels, np.int32), timings=_arr(timings, np.int64))
+        lib().orc_simulate_optical(self._s, C.c_int64(len(instructions)), _p(a['time']), _p(a['gid']), _p(a['first']),
+                                   _p(a['last']), _p(a['channels']), _p(a['timings']), C.c_int64(cutoff))
+
     def pack_records(self, samples_per_record=110):
         n = lib().orc_pack_records(self._s, C.c_int64(samples_per_record), C.c_void_p(0), C.c_int64(0))
         out = np.zeros(n * (24 + 2 * samples_per_record), dtype=np.uint8)

@@ -76,7 +76,7 @@ typedef struct {
     /* pulse cache (rawdata.py:180-190) */
     vec_i32 pl_ch, pl_runset; vec_i64 pl_left, pl_right, pl_cur_off, pl_nph; vec_f64 cur;
     i64 first_uncommitted_pulse;
-    double last_pulse_end_time;
+    i64 last_end; int has_pulse;              /* RawData.last_pulse_end_time (exact integer once a pulse exists) */
     /* all generated photons (channel sorted per pulse call) */
     vec_i64 ph_t; vec_i16 ph_ch; vec_u8 ph_dpe; vec_f64 ph_gain; vec_i64 call_ph_off; vec_i32 call_kind, call_runset;
     vec_i64 e_t; vec_i64 call_e_off;
@@ -172,7 +172,6 @@ orc_session *orc_new(const orc_config *c, const double *templates, const double 
         for (int k = 1; k < c->tlen; k++) if (templates[r * c->tlen + k] > m) m = templates[r * c->tlen + k];
         s->current_max[r] = m;
     }
-    s->last_pulse_end_time = -INFINITY;
     VEC_PUSH(s->pl_cur_off, i64, 0); VEC_PUSH(s->call_ph_off, i64, 0); VEC_PUSH(s->call_e_off, i64, 0);
     VEC_PUSH(s->dg_row_off, i64, 0); VEC_PUSH(s->row_data_off, i64, 0); VEC_PUSH(s->zl_data_off, i64, 0);
     return s;
@@ -306,8 +305,8 @@ void orc_pulse_call(orc_session *s, int kind, int runset, i64 n, const i64 *t, c
         orc_add_current(t + a, gain + a, cnt, left, c->dt, s->templates, c->tlen, cur);
         VEC_PUSH(s->pl_ch, i32, channel); VEC_PUSH(s->pl_runset, i32, runset); VEC_PUSH(s->pl_left, i64, left);
         VEC_PUSH(s->pl_right, i64, right); VEC_PUSH(s->pl_nph, i64, cnt); VEC_PUSH(s->pl_cur_off, i64, s->cur.n);
-        double end = (double)right * c->dt;                      /* rawdata.py:188-190 */
-        if (end > s->last_pulse_end_time) s->last_pulse_end_time = end;
+        i64 end = right * c->dt;                                 /* rawdata.py:188-190 */
+        if (!s->has_pulse || end > s->last_end) { s->last_end = end; s->has_pulse = 1; }
         a = b;
     }
     for (int f = 0; f < 12; f++) VEC_PUSH(s->truth, double, tr[f]);
@@ -620,6 +619,58 @@ i64 orc_s2(orc_session *s, u32 gid, int runset, i64 time, i64 amp, double cy, do
     return n;
 }
 
+/* rawdata.py:475-493 RawDataOptical.sim_primary for one instruction: supplied photons (ns relative to the instruction,
+ * channel), cut to 0 <= t < cutoff, sorted by channel, then the plain Pulse.__call__ (transit time, DPE, SPE gain). */
+i64 orc_optical(orc_session *s, u32 gid, int runset, i64 time, i64 n, const i64 *t_rel, const i32 *chan, i64 cutoff)
+{
+    const orc_config *c = &s->c;
+    photon_buf pb; memset(&pb, 0, sizeof pb);
+    for (i64 k = 0; k < n; k++) {
+        if (t_rel[k] < 0 || t_rel[k] >= cutoff) continue;
+        u32 A[4], B[4], C[4];
+        draw(s, 0, gid, (u32)k, SITE_PH_A, A); draw(s, 0, gid, (u32)k, SITE_PH_B, B); draw(s, 0, gid, (u32)k, SITE_PH_C, C);
+        int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
+        int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
+        double z0, z1; box_muller(C, &z0, &z1);
+        i64 t = time + t_rel[k];
+        t += (i64)(c->tts_mean + c->tts_sigma * z0);
+        int ch = chan[k];
+        int sc = c->n_spe_channels > ch ? ch : 0;
+        const double *row = s->spe + (i64)sc * 2001;
+        double G = s->gains[ch], gain = G * row[g1];
+        if (is_dpe) gain += G * row[g2];
+        VEC_PUSH(pb.t, i64, t); VEC_PUSH(pb.ch, int16_t, (int16_t)ch); VEC_PUSH(pb.dpe, uint8_t, (uint8_t)is_dpe); VEC_PUSH(pb.gain, double, gain);
+    }
+    i64 np = pb.t.n;
+    sort_by_channel_and_call(s, 0, runset, &pb, 0);
+    free(pb.t.p); free(pb.ch.p); free(pb.dpe.p); free(pb.gain.p);
+    return np;
+}
+
+/* scheduler for optical instructions (all type 1, rawdata.py:38-157 with RawDataOptical.sim_primary) */
+void orc_simulate_optical(orc_session *s, i64 n, const i64 *time, const u32 *gid, const i32 *first, const i32 *last,
+                          const i32 *channels, const i64 *timings, i64 cutoff)
+{
+    const orc_config *c = &s->c;
+    if (n == 0) return;
+    tkey *ord = (tkey *)malloc((size_t)n * sizeof(tkey));
+    for (i64 i = 0; i < n; i++) { ord[i].t = time[i]; ord[i].i = i; }
+    qsort(ord, (size_t)n, sizeof(tkey), tkey_cmp);
+    i64 a = 0, group_start = 0; int runset = 0;
+    while (a < n) {
+        i64 b = a + 1;
+        while (b < n && !((double)(ord[b].t - ord[b - 1].t) > c->rext)) b++;
+        if (s->has_pulse && (double)(ord[a].t - s->last_end) > c->rext) { orc_digitize_and_zle(s, gid[ord[group_start].i]); group_start = a; }
+        for (i64 k = a; k < b; k++) {
+            i64 i = ord[k].i;
+            orc_optical(s, gid[i], runset++, time[i], last[i] - first[i], timings + first[i], channels + first[i], cutoff);
+        }
+        a = b;
+    }
+    orc_digitize_and_zle(s, gid[ord[group_start].i]);
+    free(ord);
+}
+
 /* ---------------------------------------------------------------- scheduler ---------------------- */
 /* rawdata.py:38-157 RawData.__call__ with electron afterpulses off: instructions are sorted by
  * time - z/v*[S2], split where the gap exceeds rext; clusters run in order, S1 run-sets then S2 run-sets (one
@@ -646,7 +697,7 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
     while (a < n) {
         i64 b = a + 1;
         while (b < n && !((double)(ord[b].t - ord[b - 1].t) > c->rext)) b++;
-        if (!isinf(s->last_pulse_end_time) && (double)ord[a].t - s->last_pulse_end_time > c->rext) {
+        if (s->has_pulse && (double)(ord[a].t - s->last_end) > c->rext) {
             orc_digitize_and_zle(s, gid[ord[group_start].i]);    /* rawdata.py:96-98 */
             group_start = a;
         }

@@ -29,7 +29,8 @@ struct wfs_handle {
     hipStream_t stream = nullptr; bool own_stream = false;
     std::string err;
     WfsDev dev;
-    bool tables_set = false, batch_loaded = false, injected = false, ran = false;
+    bool tables_set = false, batch_loaded = false, injected = false, optical = false, ran = false;
+    DevBuf set_gid, opt_t, opt_item;
     int keep_currents = 0, profiling = 0;
     int carry_has = 0; i64 carry_runmax = 0;
     // tables
@@ -55,6 +56,7 @@ struct wfs_handle {
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
     double h_templates[WFS_DT * 22] = {0};
+    std::vector<double> h_gains;
     i64 zero64 = 0;
     DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
 
@@ -205,7 +207,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -295,6 +297,7 @@ int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, in
     d.templates = h->t_templates.as<double>(); d.spe = h->t_spe.as<double>(); d.n_spe = n_spe; d.gains = h->t_gains.as<double>();
     d.thr_truth = h->t_thr_truth.as<double>(); d.thr_zle = h->t_thr_zle.as<i64>(); d.lum_x = h->t_lumx.as<double>(); d.lum_t = h->t_lumt.as<double>();
     memcpy(h->h_templates, templates, sizeof(h->h_templates));
+    h->h_gains.assign(gains, gains + c.n_tpc);
     for (int r = 0; r < c.dt; r++) {                       // pulse.py:32 current_max
         double m = templates[r * c.tlen];
         for (int k = 1; k < c.tlen; k++) m = std::max(m, templates[r * c.tlen + k]);
@@ -373,7 +376,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     TRY(load_clusters(h, n, cluster, tmin, gid));
-    h->injected = false; h->batch_loaded = true; h->ran = false;
+    h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false;
     return WFS_OK;
 }
 
@@ -400,6 +403,7 @@ int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, 
         t0[s] = mn;
         for (i64 p = a; p < b; p++) {
             if (ch[p] < 0 || ch[p] >= nch) return h->fail(WFS_E_INVALID, "photon channel out of range");
+            if (h->h_gains[ch[p]] == 0) return h->fail(WFS_E_INVALID, "photon on a turned-off PMT (gain 0): drop it before wfs_load_photons (pulse.py:89-90)");
             if (p > a && ch[p] < ch[p - 1]) return h->fail(WFS_E_INVALID, "photons of a set must be sorted by channel");
             i64 r = t[p] - mn;
             if (r > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "photon time span of a set exceeds 2^31 ns");
@@ -424,7 +428,55 @@ int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, 
         HIPCHK(hipMemsetAsync(h->ph_code.p, 0, (size_t)P * 4, h->stream));
     }
     TRY(load_clusters(h, n_sets, set_cluster, set_tmin, nullptr));
-    h->injected = true; h->batch_loaded = true; h->ran = false;
+    h->injected = true; h->optical = false; h->batch_loaded = true; h->ran = false;
+    return WFS_OK;
+}
+
+int wfs_load_optical(wfs_handle *h, int64_t n, const int64_t *time, const uint32_t *gid, const int32_t *cluster, const int64_t *tmin,
+                     const int32_t *first, const int32_t *last, const int32_t *channels, const int64_t *timings, int64_t n_ph, int64_t cutoff)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
+    if (n <= 0 || !time || !gid || !cluster || !tmin || !first || !last || (n_ph > 0 && (!channels || !timings)))
+        return h->fail(WFS_E_INVALID, "wfs_load_optical: null or empty input");
+    HIPCHK(hipSetDevice(h->device));
+    const int nch = h->cfg.n_tpc;
+    h->n_ins = n; h->n_sets = n; h->n_tiles = n * nch; h->n_emitters = 0; h->ap_active = false;
+    if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
+    std::vector<i32> count((size_t)h->n_tiles, 0);
+    for (i64 i = 0; i < n; i++) {
+        if (first[i] < 0 || last[i] < first[i] || last[i] > n_ph) return h->fail(WFS_E_INVALID, "_first/_last out of range");
+        for (i64 k = first[i]; k < last[i]; k++) {
+            if (timings[k] < 0 || timings[k] >= cutoff) continue;              // rawdata.py:485-486
+            if (channels[k] < 0 || channels[k] >= nch) return h->fail(WFS_E_INVALID, "photon channel out of range");
+            if (h->h_gains[channels[k]] == 0) continue;                      // turned-off PMT: no pulse (pulse.py:89-90)
+            if (timings[k] > 0x7ffffff0LL) return h->fail(WFS_E_CAPACITY, "photon time beyond 2^31 ns");
+            count[(size_t)(i * nch + channels[k])]++;
+        }
+    }
+    std::vector<i64> off((size_t)h->n_tiles + 1, 0);
+    for (i64 t = 0; t < h->n_tiles; t++) off[t + 1] = off[t] + count[t];
+    const i64 P = off[h->n_tiles];
+    h->n_photons = P;
+    std::vector<i32> rel((size_t)P); std::vector<u32> item((size_t)P); std::vector<i64> cur(off.begin(), off.end() - 1);
+    for (i64 i = 0; i < n; i++)
+        for (i64 k = first[i]; k < last[i]; k++) {
+            if (timings[k] < 0 || timings[k] >= cutoff || h->h_gains[channels[k]] == 0) continue;
+            const i64 pos = cur[(size_t)(i * nch + channels[k])]++;
+            rel[pos] = (i32)timings[k]; item[pos] = (u32)(k - first[i]);
+        }
+    std::vector<i32> mode((size_t)n, 0);
+    TRY(upload(h, h->set_cluster, cluster, (size_t)n * 4)); TRY(upload(h, h->set_t0, time, (size_t)n * 8)); TRY(upload(h, h->set_mode, mode.data(), (size_t)n * 4));
+    TRY(upload(h, h->set_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_time, time, (size_t)n * 8));
+    TRY(upload(h, h->tile_count, count.data(), count.size() * 4)); TRY(upload(h, h->tile_off, off.data(), off.size() * 8));
+    TRY(upload(h, h->opt_t, rel.data(), (size_t)P * 4)); TRY(upload(h, h->opt_item, item.data(), (size_t)P * 4));
+    TRY(ensure(h, h->ph_t, (size_t)P * 4)); TRY(ensure(h, h->ph_code, (size_t)P * 4));
+    TRY(ensure(h, h->tile_tmin, (size_t)h->n_tiles * 4)); TRY(ensure(h, h->tile_tmax, (size_t)h->n_tiles * 4));
+    TRY(ensure(h, h->el_stat, (size_t)n * 32)); TRY(ensure(h, h->el_minmax, (size_t)n * 16));
+    HIPCHK(hipMemsetAsync(h->el_stat.p, 0, (size_t)n * 32, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    TRY(load_clusters(h, n, cluster, tmin, gid));
+    h->injected = false; h->optical = true; h->batch_loaded = true; h->ran = false;
     return WFS_OK;
 }
 
@@ -522,7 +574,13 @@ int wfs_run(wfs_handle *h)
     const WfsDev &d = h->dev;
     const i64 T = h->n_tiles, S = h->n_sets, C = h->n_clusters;
     HIPCHK(hipMemsetAsync(h->scal.p, 0, 128, h->stream));
-    if (!h->injected) TRY(run_generation(h));
+    if (h->optical) {
+        OpticalArgs oa{T, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_gid.as<u32>(),
+                       h->opt_t.as<i32>(), h->opt_item.as<u32>(), h->ph_t.as<i32>(), h->ph_code.as<u32>(), h->scal.as<i64>()};
+        Timer t(h, "k_optical_finish");
+        hipLaunchKernelGGL(k_optical_finish, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, oa);
+    }
+    else if (!h->injected) TRY(run_generation(h));
     else { h->ap_active = false; TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7)); }
 
     // ---- geometry: tiles -> clusters -> groups -> rows
@@ -890,6 +948,7 @@ int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t cap)
 {
     if (!h || !h->ran) return WFS_E_STATE;
     const i64 N = h->n_ins;
+    if (h->optical) { for (i64 i = 0; i < N && i < cap; i++) { estat5[i * 5] = 0; for (int q = 1; q < 5; q++) estat5[i * 5 + q] = NAN; } return WFS_OK; }
     if (cap < N) return h->fail(WFS_E_CAPACITY, "electron stats buffer too small");
     if (N == 0) return WFS_OK;
     std::vector<double> st((size_t)N * 4); std::vector<i64> mm((size_t)N * 2), t0((size_t)N);

@@ -1136,3 +1136,34 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
     atomicMin(&a.tile_tmin[tile], ap.ap_t[i]); atomicMax(&a.tile_tmax[tile], ap.ap_t[i]);
 }
 
+// Optical input (RawDataOptical.sim_primary, rawdata.py:475-493): photons are supplied, already bucketed by the host
+// side of the ABI; what is left of Pulse.__call__ before add_current is drawn here per photon: transit time spread
+// (pulse.py:53-56), double-PE flag (pulse.py:76-79) and the SPE gain indices (pulse.py:97-103).  One thread per tile.
+struct OpticalArgs { i64 n_tiles; const i32 *tile_count; const i64 *tile_off; i32 *tile_tmin, *tile_tmax; const u32 *set_gid;
+                     const i32 *in_t; const u32 *in_item; i32 *ph_t; u32 *ph_code; i64 *scal; };
+
+__global__ void k_optical_finish(WfsDev d, OpticalArgs a)
+{
+    const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= a.n_tiles) return;
+    const i32 n = a.tile_count[tile];
+    if (n <= 0) return;
+    const i64 off = a.tile_off[tile];
+    const u32 gid = a.set_gid[tile / d.n_tpc];
+    i32 tmin = 0x7fffffff, tmax = (i32)0x80000000;
+    for (i32 p = 0; p < n; p++) {
+        const u32 item = a.in_item[off + p];                 // index of the photon inside its instruction's range
+        const u32x4 A = philox4x32_10(0, gid, item, SITE_PH_A, d.k0, d.k1);
+        const u32x4 B = philox4x32_10(0, gid, item, SITE_PH_B, d.k0, d.k1);
+        const u32x4 C = philox4x32_10(0, gid, item, SITE_PH_C, d.k0, d.k1);
+        const bool is_dpe = (u64)A.z < bern_threshold(d.p_dpe);
+        const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
+        i64 t = a.in_t[off + p];
+        t += (i64)(d.tts_mean + d.tts_sigma * box_muller_z0(C));
+        if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
+        a.ph_t[off + p] = (i32)t; a.ph_code[off + p] = g1 | (is_dpe ? (g2 << 16) : 0u);
+        tmin = (i32)t < tmin ? (i32)t : tmin; tmax = (i32)t > tmax ? (i32)t : tmax;
+    }
+    a.tile_tmin[tile] = tmin; a.tile_tmax[tile] = tmax;
+}
+

@@ -37,7 +37,7 @@ class WfsError(RuntimeError):
 
 _lib = None
 EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'wfs_set_tables', 'wfs_set_ap_element',
-           'wfs_load_instructions', 'wfs_load_photons', 'wfs_run', 'wfs_get_counts', 'wfs_copy_records',
+           'wfs_load_instructions', 'wfs_load_photons', 'wfs_load_optical', 'wfs_run', 'wfs_get_counts', 'wfs_copy_records',
            'wfs_copy_records_dev', 'wfs_records_dev_ptr', 'wfs_copy_groups', 'wfs_copy_intervals',
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
            'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
@@ -138,6 +138,13 @@ class Engine:
              _arr(ip['drift_spread'], np.float64), _arr(ip['sc_gain'], np.float64), _arr(ip['cdf_row'], np.int32),
              _arr(ip['cdf_table'], np.float64)]
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0])))
+
+    def load_optical(self, ins, gid, cluster, tmin, channels, timings, time_cutoff):
+        """ins: optical instructions (with _first/_last) sorted by time; channels/timings: the flat photon arrays"""
+        a = [_arr(ins['time'], np.int64), _arr(gid, np.uint32), _arr(cluster, np.int32), _arr(tmin, np.int64),
+             _arr(ins['_first'], np.int32), _arr(ins['_last'], np.int32), _arr(channels, np.int32), _arr(timings, np.int64)]
+        self._check(self.lib.wfs_load_optical(self._h, C.c_int64(len(ins)), *[_p(x) for x in a], C.c_int64(len(a[-1])),
+                                              C.c_int64(int(time_cutoff))))
 
     def load_photons(self, set_cluster, set_tmin, set_off, t, ch, gain, dpe=None):
         a = [_arr(set_cluster, np.int32), _arr(set_tmin, np.int64), _arr(set_off, np.int64), _arr(t, np.int64),

@@ -73,8 +73,7 @@ class RawData:
         n = len(s_ins)
         self.instruction_event_number = np.min(instructions['event_number'])
         # crude photon estimate per instruction: only used to bound a batch
-        est_csum = np.cumsum(np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15,
-                                      s_ins['amp'] * float(cfg.get('s2_secondary_sc_gain', 30))))
+        est_csum = np.cumsum(self._expected_quanta(s_ins))
         a, scale = 0, 1
         has_pulse, runmax = False, 0         # RawData.last_pulse_end_time over everything emitted so far
         while a < n:
@@ -82,9 +81,8 @@ class RawData:
             ins = s_ins[a:b]
             gid = order[a:b].astype(np.uint32)
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)
-            ip = instruction_params(ins, cfg, self.resource)
             self.engine.set_window_carry(has_pulse, runmax)
-            self.engine.load_instructions(ins, gid, cl, key[a:b], ip)
+            self._load_batch(ins, gid, cl, key[a:b])
             self.engine.run()
             groups = self.engine.groups()
             records = self.engine.records()
@@ -121,6 +119,14 @@ class RawData:
                 yield dict(left=self.left, right=self.right, records=records[first[g]:first[g + 1]])
             a, scale = b, 1
         self.source_finished = True
+
+    def _expected_quanta(self, s_ins):
+        return np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15,
+                        s_ins['amp'] * float(self.config.get('s2_secondary_sc_gain', 30)))
+
+    def _load_batch(self, ins, gid, cl, key):
+        ip = instruction_params(ins, self.config, self.resource)
+        self.engine.load_instructions(ins, gid, cl, key, ip)
 
     # ---- truth (rawdata.py:313-375) ----------------------------------------------------------------
     def _truth_rows(self, ins):
@@ -193,12 +199,20 @@ class RawData:
 
 
 class RawDataOptical(RawData):
-    """Photon channels / timings supplied up front (nVeto, optical Geant4 input): rawdata.py:461-495."""
+    """Photon channels / timings supplied up front (nVeto, optical Geant4 input): rawdata.py:461-495.
+
+    ``instructions`` carry ``_first`` / ``_last`` into the flat ``channels`` / ``timings`` arrays; only S1-type
+    instructions exist in this mode (strax_interface.py:903-904)."""
 
     def __init__(self, config, channels=tuple(), timings=tuple(), device=0, resource=None, seed=None):
         super().__init__(config, device=device, resource=resource, seed=seed)
         self.channels = np.asarray(channels)
         self.timings = np.asarray(timings)
 
-    def iter_windows(self, instructions, truth_buffer=None, **kwargs):
-        raise NotImplementedError('optical instruction input lands with the nVeto path (SURVEY.md 8, config 5)')
+    def _expected_quanta(self, s_ins):
+        return (s_ins['_last'] - s_ins['_first']).astype(np.float64)
+
+    def _load_batch(self, ins, gid, cl, key):
+        assert np.all(ins['type'] == 1), 'Only s1 type is supported for generating rawdata from optical input'
+        cutoff = self.config.get('nveto_time_max_cutoff', int(1e6))
+        self.engine.load_optical(ins, gid, cl, key, self.channels, self.timings, cutoff)
