@@ -27,6 +27,7 @@ from wfsim_amd.dtypes import instruction_dtype     # noqa: E402
 from wfsim_amd.physics import instruction_params   # noqa: E402
 from wfsim_amd.resource import Resource            # noqa: E402
 from wfsim_amd.scheduler import schedule           # noqa: E402
+from wfsim_amd.distributed import gather_records   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -105,29 +106,17 @@ def main():
     eng = Engine(cfg, res, device=local_rank)
     eng.load_instructions(s_ins, gid, cluster, key, ip)   # inputs resident in HBM before the timed region
 
-    gather_buf = None
+    gathered = None
 
     def step(profile=False):
         eng.set_profiling(profile)
         counts = eng.run()
         if world > 1 and not args.no_gather:
-            # variable-length gather of the packed records on rank 0 (RCCL over xGMI)
-            n = torch.tensor([counts['n_records']], device='cuda', dtype=torch.int64)
-            ns = [torch.zeros_like(n) for _ in range(world)] if rank == 0 else None
-            dist.gather(n, ns, dst=0)
-            nonlocal gather_buf
+            # variable-length gather of the packed records on rank 0 (RCCL over xGMI), wfsim_amd/distributed.py
+            nonlocal gathered
             mine = torch.empty(counts['n_records'] * 244, dtype=torch.uint8, device='cuda')
             eng.copy_records_to_device(mine.data_ptr(), counts['n_records'])
-            if rank == 0:
-                sizes = [int(x.item()) * 244 for x in ns]
-                bufs = [torch.empty(s, dtype=torch.uint8, device='cuda') for s in sizes]
-                reqs = [dist.irecv(bufs[r], src=r) for r in range(1, world)]
-                bufs[0] = mine
-                for q in reqs:
-                    q.wait()
-                gather_buf = bufs
-            else:
-                dist.send(mine, dst=0)
+            gathered = gather_records(mine, dst=0)
         return counts
 
     def barrier():

@@ -1,0 +1,65 @@
+"""Event sharding + record gather, world_size 2 over gloo on the CPU (no GPU, no oracle)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from wfsim_amd.distributed import shard_clusters, gather_records
+from wfsim_amd.dtypes import raw_record_dtype
+
+
+def test_shard_clusters_whole_clusters_balanced():
+    rng = np.random.default_rng(0)
+    cluster = np.repeat(np.arange(200), rng.integers(1, 6, 200))
+    weight = rng.uniform(1, 100, len(cluster))
+    for world in (1, 2, 4, 8):
+        b = shard_clusters(cluster, weight, world)
+        assert b[0] == 0 and b[-1] == len(cluster) and np.all(np.diff(b) >= 0)
+        for x in b[1:-1]:
+            assert cluster[x] != cluster[x - 1]                    # cuts only between clusters
+        loads = np.array([weight[b[r]:b[r + 1]].sum() for r in range(world)])
+        assert loads.max() < 1.25 * loads.mean() + weight.max() * 6
+    assert np.array_equal(shard_clusters(np.zeros(0, int), np.zeros(0), 4), np.zeros(5))
+    assert np.array_equal(shard_clusters(np.zeros(3, int), np.ones(3), 2), [0, 3, 3])   # one cluster cannot be split
+
+
+def _fake_records(rank, n):
+    rec = np.zeros(n, dtype=raw_record_dtype())
+    rec['time'] = 10_000_000 * rank + 10 * np.arange(n)
+    rec['channel'] = np.arange(n) % 494
+    rec['length'] = 110
+    rec['data'][:] = (rank + 1)
+    return rec
+
+
+def _worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    rec = _fake_records(rank, [5, 0, 7][rank] if world == 3 else [5, 7][rank])
+    t = torch.from_numpy(rec.view(np.uint8).copy())
+    bufs = gather_records(t, dst=0)
+    if rank == 0:
+        allrec = np.concatenate([b.numpy().view(raw_record_dtype()) for b in bufs])
+        np.save(out, allrec)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_gather_records_gloo(tmp_path, world):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'gathered.npy')
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    sizes = [5, 0, 7] if world == 3 else [5, 7]
+    ref = np.concatenate([_fake_records(r, n) for r, n in enumerate(sizes)])
+    assert got.tobytes() == ref.tobytes()
+    assert np.all(np.diff(got['time']) >= 0)

@@ -1,0 +1,84 @@
+"""Multi-GPU: event-sharded data parallelism + a gather of raw_records (one process per GPU, torch.distributed).
+
+The reference is single process (``parallel = False``, /root/reference/wfsim/strax_interface.py:546).  Time clusters
+of instructions are independent, so every rank simulates a contiguous time range of whole clusters
+with the same code path as a single GPU; RNG streams are keyed by the run-wide instruction index, so the records
+do not depend on the sharding.  The only exchange is the final variable-length gather of the packed 244-byte
+records on the rank that feeds strax: sizes by ``all_gather``, payload by direct peer -> root ``send`` / ``recv``
+(RCCL over xGMI with the ``nccl`` backend: the root's seven links fill in parallel; ``gloo`` in the CPU tests).
+Concatenating the shards in rank order gives the globally time-ordered stream.
+"""
+import numpy as np
+
+
+def shard_clusters(cluster, weight, world_size):
+    """Contiguous ranges of whole clusters, balanced by ``weight`` (e.g. expected quanta per instruction).
+
+    ``cluster``: non-decreasing cluster index of every (sorted) instruction.  Returns ``bounds`` with
+    ``world_size + 1`` instruction indices: rank r owns ``[bounds[r], bounds[r + 1])``."""
+    n = len(cluster)
+    if n == 0:
+        return np.zeros(world_size + 1, dtype=np.int64)
+    w = np.cumsum(np.asarray(weight, dtype=np.float64))
+    total = w[-1]
+    starts = np.concatenate([[0], np.where(np.diff(cluster) != 0)[0] + 1])      # first instruction of every cluster
+    bounds = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        i = int(np.searchsorted(w, target))                     # instruction where the cumulative weight crosses
+        j = int(starts[np.searchsorted(starts, i, side='left')]) if np.searchsorted(starts, i, side='left') < len(starts) else n
+        bounds.append(max(j, bounds[-1]))
+    bounds.append(n)
+    return np.asarray(bounds, dtype=np.int64)
+
+
+def gather_records(records, dst=0, group=None):
+    """Variable-length gather of packed records (uint8 tensor of n * 244 bytes per rank, on the backend's device).
+
+    Returns the list of per-rank tensors on ``dst`` (rank order = time order), ``None`` elsewhere."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = torch.tensor([records.numel()], dtype=torch.int64, device=records.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    if rank == dst:
+        bufs = [records if r == dst else torch.empty(sizes[r], dtype=records.dtype, device=records.device) for r in range(world)]
+        reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(world) if r != dst and sizes[r] > 0]
+        for q in reqs:
+            q.wait()
+        return bufs
+    if sizes[rank] > 0:
+        dist.send(records, dst=dst, group=group)
+    return None
+
+
+def simulate_sharded(config, instructions, device=None, dst=0):
+    """All ranks call this with the same instructions; rank ``dst`` gets the time-ordered raw_records of the whole
+    run (numpy structured array), the others ``None``.  One process per GPU (``LOCAL_RANK`` picks the device)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from .dtypes import raw_record_dtype
+    from .rawdata import RawData
+    from .scheduler import schedule
+    rank, world = dist.get_rank(), dist.get_world_size()
+    device = int(os.environ.get('LOCAL_RANK', rank)) if device is None else device
+    order, key, cluster = schedule(instructions, config)
+    s_ins = instructions[order]
+    weight = np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15, s_ins['amp'] * float(config.get('s2_secondary_sc_gain', 30)))
+    b = shard_clusters(cluster, weight, world)
+    mine = s_ins[b[rank]:b[rank + 1]]
+    rd = RawData(config, device=device)
+    # run-wide instruction ids keep the RNG streams independent of the sharding
+    rd.global_ids = order[b[rank]:b[rank + 1]]
+    recs = [w['records'] for w in rd.iter_windows(mine)]
+    local = np.concatenate(recs) if recs else np.zeros(0, dtype=raw_record_dtype())
+    dev = torch.device('cuda', device) if dist.get_backend() == 'nccl' else torch.device('cpu')
+    t = torch.from_numpy(local.view(np.uint8).copy()).to(dev)
+    bufs = gather_records(t, dst=dst)
+    if rank != dst:
+        return None
+    return np.concatenate([x.cpu().numpy().view(raw_record_dtype()) for x in bufs])

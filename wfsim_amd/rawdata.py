@@ -41,6 +41,8 @@ class RawData:
         self.engine = Engine(config, self.resource, device=device, seed=seed)
         self.source_finished = False
         self.left = self.right = 0
+        #: run-wide index of every instruction passed to __call__ (RNG stream ids); None: position in the input
+        self.global_ids = None
 
     @staticmethod
     def symtype(ptype):
@@ -79,7 +81,7 @@ class RawData:
         while a < n:
             b = self._batch_end(a, est_csum, cluster, scale)
             ins = s_ins[a:b]
-            gid = order[a:b].astype(np.uint32)
+            gid = (order[a:b] if self.global_ids is None else np.asarray(self.global_ids)[order[a:b]]).astype(np.uint32)
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)
             self.engine.set_window_carry(has_pulse, runmax)
             self._load_batch(ins, gid, cl, key[a:b])
