@@ -142,6 +142,14 @@ def main():
     else:
         total_pe, total_rec, total_ph = counts['n_pe'], counts['n_records'], counts['n_photons']
 
+    # PCIe-inclusive rate (never the headline value): one more step plus the device -> host copy of the records
+    barrier()
+    t1 = time.perf_counter()
+    step()
+    host_records = eng.records()
+    pcie_ms = 1e3 * (time.perf_counter() - t1)
+    del host_records
+
     # one extra (untimed) profiled step: HIP-event duration of every kernel on the engine's stream
     counts = step(profile=True)
     ktimes = eng.kernel_times()
@@ -162,7 +170,8 @@ def main():
         config=dict(workload=f'{M} S2 instructions per GPU, 1e4 electrons each (~1e6 PE), 494 PMTs, z=-10 cm, '
                              f's2_secondary_sc_gain=100, noise/afterpulses off (BASELINE configs[2])',
                     instructions_per_gpu=M, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
-                    gather='none' if (world == 1 or args.no_gather) else 'rccl send/recv to rank 0'),
+                    gather='none' if (world == 1 or args.no_gather) else 'rccl send/recv to rank 0',
+                    ms_per_step_incl_d2h_of_records=pcie_ms),
         roofline=dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                       traffic=None, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,
                       pipeline_frac=b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
