@@ -161,6 +161,12 @@ def main():
     dom = max(ktimes, key=lambda k: ktimes[k][0])
     dom_ms, dom_launches = ktimes[dom]
     b_alg = algorithmic_bytes(counts)
+    traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC profile of this command
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
+            traffic = json.load(f)['kernels'][dom]['hbm_bytes'] if M == 1000 else None
+    except (OSError, KeyError):
+        pass
     achieved = b_alg / (dom_ms / dom_launches * 1e-3) / 1e9
     out = dict(
         metric='photoelectrons/sec + raw_records MB/s, 10^6-PE S2 batch', value=total_pe * args.steps / elapsed,
@@ -173,7 +179,7 @@ def main():
                     gather='none' if (world == 1 or args.no_gather) else 'rccl send/recv to rank 0',
                     ms_per_step_incl_d2h_of_records=pcie_ms),
         roofline=dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
-                      traffic=None, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,
+                      traffic=traffic, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,
                       pipeline_frac=b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       kernels_ms={k: round(v[0], 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}),
     )
