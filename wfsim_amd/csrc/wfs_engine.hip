@@ -538,7 +538,7 @@ static int run_generation(wfs_handle *h)
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart
         auto gcd = [](u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } return x; };
-        u64 stride = std::max<u64>(1, nb / 1021) | 1;
+        u64 stride = getenv("WFS_STRIDE1") ? 1 : (std::max<u64>(1, nb / 1021) | 1);
         while (gcd(stride, nb) != 1) stride += 2;
         g.n_blocks = nb; g.block_stride = (i64)stride;
         TRY(ensure(h, h->blk_e, (size_t)nb * 16));
@@ -676,19 +676,24 @@ int wfs_run(wfs_handle *h)
         PulseArgs pd = pa;
         pd.active_tiles = h->active_tiles.as<i32>() + h->n_sparse_tiles;
         if (pd.cur_off) pd.cur_off += h->n_sparse_tiles;
-        const int W_MAX = 1024;
-        int W = (int)std::min<i64>(std::max<i64>(h->max_nb_dense, d.tlen + 1), W_MAX);
+        // windows of up to W_WIN start bins, one workgroup each: LDS per workgroup stays ~24 KB (6 workgroups per CU) and a
+        // 10^6-PE tile is spread over three workgroups; very long tiles loop over further windows inside the kernel
+        const int W_WIN = 256, NWIN_MAX = 8;
+        int W = (int)std::min<i64>(std::max<i64>(h->max_nb_dense, d.tlen + 1), W_WIN);
         W = (W + 7) / 8 * 8;
         pd.W = W;
+        const i64 step = W - (d.tlen - 1);
+        pd.n_win = (int)std::min<i64>(NWIN_MAX, std::max<i64>(1, (h->max_nb_dense + step - 1) / step));
         TemplateArg tp;
         memcpy(tp.t, h->h_templates, sizeof(tp.t));
         const bool small = W <= 128;
         const int tpb = small ? 128 : 256;
         size_t lds = (size_t)(W + 2 * DENSE_PAD) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
         lds = (lds + 15) / 16 * 16;
+        const unsigned grid = (unsigned)(h->n_dense_tiles * pd.n_win);
         Timer t(h, "k_pulse_dense");
-        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128>), dim3((unsigned)h->n_dense_tiles), dim3(128), lds, h->stream, d, pd, tp);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256>), dim3((unsigned)h->n_dense_tiles), dim3(256), lds, h->stream, d, pd, tp);
+        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128>), dim3(grid), dim3(128), lds, h->stream, d, pd, tp);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256>), dim3(grid), dim3(256), lds, h->stream, d, pd, tp);
     }
 
     // ---- ZLE + records

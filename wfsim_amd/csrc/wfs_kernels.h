@@ -241,6 +241,7 @@ struct PulseArgs {
     double *currents; const i64 *cur_off;     // debug: f64 tile currents
     i32 W;                // start bins per LDS window (dense) / bins capacity (sparse)
     i32 NP;               // photon capacity of the sparse kernel's LDS list
+    i32 n_win;            // dense kernel: workgroups (windows) per tile
     i32 ablate;           // profiling only: bit0 no truth, bit1 no gather, bit2 no pass1, bit3 no place/merge, bit4 no raw atomics
 };
 
@@ -261,7 +262,11 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     u32 *wsum = (u32 *)(red + 8 * (TPB / 64));
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
 
-    const i64 tile = a.active_tiles[blockIdx.x];
+    // grid = tiles x windows: every workgroup owns one window of W start bins of one tile (a.n_win windows per tile;
+    // consecutive windows overlap by tlen - 1 bins so that every sample sees all its taps inside one window)
+    const i64 tidx = blockIdx.x / a.n_win;
+    const int win = (int)(blockIdx.x - tidx * a.n_win);
+    const i64 tile = a.active_tiles[tidx];
     const i32 n = a.tile_count[tile];
     const i64 off = a.tile_off[tile];
     const i64 set = tile / d.n_tpc; const i32 ch = (i32)(tile - set * d.n_tpc);
@@ -279,8 +284,10 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     const double thr = d.thr_truth[ch];
     const i64 rel0 = bin0 * dt - t0;                      // ns of the tile's first start bin relative to t0
 
+    // window w exists iff it is the first or the previous one did not already reach the last start bin (block-uniform)
+    if (win > 0 && (i64)win * (W - (tlen - 1)) + (tlen - 1) >= nb) return;
     i32 n_dpe_tile = 0;
-    {                         // number of DPE photons of the tile (truth quirk pulse.py:255)
+    if (win == 0) {           // number of DPE photons of the tile (truth quirk pulse.py:255); truth is window 0's job
         i32 c = 0;
         for (i32 p = tid; p < n; p += TPB) c += (a.ph_code[off + p] >> 16) != 0;
         for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     }
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2
 
-    for (i64 w0 = 0; w0 < nb; w0 += W - (tlen - 1)) {
+    for (i64 w0 = (i64)win * (W - (tlen - 1)); w0 == 0 || w0 + (tlen - 1) < nb; w0 += (i64)a.n_win * (W - (tlen - 1))) {
         const int Wc = (int)((nb - w0 < W) ? nb - w0 : W);
         const bool first = (w0 == 0), last = (w0 + Wc >= nb);
         __syncthreads();
@@ -380,15 +387,14 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 const i64 s = sb + tid + (i64)q * TPB;
                 if (s >= s_hi) continue;
                 const double c = act[q] ? cur[q] : 0.0;
-                if (a.currents) a.currents[a.cur_off[blockIdx.x] + s] = c;
+                if (a.currents) a.currents[a.cur_off[tidx] + s] = c;
                 const i64 adc = -(i64)rint(c * d.c2a);             // rawdata.py:236, np.around = round half to even
                 if (adc != 0) atomicAdd(&dst[s], (i32)adc);
             }
         }
-        if (last) break;            // block-uniform
     }
 
-    if (a.truth) {
+    if (a.truth && win == 0) {
 #pragma unroll
         for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
         __syncthreads();
