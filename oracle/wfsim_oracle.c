@@ -61,7 +61,7 @@ typedef struct { uint8_t *p; i64 n, cap; } vec_u8;
 #define VEC_RESERVE(v, T, m) do { if ((v).n + (m) > (v).cap) { while ((v).n + (m) > (v).cap) (v).cap = (v).cap ? (v).cap * 2 : 1024; \
     (v).p = (T *)realloc((v).p, (size_t)(v).cap * sizeof(T)); } } while (0)
 
-typedef struct {
+typedef struct orc_session_s {
     orc_config c;
     const double *templates;     /* [10][tlen]                       pulse.py:146-187 */
     const double *spe;           /* [n_spe_channels][2001]           pulse.py:189-223 */
@@ -88,7 +88,8 @@ typedef struct {
     /* truth accumulators per pulse call (pulse.py:229-271): 12 doubles each */
     vec_f64 truth;
     i64 n_pe_total;
-    const i64 *noise_override; i64 n_noise_override;    /* tests: ix_rand per digitise call instead of the Philox draw */
+    const i64 *noise_override; i64 n_noise_override;
+    struct { double *cum; i64 n; i64 vmin; } tab[6];   /* tts, s1 exp, s1 spread, t1, t3, s2 spread: trunc()-ed delay variates */    /* tests: ix_rand per digitise call instead of the Philox draw */
 } orc_session;
 
 /* ---------------------------------------------------------------- Philox4x32-10 ------------------ */
@@ -159,6 +160,10 @@ static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam)
     }
 }
 
+enum { TAB_TTS = 0, TAB_S1_EXP, TAB_S1_SPREAD, TAB_T1, TAB_T3, TAB_S2_SPREAD };
+static void tab_normal(struct orc_session_s *s, int slot, double mu, double sigma);
+static void tab_exp(struct orc_session_s *s, int slot, double tau);
+
 /* ---------------------------------------------------------------- session ------------------------ */
 orc_session *orc_new(const orc_config *c, const double *templates, const double *spe, const double *gains,
                      const double *thr_truth, const i64 *thr_zle, const double *lum_x, const double *lum_t,
@@ -167,6 +172,8 @@ orc_session *orc_new(const orc_config *c, const double *templates, const double 
     orc_session *s = (orc_session *)calloc(1, sizeof(orc_session));
     s->c = *c; s->templates = templates; s->spe = spe; s->gains = gains; s->thr_truth = thr_truth; s->thr_zle = thr_zle;
     s->lum_x = lum_x; s->lum_t = lum_t; s->noise = noise;
+    tab_normal(s, TAB_TTS, c->tts_mean, c->tts_sigma); tab_exp(s, TAB_S1_EXP, c->s1_decay_time); tab_normal(s, TAB_S1_SPREAD, 0.0, c->s1_decay_spread);
+    tab_exp(s, TAB_T1, c->t1_gas); tab_exp(s, TAB_T3, c->t3_gas); tab_normal(s, TAB_S2_SPREAD, 0.0, c->s2_time_spread);
     for (int r = 0; r < 10; r++) {              /* pulse.py:32 current_max */
         double m = templates[r * c->tlen];
         for (int k = 1; k < c->tlen; k++) if (templates[r * c->tlen + k] > m) m = templates[r * c->tlen + k];
@@ -199,6 +206,7 @@ void orc_free(orc_session *s)
         (void **)&s->zl_right.p, (void **)&s->zl_data_off.p, (void **)&s->zl_ch.p, (void **)&s->zl_data.p,
         (void **)&s->truth.p };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
+    for (int q = 0; q < 6; q++) free(s->tab[q].cum);
     free(s);
 }
 
@@ -427,6 +435,34 @@ void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
     s->first_uncommitted_pulse = p1;
 }
 
+/* ---------------------------------------------------------------- integer delay variates --------- */
+/* The reference draws a float variate and truncates it to int64 (pulse.py:54-56 normal, s1.py:193-194 exponential and
+ * normal, pulse.py:339-341 exponential * lifetime, s2.py:550 normal).  trunc(Y) is sampled here directly: from one
+ * uniform by inverse CDF over cum[i] = P(trunc(Y) <= vmin + i).  For Y ~ N(mu, sigma): P(X <= k) = Phi((k+1-mu)/sigma)
+ * for k >= 0 and Phi((k-mu)/sigma) for k < 0 (the C cast truncates toward zero); for Y ~ Exp(tau): 1 - exp(-(k+1)/tau). */
+static void tab_normal(orc_session *s, int slot, double mu, double sigma)
+{
+    if (!(sigma > 0)) { s->tab[slot].cum = (double *)malloc(8); s->tab[slot].cum[0] = 1.0; s->tab[slot].n = 1; s->tab[slot].vmin = (i64)mu; return; }
+    i64 lo = (i64)floor(mu - 8.5 * sigma) - 1, hi = (i64)ceil(mu + 8.5 * sigma) + 1, n = hi - lo + 1;
+    double *c = (double *)malloc((size_t)n * 8);
+    for (i64 k = lo; k <= hi; k++) { double x = ((double)(k >= 0 ? k + 1 : k) - mu) / sigma; c[k - lo] = 0.5 * erfc(-x / 1.4142135623730951); }
+    c[n - 1] = 1.0;
+    s->tab[slot].cum = c; s->tab[slot].n = n; s->tab[slot].vmin = lo;
+}
+static void tab_exp(orc_session *s, int slot, double tau)
+{
+    double *c = (double *)malloc(60000 * 8); i64 n = 0;
+    if (!(tau > 0)) { c[n++] = 1.0; }
+    else for (i64 k = 0; k < 60000; k++) { double v = -expm1(-(double)(k + 1) / tau); c[n++] = v; if (v >= 1.0) break; }
+    c[n - 1] = 1.0;
+    s->tab[slot].cum = c; s->tab[slot].n = n; s->tab[slot].vmin = 0;
+}
+static i64 sample_tab(const orc_session *s, int slot, double u)
+{
+    const double *c = s->tab[slot].cum; i64 lo = 0, hi = s->tab[slot].n - 1;
+    while (lo < hi) { i64 mid = (lo + hi) >> 1; if (u < c[mid]) hi = mid; else lo = mid + 1; }      /* first i with u < cum[i] */
+    return s->tab[slot].vmin + lo;
+}
 /* ---------------------------------------------------------------- photon generation -------------- */
 static int cmp_ch_stable(const void *a, const void *b)
 {
@@ -472,20 +508,22 @@ static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u3
     int ch = channel_from_cdf(cdf, c->n_tpc, u53(A[0], A[1]));
     int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
     int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
-    double z_tts, z_spread;
-    box_muller(C, &z_tts, &z_spread);
-    double e1 = -log(1.0 - u53(B[0], B[1]));
+    double u_exp = u53(B[0], B[1]);
     i64 t = t0;
     if (!is_s2) {
-        if (c->s1_simple) { t += (i64)(e1 * c->s1_decay_time); t += (i64)(0.0 + c->s1_decay_spread * z_spread); }
+        if (c->s1_simple) {                                                     /* s1.py:193-194 */
+            t += sample_tab(s, TAB_S1_EXP, u_exp);
+            if (c->s1_decay_spread != 0) t += sample_tab(s, TAB_S1_SPREAD, u53(C[2], C[3]));
+        }
     } else {
-        draw(s, emitter, gid, item, SITE_PH_D, D);
-        t += (i64)interp_lum(s, u53(D[0], D[1]));
-        double delay = ((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas;     /* pulse.py:339-341 */
-        t += (i64)(e1 * delay);
-        if (c->s2_time_model == 1) t += (i64)(0.0 + c->s2_time_spread * z_spread);
+        t += (i64)interp_lum(s, u53(C[2], C[3]));                               /* s2.py:338 */
+        t += sample_tab(s, ((u64)B[3] < bern_threshold(c->sf_gas)) ? TAB_T1 : TAB_T3, u_exp);   /* pulse.py:339-341 */
+        if (c->s2_time_model == 1 && c->s2_time_spread != 0) {                  /* s2.py:550 */
+            draw(s, emitter, gid, item, SITE_PH_D, D);
+            t += sample_tab(s, TAB_S2_SPREAD, u53(D[0], D[1]));
+        }
     }
-    t += (i64)(c->tts_mean + c->tts_sigma * z_tts);
+    t += sample_tab(s, TAB_TTS, u53(C[0], C[1]));                               /* pulse.py:54-56 */
     int sc = c->n_spe_channels > ch ? ch : 0;
     const double *row = s->spe + (i64)sc * 2001;
     double G = s->gains[ch], gain = G * row[g1];
@@ -631,9 +669,8 @@ i64 orc_optical(orc_session *s, u32 gid, int runset, i64 time, i64 n, const i64 
         draw(s, 0, gid, (u32)k, SITE_PH_A, A); draw(s, 0, gid, (u32)k, SITE_PH_B, B); draw(s, 0, gid, (u32)k, SITE_PH_C, C);
         int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
         int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
-        double z0, z1; box_muller(C, &z0, &z1);
         i64 t = time + t_rel[k];
-        t += (i64)(c->tts_mean + c->tts_sigma * z0);
+        t += sample_tab(s, TAB_TTS, u53(C[0], C[1]));
         int ch = chan[k];
         int sc = c->n_spe_channels > ch ? ch : 0;
         const double *row = s->spe + (i64)sc * 2001;
@@ -764,12 +801,11 @@ void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 
     for (i64 i = 0; i < n; i++) {
         u32 A[4], B[4], C[4], D[4]; u32 em = (u32)(i >> 20), item = (u32)(i & 0xfffff), gid = 777u;
         draw(s, em, gid, item, SITE_PH_B, B); draw(s, em, gid, item, SITE_PH_C, C); draw(s, em, gid, item, SITE_PH_D, D);
-        double z0, z1; box_muller(C, &z0, &z1);
-        double e1 = -log(1.0 - u53(B[0], B[1]));
-        if (kind == 0) out[i] = (i64)interp_lum(s, u53(D[0], D[1]));
-        else if (kind == 1) out[i] = (i64)(e1 * (((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas));
-        else if (kind == 2) out[i] = (i64)(c->tts_mean + c->tts_sigma * z0);
-        else if (kind == 3) out[i] = (i64)(e1 * c->s1_decay_time) + (i64)(0.0 + c->s1_decay_spread * z1);
+        double z0, z1;
+        if (kind == 0) out[i] = (i64)interp_lum(s, u53(C[2], C[3]));
+        else if (kind == 1) out[i] = sample_tab(s, ((u64)B[3] < bern_threshold(c->sf_gas)) ? TAB_T1 : TAB_T3, u53(B[0], B[1]));
+        else if (kind == 2) out[i] = sample_tab(s, TAB_TTS, u53(C[0], C[1]));
+        else if (kind == 3) out[i] = sample_tab(s, TAB_S1_EXP, u53(B[0], B[1])) + sample_tab(s, TAB_S1_SPREAD, u53(C[2], C[3]));
         else {
             draw(s, (u32)i, gid, 0, SITE_EL_A, A); draw(s, (u32)i, gid, 0, SITE_EL_B, B);
             box_muller(B, &z0, &z1);

@@ -65,6 +65,37 @@ __device__ __forceinline__ void box_muller(u32x4 w, double &z0, double &z1)
     z0 = r * c; z1 = r * s;
 }
 
+// Integer-valued random delays.  The reference draws a float variate and truncates it to int64 before adding it
+// (pulse.py:54-56, s1.py:193-194, pulse.py:341, s2.py:550).  trunc(Y) is a discrete variate; it is sampled here by inverse
+// CDF from one uniform: cum[i] = P(X <= vmin + i), result = vmin + (first i with u < cum[i]).  The tables are built on
+// the host (wfs_engine.hip, build_time_tables) from erfc / expm1; the CPU oracle builds its own the same way.
+#define DISC_G 1024
+struct DiscTab { const double *cum; const unsigned short *guide; i32 vmin, n; };
+
+// Lookup in two steps so that several lookups of one photon can have their loads in flight together:
+// disc_begin issues the two guide loads, disc_finish the (usually 4-entry) window of cumulative probabilities.
+struct DiscReq { const double *cum; int lo, hi; double u; };
+
+__device__ __forceinline__ DiscReq disc_begin(const DiscTab &t, double u)
+{
+    const int c = (int)(u * DISC_G);
+    DiscReq r; r.cum = t.cum; r.u = u; r.lo = t.guide[c]; r.hi = t.guide[c + 1];       // answer in [lo, hi]
+    return r;
+}
+
+__device__ __forceinline__ i64 disc_finish(const DiscTab &t, DiscReq r)
+{
+    int lo = r.lo, hi = r.hi;
+    while (hi - lo > 3) { const int mid = (lo + hi) >> 1; if (r.u < r.cum[mid]) hi = mid; else lo = mid + 1; }
+    // at most 4 candidates left: fetch them together (cum[n-1] == 1 > u, indices clamped to the table)
+    const int n1 = t.n - 1;
+    const double c0 = r.cum[lo], c1 = r.cum[lo + 1 < n1 ? lo + 1 : n1], c2 = r.cum[lo + 2 < n1 ? lo + 2 : n1];
+    const int k = r.u < c0 ? 0 : (r.u < c1 ? 1 : (r.u < c2 ? 2 : 3));
+    return (i64)t.vmin + lo + k;
+}
+
+__device__ __forceinline__ i64 sample_disc(const DiscTab &t, double u) { return disc_finish(t, disc_begin(t, u)); }
+
 // python-style floor division / modulo on int64 (numpy // and % on int64, pulse.py:305-306)
 __host__ __device__ __forceinline__ i64 floordiv(i64 a, i64 b) { i64 q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 __host__ __device__ __forceinline__ i64 floormod(i64 a, i64 b) { i64 m = a % b; return (m != 0 && ((m < 0) != (b < 0))) ? m + b : m; }
@@ -80,7 +111,8 @@ struct WfsDev {
     u32 k0, k1;
     double current_max[10];
     double lum_x0, lum_xl, lum_f0, lum_fl;     // first / last point of the luminescence table
-    i32 need_z1_s1, need_z1_s2;                // second Box-Muller variate needed (non-zero spread)
+    i32 need_z1_s1, need_z1_s2;                // spread term present (non-zero spread)
+    DiscTab tab_tts, tab_s1_exp, tab_s1_spread, tab_t1, tab_t3, tab_s2_spread;
     // tables
     const double *templates, *spe, *gains, *thr_truth, *lum_x, *lum_t;
     const i64 *thr_zle;

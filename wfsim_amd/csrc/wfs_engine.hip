@@ -40,7 +40,7 @@ struct wfs_handle {
     i64 n_ins = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, em_off;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
-    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e;
+    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, ph_slot;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, dense_tiles;
     DevBuf ph_t, ph_code, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
@@ -58,6 +58,7 @@ struct wfs_handle {
     double h_templates[WFS_DT * 22] = {0};
     std::vector<double> h_gains;
     i64 zero64 = 0;
+    DevBuf tt_cum[6], tt_guide[6];
     DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
@@ -146,6 +147,63 @@ int read_scal(wfs_handle *h)
     return WFS_OK;
 }
 
+// cum[i] = P(trunc(Y) <= vmin + i) for Y ~ N(mu, sigma) (trunc = C cast, toward zero)
+static void normal_trunc_table(double mu, double sigma, std::vector<double> &cum, int &vmin)
+{
+    cum.clear();
+    if (!(sigma > 0)) { vmin = (int)mu; cum.push_back(1.0); return; }
+    const int lo = (int)floor(mu - 8.5 * sigma) - 1, hi = (int)ceil(mu + 8.5 * sigma) + 1;
+    vmin = lo;
+    for (int k = lo; k <= hi; k++) {
+        const double x = ((k >= 0 ? k + 1 : k) - mu) / sigma;
+        cum.push_back(0.5 * erfc(-x / 1.4142135623730951));
+    }
+    cum.back() = 1.0;
+}
+
+// cum[i] = P(trunc(Y) <= i) for Y ~ Exp(scale tau)
+static void exp_trunc_table(double tau, std::vector<double> &cum, int &vmin)
+{
+    cum.clear(); vmin = 0;
+    if (!(tau > 0)) { cum.push_back(1.0); return; }
+    for (int k = 0; k < 60000; k++) {
+        const double c = -expm1(-(double)(k + 1) / tau);
+        cum.push_back(c);
+        if (c >= 1.0) break;
+    }
+    cum.back() = 1.0;
+}
+
+static int upload_disc(wfs_handle *h, int slot, const std::vector<double> &cum, int vmin, DiscTab &out)
+{
+    if (cum.size() > 65000) return h->fail(WFS_E_CAPACITY, "delay table too long (time constant above ~1.5 us)");
+    std::vector<unsigned short> guide(DISC_G + 2);
+    size_t idx = 0;
+    for (int c = 0; c <= DISC_G + 1; c++) {                 // first index whose cumulative probability exceeds c / DISC_G
+        const double x = (double)c / DISC_G;
+        while (idx + 1 < cum.size() && cum[idx] <= x) idx++;
+        guide[c] = (unsigned short)idx;
+    }
+    TRY(upload(h, h->tt_cum[slot], cum.data(), cum.size() * 8));
+    TRY(upload(h, h->tt_guide[slot], guide.data(), guide.size() * 2));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    out.cum = h->tt_cum[slot].as<double>(); out.guide = h->tt_guide[slot].as<unsigned short>(); out.vmin = vmin; out.n = (i32)cum.size();
+    return WFS_OK;
+}
+
+int build_time_tables(wfs_handle *h)
+{
+    const wfs_config &c = h->cfg; WfsDev &d = h->dev;
+    std::vector<double> cum; int vmin;
+    normal_trunc_table(c.tts_mean, c.tts_sigma, cum, vmin); TRY(upload_disc(h, 0, cum, vmin, d.tab_tts));
+    exp_trunc_table(c.s1_decay_time, cum, vmin); TRY(upload_disc(h, 1, cum, vmin, d.tab_s1_exp));
+    normal_trunc_table(0.0, c.s1_decay_spread, cum, vmin); TRY(upload_disc(h, 2, cum, vmin, d.tab_s1_spread));
+    exp_trunc_table(c.t1_gas, cum, vmin); TRY(upload_disc(h, 3, cum, vmin, d.tab_t1));
+    exp_trunc_table(c.t3_gas, cum, vmin); TRY(upload_disc(h, 4, cum, vmin, d.tab_t3));
+    normal_trunc_table(0.0, c.s2_time_spread, cum, vmin); TRY(upload_disc(h, 5, cum, vmin, d.tab_s2_spread));
+    return WFS_OK;
+}
+
 void refresh_dev(wfs_handle *h)
 {
     const wfs_config &c = h->cfg; WfsDev &d = h->dev;
@@ -190,6 +248,7 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     if (hipMalloc(&h->scal.p, 256) != hipSuccess) { delete h; return WFS_E_HIP; }
     h->scal.cap = 256;
     refresh_dev(h);
+    if (build_time_tables(h) != WFS_OK) { delete h; return WFS_E_HIP; }
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
     hipFuncSetAttribute((const void *)k_pulse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -207,7 +266,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->blk_base, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -216,6 +275,7 @@ int wfs_destroy(wfs_handle *h)
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
+    for (int q = 0; q < 6; q++) { if (h->tt_cum[q].p) hipFree(h->tt_cum[q].p); if (h->tt_guide[q].p) hipFree(h->tt_guide[q].p); }
     for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); }
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -532,8 +592,8 @@ static int run_generation(wfs_handle *h)
         ap.cap = ap_cap; ap.ap_ins = h->ap_ins.as<i32>(); ap.ap_ch = h->ap_ch.as<i32>(); ap.ap_t = h->ap_t.as<i32>(); ap.ap_gain = h->ap_gain.as<double>();
         ap.count = h->scal.as<i64>() + 13;
     }
-    const size_t gen_lds_count = (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 32;
-    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + (size_t)3 * GEN_BLOCK * 4 + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 32;
+    const size_t gen_lds_count = (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 48;
+    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + 8 + (size_t)GEN_BLOCK * 12 + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 32;
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart
@@ -541,8 +601,9 @@ static int run_generation(wfs_handle *h)
         u64 stride = getenv("WFS_STRIDE1") ? 1 : (std::max<u64>(1, nb / 1021) | 1);
         while (gcd(stride, nb) != 1) stride += 2;
         g.n_blocks = nb; g.block_stride = (i64)stride;
-        TRY(ensure(h, h->blk_e, (size_t)nb * 16));
-        g.blk_e = h->blk_e.as<i64>();
+        TRY(ensure(h, h->blk_e, (size_t)nb * 16)); TRY(ensure(h, h->blk_base, (size_t)nb * d.n_tpc * 4));
+        TRY(ensure(h, h->ph_slot, (size_t)P * 4));
+        g.blk_e = h->blk_e.as<i64>(); g.blk_base = h->blk_base.as<u32>(); g.ph_slot = h->ph_slot.as<u32>();
         { Timer t(h, "k_block_emitters"); hipLaunchKernelGGL(k_block_emitters, dim3(nblocks(nb, 256)), dim3(256), 0, h->stream, g); }
         { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true, false>), dim3(nb), dim3(GEN_TPB), gen_lds_count, h->stream, d, g, ap); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));

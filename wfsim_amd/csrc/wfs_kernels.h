@@ -753,6 +753,8 @@ struct GenArgs {
     i64 n_blocks, block_stride;   // photon blocks are visited in a strided order: see k_photons
     const struct LumEntry *lum_tab; const unsigned short *lum_guide;
     i64 *blk_e;                   // [n_blocks][2] first / last emitter of every photon block
+    u32 *blk_base;                // [n_blocks][n_tpc] start of the block's photons inside each tile (written by the count pass)
+    u32 *ph_slot;                 // [n_photons] slot inside its tile of every photon of a multi-instruction block (count pass)
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
     i64 *scal;
@@ -900,11 +902,10 @@ struct ApArgs {
 
 // np.interp(u, xp, fp) of s2.py:338 with the segment found through a guide table instead of a bisection:
 // same segment, same arithmetic (slope = (fp[i+1] - fp[i]) / (xp[i+1] - xp[i]), slope * (u - xp[i]) + fp[i])
-__device__ __forceinline__ double interp_lum_guided(const WfsDev &d, const LumEntry *tab, const unsigned short *guide, double u)
+__device__ __forceinline__ double interp_lum_guided(const WfsDev &d, const LumEntry *tab, int lo, double u)
 {
     if (u <= d.lum_x0) return d.lum_f0;
     if (u >= d.lum_xl) return d.lum_fl;
-    int lo = guide[(int)(u * LUM_G)];
     LumEntry e = tab[lo];
     while (u >= e.x1) { lo++; e = tab[lo]; }
     if (e.x0 == u) return e.f0;
@@ -944,12 +945,12 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
     double *cdf = (double *)(win + GEN_WIN);                 // [nch]
     i32 *hist = (i32 *)(cdf + nch);                          // [nch]
     unsigned short *cguide = (unsigned short *)(hist + nch);           // [CDF_G + 8]
-    i64 *wtime = (i64 *)(cguide + CDF_G + 8);                // [GEN_WIN] emitter times
-    i64 *hbase = wtime + GEN_WIN;                            // [nch] tile_off + reserved range
+    i64 *wtime = (i64 *)(((size_t)(cguide + CDF_G + 8) + 7) & ~(size_t)7);      // [GEN_WIN] emitter times
+    i64 *hbase = wtime + GEN_WIN;                            // [nch] first slot of this block in every tile
     i32 *hmin = (i32 *)(hbase + nch), *hmax = hmin + nch;    // [nch] each
-    i32 *st_t = hmax + nch;                                  // [GEN_BLOCK] staged photons
+    i32 *st_t = hmax + nch + (nch & 1);                      // [GEN_BLOCK] staged photons: time, code, slot in the global arrays
     u32 *st_code = (u32 *)(st_t + GEN_BLOCK);                // [GEN_BLOCK]
-    u32 *st_cr = st_code + GEN_BLOCK;                        // [GEN_BLOCK] channel << 16 | rank
+    u32 *st_cr = st_code + GEN_BLOCK;                        // [GEN_BLOCK] channel << 16 | rank inside the block
     double *aps_gain = (double *)(st_cr + GEN_BLOCK);        // [AP_STAGE] staged afterpulse photons (AP only)
     i32 *aps_ins = (i32 *)(aps_gain + AP_STAGE), *aps_ch = aps_ins + AP_STAGE, *aps_t = aps_ch + AP_STAGE;
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
@@ -986,6 +987,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             while (lo < hi) { int mid = (lo + hi) >> 1; if (x < cdf[mid]) hi = mid; else lo = mid + 1; }
             cguide[c] = (unsigned short)(lo < nch ? lo : nch - 1);
         }
+        if (!COUNT) for (int c = tid; c < nch; c += GEN_TPB) hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c];
         __syncthreads();
     }
 
@@ -1019,28 +1021,36 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         }
         if (COUNT) {
             if (single) atomicAdd(&hist[ch], 1);
-            else atomicAdd(&a.tile_count[(i64)ins * nch + ch], 1);
+            else a.ph_slot[p] = (u32)atomicAdd(&a.tile_count[(i64)ins * nch + ch], 1);     // the photon's slot in its tile
             continue;
         }
         const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
         const u32x4 C = philox4x32_10(j, gid, m, SITE_PH_C, d.k0, d.k1);
         const bool is_dpe = (u64)A.z < bern_threshold(d.p_dpe);
         const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-        double z_tts, z_spread = 0.0;
-        if (is_s2 ? d.need_z1_s2 : d.need_z1_s1) box_muller(C, z_tts, z_spread);
-        else z_tts = box_muller_z0(C);
-        const double e1 = -log(1.0 - u53(B.x, B.y));
+        const double u_exp = u53(B.x, B.y), u_tts = u53(C.x, C.y), u_c2 = u53(C.z, C.w);
         i64 t = etime - itime;                              // relative to the instruction time
+        // all guide loads first, then the table windows: the lookups of one photon overlap in the memory system
+        const DiscReq r_tts = disc_begin(d.tab_tts, u_tts);                                           // pulse.py:54-56
         if (!is_s2) {
-            if (d.s1_simple) { t += (i64)(e1 * d.s1_decay_time); t += (i64)(0.0 + d.s1_decay_spread * z_spread); }
+            if (d.s1_simple) {                              // s1.py:193-194
+                const DiscReq r_e = disc_begin(d.tab_s1_exp, u_exp);
+                if (d.need_z1_s1) t += sample_disc(d.tab_s1_spread, u_c2);
+                t += disc_finish(d.tab_s1_exp, r_e);
+            }
         } else {
-            const u32x4 D = philox4x32_10(j, gid, m, SITE_PH_D, d.k0, d.k1);
-            t += (i64)interp_lum_guided(d, a.lum_tab, a.lum_guide, u53(D.x, D.y));
-            const double delay = ((u64)B.w < bern_threshold(d.sf_gas)) ? d.t1_gas : d.t3_gas;
-            t += (i64)(e1 * delay);
-            if (d.s2_time_model == 1) t += (i64)(0.0 + d.s2_time_spread * z_spread);
+            const bool singlet = (u64)B.w < bern_threshold(d.sf_gas);                                // pulse.py:339-341
+            const DiscTab &te = singlet ? d.tab_t1 : d.tab_t3;
+            const DiscReq r_e = disc_begin(te, u_exp);
+            const int lum_lo = a.lum_guide[(int)(u_c2 * LUM_G)];
+            if (d.s2_time_model == 1 && d.need_z1_s2) {                                              // s2.py:550
+                const u32x4 D = philox4x32_10(j, gid, m, SITE_PH_D, d.k0, d.k1);
+                t += sample_disc(d.tab_s2_spread, u53(D.x, D.y));
+            }
+            t += (i64)interp_lum_guided(d, a.lum_tab, lum_lo, u_c2);                                 // s2.py:338
+            t += disc_finish(te, r_e);
         }
-        t += (i64)(d.tts_mean + d.tts_sigma * z_tts);
+        t += disc_finish(d.tab_tts, r_tts);
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
         const u32 code = g1 | (is_dpe ? (g2 << 16) : 0u);
         if (AP) {
@@ -1083,11 +1093,12 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         if (single) {
             const u32 rank = (u32)atomicAdd(&hist[ch], 1);
             atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
+            // staged: scattered stores issued inside the loop would hold up the table loads of the next photon (vmcnt order)
             const int slot = q * GEN_TPB + tid;
             st_t[slot] = (i32)t; st_code[slot] = code; st_cr[slot] = ((u32)ch << 16) | rank;
         } else {
             const i64 tile = (i64)ins * nch + ch;
-            const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
+            const i64 pos = a.tile_off[tile] + a.ph_slot[p];
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
             a.ph_t[pos] = (i32)t; a.ph_code[pos] = code;
         }
@@ -1106,10 +1117,10 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
     __syncthreads();
     for (int c = tid; c < nch; c += GEN_TPB) {
         const i32 hc = hist[c];
-        if (hc == 0) continue;
-        if (COUNT) atomicAdd(&a.tile_count[tbase + c], hc);
-        else {
-            hbase[c] = a.tile_off[tbase + c] + atomicAdd(&a.tile_cursor[tbase + c], hc);
+        if (COUNT) {
+            // reserve this block's range in every tile now; the fill pass then needs no returning atomics
+            a.blk_base[vb * nch + c] = hc ? (u32)atomicAdd(&a.tile_count[tbase + c], hc) : 0u;
+        } else if (hc) {
             atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
         }
     }
@@ -1165,7 +1176,7 @@ __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
         const bool is_dpe = (u64)A.z < bern_threshold(d.p_dpe);
         const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
         i64 t = a.in_t[off + p];
-        t += (i64)(d.tts_mean + d.tts_sigma * box_muller_z0(C));
+        t += sample_disc(d.tab_tts, u53(C.x, C.y));
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
         a.ph_t[off + p] = (i32)t; a.ph_code[off + p] = g1 | (is_dpe ? (g2 << 16) : 0u);
         tmin = (i32)t < tmin ? (i32)t : tmin; tmax = (i32)t > tmax ? (i32)t : tmax;
