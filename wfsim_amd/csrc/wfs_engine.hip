@@ -663,11 +663,11 @@ int wfs_run(wfs_handle *h)
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
     ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
     ga.noise_override = h->n_noise_override ? h->noise_override.as<i64>() : nullptr; ga.n_noise_override = h->n_noise_override;
-    { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
-    { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(64), 0, h->stream, d, ga); }
+    { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 1024)), dim3(1024), 0, h->stream, d, ga); }
+    { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(GROUPS_TPB), 0, h->stream, d, ga); }
     { Timer t(h, "k_tile_rows"); hipLaunchKernelGGL(k_tile_rows, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
     { Timer t(h, "k_group_final"); hipLaunchKernelGGL(k_group_final, dim3(nblocks(CG, 256)), dim3(256), 0, h->stream, d, ga); }
-    { Timer t(h, "k_row_len"); hipLaunchKernelGGL(k_row_len, dim3(nblocks(CG * d.row_slots, 256)), dim3(256), 0, h->stream, d, ga); }
+    { Timer t(h, "k_row_len"); hipLaunchKernelGGL(k_row_len, dim3(nblocks(CG * d.row_slots, 1024)), dim3(1024), 0, h->stream, d, ga); }
     TRY(scan(h, h->acc_len.as<i32>(), CG * d.n_tpc, h->acc_off, 8));
     TRY(scan(h, h->itv_cap.as<i32>(), CG * d.row_slots, h->itv_off, 9));
     TRY(read_scal(h));
@@ -727,7 +727,7 @@ int wfs_run(wfs_handle *h)
         ps.W = (int)((h->max_nb + 7) / 8 * 8); ps.NP = (int)((h->max_tile + 7) / 8 * 8);
         const bool small = h->max_tile <= 256 && h->max_nb <= 256;
         const int tpb = small ? 64 : 256;
-        size_t lds = (size_t)ps.NP * 12 + (size_t)8 * (tpb / 64) * 8 + ((size_t)d.dt * ps.W + 8) * 2 + 8 * 4 + std::max((size_t)d.dt * ps.W * 2, (size_t)8 * 260 * 8) + 16;
+        size_t lds = (size_t)ps.NP * 12 + (size_t)8 * (tpb / 64) * 8 + ((size_t)d.dt * ps.W + 8) * 2 + 8 * 4 + std::max((size_t)d.dt * ps.W * 2, (size_t)1 * 260 * 8) + 16;
         lds = (lds + 15) / 16 * 16;
         Timer t(h, "k_pulse_sparse");
         if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_sparse<64>), dim3((unsigned)h->n_sparse_tiles), dim3(64), lds, h->stream, d, ps);

@@ -125,42 +125,113 @@ __device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i
     right = bin1 + d.store_after + d.samples_after;
 }
 
-// per tile: end time of its pulse -> cluster (rawdata.py:188-190); list of non-empty tiles
+// per tile: end time of its pulse -> cluster (rawdata.py:188-190); work lists of non-empty tiles.
+// List appends and the two maxima are aggregated per wave (one atomic per wave instead of one per tile).
 __global__ void k_tile_geom(WfsDev d, GeomArgs a)
 {
-    i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= a.n_tiles || a.tile_count[tile] <= 0) return;
-    i64 set = tile / d.n_tpc;
-    i64 left, right, bin0, nb;
-    tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
-    atomicMax(&a.cl_end[a.set_cluster[set]], right * d.dt);
-    if (!a.force_dense && a.tile_count[tile] <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) {
-        i64 k = atomicAdd((u64 *)&a.scal[3], 1ull);
-        a.active_tiles[k] = (i32)tile;
-        atomicMax(&a.scal[4], nb);
-        atomicMax(&a.scal[5], (i64)a.tile_count[tile]);
-    } else {
-        i64 k = atomicAdd((u64 *)&a.scal[11], 1ull);
-        a.dense_tiles[k] = (i32)tile;
-        atomicMax(&a.scal[12], nb);
+    const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = tile < a.n_tiles && a.tile_count[tile] > 0;
+    bool sparse = false; i64 nb = 0; i32 cnt = 0; i32 cl = -1; i64 end = I64_MIN;
+    if (live) {
+        const i64 set = tile / d.n_tpc;
+        i64 left, right, bin0;
+        tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+        cl = a.set_cluster[set]; end = right * d.dt;
+        cnt = a.tile_count[tile];
+        sparse = !a.force_dense && cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS;
     }
+    {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
+        const u64 ml = __ballot(live);
+        if (ml) {
+            const i32 cl0 = __shfl(cl, __ffsll((long long)ml) - 1, 64);
+            if (__all(!live || cl == cl0)) {
+                i64 e = end;
+                for (int o = 32; o > 0; o >>= 1) { const i64 x = __shfl_down(e, o, 64); e = x > e ? x : e; }
+                if (lane == 0) atomicMax(&a.cl_end[cl0], e);
+            } else if (live) atomicMax(&a.cl_end[cl], end);
+        }
+    }
+    // work lists and maxima: aggregated per workgroup in LDS, then one global atomic per workgroup and counter
+    // (76k wave-level atomics on one cache line cost ~3 ms; the counters all live in the same line of scal[])
+    __shared__ i32 s_ns, s_nd; __shared__ i64 s_bs, s_bd, s_mx[3];
+    if (threadIdx.x == 0) { s_ns = 0; s_nd = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; }
+    __syncthreads();
+    i32 rk = 0;
+    if (live) {
+        rk = atomicAdd(sparse ? &s_ns : &s_nd, 1);
+        if (sparse) { atomicMax(&s_mx[0], nb); atomicMax(&s_mx[1], (i64)cnt); } else atomicMax(&s_mx[2], nb);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s_bs = s_ns ? (i64)atomicAdd((u64 *)&a.scal[3], (u64)s_ns) : 0;
+        s_bd = s_nd ? (i64)atomicAdd((u64 *)&a.scal[11], (u64)s_nd) : 0;
+        if (s_mx[0]) atomicMax(&a.scal[4], s_mx[0]);
+        if (s_mx[1]) atomicMax(&a.scal[5], s_mx[1]);
+        if (s_mx[2]) atomicMax(&a.scal[12], s_mx[2]);
+    }
+    __syncthreads();
+    if (live && sparse) a.active_tiles[s_bs + rk] = (i32)tile;
+    if (live && !sparse) a.dense_tiles[s_bd + rk] = (i32)tile;
 }
 
-// one thread: digitise groups.  The cache is digitised before cluster k when
-// min(instruction key of k) - last_pulse_end_time > rext and a pulse exists (rawdata.py:96-98); last_pulse_end_time
-// is a running maximum over everything simulated so far (rawdata.py:188-190).
-__global__ void k_groups(WfsDev d, GeomArgs a)
+// Digitise groups.  The cache is digitised before cluster k when min(instruction key of k) - last_pulse_end_time > rext
+// and a pulse exists (rawdata.py:96-98); last_pulse_end_time is a running maximum over everything simulated so far
+// (rawdata.py:188-190).  One workgroup: exclusive running maximum of the cluster end times, then a prefix sum of the flags.
+#define GROUPS_TPB 1024
+__global__ __launch_bounds__(GROUPS_TPB) void k_groups(WfsDev d, GeomArgs a)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    bool has = a.init_has != 0; i64 runmax = a.init_runmax; i32 g = 0;
-    for (i64 k = 0; k < a.n_clusters; k++) {
-        if (has && (double)(a.cl_tmin[k] - runmax) > d.rext) g++;
-        a.cl_group[k] = g;
-        if (a.grp_gid[g] == 0xffffffffu) a.grp_gid[g] = a.cl_gid[k];
-        i64 e = a.cl_end[k];
-        if (e != I64_MIN) { runmax = has ? (e > runmax ? e : runmax) : e; has = true; }
+    __shared__ i64 smax[GROUPS_TPB]; __shared__ i32 shas[GROUPS_TPB]; __shared__ i32 ssum[GROUPS_TPB];
+    const int tid = threadIdx.x;
+    const i64 C = a.n_clusters, per = (C + GROUPS_TPB - 1) / GROUPS_TPB;
+    const i64 k0 = tid * per, k1 = (k0 + per < C) ? k0 + per : C;
+    // 1) per-thread maximum of its clusters' end times
+    i64 m = I64_MIN; i32 hs = 0;
+    for (i64 k = k0; k < k1; k++) { const i64 e = a.cl_end[k]; if (e != I64_MIN) { m = hs ? (e > m ? e : m) : e; hs = 1; } }
+    smax[tid] = m; shas[tid] = hs;
+    __syncthreads();
+    // 2) exclusive running maximum over threads (plus the carry from earlier batches)
+    for (int o = 1; o < GROUPS_TPB; o <<= 1) {
+        i64 pm = I64_MIN; i32 ph = 0;
+        if (tid >= o) { pm = smax[tid - o]; ph = shas[tid - o]; }
+        __syncthreads();
+        if (ph) { smax[tid] = shas[tid] ? (pm > smax[tid] ? pm : smax[tid]) : pm; shas[tid] = 1; }
+        __syncthreads();
     }
-    a.scal[0] = g + 1;
+    i64 run = a.init_runmax; i32 has = a.init_has;
+    if (tid > 0 && shas[tid - 1]) { const i64 pm = smax[tid - 1]; run = has ? (pm > run ? pm : run) : pm; has = 1; }
+    // 3) flags of my clusters, sequentially inside the thread
+    i32 nflag = 0;
+    {
+        i64 r = run; i32 h = has;
+        for (i64 k = k0; k < k1; k++) {
+            if (h && (double)(a.cl_tmin[k] - r) > d.rext) nflag++;
+            const i64 e = a.cl_end[k];
+            if (e != I64_MIN) { r = h ? (e > r ? e : r) : e; h = 1; }
+        }
+    }
+    ssum[tid] = nflag;
+    __syncthreads();
+    for (int o = 1; o < GROUPS_TPB; o <<= 1) {
+        i32 t = tid >= o ? ssum[tid - o] : 0;
+        __syncthreads();
+        ssum[tid] += t;
+        __syncthreads();
+    }
+    // 4) group of every cluster; the first cluster of a group names its noise stream
+    i32 g = ssum[tid] - nflag;
+    {
+        i64 r = run; i32 h = has;
+        for (i64 k = k0; k < k1; k++) {
+            const bool flag = h && (double)(a.cl_tmin[k] - r) > d.rext;
+            if (flag) g++;
+            a.cl_group[k] = g;
+            if (flag || k == 0) a.grp_gid[g] = a.cl_gid[k];
+            const i64 e = a.cl_end[k];
+            if (e != I64_MIN) { r = h ? (e > r ? e : r) : e; h = 1; }
+        }
+    }
+    if (tid == GROUPS_TPB - 1) a.scal[0] = ssum[tid] + 1;
 }
 
 __global__ void k_tile_rows(WfsDev d, GeomArgs a)
@@ -196,27 +267,33 @@ __global__ void k_group_final(WfsDev d, GeomArgs a)
     a.grp_ixrand[g] = ix;
 }
 
-// per (group, row slot): accumulator length and reserved ZLE interval slots
+// per (group, row slot): accumulator length and reserved ZLE interval slots; list of rows with data
+// (appended with one global atomic per workgroup)
 __global__ void k_row_len(WfsDev d, GeomArgs a)
 {
-    i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    i64 n = a.scal[0] * d.row_slots;
-    if (idx >= a.n_gslots * d.row_slots) return;
-    i32 cap = 0;
+    __shared__ i32 s_n; __shared__ i64 s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n = a.scal[0] * d.row_slots;
+    i32 cap = 0, rk = -1;
     if (idx < n) {
-        i64 g = idx / d.row_slots; i32 slot = (i32)(idx - g * d.row_slots);
-        i32 ch = slot < d.n_tpc ? slot : slot - d.n_tpc;         // HE slot -> its top channel
-        i64 lo = a.row_lo[g * d.n_tpc + ch];
+        const i64 g = idx / d.row_slots; const i32 slot = (i32)(idx - g * d.row_slots);
+        const i32 ch = slot < d.n_tpc ? slot : slot - d.n_tpc;         // HE slot -> its top channel
+        const i64 lo = a.row_lo[g * d.n_tpc + ch];
         if (lo != I64_MAX) {
-            i64 len = a.row_hi[g * d.n_tpc + ch] - lo + 1 + 2 * (i64)d.tw;
+            const i64 len = a.row_hi[g * d.n_tpc + ch] - lo + 1 + 2 * (i64)d.tw;
             i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
             cap = (i32)((len + hold) / (hold + 1));
             if (slot < d.n_tpc) a.acc_len[g * d.n_tpc + ch] = (i32)len;
-            i64 k = atomicAdd((u64 *)&a.scal[2], 1ull);
-            a.active_rows[k] = (i32)idx;
+            rk = atomicAdd(&s_n, 1);
         }
     }
-    a.itv_cap[idx] = cap;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) s_base = (i64)atomicAdd((u64 *)&a.scal[2], (u64)s_n);
+    __syncthreads();
+    if (rk >= 0) a.active_rows[s_base + rk] = (i32)idx;
+    if (idx < a.n_gslots * d.row_slots) a.itv_cap[idx] = cap;
 }
 
 // ------------------------------------------------------------------------------------------------ pulse kernel
@@ -429,7 +506,7 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
     const int tlen = d.tlen; constexpr int dt = WFS_DT;      // sample_duration is 10 ns (checked by wfs_create)
     // T replicas: 8 copies of the templates, rows padded to tlen + 2 with a zero tap on either side, copies offset by
     // 4 bank pairs so that the 64 lanes' data-dependent template reads spread over the LDS banks
-    constexpr int TROW = 24, TREP = 260, NREP = 8;       // requires tlen == 22
+    constexpr int TROW = 24, TREP = 260, NREP = 1;       // requires tlen == 22 (tiny tiles: bank conflicts do not matter)
     double *cg = (double *)smem;                         // [NP] merged gain of the sorted photons
     double *red = cg + a.NP;                             // [TPB / 64][8]
     i32 *ctoff = (i32 *)(red + 8 * (TPB / 64));          // [NP] r * TROW - start bin
