@@ -1,0 +1,64 @@
+"""Edge cases of the HIP path (MI355X only): empty and degenerate batches, very large tiles, epoch-scale times,
+the 10^6-sample window limit."""
+import numpy as np
+import pytest
+
+import wfsim_amd
+from wfsim_amd.config import xenonnt_test_config
+from wfsim_amd.engine import WfsError
+from tests.test_gpu_generation import _instructions, _run_both, _compare, MS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_without_photons():
+    cfg = xenonnt_test_config(seed=41, s1_detection_efficiency=0.0)
+    ins = _instructions([dict(type=1, time=MS * (i + 1), x=0, y=0, z=-10, amp=100) for i in range(5)])
+    rd = wfsim_amd.RawData(cfg)
+    assert list(rd(ins)) == [] and rd.source_finished
+    sim = wfsim_amd.ChunkRawRecords(cfg)
+    chunks = list(sim(ins))
+    assert sum(len(c['raw_records']) for c in chunks) == 0
+    # like the reference, the last chunk ends at chunk_time_pre + dt when nothing was digitised (strax_interface.py:438-439),
+    # so truth rows of photon-less instructions later than that are never flushed
+    assert sum(len(c['truth']) for c in chunks) == 0
+    assert sim.truth_buffer['fill'].sum() == 5 and np.all(sim.truth_buffer['n_photon'][sim.truth_buffer['fill']] == 0)
+
+
+def test_single_instruction_and_empty_input():
+    cfg = xenonnt_test_config(seed=42)
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions([dict(type=2, time=5 * MS, x=1, y=1, z=-3, amp=7)]))
+    _compare(orc, o, eng, counts, s_ins)
+    rd = wfsim_amd.RawData(cfg)
+    assert list(rd(_instructions([]))) == [] and rd.source_finished
+
+
+def test_very_large_tiles_dense_kernel_multi_window():
+    # 3e4 electrons x ~82 photons: ~5000 photons per PMT (register batches loop), deep z: ~2000 start bins (8 windows)
+    cfg = xenonnt_test_config(seed=43, s2_secondary_sc_gain=100.0)
+    rows = [dict(type=2, time=MS, x=0, y=0, z=-95.0, amp=30000), dict(type=2, time=3 * MS, x=5, y=5, z=-2.0, amp=20000)]
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows))
+    assert counts['n_photons'] > 2_000_000            # deep electrons are attenuated by the 650 us lifetime
+    _compare(orc, o, eng, counts, s_ins)
+
+
+def test_epoch_scale_times():
+    t0 = 1_700_000_000_000_000_000          # ns since the epoch: beyond float64's integer range
+    cfg = xenonnt_test_config(seed=44)
+    rows = [dict(type=1, time=t0 + MS * i, x=0, y=0, z=-20, amp=2000) for i in range(4)]
+    rows += [dict(type=2, time=t0 + MS * i, x=0, y=0, z=-20, amp=80) for i in range(4)]
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows))
+    _compare(orc, o, eng, counts, s_ins)
+    rec = eng.records()
+    assert rec['time'].min() > t0 - MS and rec['time'].max() < t0 + 5 * MS
+
+
+def test_window_longer_than_1e6_samples_is_an_error():
+    # instructions 90 us apart never leave right_raw_extension (100 us): one window of 13 ms > 10^6 samples
+    cfg = xenonnt_test_config(seed=45)
+    ins = _instructions([dict(type=1, time=MS + 90_000 * i, x=0, y=0, z=-10, amp=500) for i in range(150)])
+    rd = wfsim_amd.RawData(cfg)
+    with pytest.raises(WfsError, match='Pulse cache too long'):     # the reference asserts (rawdata.py:219)
+        list(rd(ins))
+    # the engine stays usable afterwards
+    assert len(list(rd(ins[:20]))) > 0
