@@ -27,7 +27,7 @@ from wfsim_amd.dtypes import instruction_dtype     # noqa: E402
 from wfsim_amd.physics import instruction_params   # noqa: E402
 from wfsim_amd.resource import Resource            # noqa: E402
 from wfsim_amd.scheduler import schedule           # noqa: E402
-from wfsim_amd.distributed import gather_records   # noqa: E402
+from wfsim_amd.distributed import gather_records, wait_gather   # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
@@ -79,6 +79,7 @@ def main():
     ap.add_argument('--instructions', type=int, default=1000, help='S2 instructions per GPU per step')
     ap.add_argument('--cpu-sample', type=int, default=12, help='S2 instructions timed on the CPU oracle (0: skip)')
     ap.add_argument('--no-gather', action='store_true', help='skip the RCCL gather of records (N > 1)')
+    ap.add_argument('--sync-gather', action='store_true', help='do not overlap the gather with the next batch')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -106,18 +107,28 @@ def main():
     eng = Engine(cfg, res, device=local_rank)
     eng.load_instructions(s_ins, gid, cluster, key, ip)   # inputs resident in HBM before the timed region
 
-    gathered = None
+    pending = None        # gather of the previous step, still in flight
 
     def step(profile=False):
+        """compute one batch; the gather of the previous batch's records overlaps it (RCCL runs on its own stream)"""
+        nonlocal pending
         eng.set_profiling(profile)
         counts = eng.run()
         if world > 1 and not args.no_gather:
-            # variable-length gather of the packed records on rank 0 (RCCL over xGMI), wfsim_amd/distributed.py
-            nonlocal gathered
+            if pending is not None:
+                wait_gather(pending[1])
             mine = torch.empty(counts['n_records'] * 244, dtype=torch.uint8, device='cuda')
             eng.copy_records_to_device(mine.data_ptr(), counts['n_records'])
-            gathered = gather_records(mine, dst=0)
+            pending = gather_records(mine, dst=0, async_op=not args.sync_gather)
+            if args.sync_gather:
+                pending = None
         return counts
+
+    def drain():
+        nonlocal pending
+        if pending is not None:
+            wait_gather(pending[1])
+            pending = None
 
     def barrier():
         if world > 1:
@@ -126,10 +137,12 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         counts = step()
+    drain()                     # the last gather completes inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -146,12 +159,14 @@ def main():
     barrier()
     t1 = time.perf_counter()
     step()
+    drain()
     host_records = eng.records()
     pcie_ms = 1e3 * (time.perf_counter() - t1)
     del host_records
 
     # one extra (untimed) profiled step: HIP-event duration of every kernel on the engine's stream
     counts = step(profile=True)
+    drain()
     ktimes = eng.kernel_times()
     if rank != 0:
         if world > 1:
@@ -176,7 +191,7 @@ def main():
         config=dict(workload=f'{M} S2 instructions per GPU, 1e4 electrons each (~1e6 PE), 494 PMTs, z=-10 cm, '
                              f's2_secondary_sc_gain=100, noise/afterpulses off (BASELINE configs[2])',
                     instructions_per_gpu=M, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
-                    gather='none' if (world == 1 or args.no_gather) else 'rccl send/recv to rank 0',
+                    gather='none' if (world == 1 or args.no_gather) else ('rccl send/recv to rank 0' + ('' if args.sync_gather else ', overlapped with the next batch')),
                     ms_per_step_incl_d2h_of_records=pcie_ms),
         roofline=dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                       traffic=traffic, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,

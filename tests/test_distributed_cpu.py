@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from wfsim_amd.distributed import shard_clusters, gather_records
+from wfsim_amd.distributed import shard_clusters, gather_records, wait_gather
 from wfsim_amd.dtypes import raw_record_dtype
 
 
@@ -42,7 +42,12 @@ def _worker(rank, world, port, out):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     rec = _fake_records(rank, [5, 0, 7][rank] if world == 3 else [5, 7][rank])
     t = torch.from_numpy(rec.view(np.uint8).copy())
-    bufs = gather_records(t, dst=0)
+    if world == 3:
+        bufs = gather_records(t, dst=0)
+    else:                                   # posted, overlapped with other work, then waited for
+        bufs, handles = gather_records(t, dst=0, async_op=True)
+        _ = torch.ones(1000).sum()
+        wait_gather(handles)
     if rank == 0:
         allrec = np.concatenate([b.numpy().view(raw_record_dtype()) for b in bufs])
         np.save(out, allrec)

@@ -70,3 +70,16 @@ def test_nveto_chunker_output():
     assert np.all(np.diff(rr['time']) >= 0) and rr['data'].sum() > 0
     ok = (timings >= 0) & (timings < 1e6) & (channels != 7)
     assert truth['n_photon'].sum() == ok.sum()
+
+
+def test_nveto_plugin():
+    from wfsim_amd import ministrax
+    ins, channels, timings = optical_instructions(1500, 1000.0, 5)
+    cfg = nveto_config(seed=33, chunk_size=0.0005, instructions=ins, channels=channels, timings=timings)
+    plugin = wfsim_amd.RawRecordsFromFaxnVeto(cfg)
+    out = ministrax.run_plugin(plugin)
+    rr = np.concatenate([c.data for c in out['raw_records_nv']])
+    truth = np.concatenate([c.data for c in out['truth_nv']])
+    assert len(out['raw_records_nv']) >= 2 and len(rr) > 500
+    assert rr['channel'].min() >= 2000 and rr['channel'].max() <= 2119
+    assert len(truth) == len(ins) and np.all(np.diff(rr['time']) >= 0)

@@ -11,6 +11,6 @@ from .resource import DummyMap, make_map, Resource  # noqa: F401
 from .config import load_fax_config, xenonnt_test_config, kernel_params  # noqa: F401
 from .rawdata import RawData, RawDataOptical, PULSE_TYPE_NAMES  # noqa: F401
 from .strax_interface import (ChunkRawRecords, SimulatorPlugin, RawRecordsFromFaxNT, RawRecordsFromFax1T,  # noqa: F401
-                              instruction_from_csv)
+                              RawRecordsFromFaxOpticalNT, RawRecordsFromFaxnVeto, instruction_from_csv)
 
 __version__ = '0.1.0'

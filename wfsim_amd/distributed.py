@@ -32,10 +32,12 @@ def shard_clusters(cluster, weight, world_size):
     return np.asarray(bounds, dtype=np.int64)
 
 
-def gather_records(records, dst=0, group=None):
+def gather_records(records, dst=0, group=None, async_op=False):
     """Variable-length gather of packed records (uint8 tensor of n * 244 bytes per rank, on the backend's device).
 
-    Returns the list of per-rank tensors on ``dst`` (rank order = time order), ``None`` elsewhere."""
+    Returns the list of per-rank tensors on ``dst`` (rank order = time order), ``None`` elsewhere.  With
+    ``async_op=True`` returns ``(buffers_or_None, work_handles)``: the payload transfers are only posted, call
+    ``wait_gather`` before touching the buffers (lets the transfer overlap the next batch's kernels)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
@@ -44,15 +46,22 @@ def gather_records(records, dst=0, group=None):
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
+    bufs, reqs = None, []
     if rank == dst:
         bufs = [records if r == dst else torch.empty(sizes[r], dtype=records.dtype, device=records.device) for r in range(world)]
         reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(world) if r != dst and sizes[r] > 0]
-        for q in reqs:
-            q.wait()
-        return bufs
-    if sizes[rank] > 0:
-        dist.send(records, dst=dst, group=group)
-    return None
+    elif sizes[rank] > 0:
+        reqs = [dist.isend(records, dst=dst, group=group)]
+    if async_op:
+        return bufs, (reqs, records)          # keep the send buffer alive until the transfer is done
+    wait_gather(reqs)
+    return bufs
+
+
+def wait_gather(handles):
+    reqs = handles[0] if isinstance(handles, tuple) else handles
+    for q in reqs:
+        q.wait()
 
 
 def simulate_sharded(config, instructions, device=None, dst=0):

@@ -334,3 +334,61 @@ class RawRecordsFromFaxNT(SimulatorPlugin):
 
 class RawRecordsFromFax1T(RawRecordsFromFaxNT):
     provides = ('raw_records', 'truth')
+
+
+class RawRecordsFromFaxOpticalNT(RawRecordsFromFaxNT):
+    """strax_interface.py:722-737: photon channels / timings supplied with the instructions (optical Geant4 input).
+    The ROOT reader (read_optical, needs uproot) is out of scope: pass ``instructions``, ``channels``, ``timings``."""
+
+    def _setup(self):
+        self.sim = ChunkRawRecords(self.config, rawdata_generator=RawDataOptical, channels=self.channels,
+                                   timings=self.timings, device=self.device)
+        self.sim.truth_buffer = np.zeros(10000, dtype=instruction_dtype + optical_extra_dtype
+                                         + self._truth_dtype + [('fill', bool)])
+        self.sim_iter = self.sim(self.instructions)
+
+    def get_instructions(self):
+        c = self.config
+        if c.get('instructions') is None or c.get('channels') is None or c.get('timings') is None:
+            raise NotImplementedError('read_optical needs uproot (SURVEY.md 2.1 row 7): pass instructions, channels, timings')
+        self.instructions = np.asarray(c['instructions'])
+        self.channels, self.timings = np.asarray(c['channels']), np.asarray(c['timings'])
+
+    def check_instructions(self):
+        assert '_first' in self.instructions.dtype.names, 'Require indexing info in optical instruction see optical extra dtype'
+        assert np.all(self.instructions['type'] == 1), 'Only s1 type is supported for generating rawdata from optical input'
+
+
+class RawRecordsFromFaxnVeto(RawRecordsFromFaxOpticalNT):
+    """strax_interface.py:1008-1011 with only the nVeto target of RawRecordsFromMcChain (:753-1005): optical instructions
+    for the neutron veto, detector ``XENONnT_neutron_veto``, channels shifted by channel_map['nveto'][0] on output."""
+    provides = ('raw_records_nv', 'truth_nv')
+
+    def set_config(self):
+        self.config.setdefault('detector', 'XENONnT_neutron_veto')
+        self.config['detector'] = 'XENONnT_neutron_veto'
+        c = self.config
+        overrides = c.get('fax_config_override_nveto') or c.get('fax_config_override')
+        if overrides is not None:
+            c.update(overrides)
+        if 'gains' not in c:
+            to_pe = np.asarray(c['to_pe_nveto'], dtype=np.float64)
+            # strax_interface.py:776: nveto digitiser 2 V range, 14 bit, 50 Ohm, 2 ns sampling constant
+            c['gains'] = np.divide((2e-9 * 2 / 2 ** 14) / (1.6e-19 * 1 * 50), to_pe, out=np.zeros_like(to_pe), where=to_pe != 0)
+        c['channel_map'] = dict(c['channel_map'])
+        c['channels_bottom'] = np.array([], np.int64)
+
+    def infer_dtype(self):
+        return {'raw_records_nv': raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH),
+                'truth_nv': instruction_dtype + optical_extra_dtype + self._truth_dtype}
+
+    def compute(self):
+        try:
+            result = next(self.sim_iter)
+        except StopIteration:
+            raise RuntimeError("Bug in chunk count computation")
+        rr = result['raw_records'].copy()
+        rr['channel'] += self.config['channel_map']['nveto'][0]           # strax_interface.py:937
+        self._sort_check(rr)
+        return {'raw_records_nv': self.chunk(start=self.sim.chunk_time_pre, end=self.sim.chunk_time, data=rr, data_type='raw_records_nv'),
+                'truth_nv': self.chunk(start=self.sim.chunk_time_pre, end=self.sim.chunk_time, data=result['truth'], data_type='truth_nv')}
