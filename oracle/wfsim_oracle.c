@@ -438,8 +438,9 @@ void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
 /* ---------------------------------------------------------------- integer delay variates --------- */
 /* The reference draws a float variate and truncates it to int64 (pulse.py:54-56 normal, s1.py:193-194 exponential and
  * normal, pulse.py:339-341 exponential * lifetime, s2.py:550 normal).  trunc(Y) is sampled here directly: from one
- * uniform by inverse CDF over cum[i] = P(trunc(Y) <= vmin + i).  For Y ~ N(mu, sigma): P(X <= k) = Phi((k+1-mu)/sigma)
- * for k >= 0 and Phi((k-mu)/sigma) for k < 0 (the C cast truncates toward zero); for Y ~ Exp(tau): 1 - exp(-(k+1)/tau). */
+ * uniform by inverse CDF over cum[i] = P(trunc(Y) <= vmin + i) for the NORMAL terms (transit time, S1/S2 spread):
+ * P(X <= k) = Phi((k+1-mu)/sigma) for k >= 0 and Phi((k-mu)/sigma) for k < 0 (the C cast truncates toward zero).
+ * Exponential terms use the closed form trunc(-log(1-u) * tau). */
 static void tab_normal(orc_session *s, int slot, double mu, double sigma)
 {
     if (!(sigma > 0)) { s->tab[slot].cum = (double *)malloc(8); s->tab[slot].cum[0] = 1.0; s->tab[slot].n = 1; s->tab[slot].vmin = (i64)mu; return; }
@@ -512,12 +513,12 @@ static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u3
     i64 t = t0;
     if (!is_s2) {
         if (c->s1_simple) {                                                     /* s1.py:193-194 */
-            t += sample_tab(s, TAB_S1_EXP, u_exp);
+            t += (i64)(-log(1.0 - u_exp) * c->s1_decay_time);
             if (c->s1_decay_spread != 0) t += sample_tab(s, TAB_S1_SPREAD, u53(C[2], C[3]));
         }
     } else {
         t += (i64)interp_lum(s, u53(C[2], C[3]));                               /* s2.py:338 */
-        t += sample_tab(s, ((u64)B[3] < bern_threshold(c->sf_gas)) ? TAB_T1 : TAB_T3, u_exp);   /* pulse.py:339-341 */
+        t += (i64)(-log(1.0 - u_exp) * (((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas));   /* pulse.py:339-341 */
         if (c->s2_time_model == 1 && c->s2_time_spread != 0) {                  /* s2.py:550 */
             draw(s, emitter, gid, item, SITE_PH_D, D);
             t += sample_tab(s, TAB_S2_SPREAD, u53(D[0], D[1]));
@@ -803,9 +804,9 @@ void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 
         draw(s, em, gid, item, SITE_PH_B, B); draw(s, em, gid, item, SITE_PH_C, C); draw(s, em, gid, item, SITE_PH_D, D);
         double z0, z1;
         if (kind == 0) out[i] = (i64)interp_lum(s, u53(C[2], C[3]));
-        else if (kind == 1) out[i] = sample_tab(s, ((u64)B[3] < bern_threshold(c->sf_gas)) ? TAB_T1 : TAB_T3, u53(B[0], B[1]));
+        else if (kind == 1) out[i] = (i64)(-log(1.0 - u53(B[0], B[1])) * (((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas));
         else if (kind == 2) out[i] = sample_tab(s, TAB_TTS, u53(C[0], C[1]));
-        else if (kind == 3) out[i] = sample_tab(s, TAB_S1_EXP, u53(B[0], B[1])) + sample_tab(s, TAB_S1_SPREAD, u53(C[2], C[3]));
+        else if (kind == 3) out[i] = (i64)(-log(1.0 - u53(B[0], B[1])) * c->s1_decay_time) + sample_tab(s, TAB_S1_SPREAD, u53(C[2], C[3]));
         else {
             draw(s, (u32)i, gid, 0, SITE_EL_A, A); draw(s, (u32)i, gid, 0, SITE_EL_B, B);
             box_muller(B, &z0, &z1);

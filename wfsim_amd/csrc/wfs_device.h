@@ -65,10 +65,11 @@ __device__ __forceinline__ void box_muller(u32x4 w, double &z0, double &z1)
     z0 = r * c; z1 = r * s;
 }
 
-// Integer-valued random delays.  The reference draws a float variate and truncates it to int64 before adding it
-// (pulse.py:54-56, s1.py:193-194, pulse.py:341, s2.py:550).  trunc(Y) is a discrete variate; it is sampled here by inverse
-// CDF from one uniform: cum[i] = P(X <= vmin + i), result = vmin + (first i with u < cum[i]).  The tables are built on
-// the host (wfs_engine.hip, build_time_tables) from erfc / expm1; the CPU oracle builds its own the same way.
+// Integer-valued normal delays.  The reference draws a normal variate and truncates it to int64 before adding it
+// (pulse.py:54-56 transit time, s1.py:194 and s2.py:550 spreads).  trunc(Y) is a discrete variate; it is sampled here by
+// inverse CDF from one uniform: cum[i] = P(X <= vmin + i), result = vmin + (first i with u < cum[i]).  The tables are
+// built on the host (wfs_engine.hip, build_time_tables) from erfc; the CPU oracle builds its own the same way.
+// (Exponential delays use the closed form trunc(-log(1-u) * tau).)
 #define DISC_G 1024
 struct DiscTab { const double *cum; const unsigned short *guide; i32 vmin, n; };
 
@@ -109,10 +110,11 @@ struct WfsDev {
     double c2a, tts_mean, tts_sigma, p_dpe, s1_decay_time, s1_decay_spread, sf_gas, t1_gas, t3_gas, s2_time_spread;
     double trap_time, gain_spread, pmt_ap_modifier, pmt_ap_t_modifier, rext;
     u32 k0, k1;
+    u64 thr_dpe, thr_sf_gas;                   // Bernoulli thresholds on 32-bit words: floor(p * 2^32)
     double current_max[10];
     double lum_x0, lum_xl, lum_f0, lum_fl;     // first / last point of the luminescence table
     i32 need_z1_s1, need_z1_s2;                // spread term present (non-zero spread)
-    DiscTab tab_tts, tab_s1_exp, tab_s1_spread, tab_t1, tab_t3, tab_s2_spread;
+    DiscTab tab_tts, tab_s1_spread, tab_s2_spread;      // trunc(normal) delay terms: inverse-CDF tables
     // tables
     const double *templates, *spe, *gains, *thr_truth, *lum_x, *lum_t;
     const i64 *thr_zle;

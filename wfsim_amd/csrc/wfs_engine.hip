@@ -161,19 +161,6 @@ static void normal_trunc_table(double mu, double sigma, std::vector<double> &cum
     cum.back() = 1.0;
 }
 
-// cum[i] = P(trunc(Y) <= i) for Y ~ Exp(scale tau)
-static void exp_trunc_table(double tau, std::vector<double> &cum, int &vmin)
-{
-    cum.clear(); vmin = 0;
-    if (!(tau > 0)) { cum.push_back(1.0); return; }
-    for (int k = 0; k < 60000; k++) {
-        const double c = -expm1(-(double)(k + 1) / tau);
-        cum.push_back(c);
-        if (c >= 1.0) break;
-    }
-    cum.back() = 1.0;
-}
-
 static int upload_disc(wfs_handle *h, int slot, const std::vector<double> &cum, int vmin, DiscTab &out)
 {
     if (cum.size() > 65000) return h->fail(WFS_E_CAPACITY, "delay table too long (time constant above ~1.5 us)");
@@ -196,11 +183,8 @@ int build_time_tables(wfs_handle *h)
     const wfs_config &c = h->cfg; WfsDev &d = h->dev;
     std::vector<double> cum; int vmin;
     normal_trunc_table(c.tts_mean, c.tts_sigma, cum, vmin); TRY(upload_disc(h, 0, cum, vmin, d.tab_tts));
-    exp_trunc_table(c.s1_decay_time, cum, vmin); TRY(upload_disc(h, 1, cum, vmin, d.tab_s1_exp));
-    normal_trunc_table(0.0, c.s1_decay_spread, cum, vmin); TRY(upload_disc(h, 2, cum, vmin, d.tab_s1_spread));
-    exp_trunc_table(c.t1_gas, cum, vmin); TRY(upload_disc(h, 3, cum, vmin, d.tab_t1));
-    exp_trunc_table(c.t3_gas, cum, vmin); TRY(upload_disc(h, 4, cum, vmin, d.tab_t3));
-    normal_trunc_table(0.0, c.s2_time_spread, cum, vmin); TRY(upload_disc(h, 5, cum, vmin, d.tab_s2_spread));
+    normal_trunc_table(0.0, c.s1_decay_spread, cum, vmin); TRY(upload_disc(h, 1, cum, vmin, d.tab_s1_spread));
+    normal_trunc_table(0.0, c.s2_time_spread, cum, vmin); TRY(upload_disc(h, 2, cum, vmin, d.tab_s2_spread));
     return WFS_OK;
 }
 
@@ -216,6 +200,8 @@ void refresh_dev(wfs_handle *h)
     d.s2_time_spread = c.s2_time_spread; d.trap_time = c.trap_time; d.gain_spread = c.gain_spread;
     d.pmt_ap_modifier = c.pmt_ap_modifier; d.pmt_ap_t_modifier = c.pmt_ap_t_modifier; d.rext = c.rext;
     d.k0 = (u32)c.seed; d.k1 = (u32)(c.seed >> 32);
+    auto thr = [](double p) -> u64 { if (!(p > 0)) return 0; if (p >= 1) return 4294967296ull; return (u64)(p * 4294967296.0); };
+    d.thr_dpe = thr(c.p_dpe); d.thr_sf_gas = thr(c.sf_gas);
     d.need_z1_s1 = (c.s1_simple && c.s1_decay_spread != 0.0) ? 1 : 0;
     d.need_z1_s2 = (c.s2_time_model == 1 && c.s2_time_spread != 0.0) ? 1 : 0;
     // HE rows are only materialised when they can differ from a flat baseline: a non-zero int(factor)
@@ -593,7 +579,7 @@ static int run_generation(wfs_handle *h)
         ap.count = h->scal.as<i64>() + 13;
     }
     const size_t gen_lds_count = (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 48;
-    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + 8 + (size_t)GEN_BLOCK * 12 + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 32;
+    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + 8 + (GEN_STAGE ? (size_t)GEN_BLOCK * 12 : 0) + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 32;
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart

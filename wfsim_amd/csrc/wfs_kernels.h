@@ -958,11 +958,24 @@ __device__ __forceinline__ double interp_lum(const WfsDev &d, double u)
 }
 
 #define GEN_TPB 256
+#ifndef GEN_STAGE
+#define GEN_STAGE 1                // 1: photons staged in LDS and written after the loop (faster: 20.5 vs 24.7 ms); 0: written from the loop
+#endif
 #define GEN_PPT 8
 #define GEN_BLOCK (GEN_TPB * GEN_PPT)
 #define GEN_WIN 512                // emitter offsets staged in LDS per block
 #define CDF_G 512                  // guide cells of the per-block channel search
 #define LUM_G 4096                 // guide cells of the luminescence table
+#define LDS_TAB_N 160              // normal-variate tables up to this length are copied to LDS (sigma up to ~9 ns)
+
+// trunc(N(mu, sigma)) from one uniform: bisection over the cumulative table, in LDS when it is small
+__device__ __forceinline__ i64 sample_normal(const DiscTab &t, const double *lds, double u)
+{
+    if (t.n > LDS_TAB_N) return sample_disc(t, u);
+    int lo = 0, hi = t.n - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (u < lds[mid]) hi = mid; else lo = mid + 1; }     // first i with u < cum[i]
+    return (i64)t.vmin + lo;
+}
 
 struct LumEntry { double x0, x1, f0, slope; };
 
@@ -1025,14 +1038,23 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
     i64 *wtime = (i64 *)(((size_t)(cguide + CDF_G + 8) + 7) & ~(size_t)7);      // [GEN_WIN] emitter times
     i64 *hbase = wtime + GEN_WIN;                            // [nch] first slot of this block in every tile
     i32 *hmin = (i32 *)(hbase + nch), *hmax = hmin + nch;    // [nch] each
+#if GEN_STAGE
     i32 *st_t = hmax + nch + (nch & 1);                      // [GEN_BLOCK] staged photons: time, code, slot in the global arrays
     u32 *st_code = (u32 *)(st_t + GEN_BLOCK);                // [GEN_BLOCK]
     u32 *st_cr = st_code + GEN_BLOCK;                        // [GEN_BLOCK] channel << 16 | rank inside the block
     double *aps_gain = (double *)(st_cr + GEN_BLOCK);        // [AP_STAGE] staged afterpulse photons (AP only)
+#else
+    double *aps_gain = (double *)(hmax + nch + (nch & 1));   // [AP_STAGE] staged afterpulse photons (AP only)
+#endif
     i32 *aps_ins = (i32 *)(aps_gain + AP_STAGE), *aps_ch = aps_ins + AP_STAGE, *aps_t = aps_ch + AP_STAGE;
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
+    __shared__ double lds_tab[3][LDS_TAB_N];                 // transit time, S1 spread, S2 spread: cumulative tables when they are small
     const int tid = threadIdx.x;
     if (AP && tid == 0) s_apn = 0;
+    if (!COUNT) {
+        const DiscTab *tabs[3] = {&d.tab_tts, &d.tab_s1_spread, &d.tab_s2_spread};
+        for (int q = 0; q < 3; q++) if (tabs[q]->n <= LDS_TAB_N) for (int i = tid; i < tabs[q]->n; i += GEN_TPB) lds_tab[q][i] = tabs[q]->cum[i];
+    }
     // Blocks that run at the same time work on different instructions (strided order): consecutive photon blocks
     // belong to one instruction and would otherwise all add into the same n_tpc tile counters.
     const i64 vb = (i64)(((u64)blockIdx.x * (u64)a.block_stride) % (u64)a.n_blocks);
@@ -1103,31 +1125,27 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         }
         const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
         const u32x4 C = philox4x32_10(j, gid, m, SITE_PH_C, d.k0, d.k1);
-        const bool is_dpe = (u64)A.z < bern_threshold(d.p_dpe);
+        const bool is_dpe = (u64)A.z < d.thr_dpe;
         const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-        const double u_exp = u53(B.x, B.y), u_tts = u53(C.x, C.y), u_c2 = u53(C.z, C.w);
+        const double u_tts = u53(C.x, C.y), u_c2 = u53(C.z, C.w);
+        const double e1 = -log(1.0 - u53(B.x, B.y));        // standard exponential variate
         i64 t = etime - itime;                              // relative to the instruction time
-        // all guide loads first, then the table windows: the lookups of one photon overlap in the memory system
-        const DiscReq r_tts = disc_begin(d.tab_tts, u_tts);                                           // pulse.py:54-56
         if (!is_s2) {
             if (d.s1_simple) {                              // s1.py:193-194
-                const DiscReq r_e = disc_begin(d.tab_s1_exp, u_exp);
-                if (d.need_z1_s1) t += sample_disc(d.tab_s1_spread, u_c2);
-                t += disc_finish(d.tab_s1_exp, r_e);
+                t += (i64)(e1 * d.s1_decay_time);
+                if (d.need_z1_s1) t += sample_normal(d.tab_s1_spread, lds_tab[1], u_c2);
             }
         } else {
-            const bool singlet = (u64)B.w < bern_threshold(d.sf_gas);                                // pulse.py:339-341
-            const DiscTab &te = singlet ? d.tab_t1 : d.tab_t3;
-            const DiscReq r_e = disc_begin(te, u_exp);
             const int lum_lo = a.lum_guide[(int)(u_c2 * LUM_G)];
+            const double delay = ((u64)B.w < d.thr_sf_gas) ? d.t1_gas : d.t3_gas;                      // pulse.py:339-341
+            t += (i64)(e1 * delay);
             if (d.s2_time_model == 1 && d.need_z1_s2) {                                              // s2.py:550
                 const u32x4 D = philox4x32_10(j, gid, m, SITE_PH_D, d.k0, d.k1);
-                t += sample_disc(d.tab_s2_spread, u53(D.x, D.y));
+                t += sample_normal(d.tab_s2_spread, lds_tab[2], u53(D.x, D.y));
             }
             t += (i64)interp_lum_guided(d, a.lum_tab, lum_lo, u_c2);                                 // s2.py:338
-            t += disc_finish(te, r_e);
         }
-        t += disc_finish(d.tab_tts, r_tts);
+        t += sample_normal(d.tab_tts, lds_tab[0], u_tts);   // pulse.py:54-56
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
         const u32 code = g1 | (is_dpe ? (g2 << 16) : 0u);
         if (AP) {
@@ -1170,9 +1188,14 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         if (single) {
             const u32 rank = (u32)atomicAdd(&hist[ch], 1);
             atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
-            // staged: scattered stores issued inside the loop would hold up the table loads of the next photon (vmcnt order)
+#if GEN_STAGE
+            // staged: scattered stores issued inside the loop hold up later loads of the same wave (vmcnt order)
             const int slot = q * GEN_TPB + tid;
             st_t[slot] = (i32)t; st_code[slot] = code; st_cr[slot] = ((u32)ch << 16) | rank;
+#else
+            const i64 pos = hbase[ch] + rank;
+            a.ph_t[pos] = (i32)t; a.ph_code[pos] = code;
+#endif
         } else {
             const i64 tile = (i64)ins * nch + ch;
             const i64 pos = a.tile_off[tile] + a.ph_slot[p];
@@ -1201,6 +1224,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
         }
     }
+#if GEN_STAGE
     if (COUNT) return;
     __syncthreads();
     for (int slot = tid; slot < (int)(p1 - p0); slot += GEN_TPB) {
@@ -1208,6 +1232,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         const i64 pos = hbase[cr >> 16] + (cr & 0xffffu);
         a.ph_t[pos] = st_t[slot]; a.ph_code[pos] = st_code[slot];
     }
+#endif
 }
 
 // afterpulse photons -> tiles of the afterpulse pulse set of their instruction (set n_ins + ins): count, then place
@@ -1250,7 +1275,7 @@ __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
         const u32x4 A = philox4x32_10(0, gid, item, SITE_PH_A, d.k0, d.k1);
         const u32x4 B = philox4x32_10(0, gid, item, SITE_PH_B, d.k0, d.k1);
         const u32x4 C = philox4x32_10(0, gid, item, SITE_PH_C, d.k0, d.k1);
-        const bool is_dpe = (u64)A.z < bern_threshold(d.p_dpe);
+        const bool is_dpe = (u64)A.z < d.thr_dpe;
         const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
         i64 t = a.in_t[off + p];
         t += sample_disc(d.tab_tts, u53(C.x, C.y));
