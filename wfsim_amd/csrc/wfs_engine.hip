@@ -584,7 +584,7 @@ static int run_generation(wfs_handle *h)
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart
         auto gcd = [](u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } return x; };
-        u64 stride = getenv("WFS_STRIDE1") ? 1 : (std::max<u64>(1, nb / 1021) | 1);
+        u64 stride = std::max<u64>(1, nb / 1021) | 1;
         while (gcd(stride, nb) != 1) stride += 2;
         g.n_blocks = nb; g.block_stride = (i64)stride;
         TRY(ensure(h, h->blk_e, (size_t)nb * 16)); TRY(ensure(h, h->blk_base, (size_t)nb * d.n_tpc * 4));
@@ -685,7 +685,6 @@ int wfs_run(wfs_handle *h)
     pa.ph_gain = (!h->injected && h->ap_active) ? h->ph_gain.as<double>() - h->n_photons : h->ph_gain.as<double>();
     pa.cl_group = h->cl_group.as<i32>(); pa.row_lo = h->row_lo.as<i64>(); pa.acc_off = h->acc_off.as<i64>(); pa.raw = h->raw.as<i32>();
     pa.truth = h->truth.as<double>(); pa.tminmax = h->tminmax.as<i64>();
-    { const char *ab = getenv("WFS_ABLATE"); pa.ablate = ab ? atoi(ab) : 0; }
     h->cur_total = 0;
     if ((h->keep_currents & 1) && h->n_active_tiles > 0) {
         // debug: tile lengths in work-list order -> offsets

@@ -319,7 +319,6 @@ struct PulseArgs {
     i32 W;                // start bins per LDS window (dense) / bins capacity (sparse)
     i32 NP;               // photon capacity of the sparse kernel's LDS list
     i32 n_win;            // dense kernel: workgroups (windows) per tile
-    i32 ablate;           // profiling only: bit0 no truth, bit1 no gather, bit2 no pass1, bit3 no place/merge, bit4 no raw atomics
 };
 
 #define DENSE_PPT 8        // photons per thread per batch held in registers
