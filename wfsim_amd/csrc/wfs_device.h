@@ -22,6 +22,7 @@ enum WfsSite : u32 {
 };
 
 struct u32x4 { u32 x, y, z, w; };
+struct __attribute__((aligned(8))) PhotonRec { i32 t; u32 code; };   // one bucketed photon: ns relative to its set, SPE codes
 
 __device__ __forceinline__ u32x4 philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1)
 {

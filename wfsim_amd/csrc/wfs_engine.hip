@@ -42,7 +42,7 @@ struct wfs_handle {
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, ph_slot;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, dense_tiles;
-    DevBuf ph_t, ph_code, ph_gain;
+    DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
@@ -256,7 +256,7 @@ int wfs_destroy(wfs_handle *h)
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
-        &h->active_tiles, &h->dense_tiles, &h->ph_t, &h->ph_code, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
+        &h->active_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
@@ -463,15 +463,12 @@ int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, 
     TRY(upload(h, h->set_mode, mode.data(), (size_t)n_sets * 4));
     TRY(upload(h, h->tile_count, count.data(), count.size() * 4)); TRY(upload(h, h->tile_tmin, tmn.data(), tmn.size() * 4));
     TRY(upload(h, h->tile_tmax, tmx.data(), tmx.size() * 4));
-    TRY(upload(h, h->ph_t, rel.data(), (size_t)P * 4)); TRY(upload(h, h->ph_gain, gain, (size_t)P * 8));
-    TRY(ensure(h, h->ph_code, (size_t)P * 4));
-    if (dpe) {   // DPE flags ride in the code word (only the truth quirk pulse.py:255 reads them in explicit-gain mode)
-        std::vector<u32> code((size_t)P);
-        for (i64 p = 0; p < P; p++) code[p] = dpe[p] ? (1u << 16) : 0u;
-        TRY(upload(h, h->ph_code, code.data(), (size_t)P * 4));
+    TRY(upload(h, h->ph_gain, gain, (size_t)P * 8));
+    {   // DPE flags ride in the code word (only the truth quirk pulse.py:255 reads them in explicit-gain mode)
+        std::vector<PhotonRec> recs((size_t)P);
+        for (i64 p = 0; p < P; p++) recs[p] = PhotonRec{rel[p], (dpe && dpe[p]) ? (1u << 16) : 0u};
+        TRY(upload(h, h->ph, recs.data(), (size_t)P * 8));
         HIPCHK(hipStreamSynchronize(h->stream));
-    } else {
-        HIPCHK(hipMemsetAsync(h->ph_code.p, 0, (size_t)P * 4, h->stream));
     }
     TRY(load_clusters(h, n_sets, set_cluster, set_tmin, nullptr));
     h->injected = true; h->optical = false; h->batch_loaded = true; h->ran = false;
@@ -516,7 +513,7 @@ int wfs_load_optical(wfs_handle *h, int64_t n, const int64_t *time, const uint32
     TRY(upload(h, h->set_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_time, time, (size_t)n * 8));
     TRY(upload(h, h->tile_count, count.data(), count.size() * 4)); TRY(upload(h, h->tile_off, off.data(), off.size() * 8));
     TRY(upload(h, h->opt_t, rel.data(), (size_t)P * 4)); TRY(upload(h, h->opt_item, item.data(), (size_t)P * 4));
-    TRY(ensure(h, h->ph_t, (size_t)P * 4)); TRY(ensure(h, h->ph_code, (size_t)P * 4));
+    TRY(ensure(h, h->ph, (size_t)P * 8));
     TRY(ensure(h, h->tile_tmin, (size_t)h->n_tiles * 4)); TRY(ensure(h, h->tile_tmax, (size_t)h->n_tiles * 4));
     TRY(ensure(h, h->el_stat, (size_t)n * 32)); TRY(ensure(h, h->el_minmax, (size_t)n * 16));
     HIPCHK(hipMemsetAsync(h->el_stat.p, 0, (size_t)n * 32, h->stream));
@@ -560,10 +557,10 @@ static int run_generation(wfs_handle *h)
     TRY(ensure(h, h->tile_count, (size_t)T * 4)); TRY(ensure(h, h->tile_cursor, (size_t)T * 4));
     HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (size_t)T * 4, h->stream)); HIPCHK(hipMemsetAsync(h->tile_cursor.p, 0, (size_t)T * 4, h->stream));
     TRY(fill32(h, h->tile_tmin, T, 0x7fffffff)); TRY(fill32(h, h->tile_tmax, T, (i32)0x80000000));
-    TRY(ensure(h, h->ph_t, (size_t)(P + ap_cap) * 4)); TRY(ensure(h, h->ph_code, (size_t)(P + ap_cap) * 4));
+    TRY(ensure(h, h->ph, (size_t)(P + ap_cap) * 8));
     TRY(ensure(h, h->tile_off, (size_t)(T + 1) * 8));
     g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
-    g.tile_tmax = h->tile_tmax.as<i32>(); g.ph_t = h->ph_t.as<i32>(); g.ph_code = h->ph_code.as<u32>();
+    g.tile_tmax = h->tile_tmax.as<i32>(); g.ph = h->ph.as<PhotonRec>();
     g.tile_off = h->tile_off.as<i64>();
     g.lum_tab = h->t_lumtab.as<LumEntry>(); g.lum_guide = h->t_lumguide.as<unsigned short>();
     ApArgs ap{};
@@ -623,7 +620,7 @@ int wfs_run(wfs_handle *h)
     HIPCHK(hipMemsetAsync(h->scal.p, 0, 128, h->stream));
     if (h->optical) {
         OpticalArgs oa{T, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_gid.as<u32>(),
-                       h->opt_t.as<i32>(), h->opt_item.as<u32>(), h->ph_t.as<i32>(), h->ph_code.as<u32>(), h->scal.as<i64>()};
+                       h->opt_t.as<i32>(), h->opt_item.as<u32>(), h->ph.as<PhotonRec>(), h->scal.as<i64>()};
         Timer t(h, "k_optical_finish");
         hipLaunchKernelGGL(k_optical_finish, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, oa);
     }
@@ -681,7 +678,7 @@ int wfs_run(wfs_handle *h)
     pa.active_tiles = h->active_tiles.as<i32>(); pa.n_active = h->n_active_tiles;
     pa.tile_count = h->tile_count.as<i32>(); pa.tile_tmin = h->tile_tmin.as<i32>(); pa.tile_tmax = h->tile_tmax.as<i32>(); pa.tile_off = h->tile_off.as<i64>();
     pa.set_cluster = h->set_cluster.as<i32>(); pa.set_t0 = h->set_t0.as<i64>(); pa.set_mode = h->set_mode.as<i32>();
-    pa.ph_t = h->ph_t.as<i32>(); pa.ph_code = h->ph_code.as<u32>();
+    pa.ph = h->ph.as<PhotonRec>();
     pa.ph_gain = (!h->injected && h->ap_active) ? h->ph_gain.as<double>() - h->n_photons : h->ph_gain.as<double>();
     pa.cl_group = h->cl_group.as<i32>(); pa.row_lo = h->row_lo.as<i64>(); pa.acc_off = h->acc_off.as<i64>(); pa.raw = h->raw.as<i32>();
     pa.truth = h->truth.as<double>(); pa.tminmax = h->tminmax.as<i64>();
@@ -952,10 +949,10 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
     const i64 P = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0), T = h->n_tiles;
     if (cap < P) return h->fail(WFS_E_CAPACITY, "photon buffer too small");
     std::vector<i64> off((size_t)T + 1), t0((size_t)h->n_sets);
-    std::vector<i32> rel((size_t)P); std::vector<u32> code((size_t)P);
+    std::vector<PhotonRec> recs((size_t)P);
     HIPCHK(hipMemcpy(off.data(), h->tile_off.p, off.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(t0.data(), h->set_t0.p, t0.size() * 8, hipMemcpyDeviceToHost));
-    if (P) { HIPCHK(hipMemcpy(rel.data(), h->ph_t.p, rel.size() * 4, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(code.data(), h->ph_code.p, code.size() * 4, hipMemcpyDeviceToHost)); }
+    if (P) HIPCHK(hipMemcpy(recs.data(), h->ph.p, recs.size() * 8, hipMemcpyDeviceToHost));
     std::vector<double> gains((size_t)d.n_tpc), spe((size_t)2001 * d.n_spe), pg;
     HIPCHK(hipMemcpy(gains.data(), h->t_gains.p, gains.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(spe.data(), h->t_spe.p, spe.size() * 8, hipMemcpyDeviceToHost));
@@ -966,8 +963,8 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
         i64 s = tile / d.n_tpc; int c = (int)(tile - s * d.n_tpc);
         const double *row = &spe[(size_t)(d.n_spe > 1 ? c : 0) * 2001];
         for (i64 p = off[tile]; p < off[tile + 1]; p++) {
-            t[p] = t0[s] + rel[p]; ch[p] = (int16_t)c;
-            u32 g1 = code[p] & 0xffffu, g2 = code[p] >> 16;
+            t[p] = t0[s] + recs[p].t; ch[p] = (int16_t)c;
+            u32 g1 = recs[p].code & 0xffffu, g2 = recs[p].code >> 16;
             if (h->injected || p >= h->n_photons) { gain[p] = pg[(size_t)(p - gain_first)]; dpe[p] = g2 != 0; }
             else { double g = gains[c] * row[g1]; if (g2) g += gains[c] * row[g2]; gain[p] = g; dpe[p] = g2 != 0; }
         }

@@ -3,8 +3,8 @@
 // Data layout in HBM (one batch):
 //   pulse set   = one Pulse.__call__ of the reference (one S1 or S2 instruction, or its PMT afterpulses)
 //   tile        = (pulse set, channel): the photons of one pulse in one PMT; tile id = set * n_tpc + channel
-//   photons     = SoA bucketed by tile: ph_t i32 (ns relative to the set's t0), ph_code u32 (SPE table indices
-//                 g1 | g2 << 16, g2 = 0: no double-PE) or ph_gain f64 (pre-assigned gains)
+//   photons     = bucketed by tile: 8-byte records {t i32 (ns relative to the set's t0), code u32 (SPE table indices
+//                 g1 | g2 << 16, g2 = 0: no double-PE)}; ph_gain f64 only for pre-assigned gains
 //   group       = digitise window (one digitize_pulse_cache call): clusters merged by the rule of rawdata.py:96-98
 //   row         = (group, channel) active range [row_lo - tw, row_hi + tw]; int32 accumulators in one arena
 //   intervals   = ZLE output per row, reserved slots; records = 244-byte strax raw_records
@@ -310,7 +310,7 @@ struct PulseArgs {
     const i32 *active_tiles; i64 n_active;
     const i32 *tile_count, *tile_tmin, *tile_tmax; const i64 *tile_off;
     const i32 *set_cluster; const i64 *set_t0; const i32 *set_mode;       // mode 0: SPE codes, 1: explicit gains
-    const i32 *ph_t; const u32 *ph_code; const double *ph_gain;
+    const PhotonRec *ph; const double *ph_gain;
     const i32 *cl_group; const i64 *row_lo; const i64 *acc_off;
     i32 *raw;
     double *truth;        // [n_sets][16]: 12 accumulators (pulse.py:259-271) + n, sum t, sum t^2, (min,max kept separately)
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     i32 n_dpe_tile = 0;
     if (win == 0) {           // number of DPE photons of the tile (truth quirk pulse.py:255); truth is window 0's job
         i32 c = 0;
-        for (i32 p = tid; p < n; p += TPB) c += (a.ph_code[off + p] >> 16) != 0;
+        for (i32 p = tid; p < n; p += TPB) c += (a.ph[off + p].code >> 16) != 0;
         for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
         if (lane == 0) wsum[wid] = (u32)c;
         __syncthreads();
@@ -386,8 +386,9 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             for (int k = 0; k < DENSE_PPT; k++) {
                 const i32 p = base + tid + k * TPB;
                 const bool v = p < n;
-                ns[k] = v ? (i32)(a.ph_t[off + p] - rel0) : -1;
-                code[k] = v ? a.ph_code[off + p] : 0u;
+                const PhotonRec rec = a.ph[off + (v ? p : 0)];        // branch-free: tiles on the work list have n >= 1
+                ns[k] = v ? (i32)(rec.t - rel0) : -1;
+                code[k] = v ? rec.code : 0u;
                 gain[k] = (v && mode != 0) ? a.ph_gain[off + p] : 0.0;
             }
             if (mode == 0) {
@@ -538,8 +539,9 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
     for (int k = 0; k < SPARSE_PPT; k++) {
         const i32 p = tid + k * TPB;
         const bool v = p < n;
-        ns[k] = v ? a.ph_t[off + p] - rel0 : -1;
-        code[k] = v ? a.ph_code[off + p] : 0u;
+        const PhotonRec rec = a.ph[off + (v ? p : 0)];
+        ns[k] = v ? rec.t - rel0 : -1;
+        code[k] = v ? rec.code : 0u;
         gain[k] = (v && mode != 0) ? a.ph_gain[off + p] : 0.0;
     }
     if (mode == 0) {
@@ -825,7 +827,7 @@ struct GenArgs {
     const i64 *em_off;            // [n_ins + 1] first emitter of each instruction
     i64 *em_time; i32 *em_nph; i32 *em_ins; const i64 *em_ph_off;
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
-    i32 *ph_t; u32 *ph_code;
+    PhotonRec *ph;
     i64 n_blocks, block_stride;   // photon blocks are visited in a strided order: see k_photons
     const struct LumEntry *lum_tab; const unsigned short *lum_guide;
     i64 *blk_e;                   // [n_blocks][2] first / last emitter of every photon block
@@ -1193,13 +1195,13 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             st_t[slot] = (i32)t; st_code[slot] = code; st_cr[slot] = ((u32)ch << 16) | rank;
 #else
             const i64 pos = hbase[ch] + rank;
-            a.ph_t[pos] = (i32)t; a.ph_code[pos] = code;
+            a.ph[pos] = PhotonRec{(i32)t, code};
 #endif
         } else {
             const i64 tile = (i64)ins * nch + ch;
             const i64 pos = a.tile_off[tile] + a.ph_slot[p];
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
-            a.ph_t[pos] = (i32)t; a.ph_code[pos] = code;
+            a.ph[pos] = PhotonRec{(i32)t, code};
         }
     }
     if (AP && !COUNT) {
@@ -1229,7 +1231,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
     for (int slot = tid; slot < (int)(p1 - p0); slot += GEN_TPB) {
         const u32 cr = st_cr[slot];
         const i64 pos = hbase[cr >> 16] + (cr & 0xffffu);
-        a.ph_t[pos] = st_t[slot]; a.ph_code[pos] = st_code[slot];
+        a.ph[pos] = PhotonRec{st_t[slot], st_code[slot]};
     }
 #endif
 }
@@ -1250,7 +1252,7 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
     if (i >= n) return;
     const i64 tile = ((i64)a.n_ins + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i];
     const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
-    a.ph_t[pos] = ap.ap_t[i]; a.ph_code[pos] = 0u; ph_gain_base[pos] = ap.ap_gain[i];
+    a.ph[pos] = PhotonRec{ap.ap_t[i], 0u}; ph_gain_base[pos] = ap.ap_gain[i];
     atomicMin(&a.tile_tmin[tile], ap.ap_t[i]); atomicMax(&a.tile_tmax[tile], ap.ap_t[i]);
 }
 
@@ -1258,7 +1260,7 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
 // side of the ABI; what is left of Pulse.__call__ before add_current is drawn here per photon: transit time spread
 // (pulse.py:53-56), double-PE flag (pulse.py:76-79) and the SPE gain indices (pulse.py:97-103).  One thread per tile.
 struct OpticalArgs { i64 n_tiles; const i32 *tile_count; const i64 *tile_off; i32 *tile_tmin, *tile_tmax; const u32 *set_gid;
-                     const i32 *in_t; const u32 *in_item; i32 *ph_t; u32 *ph_code; i64 *scal; };
+                     const i32 *in_t; const u32 *in_item; PhotonRec *ph; i64 *scal; };
 
 __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
 {
@@ -1279,7 +1281,7 @@ __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
         i64 t = a.in_t[off + p];
         t += sample_disc(d.tab_tts, u53(C.x, C.y));
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-        a.ph_t[off + p] = (i32)t; a.ph_code[off + p] = g1 | (is_dpe ? (g2 << 16) : 0u);
+        a.ph[off + p] = PhotonRec{(i32)t, g1 | (is_dpe ? (g2 << 16) : 0u)};
         tmin = (i32)t < tmin ? (i32)t : tmin; tmax = (i32)t > tmax ? (i32)t : tmax;
     }
     a.tile_tmin[tile] = tmin; a.tile_tmax[tile] = tmax;
