@@ -89,7 +89,7 @@ typedef struct orc_session_s {
     vec_f64 truth;
     i64 n_pe_total;
     const i64 *noise_override; i64 n_noise_override;
-    struct { double *cum; i64 n; i64 vmin; } tab[6];   /* tts, s1 exp, s1 spread, t1, t3, s2 spread: trunc()-ed delay variates */    /* tests: ix_rand per digitise call instead of the Philox draw */
+    struct { double *cum; i64 n; i64 vmin; } tab[9];   /* trunc()-ed delay variates: the individual terms and their sums, see TAB_* */    /* tests: ix_rand per digitise call instead of the Philox draw */
 } orc_session;
 
 /* ---------------------------------------------------------------- Philox4x32-10 ------------------ */
@@ -109,7 +109,7 @@ void orc_philox(const u32 *ctr, const u32 *key, u32 *out) { philox4x32_10(ctr[0]
 
 /* draw sites (counter word 3); counter = (emitter, instruction gid, item, site) -- DESIGN.md "RNG streams" */
 enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
-       SITE_PH_A = 16, SITE_PH_B = 17, SITE_PH_C = 18, SITE_PH_D = 19, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
+       SITE_PH_A = 16, SITE_PH_B = 17, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
 
 static inline void draw(const orc_session *s, u32 emitter, u32 gid, u32 item, u32 site, u32 w[4])
 {
@@ -160,9 +160,10 @@ static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam)
     }
 }
 
-enum { TAB_TTS = 0, TAB_S1_EXP, TAB_S1_SPREAD, TAB_T1, TAB_T3, TAB_S2_SPREAD };
-static void tab_normal(struct orc_session_s *s, int slot, double mu, double sigma);
+enum { TAB_TTS = 0, TAB_S1_EXP, TAB_S1_SPREAD, TAB_T1, TAB_T3, TAB_S2_SPREAD, TAB_LUM, TAB_S1_TOTAL, TAB_S2_TOTAL, TAB_N };
 static void tab_exp(struct orc_session_s *s, int slot, double tau);
+static void tab_totals(struct orc_session_s *s);
+static void tab_normal(struct orc_session_s *s, int slot, double mu, double sigma);
 
 /* ---------------------------------------------------------------- session ------------------------ */
 orc_session *orc_new(const orc_config *c, const double *templates, const double *spe, const double *gains,
@@ -174,6 +175,7 @@ orc_session *orc_new(const orc_config *c, const double *templates, const double 
     s->lum_x = lum_x; s->lum_t = lum_t; s->noise = noise;
     tab_normal(s, TAB_TTS, c->tts_mean, c->tts_sigma); tab_exp(s, TAB_S1_EXP, c->s1_decay_time); tab_normal(s, TAB_S1_SPREAD, 0.0, c->s1_decay_spread);
     tab_exp(s, TAB_T1, c->t1_gas); tab_exp(s, TAB_T3, c->t3_gas); tab_normal(s, TAB_S2_SPREAD, 0.0, c->s2_time_spread);
+    tab_totals(s);
     for (int r = 0; r < 10; r++) {              /* pulse.py:32 current_max */
         double m = templates[r * c->tlen];
         for (int k = 1; k < c->tlen; k++) if (templates[r * c->tlen + k] > m) m = templates[r * c->tlen + k];
@@ -206,7 +208,7 @@ void orc_free(orc_session *s)
         (void **)&s->zl_right.p, (void **)&s->zl_data_off.p, (void **)&s->zl_ch.p, (void **)&s->zl_data.p,
         (void **)&s->truth.p };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
-    for (int q = 0; q < 6; q++) free(s->tab[q].cum);
+    for (int q = 0; q < TAB_N; q++) free(s->tab[q].cum);
     free(s);
 }
 
@@ -464,6 +466,83 @@ static i64 sample_tab(const orc_session *s, int slot, double u)
     while (lo < hi) { i64 mid = (lo + hi) >> 1; if (u < c[mid]) hi = mid; else lo = mid + 1; }      /* first i with u < cum[i] */
     return s->tab[slot].vmin + lo;
 }
+/* The delay of a photon is a SUM of independent terms, each truncated to an integer on its own, and only
+ * the sum reaches the pulse.  The sum of independent integer variates is sampled from one uniform through the
+ * convolution of their probability mass functions -- the same distribution as adding separately drawn terms:
+ *   S1 (s1.py:193-194 + pulse.py:54-56):  trunc(Exp * s1_decay_time) + trunc(N(0, s1_decay_spread)) + trunc(N(tts))
+ *   S2 (s2.py:338, pulse.py:339-341, s2.py:550, pulse.py:54-56):
+ *        trunc(luminescence) + trunc(Exp * (t1 w.p. sf, else t3)) + trunc(N(0, s2_time_spread)) + trunc(N(tts))
+ * pmf of trunc(np.interp(u, lum_x, lum_t)): P(trunc(L) <= k) = F(k + 1) for k >= 0, F(k) for k < 0 with
+ * F(x) = P(L <= x) the inverse of the piecewise linear map u -> L. */
+typedef struct { double *p; i64 n, vmin; } pmf_t;
+static pmf_t pmf_of_tab(const orc_session *s, int slot)
+{
+    pmf_t r; r.n = s->tab[slot].n; r.vmin = s->tab[slot].vmin; r.p = (double *)malloc((size_t)r.n * 8);
+    for (i64 i = 0; i < r.n; i++) r.p[i] = s->tab[slot].cum[i] - (i ? s->tab[slot].cum[i - 1] : 0.0);
+    return r;
+}
+static pmf_t pmf_delta(i64 v) { pmf_t r; r.n = 1; r.vmin = v; r.p = (double *)malloc(8); r.p[0] = 1.0; return r; }
+static pmf_t pmf_mix(pmf_t a, double wa, pmf_t b, double wb)
+{
+    pmf_t r; r.vmin = a.vmin < b.vmin ? a.vmin : b.vmin;
+    i64 hi = (a.vmin + a.n > b.vmin + b.n) ? a.vmin + a.n : b.vmin + b.n;
+    r.n = hi - r.vmin; r.p = (double *)calloc((size_t)r.n, 8);
+    for (i64 i = 0; i < a.n; i++) r.p[a.vmin - r.vmin + i] += wa * a.p[i];
+    for (i64 i = 0; i < b.n; i++) r.p[b.vmin - r.vmin + i] += wb * b.p[i];
+    return r;
+}
+static pmf_t pmf_conv(pmf_t a, pmf_t b)
+{
+    pmf_t r; r.vmin = a.vmin + b.vmin; r.n = a.n + b.n - 1; r.p = (double *)calloc((size_t)r.n, 8);
+    for (i64 i = 0; i < a.n; i++) { const double ai = a.p[i]; if (ai == 0.0) continue; for (i64 j = 0; j < b.n; j++) r.p[i + j] += ai * b.p[j]; }
+    return r;
+}
+static double lum_cdf(const orc_session *s, double x)
+{
+    const double *xp = s->lum_x, *fp = s->lum_t; const int n = s->c.n_lum;
+    if (x < fp[0]) return 0.0;
+    if (x >= fp[n - 1]) return 1.0;
+    int lo = 0, hi = n - 1;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (fp[mid] <= x) lo = mid; else hi = mid; }
+    return xp[lo] + (x - fp[lo]) / (fp[lo + 1] - fp[lo]) * (xp[lo + 1] - xp[lo]);
+}
+static void tab_lum(orc_session *s)
+{
+    const int n = s->c.n_lum;
+    if (n < 2 || !s->lum_x || !s->lum_t) { s->tab[TAB_LUM].cum = (double *)malloc(8); s->tab[TAB_LUM].cum[0] = 1.0; s->tab[TAB_LUM].n = 1; s->tab[TAB_LUM].vmin = 0; return; }
+    const i64 lo = (i64)floor(s->lum_t[0]) - 1, hi = (i64)ceil(s->lum_t[n - 1]) + 1;
+    double *c = (double *)malloc((size_t)(hi - lo + 1) * 8);
+    for (i64 k = lo; k <= hi; k++) c[k - lo] = lum_cdf(s, (double)(k >= 0 ? k + 1 : k));
+    c[hi - lo] = 1.0;
+    s->tab[TAB_LUM].cum = c; s->tab[TAB_LUM].n = hi - lo + 1; s->tab[TAB_LUM].vmin = lo;
+}
+static void tab_from_pmf(orc_session *s, int slot, pmf_t a)
+{
+    i64 first = 0; while (first < a.n - 1 && a.p[first] == 0.0) first++;
+    double *c = (double *)malloc((size_t)(a.n - first) * 8); double acc = 0; i64 n = 0;
+    for (i64 i = first; i < a.n; i++) { acc += a.p[i]; c[n++] = acc; if (acc >= 1.0) break; }
+    while (n > 1 && c[n - 2] >= 1.0) n--;
+    c[n - 1] = 1.0;
+    s->tab[slot].cum = c; s->tab[slot].n = n; s->tab[slot].vmin = a.vmin + first;
+}
+static void tab_totals(orc_session *s)
+{
+    const orc_config *c = &s->c;
+    tab_lum(s);
+    pmf_t tts = pmf_of_tab(s, TAB_TTS);
+    /* S1 */
+    pmf_t a = c->s1_simple ? pmf_of_tab(s, TAB_S1_EXP) : pmf_delta(0);
+    if (c->s1_simple && c->s1_decay_spread != 0) { pmf_t b = pmf_of_tab(s, TAB_S1_SPREAD), r = pmf_conv(a, b); free(a.p); free(b.p); a = r; }
+    { pmf_t r = pmf_conv(a, tts); free(a.p); tab_from_pmf(s, TAB_S1_TOTAL, r); free(r.p); }
+    /* S2 */
+    pmf_t t1 = pmf_of_tab(s, TAB_T1), t3 = pmf_of_tab(s, TAB_T3), lum = pmf_of_tab(s, TAB_LUM);
+    pmf_t st = pmf_mix(t1, c->sf_gas, t3, 1.0 - c->sf_gas);
+    pmf_t b = pmf_conv(st, lum);
+    if (c->s2_time_model == 1 && c->s2_time_spread != 0) { pmf_t sp = pmf_of_tab(s, TAB_S2_SPREAD), r = pmf_conv(b, sp); free(b.p); free(sp.p); b = r; }
+    { pmf_t r = pmf_conv(b, tts); tab_from_pmf(s, TAB_S2_TOTAL, r); free(r.p); }
+    free(t1.p); free(t3.p); free(lum.p); free(st.p); free(b.p); free(tts.p);
+}
+
 /* ---------------------------------------------------------------- photon generation -------------- */
 static int cmp_ch_stable(const void *a, const void *b)
 {
@@ -502,29 +581,13 @@ static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u3
                        const double *cdf, i64 *t_out, int *ch_out, int *dpe_out, double *gain_out)
 {
     const orc_config *c = &s->c;
-    u32 A[4], B[4], C[4], D[4];
+    u32 A[4], B[4];
     draw(s, emitter, gid, item, SITE_PH_A, A);
     draw(s, emitter, gid, item, SITE_PH_B, B);
-    draw(s, emitter, gid, item, SITE_PH_C, C);
     int ch = channel_from_cdf(cdf, c->n_tpc, u53(A[0], A[1]));
     int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
     int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
-    double u_exp = u53(B[0], B[1]);
-    i64 t = t0;
-    if (!is_s2) {
-        if (c->s1_simple) {                                                     /* s1.py:193-194 */
-            t += (i64)(-log(1.0 - u_exp) * c->s1_decay_time);
-            if (c->s1_decay_spread != 0) t += sample_tab(s, TAB_S1_SPREAD, u53(C[2], C[3]));
-        }
-    } else {
-        t += (i64)interp_lum(s, u53(C[2], C[3]));                               /* s2.py:338 */
-        t += (i64)(-log(1.0 - u_exp) * (((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas));   /* pulse.py:339-341 */
-        if (c->s2_time_model == 1 && c->s2_time_spread != 0) {                  /* s2.py:550 */
-            draw(s, emitter, gid, item, SITE_PH_D, D);
-            t += sample_tab(s, TAB_S2_SPREAD, u53(D[0], D[1]));
-        }
-    }
-    t += sample_tab(s, TAB_TTS, u53(C[0], C[1]));                               /* pulse.py:54-56 */
+    i64 t = t0 + sample_tab(s, is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL, u53(B[0], B[1]));     /* all delay terms, see tab_totals */
     int sc = c->n_spe_channels > ch ? ch : 0;
     const double *row = s->spe + (i64)sc * 2001;
     double G = s->gains[ch], gain = G * row[g1];
@@ -666,12 +729,12 @@ i64 orc_optical(orc_session *s, u32 gid, int runset, i64 time, i64 n, const i64 
     photon_buf pb; memset(&pb, 0, sizeof pb);
     for (i64 k = 0; k < n; k++) {
         if (t_rel[k] < 0 || t_rel[k] >= cutoff) continue;
-        u32 A[4], B[4], C[4];
-        draw(s, 0, gid, (u32)k, SITE_PH_A, A); draw(s, 0, gid, (u32)k, SITE_PH_B, B); draw(s, 0, gid, (u32)k, SITE_PH_C, C);
+        u32 A[4], B[4];
+        draw(s, 0, gid, (u32)k, SITE_PH_A, A); draw(s, 0, gid, (u32)k, SITE_PH_B, B);
         int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
         int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
         i64 t = time + t_rel[k];
-        t += sample_tab(s, TAB_TTS, u53(C[0], C[1]));
+        t += sample_tab(s, TAB_TTS, u53(B[0], B[1]));
         int ch = chan[k];
         int sc = c->n_spe_channels > ch ? ch : 0;
         const double *row = s->spe + (i64)sc * 2001;
@@ -795,18 +858,25 @@ i64 orc_n_pe(const orc_session *s) { return s->n_pe_total; }
 /* stand-alone samplers used by the distribution tests: the individual random terms exactly as one_photon() and
  * orc_s2() compute them (same draw sites), so each can be compared with a histogram of the reference's own draws.
  * kind: 0 luminescence delay (s2.py:338), 1 gas singlet/triplet delay (pulse.py:339-341), 2 transit time (pulse.py:54-56),
- *       3 S1 'simple' delay (s1.py:193-194), 4 electron arrival (s2.py:280-282, p0 = drift mean, p1 = drift spread) */
+ *       3 S1 'simple' delay (s1.py:193-194), 4 electron arrival (s2.py:280-282, p0 = drift mean, p1 = drift spread),
+ *       5 / 6 the summed delay of an S1 / S2 photon (tab_totals), 7 / 8 trunc(Exp * t3) / trunc(np.interp) evaluated directly,
+ *       9 trunc(Exp * t3) from its table */
 void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 *out)
 {
     const orc_config *c = &s->c;
     for (i64 i = 0; i < n; i++) {
-        u32 A[4], B[4], C[4], D[4]; u32 em = (u32)(i >> 20), item = (u32)(i & 0xfffff), gid = 777u;
-        draw(s, em, gid, item, SITE_PH_B, B); draw(s, em, gid, item, SITE_PH_C, C); draw(s, em, gid, item, SITE_PH_D, D);
+        u32 A[4], B[4]; u32 em = (u32)(i >> 20), item = (u32)(i & 0xfffff), gid = 777u;
+        draw(s, em, gid, item, SITE_PH_A, A); draw(s, em, gid, item, SITE_PH_B, B);
         double z0, z1;
-        if (kind == 0) out[i] = (i64)interp_lum(s, u53(C[2], C[3]));
-        else if (kind == 1) out[i] = (i64)(-log(1.0 - u53(B[0], B[1])) * (((u64)B[3] < bern_threshold(c->sf_gas)) ? c->t1_gas : c->t3_gas));
-        else if (kind == 2) out[i] = sample_tab(s, TAB_TTS, u53(C[0], C[1]));
-        else if (kind == 3) out[i] = (i64)(-log(1.0 - u53(B[0], B[1])) * c->s1_decay_time) + sample_tab(s, TAB_S1_SPREAD, u53(C[2], C[3]));
+        if (kind == 0) out[i] = sample_tab(s, TAB_LUM, u53(B[0], B[1]));
+        else if (kind == 1) out[i] = sample_tab(s, ((u64)B[3] < bern_threshold(c->sf_gas)) ? TAB_T1 : TAB_T3, u53(B[0], B[1]));
+        else if (kind == 2) out[i] = sample_tab(s, TAB_TTS, u53(B[0], B[1]));
+        else if (kind == 3) out[i] = sample_tab(s, TAB_S1_EXP, u53(B[0], B[1])) + sample_tab(s, TAB_S1_SPREAD, u53(A[0], A[1]));
+        else if (kind == 5) out[i] = sample_tab(s, TAB_S1_TOTAL, u53(B[0], B[1]));
+        else if (kind == 6) out[i] = sample_tab(s, TAB_S2_TOTAL, u53(B[0], B[1]));
+        else if (kind == 7) out[i] = (i64)(-log(1.0 - u53(B[0], B[1])) * c->t3_gas);          /* the reference's expressions on the same uniform, */
+        else if (kind == 8) out[i] = (i64)interp_lum(s, u53(B[0], B[1]));                      /* to check the tables sample by sample */
+        else if (kind == 9) out[i] = sample_tab(s, TAB_T3, u53(B[0], B[1]));
         else {
             draw(s, (u32)i, gid, 0, SITE_EL_A, A); draw(s, (u32)i, gid, 0, SITE_EL_B, B);
             box_muller(B, &z0, &z1);

@@ -50,6 +50,25 @@ def test_timing_terms(orc, kind, key):
     assert abs(x.std() / s - 1) < 0.01
 
 
+def test_tables_reproduce_the_reference_expressions(orc):
+    """trunc(Exp * tau) and trunc(np.interp(u, ...)) sampled from their tables == the reference's expressions on the
+    same uniforms (pulse.py:341, s2.py:338)"""
+    assert np.array_equal(orc.sample_term(7, N), orc.sample_term(9, N))
+    assert np.array_equal(orc.sample_term(8, N), orc.sample_term(0, N))
+
+
+@pytest.mark.parametrize('total,parts', [(5, (3, 2)), (6, (0, 1, 2))])
+def test_summed_delay_table_is_the_sum_of_its_terms(orc, total, parts):
+    """one draw from the convolution table vs independently drawn terms added up (s1.py:193-194 / s2.py:504-557 + pulse.py:54-56)"""
+    x = orc.sample_term(total, N)
+    rng = np.random.default_rng(7)
+    y = sum(orc.sample_term(k, N)[rng.permutation(N)] for k in parts)      # permuted: the term samplers share draw sites
+    sv, sc = np.unique(y, return_counts=True)
+    assert _ks(sv, sc, x) < _ks_limit(N, N)
+    assert abs(x.mean() - y.mean()) < 5 * x.std() * np.sqrt(2 / N)
+    assert abs(x.std() / y.std() - 1) < 0.01
+
+
 @pytest.mark.parametrize('tag', ['z10', 'z90'])
 def test_electron_arrival_and_photons_per_electron(orc, tag):
     d = golden('dists.npz')

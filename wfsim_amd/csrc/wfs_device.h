@@ -18,7 +18,7 @@ typedef unsigned int u32;
 
 enum WfsSite : u32 {
     SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
-    SITE_PH_A = 16, SITE_PH_B = 17, SITE_PH_C = 18, SITE_PH_D = 19, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
+    SITE_PH_A = 16, SITE_PH_B = 17, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
 };
 
 struct u32x4 { u32 x, y, z, w; };
@@ -111,11 +111,9 @@ struct WfsDev {
     double c2a, tts_mean, tts_sigma, p_dpe, s1_decay_time, s1_decay_spread, sf_gas, t1_gas, t3_gas, s2_time_spread;
     double trap_time, gain_spread, pmt_ap_modifier, pmt_ap_t_modifier, rext;
     u32 k0, k1;
-    u64 thr_dpe, thr_sf_gas;                   // Bernoulli thresholds on 32-bit words: floor(p * 2^32)
+    u64 thr_dpe;                               // Bernoulli threshold on a 32-bit word: floor(p * 2^32)
     double current_max[10];
-    double lum_x0, lum_xl, lum_f0, lum_fl;     // first / last point of the luminescence table
-    i32 need_z1_s1, need_z1_s2;                // spread term present (non-zero spread)
-    DiscTab tab_tts, tab_s1_spread, tab_s2_spread;      // trunc(normal) delay terms: inverse-CDF tables
+    DiscTab tab_tts, tab_s1, tab_s2;           // inverse-CDF tables of integer delays: transit time alone, all terms of an S1 / S2 photon
     // tables
     const double *templates, *spe, *gains, *thr_truth, *lum_x, *lum_t;
     const i64 *thr_zle;

@@ -34,7 +34,7 @@ struct wfs_handle {
     int keep_currents = 0, profiling = 0;
     int carry_has = 0; i64 carry_runmax = 0;
     // tables
-    DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise, t_lumtab, t_lumguide;
+    DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise;
     ApElem ap[WFS_MAX_AP];
     // instructions
     i64 n_ins = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
@@ -59,6 +59,7 @@ struct wfs_handle {
     std::vector<double> h_gains;
     i64 zero64 = 0;
     DevBuf tt_cum[6], tt_guide[6];
+    std::vector<double> h_lum_x, h_lum_t;          // luminescence table (host copy, enters the S2 delay table)
     DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
@@ -178,13 +179,82 @@ static int upload_disc(wfs_handle *h, int slot, const std::vector<double> &cum, 
     return WFS_OK;
 }
 
+// ---- delay of a photon = sum of independent, separately truncated terms: sampled from ONE uniform through
+// the convolution of the terms' probability mass functions (same distribution as adding separately drawn terms)
+struct Pmf { std::vector<double> p; long vmin = 0; };
+
+static Pmf pmf_from_cum(const std::vector<double> &cum, long vmin)
+{
+    Pmf r; r.vmin = vmin; r.p.resize(cum.size());
+    for (size_t i = 0; i < cum.size(); i++) r.p[i] = cum[i] - (i ? cum[i - 1] : 0.0);
+    return r;
+}
+static Pmf pmf_normal(double mu, double sigma) { std::vector<double> cum; int vmin; normal_trunc_table(mu, sigma, cum, vmin); return pmf_from_cum(cum, vmin); }
+// trunc(Exp * tau) (s1.py:193, pulse.py:341): P(X <= k) = 1 - exp(-(k + 1) / tau)
+static Pmf pmf_exp(double tau)
+{
+    std::vector<double> cum;
+    if (!(tau > 0)) cum.push_back(1.0);
+    else for (long k = 0; k < 60000; k++) { const double v = -expm1(-(double)(k + 1) / tau); cum.push_back(v); if (v >= 1.0) break; }
+    cum.back() = 1.0;
+    return pmf_from_cum(cum, 0);
+}
+// trunc(np.interp(u, x, t)) (s2.py:338): P(L <= y) is the inverse of the increasing piecewise linear map u -> L
+static Pmf pmf_luminescence(const std::vector<double> &x, const std::vector<double> &t)
+{
+    const int n = (int)x.size();
+    if (n < 2) { Pmf r; r.p = {1.0}; return r; }
+    auto cdf = [&](double y) {
+        if (y < t[0]) return 0.0;
+        if (y >= t[n - 1]) return 1.0;
+        int lo = 0, hi = n - 1;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (t[mid] <= y) lo = mid; else hi = mid; }
+        return x[lo] + (y - t[lo]) / (t[lo + 1] - t[lo]) * (x[lo + 1] - x[lo]);
+    };
+    const long lo = (long)floor(t[0]) - 1, hi = (long)ceil(t[n - 1]) + 1;
+    std::vector<double> cum;
+    for (long k = lo; k <= hi; k++) cum.push_back(cdf((double)(k >= 0 ? k + 1 : k)));      // the cast truncates toward zero
+    cum.back() = 1.0;
+    return pmf_from_cum(cum, lo);
+}
+static Pmf pmf_mix(const Pmf &a, double wa, const Pmf &b, double wb)
+{
+    Pmf r; r.vmin = std::min(a.vmin, b.vmin);
+    const long hi = std::max(a.vmin + (long)a.p.size(), b.vmin + (long)b.p.size());
+    r.p.assign((size_t)(hi - r.vmin), 0.0);
+    for (size_t i = 0; i < a.p.size(); i++) r.p[(size_t)(a.vmin - r.vmin) + i] += wa * a.p[i];
+    for (size_t i = 0; i < b.p.size(); i++) r.p[(size_t)(b.vmin - r.vmin) + i] += wb * b.p[i];
+    return r;
+}
+static Pmf pmf_conv(const Pmf &a, const Pmf &b)
+{
+    Pmf r; r.vmin = a.vmin + b.vmin; r.p.assign(a.p.size() + b.p.size() - 1, 0.0);
+    for (size_t i = 0; i < a.p.size(); i++) { const double ai = a.p[i]; if (ai == 0.0) continue; for (size_t j = 0; j < b.p.size(); j++) r.p[i + j] += ai * b.p[j]; }
+    return r;
+}
+static int upload_pmf(wfs_handle *h, int slot, const Pmf &a, DiscTab &out)
+{
+    size_t first = 0; while (first + 1 < a.p.size() && a.p[first] == 0.0) first++;
+    std::vector<double> cum; double acc = 0;
+    for (size_t i = first; i < a.p.size(); i++) { acc += a.p[i]; cum.push_back(acc); if (acc >= 1.0) break; }
+    while (cum.size() > 1 && cum[cum.size() - 2] >= 1.0) cum.pop_back();
+    cum.back() = 1.0;
+    return upload_disc(h, slot, cum, (int)(a.vmin + (long)first), out);
+}
+
+// tab_tts: transit time alone (photons that arrive with their times: RawDataOptical); tab_s1 / tab_s2: every delay term of
+// an S1 / S2 photon relative to its emitter (s1.py:193-194, s2.py:338 + pulse.py:339-341 + s2.py:550, pulse.py:54-56)
 int build_time_tables(wfs_handle *h)
 {
     const wfs_config &c = h->cfg; WfsDev &d = h->dev;
-    std::vector<double> cum; int vmin;
-    normal_trunc_table(c.tts_mean, c.tts_sigma, cum, vmin); TRY(upload_disc(h, 0, cum, vmin, d.tab_tts));
-    normal_trunc_table(0.0, c.s1_decay_spread, cum, vmin); TRY(upload_disc(h, 1, cum, vmin, d.tab_s1_spread));
-    normal_trunc_table(0.0, c.s2_time_spread, cum, vmin); TRY(upload_disc(h, 2, cum, vmin, d.tab_s2_spread));
+    const Pmf tts = pmf_normal(c.tts_mean, c.tts_sigma);
+    TRY(upload_pmf(h, 0, tts, d.tab_tts));
+    Pmf s1; s1.p = {1.0};
+    if (c.s1_simple) { s1 = pmf_exp(c.s1_decay_time); if (c.s1_decay_spread != 0.0) s1 = pmf_conv(s1, pmf_normal(0.0, c.s1_decay_spread)); }
+    TRY(upload_pmf(h, 1, pmf_conv(s1, tts), d.tab_s1));
+    Pmf s2 = pmf_conv(pmf_mix(pmf_exp(c.t1_gas), c.sf_gas, pmf_exp(c.t3_gas), 1.0 - c.sf_gas), pmf_luminescence(h->h_lum_x, h->h_lum_t));
+    if (c.s2_time_model == 1 && c.s2_time_spread != 0.0) s2 = pmf_conv(s2, pmf_normal(0.0, c.s2_time_spread));
+    TRY(upload_pmf(h, 2, pmf_conv(s2, tts), d.tab_s2));
     return WFS_OK;
 }
 
@@ -201,9 +271,7 @@ void refresh_dev(wfs_handle *h)
     d.pmt_ap_modifier = c.pmt_ap_modifier; d.pmt_ap_t_modifier = c.pmt_ap_t_modifier; d.rext = c.rext;
     d.k0 = (u32)c.seed; d.k1 = (u32)(c.seed >> 32);
     auto thr = [](double p) -> u64 { if (!(p > 0)) return 0; if (p >= 1) return 4294967296ull; return (u64)(p * 4294967296.0); };
-    d.thr_dpe = thr(c.p_dpe); d.thr_sf_gas = thr(c.sf_gas);
-    d.need_z1_s1 = (c.s1_simple && c.s1_decay_spread != 0.0) ? 1 : 0;
-    d.need_z1_s2 = (c.s2_time_model == 1 && c.s2_time_spread != 0.0) ? 1 : 0;
+    d.thr_dpe = thr(c.p_dpe);
     // HE rows are only materialised when they can differ from a flat baseline: a non-zero int(factor)
     // (rawdata.py:242) or noise columns for the HE channels
     d.enable_noise = (c.enable_noise && d.noise != nullptr) ? 1 : 0;
@@ -252,7 +320,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->t_lumtab, &h->t_lumguide, &h->blk_e, &h->blk_base, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -312,29 +380,14 @@ int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, in
     TRY(upload(h, h->t_thr_truth, thr_truth, sizeof(double) * c.n_rows));
     TRY(upload(h, h->t_thr_zle, thr_zle, sizeof(int64_t) * c.n_rows));
     WfsDev &d = h->dev;
-    d.n_lum = 0;
+    d.n_lum = 0; h->h_lum_x.clear(); h->h_lum_t.clear();
     if (lum_x && lum_t && n_lum >= 2) {
+        for (int i = 0; i + 1 < n_lum; i++)
+            if (!(lum_x[i + 1] >= lum_x[i]) || !(lum_t[i + 1] > lum_t[i])) return h->fail(WFS_E_INVALID, "luminescence table must be increasing");
         TRY(upload(h, h->t_lumx, lum_x, sizeof(double) * n_lum)); TRY(upload(h, h->t_lumt, lum_t, sizeof(double) * n_lum));
-        d.n_lum = n_lum;
-        // segment table + guide for interp_lum_guided
-        std::vector<LumEntry> tab((size_t)n_lum - 1);
-        for (int i = 0; i + 1 < n_lum; i++) {
-            if (!(lum_x[i + 1] >= lum_x[i])) return h->fail(WFS_E_INVALID, "luminescence table abscissa must be non-decreasing");
-            tab[i] = LumEntry{lum_x[i], lum_x[i + 1], lum_t[i], (lum_t[i + 1] - lum_t[i]) / (lum_x[i + 1] - lum_x[i])};
-        }
-        std::vector<unsigned short> guide(LUM_G + 2);
-        if (n_lum - 1 > 65535) return h->fail(WFS_E_CAPACITY, "luminescence table too long");
-        int lo = 0;
-        for (int c = 0; c <= LUM_G + 1; c++) {                 // largest lo with x[lo] <= c / LUM_G
-            const double x = (double)c / LUM_G;
-            while (lo + 1 < n_lum - 1 && lum_x[lo + 1] <= x) lo++;
-            guide[c] = (unsigned short)lo;
-        }
-        TRY(upload(h, h->t_lumtab, tab.data(), tab.size() * sizeof(LumEntry)));
-        TRY(upload(h, h->t_lumguide, guide.data(), guide.size() * 2));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        d.lum_x0 = lum_x[0]; d.lum_xl = lum_x[n_lum - 1]; d.lum_f0 = lum_t[0]; d.lum_fl = lum_t[n_lum - 1];
+        d.n_lum = n_lum; h->h_lum_x.assign(lum_x, lum_x + n_lum); h->h_lum_t.assign(lum_t, lum_t + n_lum);
     }
+    TRY(build_time_tables(h));         // the S2 delay table contains the luminescence term
     d.noise = nullptr; d.noise_len = 0; d.noise_channels = 0;
     if (noise && noise_len > 0 && noise_channels > 0) {
         TRY(upload(h, h->t_noise, noise, sizeof(int16_t) * (size_t)noise_len * noise_channels));
@@ -562,7 +615,6 @@ static int run_generation(wfs_handle *h)
     g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
     g.tile_tmax = h->tile_tmax.as<i32>(); g.ph = h->ph.as<PhotonRec>();
     g.tile_off = h->tile_off.as<i64>();
-    g.lum_tab = h->t_lumtab.as<LumEntry>(); g.lum_guide = h->t_lumguide.as<unsigned short>();
     ApArgs ap{};
     if (ap_on) {
         ap.n = d.n_ap;

@@ -829,7 +829,6 @@ struct GenArgs {
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
     PhotonRec *ph;
     i64 n_blocks, block_stride;   // photon blocks are visited in a strided order: see k_photons
-    const struct LumEntry *lum_tab; const unsigned short *lum_guide;
     i64 *blk_e;                   // [n_blocks][2] first / last emitter of every photon block
     u32 *blk_base;                // [n_blocks][n_tpc] start of the block's photons inside each tile (written by the count pass)
     u32 *ph_slot;                 // [n_photons] slot inside its tile of every photon of a multi-instruction block (count pass)
@@ -946,18 +945,6 @@ __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double
     return lo < n ? lo : n - 1;
 }
 
-__device__ __forceinline__ double interp_lum(const WfsDev &d, double u)
-{
-    const double *xp = d.lum_x, *fp = d.lum_t; const int n = d.n_lum;      // np.interp, s2.py:338
-    if (u <= xp[0]) return fp[0];
-    if (u >= xp[n - 1]) return fp[n - 1];
-    int lo = 0, hi = n - 1;
-    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (xp[mid] <= u) lo = mid; else hi = mid; }
-    if (xp[lo] == u) return fp[lo];
-    double slope = (fp[lo + 1] - fp[lo]) / (xp[lo + 1] - xp[lo]);
-    return slope * (u - xp[lo]) + fp[lo];
-}
-
 #define GEN_TPB 256
 #ifndef GEN_STAGE
 #define GEN_STAGE 1                // 1: photons staged in LDS and written after the loop (faster: 20.5 vs 24.7 ms); 0: written from the loop
@@ -966,19 +953,6 @@ __device__ __forceinline__ double interp_lum(const WfsDev &d, double u)
 #define GEN_BLOCK (GEN_TPB * GEN_PPT)
 #define GEN_WIN 512                // emitter offsets staged in LDS per block
 #define CDF_G 512                  // guide cells of the per-block channel search
-#define LUM_G 4096                 // guide cells of the luminescence table
-#define LDS_TAB_N 160              // normal-variate tables up to this length are copied to LDS (sigma up to ~9 ns)
-
-// trunc(N(mu, sigma)) from one uniform: bisection over the cumulative table, in LDS when it is small
-__device__ __forceinline__ i64 sample_normal(const DiscTab &t, const double *lds, double u)
-{
-    if (t.n > LDS_TAB_N) return sample_disc(t, u);
-    int lo = 0, hi = t.n - 1;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (u < lds[mid]) hi = mid; else lo = mid + 1; }     // first i with u < cum[i]
-    return (i64)t.vmin + lo;
-}
-
-struct LumEntry { double x0, x1, f0, slope; };
 
 // PMT afterpulse element tables (afterpulse.py:181-186) and the staging list of generated afterpulse photons
 struct ApElemDev { i32 n_bins_delay, n_bins_amp, amp_2d, is_uniform; double delay_bin, amp_bin; const double *delay_cdf, *amp_cdf; };
@@ -989,19 +963,7 @@ struct ApArgs {
     i32 *ap_ins; i32 *ap_ch; i32 *ap_t; double *ap_gain;     // [cap] instruction, channel, ns relative to the instruction, gain
     i64 *count;                     // number of staged afterpulse photons (device scalar)
 };
-#define AP_STAGE 384               // afterpulse photons a block stages in LDS before it reserves space in the global list     // np.interp segment [x0, x1): f0 + slope * (u - x0)
-
-// np.interp(u, xp, fp) of s2.py:338 with the segment found through a guide table instead of a bisection:
-// same segment, same arithmetic (slope = (fp[i+1] - fp[i]) / (xp[i+1] - xp[i]), slope * (u - xp[i]) + fp[i])
-__device__ __forceinline__ double interp_lum_guided(const WfsDev &d, const LumEntry *tab, int lo, double u)
-{
-    if (u <= d.lum_x0) return d.lum_f0;
-    if (u >= d.lum_xl) return d.lum_fl;
-    LumEntry e = tab[lo];
-    while (u >= e.x1) { lo++; e = tab[lo]; }
-    if (e.x0 == u) return e.f0;
-    return e.slope * (u - e.x0) + e.f0;
-}
+#define AP_STAGE 384               // afterpulse photons a block stages in LDS before it reserves space in the global list
 
 // first and last emitter of every photon block: one bisection per thread, all in flight together (a block doing
 // its own two bisections serially costs ~20 us of dependent HBM latency before its 2048 photons can start)
@@ -1049,13 +1011,8 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
 #endif
     i32 *aps_ins = (i32 *)(aps_gain + AP_STAGE), *aps_ch = aps_ins + AP_STAGE, *aps_t = aps_ch + AP_STAGE;
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
-    __shared__ double lds_tab[3][LDS_TAB_N];                 // transit time, S1 spread, S2 spread: cumulative tables when they are small
     const int tid = threadIdx.x;
     if (AP && tid == 0) s_apn = 0;
-    if (!COUNT) {
-        const DiscTab *tabs[3] = {&d.tab_tts, &d.tab_s1_spread, &d.tab_s2_spread};
-        for (int q = 0; q < 3; q++) if (tabs[q]->n <= LDS_TAB_N) for (int i = tid; i < tabs[q]->n; i += GEN_TPB) lds_tab[q][i] = tabs[q]->cum[i];
-    }
     // Blocks that run at the same time work on different instructions (strided order): consecutive photon blocks
     // belong to one instruction and would otherwise all add into the same n_tpc tile counters.
     const i64 vb = (i64)(((u64)blockIdx.x * (u64)a.block_stride) % (u64)a.n_blocks);
@@ -1125,28 +1082,11 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             continue;
         }
         const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
-        const u32x4 C = philox4x32_10(j, gid, m, SITE_PH_C, d.k0, d.k1);
         const bool is_dpe = (u64)A.z < d.thr_dpe;
         const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-        const double u_tts = u53(C.x, C.y), u_c2 = u53(C.z, C.w);
-        const double e1 = -log(1.0 - u53(B.x, B.y));        // standard exponential variate
-        i64 t = etime - itime;                              // relative to the instruction time
-        if (!is_s2) {
-            if (d.s1_simple) {                              // s1.py:193-194
-                t += (i64)(e1 * d.s1_decay_time);
-                if (d.need_z1_s1) t += sample_normal(d.tab_s1_spread, lds_tab[1], u_c2);
-            }
-        } else {
-            const int lum_lo = a.lum_guide[(int)(u_c2 * LUM_G)];
-            const double delay = ((u64)B.w < d.thr_sf_gas) ? d.t1_gas : d.t3_gas;                      // pulse.py:339-341
-            t += (i64)(e1 * delay);
-            if (d.s2_time_model == 1 && d.need_z1_s2) {                                              // s2.py:550
-                const u32x4 D = philox4x32_10(j, gid, m, SITE_PH_D, d.k0, d.k1);
-                t += sample_normal(d.tab_s2_spread, lds_tab[2], u53(D.x, D.y));
-            }
-            t += (i64)interp_lum_guided(d, a.lum_tab, lum_lo, u_c2);                                 // s2.py:338
-        }
-        t += sample_normal(d.tab_tts, lds_tab[0], u_tts);   // pulse.py:54-56
+        // every delay term of the photon (s1.py:193-194 | s2.py:338, pulse.py:339-341, s2.py:550; pulse.py:54-56) in one
+        // draw from the table of their sum, relative to the instruction time
+        i64 t = etime - itime + sample_disc(is_s2 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
         const u32 code = g1 | (is_dpe ? (g2 << 16) : 0u);
         if (AP) {
@@ -1275,11 +1215,10 @@ __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
         const u32 item = a.in_item[off + p];                 // index of the photon inside its instruction's range
         const u32x4 A = philox4x32_10(0, gid, item, SITE_PH_A, d.k0, d.k1);
         const u32x4 B = philox4x32_10(0, gid, item, SITE_PH_B, d.k0, d.k1);
-        const u32x4 C = philox4x32_10(0, gid, item, SITE_PH_C, d.k0, d.k1);
         const bool is_dpe = (u64)A.z < d.thr_dpe;
         const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
         i64 t = a.in_t[off + p];
-        t += sample_disc(d.tab_tts, u53(C.x, C.y));
+        t += sample_disc(d.tab_tts, u53(B.x, B.y));
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
         a.ph[off + p] = PhotonRec{(i32)t, g1 | (is_dpe ? (g2 << 16) : 0u)};
         tmin = (i32)t < tmin ? (i32)t : tmin; tmax = (i32)t > tmax ? (i32)t : tmax;
