@@ -627,8 +627,8 @@ static int run_generation(wfs_handle *h)
         ap.cap = ap_cap; ap.ap_ins = h->ap_ins.as<i32>(); ap.ap_ch = h->ap_ch.as<i32>(); ap.ap_t = h->ap_t.as<i32>(); ap.ap_gain = h->ap_gain.as<double>();
         ap.count = h->scal.as<i64>() + 13;
     }
-    const size_t gen_lds_count = (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 48;
-    const size_t gen_lds = gen_lds_count + (size_t)GEN_WIN * 8 + (size_t)d.n_tpc * 16 + 8 + (GEN_STAGE ? (size_t)GEN_BLOCK * 12 : 0) + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 32;
+    const size_t gen_lds_count = (size_t)GEN_WIN * 4 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 16;
+    const size_t gen_lds = (((size_t)GEN_WIN * 12 + (size_t)d.n_tpc * 20 + 7) & ~(size_t)7) + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 16;
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart

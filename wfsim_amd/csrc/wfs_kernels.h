@@ -946,9 +946,6 @@ __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double
 }
 
 #define GEN_TPB 256
-#ifndef GEN_STAGE
-#define GEN_STAGE 1                // 1: photons staged in LDS and written after the loop (faster: 20.5 vs 24.7 ms); 0: written from the loop
-#endif
 #define GEN_PPT 8
 #define GEN_BLOCK (GEN_TPB * GEN_PPT)
 #define GEN_WIN 512                // emitter offsets staged in LDS per block
@@ -981,167 +978,188 @@ __global__ void k_block_emitters(GenArgs a)
     }
 }
 
-// Pass A (COUNT = true): channel of every photon -> photons per tile.
-// Pass B (COUNT = false): the whole photon (s1.py:180-194 / s2.py:504-557 timing terms, pulse.py:53-56 transit time,
-// pulse.py:76-79 double-PE, pulse.py:97-103 SPE gain indices) written straight into its tile's bucket.
-// A block works on GEN_BLOCK consecutive photons.  When they all belong to one instruction (the normal case for an
-// S2) the instruction's scalars, its channel CDF (+ a guide table), the emitter window and the tile offsets are
-// staged in LDS once and the per-tile ranks are taken from an LDS histogram; photons are staged in LDS and written
-// out after the block has reserved its ranges with one global atomic per non-empty tile.
+// PMT afterpulses of one photon (afterpulse.py:172-249): one uniform pair per element; generated photons are staged in
+// LDS (aps_*) and, past AP_STAGE, appended to the global list directly.
+struct ApStage { i32 *n; double *gain; i32 *ins, *ch, *t; };
+__device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st,
+                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t)
+{
+    for (int e = 0; e < ap.n; e++) {
+        const ApElemDev &el = ap.el[e];
+        const u32x4 w = philox4x32_10(j, gid, m, SITE_AP + (u32)e, d.k0, d.k1);
+        double rU0 = 1.0 - u53(w.x, w.y);
+        const double rU1 = 1.0 - u53(w.z, w.w);
+        const double *dc = el.delay_cdf + (size_t)ch * el.n_bins_delay;
+        const double prob = dc[el.n_bins_delay - 1];
+        rU0 /= d.pmt_ap_modifier;
+        if (is_dpe) rU0 /= 2;
+        if (!(rU0 <= prob)) continue;
+        double delay, amp;
+        if (el.is_uniform) {
+            const u32x4 x = philox4x32_10(j, gid, m, SITE_AP_X + (u32)e, d.k0, d.k1);
+            delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
+        } else {
+            int best = 0; double bd = fabs(dc[0] - rU0);            // np.argmin(|cdf - u|): first minimum
+            for (int k = 1; k < el.n_bins_delay; k++) { const double dd = fabs(dc[k] - rU0); if (dd < bd) { bd = dd; best = k; } }
+            delay = best * el.delay_bin - d.pmt_ap_t_modifier;
+            const double *ac = el.amp_2d ? el.amp_cdf + (size_t)ch * el.n_bins_amp : el.amp_cdf;
+            int ba = 0; double bad = fabs(ac[0] - rU1);
+            for (int k = 1; k < el.n_bins_amp; k++) { const double dd = fabs(ac[k] - rU1); if (dd < bad) { bad = dd; ba = k; } }
+            amp = ba * el.amp_bin;
+        }
+        const double tf = (double)(itime + t) + delay;              // afterpulse.py:235, int64 + float
+        i64 tap = (i64)tf - itime;
+        if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
+        const double gap = d.gains[ch] * amp;
+        const i32 k = atomicAdd(st.n, 1);
+        if (k < AP_STAGE) { st.ins[k] = ins; st.ch[k] = ch; st.t[k] = (i32)tap; st.gain[k] = gap; }
+        else {
+            const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull);
+            if (gk < ap.cap) { ap.ap_ins[gk] = ins; ap.ap_ch[gk] = ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = gap; }
+        }
+    }
+}
+
+// Photon generator, two passes over the same photon index space (GEN_BLOCK consecutive photons per block).
+// Pass A (COUNT = true): Philox site A of every photon -> channel (s1.py:154-158 / s2.py:673-677), double-PE flag
+//   (pulse.py:76-79) and first SPE index (pulse.py:97-103); photons per tile.
+// Pass B (COUNT = false): Philox site B -> summed delay (s1.py:180-194 / s2.py:504-557, pulse.py:53-56) and the second
+//   SPE index; the finished photon is written straight into its tile's bucket.
+// Fast path ("single": all photons of the block belong to one instruction, the normal case for an S2): the emitter
+//   window, the instruction's channel CDF + a guide table, and the block's tile offsets live in LDS; pass A leaves one
+//   packed word per photon (channel | dpe << 10 | spe index << 11 | emitter slot << 22) so that pass B neither repeats
+//   Philox A nor the searches, and reserves the block's range in every tile with ONE global atomic per non-empty tile
+//   (ranks inside the block come from an LDS histogram).
+// Generic path (a block spanning instructions: S1s, small S2s): per-photon global lookups and atomics.
+#define PW_CH(w) ((int)((w) & 1023u))
+#define PW_DPE(w) ((((w) >> 10) & 1u) != 0u)
+#define PW_G1(w) (((w) >> 11) & 2047u)
+#define PW_SLOT(w) ((int)((w) >> 22))
 template <bool COUNT, bool AP>
 __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs ap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nch = d.n_tpc;
-    // arrays used by both passes first; the count pass launches with only that much LDS
-    i64 *win = (i64 *)smem;                                  // [GEN_WIN] em_ph_off of the block's emitters
-    double *cdf = (double *)(win + GEN_WIN);                 // [nch]
-    i32 *hist = (i32 *)(cdf + nch);                          // [nch]
-    unsigned short *cguide = (unsigned short *)(hist + nch);           // [CDF_G + 8]
-    i64 *wtime = (i64 *)(((size_t)(cguide + CDF_G + 8) + 7) & ~(size_t)7);      // [GEN_WIN] emitter times
-    i64 *hbase = wtime + GEN_WIN;                            // [nch] first slot of this block in every tile
-    i32 *hmin = (i32 *)(hbase + nch), *hmax = hmin + nch;    // [nch] each
-#if GEN_STAGE
-    i32 *st_t = hmax + nch + (nch & 1);                      // [GEN_BLOCK] staged photons: time, code, slot in the global arrays
-    u32 *st_code = (u32 *)(st_t + GEN_BLOCK);                // [GEN_BLOCK]
-    u32 *st_cr = st_code + GEN_BLOCK;                        // [GEN_BLOCK] channel << 16 | rank inside the block
-    double *aps_gain = (double *)(st_cr + GEN_BLOCK);        // [AP_STAGE] staged afterpulse photons (AP only)
-#else
-    double *aps_gain = (double *)(hmax + nch + (nch & 1));   // [AP_STAGE] staged afterpulse photons (AP only)
-#endif
-    i32 *aps_ins = (i32 *)(aps_gain + AP_STAGE), *aps_ch = aps_ins + AP_STAGE, *aps_t = aps_ch + AP_STAGE;
+    // LDS layout (plain integer offsets: a pointer that went through an integer cast loses its LDS address space)
+    //   count: win i32[GEN_WIN] | cdf f64[nch] | hist i32[nch] | cguide u16[CDF_G + 8]
+    //   fill : win i32[GEN_WIN] | wtime i64[GEN_WIN] | hbase i64[nch] | hist i32[nch] | hmin i32[nch] | hmax i32[nch] | afterpulse staging
+    i32 *win = (i32 *)smem;                                  // first photon of the block's emitters, relative to the block's first photon
+    double *cdf = (double *)(smem + GEN_WIN * 4);
+    i64 *wtime = (i64 *)(smem + GEN_WIN * 4);                // emitter times
+    i64 *hbase = (i64 *)(smem + GEN_WIN * 12);               // first slot of this block in every tile
+    i32 *hist = (i32 *)(smem + (COUNT ? GEN_WIN * 4 + nch * 8 : GEN_WIN * 12 + nch * 8));
+    unsigned short *cguide = (unsigned short *)(smem + GEN_WIN * 4 + nch * 12);
+    i32 *hmin = (i32 *)(smem + GEN_WIN * 12 + nch * 12), *hmax = (i32 *)(smem + GEN_WIN * 12 + nch * 16);
+    const int o_ap = (GEN_WIN * 12 + nch * 20 + 7) & ~7;
+    ApStage aps;
+    aps.gain = (double *)(smem + o_ap); aps.ins = (i32 *)(smem + o_ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE;
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
+    aps.n = &s_apn;
     const int tid = threadIdx.x;
     if (AP && tid == 0) s_apn = 0;
     // Blocks that run at the same time work on different instructions (strided order): consecutive photon blocks
     // belong to one instruction and would otherwise all add into the same n_tpc tile counters.
     const i64 vb = (i64)(((u64)blockIdx.x * (u64)a.block_stride) % (u64)a.n_blocks);
     const i64 p0 = vb * GEN_BLOCK;
-    const i64 p1 = (p0 + GEN_BLOCK < a.n_photons) ? p0 + GEN_BLOCK : a.n_photons;
-    for (int c = tid; c < nch; c += GEN_TPB) { hist[c] = 0; if (!COUNT) { hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; } }
+    const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
     const i64 e_lo = a.blk_e[2 * vb], e_hi = a.blk_e[2 * vb + 1];
     const int nwin = (e_hi - e_lo + 2 <= GEN_WIN) ? (int)(e_hi - e_lo + 2) : 0;
-    for (int k = tid; k < nwin; k += GEN_TPB) {
-        win[k] = a.em_ph_off[e_lo + k];
-        if (!COUNT) wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] : 0;
-    }
     const i32 ins_lo = a.em_ins[e_lo];
     const bool single = nwin > 0 && ins_lo == a.em_ins[e_hi];      // all photons of the block in one pulse set
-    // block-uniform instruction data (used when single)
-    const u32 u_gid = a.ins_gid[ins_lo]; const i64 u_emoff = a.em_off[ins_lo]; const i64 u_time = a.ins_time[ins_lo];
-    const bool u_s2 = a.ins_type[ins_lo] == 2;
-    const i64 tbase = (i64)ins_lo * nch;
-    if (single) {
-        const double *row = a.cdf_table + (size_t)a.ins_cdfrow[ins_lo] * nch;
-        for (int c = tid; c < nch; c += GEN_TPB) cdf[c] = row[c];
-    }
-    __syncthreads();
-    if (single) {
-        // guide[c] = first channel whose cumulative probability exceeds c / CDF_G (searchsorted side='right')
-        for (int c = tid; c <= CDF_G; c += GEN_TPB) {
-            const double x = (double)c / CDF_G;
-            int lo = 0, hi = nch;
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (x < cdf[mid]) hi = mid; else lo = mid + 1; }
-            cguide[c] = (unsigned short)(lo < nch ? lo : nch - 1);
-        }
-        if (!COUNT) for (int c = tid; c < nch; c += GEN_TPB) hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c];
-        __syncthreads();
-    }
 
-#pragma unroll 2
-    for (int q = 0; q < GEN_PPT; q++) {
-        const i64 p = p0 + (i64)q * GEN_TPB + tid;
-        if (p >= p1) break;
-        // ---- photon -> (emitter e, instruction, emitter index j in the instruction, item m)
-        i64 e; u32 m; i64 etime = 0;
-        if (nwin > 0) {
-            int lo = 0, hi = nwin;                           // last k with win[k] <= p
-            while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win[mid] <= p) lo = mid; else hi = mid; }
-            e = e_lo + lo; m = (u32)(p - win[lo]);
-            if (!COUNT) etime = wtime[lo];
-        } else {
-            i64 lo = 0, hi = a.n_emitters;
-            while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
-            e = lo; m = (u32)(p - a.em_ph_off[lo]);
-            if (!COUNT) etime = a.em_time[lo];
+    if (single) {
+        const u32 gid = a.ins_gid[ins_lo]; const i64 emoff = a.em_off[ins_lo]; const i64 itime = a.ins_time[ins_lo];
+        const DiscTab &tab = (a.ins_type[ins_lo] == 2) ? d.tab_s2 : d.tab_s1;
+        const i64 tbase = (i64)ins_lo * nch;
+        const u32 jbase = (u32)(e_lo - emoff);
+        u32 pw[GEN_PPT];                                      // pass B: the packed words of this thread's photons, loaded up front
+        if (!COUNT) {
+#pragma unroll
+            for (int q = 0; q < GEN_PPT; q++) { const int pr = q * GEN_TPB + tid; pw[q] = pr < np ? a.ph_slot[p0 + pr] : 0u; }
         }
-        i32 ins; u32 gid, j; i64 itime; bool is_s2; int ch;
-        if (single) { ins = ins_lo; gid = u_gid; j = (u32)(e - u_emoff); itime = u_time; is_s2 = u_s2; }
-        else { ins = a.em_ins[e]; gid = a.ins_gid[ins]; j = (u32)(e - a.em_off[ins]); itime = a.ins_time[ins]; is_s2 = a.ins_type[ins] == 2; }
-        const u32x4 A = philox4x32_10(j, gid, m, SITE_PH_A, d.k0, d.k1);
-        const double uc = u53(A.x, A.y);
-        if (single) {
-            ch = cguide[(int)(uc * CDF_G)];
-            while (ch < nch - 1 && uc >= cdf[ch]) ch++;
-        } else {
-            ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * nch, nch, uc);
+        for (int c = tid; c < nch; c += GEN_TPB) {
+            hist[c] = 0;
+            if (COUNT) cdf[c] = a.cdf_table[(size_t)a.ins_cdfrow[ins_lo] * nch + c];
+            else { hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c]; }
         }
+        for (int k = tid; k < nwin; k += GEN_TPB) {
+            if (COUNT) win[k] = (i32)(a.em_ph_off[e_lo + k] - p0);
+            else { win[k] = (i32)(a.em_ph_off[e_lo + k] - p0); wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] - itime : 0; }
+        }
+        __syncthreads();
         if (COUNT) {
-            if (single) atomicAdd(&hist[ch], 1);
-            else a.ph_slot[p] = (u32)atomicAdd(&a.tile_count[(i64)ins * nch + ch], 1);     // the photon's slot in its tile
-            continue;
+            // guide[c] = first channel whose cumulative probability exceeds c / CDF_G (searchsorted side='right')
+            for (int c = tid; c <= CDF_G; c += GEN_TPB) {
+                const double x = (double)c / CDF_G;
+                int lo = 0, hi = nch;
+                while (lo < hi) { int mid = (lo + hi) >> 1; if (x < cdf[mid]) hi = mid; else lo = mid + 1; }
+                cguide[c] = (unsigned short)(lo < nch ? lo : nch - 1);
+            }
+            __syncthreads();
         }
-        const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
-        const bool is_dpe = (u64)A.z < d.thr_dpe;
-        const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-        // every delay term of the photon (s1.py:193-194 | s2.py:338, pulse.py:339-341, s2.py:550; pulse.py:54-56) in one
-        // draw from the table of their sum, relative to the instruction time
-        i64 t = etime - itime + sample_disc(is_s2 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
-        if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-        const u32 code = g1 | (is_dpe ? (g2 << 16) : 0u);
-        if (AP) {
-            // PMT afterpulses of this photon (afterpulse.py:172-249): one uniform pair per element
-            for (int e = 0; e < ap.n; e++) {
-                const ApElemDev &el = ap.el[e];
-                const u32x4 w = philox4x32_10(j, gid, m, SITE_AP + (u32)e, d.k0, d.k1);
-                double rU0 = 1.0 - u53(w.x, w.y);
-                const double rU1 = 1.0 - u53(w.z, w.w);
-                const double *dc = el.delay_cdf + (size_t)ch * el.n_bins_delay;
-                const double prob = dc[el.n_bins_delay - 1];
-                rU0 /= d.pmt_ap_modifier;
-                if (is_dpe) rU0 /= 2;
-                if (!(rU0 <= prob)) continue;
-                double delay, amp;
-                if (el.is_uniform) {
-                    const u32x4 x = philox4x32_10(j, gid, m, SITE_AP_X + (u32)e, d.k0, d.k1);
-                    delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
-                } else {
-                    int best = 0; double bd = fabs(dc[0] - rU0);            // np.argmin(|cdf - u|): first minimum
-                    for (int k = 1; k < el.n_bins_delay; k++) { const double dd = fabs(dc[k] - rU0); if (dd < bd) { bd = dd; best = k; } }
-                    delay = best * el.delay_bin - d.pmt_ap_t_modifier;
-                    const double *ac = el.amp_2d ? el.amp_cdf + (size_t)ch * el.n_bins_amp : el.amp_cdf;
-                    int ba = 0; double bad = fabs(ac[0] - rU1);
-                    for (int k = 1; k < el.n_bins_amp; k++) { const double dd = fabs(ac[k] - rU1); if (dd < bad) { bad = dd; ba = k; } }
-                    amp = ba * el.amp_bin;
-                }
-                const double tf = (double)(itime + t) + delay;              // afterpulse.py:235, int64 + float
-                i64 tap = (i64)tf - itime;
-                if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
-                const double gap = d.gains[ch] * amp;
-                const i32 k = atomicAdd(&s_apn, 1);
-                if (k < AP_STAGE) { aps_ins[k] = ins; aps_ch[k] = ch; aps_t[k] = (i32)tap; aps_gain[k] = gap; }
-                else {
-                    const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull);
-                    if (gk < ap.cap) { ap.ap_ins[gk] = ins; ap.ap_ch[gk] = ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = gap; }
-                }
+#pragma unroll 2
+        for (int q = 0; q < GEN_PPT; q++) {
+            const int pr = q * GEN_TPB + tid;
+            if (pr >= np) break;
+            if (COUNT) {
+                int lo = 0, hi = nwin;                       // last k with win[k] <= pr
+                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win[mid] <= pr) lo = mid; else hi = mid; }
+                const u32x4 A = philox4x32_10(jbase + (u32)lo, gid, (u32)(pr - win[lo]), SITE_PH_A, d.k0, d.k1);
+                const double uc = u53(A.x, A.y);
+                int ch = cguide[(int)(uc * CDF_G)];
+                while (ch < nch - 1 && uc >= cdf[ch]) ch++;
+                atomicAdd(&hist[ch], 1);
+                const u32 is_dpe = ((u64)A.z < d.thr_dpe) ? 1u : 0u, g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u;
+                a.ph_slot[p0 + pr] = (u32)ch | (is_dpe << 10) | (g1 << 11) | ((u32)lo << 22);
+            } else {
+                const u32 w = pw[q];
+                const int ch = PW_CH(w), lo = PW_SLOT(w); const bool is_dpe = PW_DPE(w);
+                const u32 j = jbase + (u32)lo, m = (u32)(pr - win[lo]);
+                const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
+                const u32 g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
+                // every delay term of the photon in one draw from the table of their sum, relative to the instruction time
+                i64 t = wtime[lo] + sample_disc(tab, u53(B.x, B.y));
+                if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
+                if (AP) ap_generate(d, a, ap, aps, j, gid, m, ins_lo, ch, is_dpe, itime, t);
+                const u32 rank = (u32)atomicAdd(&hist[ch], 1);
+                atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
+                a.ph[hbase[ch] + rank] = PhotonRec{(i32)t, PW_G1(w) | (is_dpe ? (g2 << 16) : 0u)};
             }
         }
-        if (single) {
-            const u32 rank = (u32)atomicAdd(&hist[ch], 1);
-            atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
-#if GEN_STAGE
-            // staged: scattered stores issued inside the loop hold up later loads of the same wave (vmcnt order)
-            const int slot = q * GEN_TPB + tid;
-            st_t[slot] = (i32)t; st_code[slot] = code; st_cr[slot] = ((u32)ch << 16) | rank;
-#else
-            const i64 pos = hbase[ch] + rank;
-            a.ph[pos] = PhotonRec{(i32)t, code};
-#endif
-        } else {
+        __syncthreads();
+        for (int c = tid; c < nch; c += GEN_TPB) {
+            const i32 hc = hist[c];
+            if (COUNT) {
+                // reserve this block's range in every tile now; the fill pass then needs no returning global atomics
+                a.blk_base[vb * nch + c] = hc ? (u32)atomicAdd(&a.tile_count[tbase + c], hc) : 0u;
+            } else if (hc) {
+                atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
+            }
+        }
+    } else {
+        if (AP) __syncthreads();                             // s_apn
+        for (int q = 0; q < GEN_PPT; q++) {
+            const int pr = q * GEN_TPB + tid;
+            if (pr >= np) break;
+            const i64 p = p0 + pr;
+            i64 lo = 0, hi = a.n_emitters;                   // photon -> emitter, instruction, emitter index j, item m
+            while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
+            const u32 m = (u32)(p - a.em_ph_off[lo]);
+            const i32 ins = a.em_ins[lo];
+            const u32 gid = a.ins_gid[ins], j = (u32)(lo - a.em_off[ins]);
+            const u32x4 A = philox4x32_10(j, gid, m, SITE_PH_A, d.k0, d.k1);
+            const int ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * nch, nch, u53(A.x, A.y));
             const i64 tile = (i64)ins * nch + ch;
-            const i64 pos = a.tile_off[tile] + a.ph_slot[p];
+            if (COUNT) { a.ph_slot[p] = (u32)atomicAdd(&a.tile_count[tile], 1); continue; }      // the photon's slot in its tile
+            const i64 itime = a.ins_time[ins];
+            const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
+            const bool is_dpe = (u64)A.z < d.thr_dpe;
+            const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
+            i64 t = a.em_time[lo] - itime + sample_disc(a.ins_type[ins] == 2 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
+            if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
+            if (AP) ap_generate(d, a, ap, aps, j, gid, m, ins, ch, is_dpe, itime, t);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
-            a.ph[pos] = PhotonRec{(i32)t, code};
+            a.ph[a.tile_off[tile] + a.ph_slot[p]] = PhotonRec{(i32)t, g1 | (is_dpe ? (g2 << 16) : 0u)};
         }
     }
     if (AP && !COUNT) {
@@ -1151,29 +1169,9 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         __syncthreads();
         for (int k = tid; k < nst; k += GEN_TPB) {
             const i64 gk = s_apbase + k;
-            if (gk < ap.cap) { ap.ap_ins[gk] = aps_ins[k]; ap.ap_ch[gk] = aps_ch[k]; ap.ap_t[gk] = aps_t[k]; ap.ap_gain[gk] = aps_gain[k]; }
+            if (gk < ap.cap) { ap.ap_ins[gk] = aps.ins[k]; ap.ap_ch[gk] = aps.ch[k]; ap.ap_t[gk] = aps.t[k]; ap.ap_gain[gk] = aps.gain[k]; }
         }
     }
-    if (!single) return;
-    __syncthreads();
-    for (int c = tid; c < nch; c += GEN_TPB) {
-        const i32 hc = hist[c];
-        if (COUNT) {
-            // reserve this block's range in every tile now; the fill pass then needs no returning atomics
-            a.blk_base[vb * nch + c] = hc ? (u32)atomicAdd(&a.tile_count[tbase + c], hc) : 0u;
-        } else if (hc) {
-            atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
-        }
-    }
-#if GEN_STAGE
-    if (COUNT) return;
-    __syncthreads();
-    for (int slot = tid; slot < (int)(p1 - p0); slot += GEN_TPB) {
-        const u32 cr = st_cr[slot];
-        const i64 pos = hbase[cr >> 16] + (cr & 0xffffu);
-        a.ph[pos] = PhotonRec{st_t[slot], st_code[slot]};
-    }
-#endif
 }
 
 // afterpulse photons -> tiles of the afterpulse pulse set of their instruction (set n_ins + ins): count, then place

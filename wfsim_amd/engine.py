@@ -13,7 +13,7 @@ from .dtypes import raw_record_dtype
 from . import tables as T
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libwfsim_amd.so')
+LIB_PATH = os.environ.get('WFSIM_AMD_LIB') or os.path.join(HERE, 'libwfsim_amd.so')
 
 _I32 = ['dt', 'samples_before', 'samples_after', 'store_before', 'store_after', 'tlen', 'trigger_window', 'baseline',
         'n_rows', 'n_tpc', 'n_top', 'he_first', 'he_factor', 'sum_channel', 'last_bottom', 'detector_nt', 'enable_noise',
