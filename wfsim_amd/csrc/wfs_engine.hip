@@ -46,13 +46,13 @@ struct wfs_handle {
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
-    DevBuf truth, tminmax, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
+    DevBuf truth, tminmax, tile_truth, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
     DevBuf scan_tmp, scal, noise_override; i64 n_noise_override = 0;
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
     i64 h_scal[16] = {0};
-    i64 n_active_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0;
+    i64 n_active_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
     double h_templates[WFS_DT * 22] = {0};
@@ -304,8 +304,10 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     refresh_dev(h);
     if (build_time_tables(h) != WFS_OK) { delete h; return WFS_E_HIP; }
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
-    hipFuncSetAttribute((const void *)k_pulse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_pulse<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photons<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photons<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photons<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -326,7 +328,7 @@ int wfs_destroy(wfs_handle *h)
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
-        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->currents, &h->cur_len, &h->cur_off,
+        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) { if (h->tt_cum[q].p) hipFree(h->tt_cum[q].p); if (h->tt_guide[q].p) hipFree(h->tt_guide[q].p); }
@@ -708,7 +710,7 @@ int wfs_run(wfs_handle *h)
     TRY(read_scal(h));
     if (h->h_scal[1] == 1) return h->fail(WFS_E_CAPACITY, "Pulse cache too long (digitise window of 10^6 samples or more, rawdata.py:219)");
     if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
-    h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5];
+    h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5]; h->max_tile_dense = h->h_scal[15];
     h->n_dense_tiles = h->h_scal[11]; h->max_nb_dense = h->h_scal[12]; h->n_active_tiles = h->n_sparse_tiles + h->n_dense_tiles;
     if (h->n_dense_tiles > 0)       // one work list: sparse tiles first, dense tiles behind them
         HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_sparse_tiles, h->dense_tiles.p, (size_t)h->n_dense_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
@@ -719,13 +721,7 @@ int wfs_run(wfs_handle *h)
     // ---- pulses
     TRY(ensure(h, h->raw, (size_t)h->s_raw * 4)); HIPCHK(hipMemsetAsync(h->raw.p, 0, (size_t)h->s_raw * 4, h->stream));
     TRY(ensure(h, h->truth, (size_t)S * 16 * 8)); HIPCHK(hipMemsetAsync(h->truth.p, 0, (size_t)S * 16 * 8, h->stream));
-    TRY(ensure(h, h->tminmax, (size_t)S * 16));
-    {
-        std::vector<i64> mm((size_t)S * 2);
-        for (i64 i = 0; i < S; i++) { mm[2 * i] = I64_MAX; mm[2 * i + 1] = I64_MIN; }
-        HIPCHK(hipMemcpyAsync(h->tminmax.p, mm.data(), mm.size() * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
+    TRY(ensure(h, h->tminmax, (size_t)S * 16)); TRY(ensure(h, h->tile_truth, (size_t)T * 8 * 8));
     PulseArgs pa{};
     pa.active_tiles = h->active_tiles.as<i32>(); pa.n_active = h->n_active_tiles;
     pa.tile_count = h->tile_count.as<i32>(); pa.tile_tmin = h->tile_tmin.as<i32>(); pa.tile_tmax = h->tile_tmax.as<i32>(); pa.tile_off = h->tile_off.as<i64>();
@@ -733,7 +729,7 @@ int wfs_run(wfs_handle *h)
     pa.ph = h->ph.as<PhotonRec>();
     pa.ph_gain = (!h->injected && h->ap_active) ? h->ph_gain.as<double>() - h->n_photons : h->ph_gain.as<double>();
     pa.cl_group = h->cl_group.as<i32>(); pa.row_lo = h->row_lo.as<i64>(); pa.acc_off = h->acc_off.as<i64>(); pa.raw = h->raw.as<i32>();
-    pa.truth = h->truth.as<double>(); pa.tminmax = h->tminmax.as<i64>();
+    pa.tile_truth = h->tile_truth.as<double>();
     h->cur_total = 0;
     if ((h->keep_currents & 1) && h->n_active_tiles > 0) {
         // debug: tile lengths in work-list order -> offsets
@@ -778,17 +774,31 @@ int wfs_run(wfs_handle *h)
         W = (W + 7) / 8 * 8;
         pd.W = W;
         const i64 step = W - (d.tlen - 1);
-        pd.n_win = (int)std::min<i64>(NWIN_MAX, std::max<i64>(1, (h->max_nb_dense + step - 1) / step));
-        TemplateArg tp;
-        memcpy(tp.t, h->h_templates, sizeof(tp.t));
         const bool small = W <= 128;
         const int tpb = small ? 128 : 256;
+        // tiles that fit one register batch: one workgroup per tile walks the windows with the photons resident in
+        // registers; longer tiles: one workgroup per window (each re-reads the tile's photons)
+        pd.n_win = (h->max_tile_dense <= (i64)tpb * DENSE_PPT) ? 1 : (int)std::min<i64>(NWIN_MAX, std::max<i64>(1, (h->max_nb_dense + step - 1) / step));
+        TemplateArg tp;
+        memcpy(tp.t, h->h_templates, sizeof(tp.t));
         size_t lds = (size_t)(W + 2 * DENSE_PAD) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
         lds = (lds + 15) / 16 * 16;
         const unsigned grid = (unsigned)(h->n_dense_tiles * pd.n_win);
         Timer t(h, "k_pulse_dense");
-        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128>), dim3(grid), dim3(128), lds, h->stream, d, pd, tp);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256>), dim3(grid), dim3(256), lds, h->stream, d, pd, tp);
+        if (pd.n_win == 1) {
+            if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128, true>), dim3(grid), dim3(128), lds, h->stream, d, pd, tp);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256, true>), dim3(grid), dim3(256), lds, h->stream, d, pd, tp);
+        } else {
+            if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128, false>), dim3(grid), dim3(128), lds, h->stream, d, pd, tp);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256, false>), dim3(grid), dim3(256), lds, h->stream, d, pd, tp);
+        }
+    }
+
+    {   // truth accumulators of every pulse set from the per-tile partial sums
+        TruthArgs ta{S, h->tile_count.as<i32>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_t0.as<i64>(), h->tile_truth.as<double>(),
+                     h->truth.as<double>(), h->tminmax.as<i64>()};
+        Timer t(h, "k_truth_reduce");
+        hipLaunchKernelGGL(k_truth_reduce, dim3(nblocks(S, 4)), dim3(256), 0, h->stream, d, ta);
     }
 
     // ---- ZLE + records

@@ -154,13 +154,13 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     }
     // work lists and maxima: aggregated per workgroup in LDS, then one global atomic per workgroup and counter
     // (76k wave-level atomics on one cache line cost ~3 ms; the counters all live in the same line of scal[])
-    __shared__ i32 s_ns, s_nd; __shared__ i64 s_bs, s_bd, s_mx[3];
-    if (threadIdx.x == 0) { s_ns = 0; s_nd = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; }
+    __shared__ i32 s_ns, s_nd; __shared__ i64 s_bs, s_bd, s_mx[4];
+    if (threadIdx.x == 0) { s_ns = 0; s_nd = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; s_mx[3] = 0; }
     __syncthreads();
     i32 rk = 0;
     if (live) {
         rk = atomicAdd(sparse ? &s_ns : &s_nd, 1);
-        if (sparse) { atomicMax(&s_mx[0], nb); atomicMax(&s_mx[1], (i64)cnt); } else atomicMax(&s_mx[2], nb);
+        if (sparse) { atomicMax(&s_mx[0], nb); atomicMax(&s_mx[1], (i64)cnt); } else { atomicMax(&s_mx[2], nb); atomicMax(&s_mx[3], (i64)cnt); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -169,6 +169,7 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
         if (s_mx[0]) atomicMax(&a.scal[4], s_mx[0]);
         if (s_mx[1]) atomicMax(&a.scal[5], s_mx[1]);
         if (s_mx[2]) atomicMax(&a.scal[12], s_mx[2]);
+        if (s_mx[3]) atomicMax(&a.scal[15], s_mx[3]);
     }
     __syncthreads();
     if (live && sparse) a.active_tiles[s_bs + rk] = (i32)tile;
@@ -313,8 +314,7 @@ struct PulseArgs {
     const PhotonRec *ph; const double *ph_gain;
     const i32 *cl_group; const i64 *row_lo; const i64 *acc_off;
     i32 *raw;
-    double *truth;        // [n_sets][16]: 12 accumulators (pulse.py:259-271) + n, sum t, sum t^2, (min,max kept separately)
-    i64 *tminmax;         // [n_sets][2] absolute min / max photon time
+    double *tile_truth;   // [n_tiles][8] per-tile partial sums: n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2 -> k_truth_reduce
     double *currents; const i64 *cur_off;     // debug: f64 tile currents
     i32 W;                // start bins per LDS window (dense) / bins capacity (sparse)
     i32 NP;               // photon capacity of the sparse kernel's LDS list
@@ -322,12 +322,12 @@ struct PulseArgs {
 };
 
 #define DENSE_PPT 8        // photons per thread per batch held in registers
-#define DENSE_SPT 4        // samples per thread carried through the tap loop
+#define DENSE_SPT 1        // samples per thread carried through the tap loop (more costs registers, i.e. occupancy)
 #define DENSE_PAD 21       // zero start bins on either side of the window: no bounds checks in the tap loop
 
 struct TemplateArg { double t[WFS_DT * 22]; };    // kernarg segment -> scalar loads, the taps live in SGPRs
 
-template <int TPB>
+template <int TPB, bool RESIDENT>
 __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateArg tp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -337,6 +337,9 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     double *red = H + (size_t)(W + 2 * DENSE_PAD) * dt;   // [TPB / 64][8]
     u32 *wsum = (u32 *)(red + 8 * (TPB / 64));
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    // pulse.py:32 current_max, indexed per photon: from LDS (indexing the kernarg copy per lane becomes a global load)
+    __shared__ double s_cmax[WFS_DT];
+    if (tid < WFS_DT) s_cmax[tid] = d.current_max[tid];
 
     // grid = tiles x windows: every workgroup owns one window of W start bins of one tile (a.n_win windows per tile;
     // consecutive windows overlap by tlen - 1 bins so that every sample sees all its taps inside one window)
@@ -362,8 +365,11 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
 
     // window w exists iff it is the first or the previous one did not already reach the last start bin (block-uniform)
     if (win > 0 && (i64)win * (W - (tlen - 1)) + (tlen - 1) >= nb) return;
+    // number of DPE photons of the tile (truth quirk pulse.py:255); truth is window 0's job.  A tile that fits one
+    // register batch is counted from the registers inside the photon loop, longer ones with a scan of their own.
     i32 n_dpe_tile = 0;
-    if (win == 0) {           // number of DPE photons of the tile (truth quirk pulse.py:255); truth is window 0's job
+    const bool one_batch = n <= TPB * DENSE_PPT;
+    if (!RESIDENT && win == 0 && !one_batch) {
         i32 c = 0;
         for (i32 p = tid; p < n; p += TPB) c += (a.ph[off + p].code >> 16) != 0;
         for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
@@ -373,15 +379,74 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     }
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2
 
+    // A tile that fits one register batch and is worked on by a single workgroup (n_win == 1) is read ONCE: its photons
+    // (ns, gain) stay in registers over all windows, and the truth sums are taken here.
+    i32 r_ns[DENSE_PPT]; double r_gain[DENSE_PPT];
+    if (RESIDENT) {
+        u32 code[DENSE_PPT];
+#pragma unroll
+        for (int k = 0; k < DENSE_PPT; k++) {
+            const i32 p = tid + k * TPB;
+            const bool v = p < n;
+            const PhotonRec rec = a.ph[off + (v ? p : 0)];            // branch-free: tiles on the work list have n >= 1
+            r_ns[k] = v ? (i32)(rec.t - rel0) : -1;
+            code[k] = v ? rec.code : 0u;
+            r_gain[k] = (v && mode != 0) ? a.ph_gain[off + p] : 0.0;
+        }
+        {
+            i32 c = 0;
+#pragma unroll
+            for (int k = 0; k < DENSE_PPT; k++) c += (code[k] >> 16) != 0;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+            if (lane == 0) wsum[wid] = (u32)c;
+            __syncthreads();
+            for (int w = 0; w < TPB / 64; w++) n_dpe_tile += (i32)wsum[w];
+        }
+        if (mode == 0) {
+            double s1[DENSE_PPT], s2[DENSE_PPT];
+#pragma unroll
+            for (int k = 0; k < DENSE_PPT; k++) {
+                s1[k] = spe_row[code[k] & 0xffffu];                    // index 0 for the unused slots: a valid address
+                s2[k] = 0;
+                if (code[k] >> 16) s2[k] = spe_row[code[k] >> 16];
+            }
+#pragma unroll
+            for (int k = 0; k < DENSE_PPT; k++) {
+                double gk = G * s1[k];                                  // pulse.py:97-98
+                if (code[k] >> 16) gk += G * s2[k];                     // pulse.py:101-103
+                r_gain[k] = gk;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DENSE_PPT; k++) {
+            if (r_ns[k] < 0) continue;
+            const int r = r_ns[k] % dt;
+            const bool above = r_gain[k] * s_cmax[r] * d.c2a > thr;
+            acc[0] += 1; acc[1] += (code[k] >> 16) != 0; acc[4] += r_gain[k];
+            if (above) { acc[2] += 1; acc[5] += r_gain[k]; if (tid + k * TPB < n_dpe_tile) acc[3] += 1; }
+            const double tr = (double)(r_ns[k] + rel0);
+            acc[6] += tr; acc[7] += tr * tr;
+        }
+    }
+
     for (i64 w0 = (i64)win * (W - (tlen - 1)); w0 == 0 || w0 + (tlen - 1) < nb; w0 += (i64)a.n_win * (W - (tlen - 1))) {
         const int Wc = (int)((nb - w0 < W) ? nb - w0 : W);
         const bool first = (w0 == 0), last = (w0 + Wc >= nb);
         __syncthreads();
         for (int i = tid; i < (W + 2 * DENSE_PAD) * dt; i += TPB) H[i] = 0.0;
         __syncthreads();
+        if (RESIDENT) {
+            const i32 ns_lo = (i32)w0 * dt, ns_hi = ns_lo + Wc * dt;       // the window in ns relative to the tile's first start bin
+#pragma unroll
+            for (int k = 0; k < DENSE_PPT; k++) {
+                if (r_ns[k] < ns_lo || r_ns[k] >= ns_hi) continue;
+                const int q = r_ns[k] - ns_lo;                             // (start bin - w0) * dt + r
+                atomicAdd(&H[DENSE_PAD * dt + q], r_gain[k]);
+            }
+        } else
         // ---- photons -> H, in register batches so that the global loads of a batch are all in flight together
         for (i32 base = 0; base < n; base += TPB * DENSE_PPT) {
-            i32 ns[DENSE_PPT]; u32 code[DENSE_PPT]; double gain[DENSE_PPT];
+            i32 ns[DENSE_PPT]; u32 code[DENSE_PPT]; double gain[DENSE_PPT]; bool use[DENSE_PPT];
 #pragma unroll
             for (int k = 0; k < DENSE_PPT; k++) {
                 const i32 p = base + tid + k * TPB;
@@ -389,14 +454,25 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 const PhotonRec rec = a.ph[off + (v ? p : 0)];        // branch-free: tiles on the work list have n >= 1
                 ns[k] = v ? (i32)(rec.t - rel0) : -1;
                 code[k] = v ? rec.code : 0u;
-                gain[k] = (v && mode != 0) ? a.ph_gain[off + p] : 0.0;
+                const i64 jw = (i64)(ns[k] / dt) - w0;
+                use[k] = v && (first || (jw >= 0 && jw < Wc));         // window 0 needs every photon (truth), the others only their own
+                gain[k] = (use[k] && mode != 0) ? a.ph_gain[off + p] : 0.0;
+            }
+            if (first && one_batch) {                // (one batch, several workgroups per tile)
+                i32 c = 0;
+#pragma unroll
+                for (int k = 0; k < DENSE_PPT; k++) c += (code[k] >> 16) != 0;
+                for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+                if (lane == 0) wsum[wid] = (u32)c;
+                __syncthreads();
+                for (int w = 0; w < TPB / 64; w++) n_dpe_tile += (i32)wsum[w];
             }
             if (mode == 0) {
                 double s1[DENSE_PPT], s2[DENSE_PPT];
 #pragma unroll
                 for (int k = 0; k < DENSE_PPT; k++) {
                     s1[k] = 0; s2[k] = 0;
-                    if (base + k * TPB < n) { s1[k] = spe_row[code[k] & 0xffffu]; if (__any((code[k] >> 16) != 0)) s2[k] = spe_row[code[k] >> 16]; }
+                    if (use[k]) { s1[k] = spe_row[code[k] & 0xffffu]; if (code[k] >> 16) s2[k] = spe_row[code[k] >> 16]; }
                 }
 #pragma unroll
                 for (int k = 0; k < DENSE_PPT; k++) {
@@ -407,12 +483,12 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             }
 #pragma unroll
             for (int k = 0; k < DENSE_PPT; k++) {
-                if (ns[k] < 0) continue;
+                if (!use[k]) continue;
                 const int bin = ns[k] / dt, r = ns[k] - bin * dt;
                 const i64 jw = bin - w0;
                 if (jw >= 0 && jw < Wc) atomicAdd(&H[((int)jw + DENSE_PAD) * dt + r], gain[k]);
                 if (first) {
-                    const bool above = gain[k] * d.current_max[r] * d.c2a > thr;
+                    const bool above = gain[k] * s_cmax[r] * d.c2a > thr;
                     const bool is_dpe = (code[k] >> 16) != 0;
                     acc[0] += 1; acc[1] += is_dpe; acc[4] += gain[k];
                     if (above) { acc[2] += 1; acc[5] += gain[k]; if (base + tid + k * TPB < n_dpe_tile) acc[3] += 1; }
@@ -440,7 +516,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             bool wact[DENSE_SPT];
 #pragma unroll
             for (int q = 0; q < DENSE_SPT; q++) wact[q] = __any(act[q]);
-#pragma unroll 1
+#pragma unroll 2
             for (int k = tlen - 1; k >= 0; k--) {
                 const double T0 = tp.t[0 * tlen + k], T1 = tp.t[1 * tlen + k], T2 = tp.t[2 * tlen + k], T3 = tp.t[3 * tlen + k],
                              T4 = tp.t[4 * tlen + k], T5 = tp.t[5 * tlen + k], T6 = tp.t[6 * tlen + k], T7 = tp.t[7 * tlen + k],
@@ -471,24 +547,13 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         }
     }
 
-    if (a.truth && win == 0) {
+    if (a.tile_truth && win == 0) {
 #pragma unroll
         for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
         __syncthreads();
         if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
         __syncthreads();
-        if (tid < 15) {
-            double v[8];
-            for (int q = 0; q < 8; q++) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + q]; v[q] = sum; }
-            double *tr = a.truth + set * 16;
-            const double vals[6] = {v[0], v[0] + v[1], v[2], v[2] + v[3], v[4] / G, v[5] / G};
-            const bool bottom = ch >= d.n_top && ch <= d.last_bottom;
-            if (tid < 6) { if (vals[tid] != 0) atomicAdd(&tr[tid], vals[tid]); }
-            else if (tid < 12) { if (bottom && vals[tid - 6] != 0) atomicAdd(&tr[tid], vals[tid - 6]); }
-            else if (tid == 12) { atomicAdd(&tr[12], v[0]); atomicMin(&a.tminmax[set * 2], t0 + a.tile_tmin[tile]); }
-            else if (tid == 13) { atomicAdd(&tr[13], v[6]); atomicMax(&a.tminmax[set * 2 + 1], t0 + a.tile_tmax[tile]); }
-            else atomicAdd(&tr[14], v[7]);
-        }
+        if (tid < 8) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + tid]; a.tile_truth[tile * 8 + tid] = sum; }
     }
 }
 
@@ -515,6 +580,8 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
     u32 *cnt = wsum + 8;                                 // [dt * W / 2] packed u16 pairs: photons per ns ...
     double *Trep = (double *)cnt;                        // ... later reused for [NREP][TREP] template copies
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    __shared__ double s_cmax[WFS_DT];                    // pulse.py:32 current_max (see k_pulse)
+    if (tid < WFS_DT) s_cmax[tid] = d.current_max[tid];
 
     const i64 tile = a.active_tiles[blockIdx.x];
     const i32 n = a.tile_count[tile];
@@ -578,7 +645,7 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
         if (ns[k] < 0) continue;
         atomicAdd(&cnt[ns[k] >> 1], 1u << ((ns[k] & 1) * 16));
         const int r = ns[k] % dt;
-        const bool above = gain[k] * d.current_max[r] * d.c2a > thr;
+        const bool above = gain[k] * s_cmax[r] * d.c2a > thr;
         const bool is_dpe = (code[k] >> 16) != 0;
         acc[0] += 1; acc[1] += is_dpe; acc[4] += gain[k];
         if (above) { acc[2] += 1; acc[5] += gain[k]; if (tid + k * TPB < n_dpe_tile) acc[3] += 1; }
@@ -662,23 +729,52 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
         if (adc1 != 0 && sa + 1 < L) atomicAdd(&dst[sa + 1], (i32)adc1);
     }
 
-    if (a.truth) {
+    if (a.tile_truth) {
 #pragma unroll
         for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
         if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
         __syncthreads();
-        if (tid < 15) {
-            double v[8];
-            for (int q = 0; q < 8; q++) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + q]; v[q] = sum; }
-            double *tr = a.truth + set * 16;
-            const double vals[6] = {v[0], v[0] + v[1], v[2], v[2] + v[3], v[4] / G, v[5] / G};
-            const bool bottom = ch >= d.n_top && ch <= d.last_bottom;
-            if (tid < 6) { if (vals[tid] != 0) atomicAdd(&tr[tid], vals[tid]); }
-            else if (tid < 12) { if (bottom && vals[tid - 6] != 0) atomicAdd(&tr[tid], vals[tid - 6]); }
-            else if (tid == 12) { atomicAdd(&tr[12], v[0]); atomicMin(&a.tminmax[set * 2], t0 + a.tile_tmin[tile]); }
-            else if (tid == 13) { atomicAdd(&tr[13], v[6]); atomicMax(&a.tminmax[set * 2 + 1], t0 + a.tile_tmax[tile]); }
-            else atomicAdd(&tr[14], v[7]);
-        }
+        if (tid < 8) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + tid]; a.tile_truth[tile * 8 + tid] = sum; }
+    }
+}
+
+// Truth accumulators of a pulse set (pulse.py:229-271 add_truth: totals, bottom-array totals; rawdata.py:330-345 photon
+// time moments) from the per-tile partial sums, one wave per set.  Channels are summed in a fixed order (lane, then a
+// shuffle tree), so the result does not depend on the order the tiles were processed in.
+struct TruthArgs { i64 n_sets; const i32 *tile_count, *tile_tmin, *tile_tmax; const i64 *set_t0; const double *tile_truth;
+                   double *truth; i64 *tminmax; };
+__global__ __launch_bounds__(256) void k_truth_reduce(WfsDev d, TruthArgs a)
+{
+    const i64 set = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (set >= a.n_sets) return;
+    double v[15];
+#pragma unroll
+    for (int q = 0; q < 15; q++) v[q] = 0.0;
+    i64 tmin = I64_MAX, tmax = I64_MIN;
+    const i64 t0 = a.set_t0[set];
+    for (int ch = lane; ch < d.n_tpc; ch += 64) {
+        const i64 tile = set * d.n_tpc + ch;
+        if (a.tile_count[tile] <= 0) continue;
+        const double *p = a.tile_truth + tile * 8;
+        const double G = d.gains[ch];
+        const double vals[6] = {p[0], p[0] + p[1], p[2], p[2] + p[3], p[4] / G, p[5] / G};
+        const bool bottom = ch >= d.n_top && ch <= d.last_bottom;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { v[q] += vals[q]; if (bottom) v[6 + q] += vals[q]; }
+        v[12] += p[0]; v[13] += p[6]; v[14] += p[7];
+        const i64 lo = t0 + a.tile_tmin[tile], hi = t0 + a.tile_tmax[tile];
+        tmin = lo < tmin ? lo : tmin; tmax = hi > tmax ? hi : tmax;
+    }
+#pragma unroll
+    for (int q = 0; q < 15; q++) for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_down(v[q], o, 64);
+    for (int o = 32; o > 0; o >>= 1) {
+        const i64 lo = __shfl_down(tmin, o, 64), hi = __shfl_down(tmax, o, 64);
+        tmin = lo < tmin ? lo : tmin; tmax = hi > tmax ? hi : tmax;
+    }
+    if (lane == 0) {
+        for (int q = 0; q < 15; q++) a.truth[set * 16 + q] = v[q];
+        a.tminmax[set * 2] = tmin; a.tminmax[set * 2 + 1] = tmax;
     }
 }
 
