@@ -40,7 +40,7 @@ struct wfs_handle {
     i64 n_ins = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, em_off;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
-    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, ph_slot;
+    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, ph_slot;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, dense_tiles;
     DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
@@ -322,7 +322,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -629,24 +629,26 @@ static int run_generation(wfs_handle *h)
         ap.cap = ap_cap; ap.ap_ins = h->ap_ins.as<i32>(); ap.ap_ch = h->ap_ch.as<i32>(); ap.ap_t = h->ap_t.as<i32>(); ap.ap_gain = h->ap_gain.as<double>();
         ap.count = h->scal.as<i64>() + 13;
     }
-    const size_t gen_lds_count = (size_t)GEN_WIN * 4 + (size_t)d.n_tpc * 12 + (CDF_G + 8) * 2 + 16;
-    const size_t gen_lds = (((size_t)GEN_WIN * 12 + (size_t)d.n_tpc * 20 + 7) & ~(size_t)7) + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 16;
+    const size_t nch1 = (size_t)d.n_tpc + 1 + ((d.n_tpc + 1) & 1);
+    const size_t gen_lds_count = (size_t)GEN_WIN * 4 + (size_t)d.n_tpc * 8 + nch1 * 4 + (CDF_G + 8) * 2 + (size_t)GEN_BLOCK * 4 + 16;
+    const size_t gen_lds = (((size_t)GEN_WIN * 12 + (size_t)d.n_tpc * 16 + nch1 * 4 + (size_t)GEN_BLOCK * 2 + 7) & ~(size_t)7) + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 16;
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
-        // stride coprime to the block count, about 1/1021 of it: neighbours in launch order are ~nb/1021 blocks apart
-        auto gcd = [](u64 x, u64 y) { while (y) { u64 t = x % y; x = y; y = t; } return x; };
-        u64 stride = std::max<u64>(1, nb / 1021) | 1;
-        while (gcd(stride, nb) != 1) stride += 2;
-        g.n_blocks = nb; g.block_stride = (i64)stride;
-        TRY(ensure(h, h->blk_e, (size_t)nb * 16)); TRY(ensure(h, h->blk_base, (size_t)nb * d.n_tpc * 4));
+        g.n_blocks = nb;
+        TRY(ensure(h, h->blk_e, (size_t)nb * 16)); TRY(ensure(h, h->blk_base, (size_t)nb * d.n_tpc * 4)); TRY(ensure(h, h->blk_cnt, (size_t)nb * d.n_tpc * 2)); TRY(ensure(h, h->blk_ins, (size_t)nb * 4));
         TRY(ensure(h, h->ph_slot, (size_t)P * 4));
-        g.blk_e = h->blk_e.as<i64>(); g.blk_base = h->blk_base.as<u32>(); g.ph_slot = h->ph_slot.as<u32>();
+        g.blk_e = h->blk_e.as<i64>(); g.blk_base = h->blk_base.as<u32>(); g.blk_cnt = h->blk_cnt.as<unsigned short>(); g.blk_ins = h->blk_ins.as<i32>(); g.ph_slot = h->ph_slot.as<u32>();
         { Timer t(h, "k_block_emitters"); hipLaunchKernelGGL(k_block_emitters, dim3(nblocks(nb, 256)), dim3(256), 0, h->stream, g); }
-        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true, false>), dim3(nb), dim3(GEN_TPB), gen_lds_count, h->stream, d, g, ap); }
+        // XCD x (workgroup id % 8) walks the photon blocks [x * chunk, (x + 1) * chunk) in order: the blocks that share
+        // cache lines of a tile (consecutive ranges, k_block_ranges) run close together in time on the same L2
+        g.xcd_chunk = (nb + 7) / 8;
+        const unsigned nbx = (unsigned)(g.xcd_chunk * 8);
+        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true, false>), dim3(nbx), dim3(GEN_TPB), gen_lds_count, h->stream, d, g, ap); }
+        { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(N * d.n_tpc, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
         { Timer t(h, "k_photons_fill");
-          if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true>), dim3(nb), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, false>), dim3(nb), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap); }
+          if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, false>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap); }
     } else {
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
     }

@@ -924,9 +924,12 @@ struct GenArgs {
     i64 *em_time; i32 *em_nph; i32 *em_ins; const i64 *em_ph_off;
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
     PhotonRec *ph;
-    i64 n_blocks, block_stride;   // photon blocks are visited in a strided order: see k_photons
+    i64 n_blocks;
+    i64 xcd_chunk;                // XCD x (workgroup id % 8) walks the photon blocks [x * xcd_chunk, (x + 1) * xcd_chunk) in order
     i64 *blk_e;                   // [n_blocks][2] first / last emitter of every photon block
     u32 *blk_base;                // [n_blocks][n_tpc] start of the block's photons inside each tile (written by the count pass)
+    unsigned short *blk_cnt;      // [n_blocks][n_tpc] the block's photons per channel (count pass, single-instruction blocks)
+    i32 *blk_ins;                 // [n_blocks] instruction of a single-instruction block, -1 otherwise
     u32 *ph_slot;                 // [n_photons] slot inside its tile of every photon of a multi-instruction block (count pass)
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
@@ -1122,40 +1125,89 @@ __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, c
 // Pass B (COUNT = false): Philox site B -> summed delay (s1.py:180-194 / s2.py:504-557, pulse.py:53-56) and the second
 //   SPE index; the finished photon is written straight into its tile's bucket.
 // Fast path ("single": all photons of the block belong to one instruction, the normal case for an S2): the emitter
-//   window, the instruction's channel CDF + a guide table, and the block's tile offsets live in LDS; pass A leaves one
-//   packed word per photon (channel | dpe << 10 | spe index << 11 | emitter slot << 22) so that pass B neither repeats
-//   Philox A nor the searches, and reserves the block's range in every tile with ONE global atomic per non-empty tile
-//   (ranks inside the block come from an LDS histogram).
+//   window, the instruction's channel CDF + a guide table, and the block's tile offsets live in LDS.  Pass A buckets the
+//   block's photons BY CHANNEL inside the block (LDS histogram -> ranks -> prefix sum) and leaves one packed word per
+//   photon in that order (photon index in the block | dpe << 11 | spe index << 12 | emitter slot << 23) plus the
+//   block's photons per channel; it reserves the block's range in every tile with ONE global atomic per non-empty tile.
+//   Pass B walks the words in bucket order: neighbouring lanes finish photons of the same tile and store them to
+//   consecutive addresses (a scattered 8-byte store per lane is bound by the L2 request rate), and it repeats neither
+//   Philox A nor the searches.
 // Generic path (a block spanning instructions: S1s, small S2s): per-photon global lookups and atomics.
-#define PW_CH(w) ((int)((w) & 1023u))
-#define PW_DPE(w) ((((w) >> 10) & 1u) != 0u)
-#define PW_G1(w) (((w) >> 11) & 2047u)
-#define PW_SLOT(w) ((int)((w) >> 22))
+#define PW_PR(w) ((int)((w) & 2047u))
+#define PW_DPE(w) ((((w) >> 11) & 1u) != 0u)
+#define PW_G1(w) (((w) >> 12) & 2047u)
+#define PW_SLOT(w) ((int)((w) >> 23))
+
+// exclusive prefix sum over n <= 4 * GEN_TPB LDS integers, in place; v[n] receives the total.  All threads call it.
+__device__ __forceinline__ void block_excl_scan(i32 *v, int n, i32 *wtmp)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int per = (n + GEN_TPB - 1) / GEN_TPB, b = tid * per;
+    i32 loc[4], s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { loc[k] = (k < per && b + k < n) ? v[b + k] : 0; s += loc[k]; }
+    i32 x = s;
+    for (int o = 1; o < 64; o <<= 1) { const i32 y = __shfl_up(x, o, 64); if (lane >= o) x += y; }
+    if (lane == 63) wtmp[wid] = x;
+    __syncthreads();
+    i32 run = x - s;
+    for (int w = 0; w < wid; w++) run += wtmp[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (k < per && b + k < n) { v[b + k] = run; run += loc[k]; }
+    if (tid == GEN_TPB - 1) v[n] = run;
+    __syncthreads();
+}
+
+// Between the passes: where in its tile every single-instruction block puts its photons.  Thread = (instruction,
+// channel): a running sum over the instruction's blocks in block order, starting behind whatever the generic path
+// already counted into the tile.  Consecutive blocks get consecutive ranges (no atomics, a reproducible layout).
+__global__ void k_block_ranges(WfsDev d, GenArgs a)
+{
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nch = d.n_tpc;
+    if (idx >= a.n_ins * nch) return;
+    const i32 ins = (i32)(idx / nch); const int c = (int)(idx - (i64)ins * nch);
+    const i64 pa = a.em_ph_off[a.em_off[ins]], pb = a.em_ph_off[a.em_off[ins + 1]];     // photons [pa, pb) of the instruction
+    if (pb <= pa) return;
+    u32 run = (u32)a.tile_count[idx];
+    for (i64 b = pa / GEN_BLOCK; b <= (pb - 1) / GEN_BLOCK; b++) {
+        if (a.blk_ins[b] != ins) continue;
+        a.blk_base[b * nch + c] = run;
+        run += a.blk_cnt[b * nch + c];
+    }
+    a.tile_count[idx] = (i32)run;
+}
+
 template <bool COUNT, bool AP>
 __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs ap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nch = d.n_tpc;
     // LDS layout (plain integer offsets: a pointer that went through an integer cast loses its LDS address space)
-    //   count: win i32[GEN_WIN] | cdf f64[nch] | hist i32[nch] | cguide u16[CDF_G + 8]
-    //   fill : win i32[GEN_WIN] | wtime i64[GEN_WIN] | hbase i64[nch] | hist i32[nch] | hmin i32[nch] | hmax i32[nch] | afterpulse staging
+    //   count: win i32[GEN_WIN] | cdf f64[nch] | hist i32[nch + 1] | cguide u16[CDF_G + 8] | stage u32[GEN_BLOCK]
+    //   fill : win i32[GEN_WIN] | wtime i64[GEN_WIN] | hbase i64[nch] | hist i32[nch + 1] | hmin i32[nch] | hmax i32[nch] | chmap u16[GEN_BLOCK] | afterpulse staging
     i32 *win = (i32 *)smem;                                  // first photon of the block's emitters, relative to the block's first photon
     double *cdf = (double *)(smem + GEN_WIN * 4);
     i64 *wtime = (i64 *)(smem + GEN_WIN * 4);                // emitter times
-    i64 *hbase = (i64 *)(smem + GEN_WIN * 12);               // first slot of this block in every tile
-    i32 *hist = (i32 *)(smem + (COUNT ? GEN_WIN * 4 + nch * 8 : GEN_WIN * 12 + nch * 8));
-    unsigned short *cguide = (unsigned short *)(smem + GEN_WIN * 4 + nch * 12);
-    i32 *hmin = (i32 *)(smem + GEN_WIN * 12 + nch * 12), *hmax = (i32 *)(smem + GEN_WIN * 12 + nch * 16);
-    const int o_ap = (GEN_WIN * 12 + nch * 20 + 7) & ~7;
+    i64 *hbase = (i64 *)(smem + GEN_WIN * 12);               // fill: global slot of bucket position 0 of every channel
+    i32 *hist = (i32 *)(smem + (COUNT ? GEN_WIN * 4 + nch * 8 : GEN_WIN * 12 + nch * 8));      // counts, then their prefix sums
+    const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
+    unsigned short *cguide = (unsigned short *)(smem + GEN_WIN * 4 + nch * 8 + nch1 * 4);
+    u32 *stage = (u32 *)(smem + GEN_WIN * 4 + nch * 8 + nch1 * 4 + (CDF_G + 8) * 2);
+    i32 *hmin = (i32 *)(smem + GEN_WIN * 12 + nch * 8 + nch1 * 4), *hmax = hmin + nch;
+    unsigned short *chmap = (unsigned short *)(smem + GEN_WIN * 12 + nch * 16 + nch1 * 4);     // channel of every bucket position
+    const int o_ap = (GEN_WIN * 12 + nch * 16 + nch1 * 4 + GEN_BLOCK * 2 + 7) & ~7;
+    __shared__ i32 s_wtmp[GEN_TPB / 64];
     ApStage aps;
     aps.gain = (double *)(smem + o_ap); aps.ins = (i32 *)(smem + o_ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE;
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
     aps.n = &s_apn;
     const int tid = threadIdx.x;
     if (AP && tid == 0) s_apn = 0;
-    // Blocks that run at the same time work on different instructions (strided order): consecutive photon blocks
-    // belong to one instruction and would otherwise all add into the same n_tpc tile counters.
-    const i64 vb = (i64)(((u64)blockIdx.x * (u64)a.block_stride) % (u64)a.n_blocks);
+    // Workgroups are dealt to the 8 XCDs round robin: XCD x takes the photon blocks [x * chunk, (x + 1) * chunk) in
+    // order, so that the blocks writing neighbouring ranges of a tile run close together in time behind the same L2.
+    const i64 vb = (i64)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);
+    if (vb >= a.n_blocks) return;                            // block-uniform (padding of the XCD order)
     const i64 p0 = vb * GEN_BLOCK;
     const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
     const i64 e_lo = a.blk_e[2 * vb], e_hi = a.blk_e[2 * vb + 1];
@@ -1168,19 +1220,18 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         const DiscTab &tab = (a.ins_type[ins_lo] == 2) ? d.tab_s2 : d.tab_s1;
         const i64 tbase = (i64)ins_lo * nch;
         const u32 jbase = (u32)(e_lo - emoff);
-        u32 pw[GEN_PPT];                                      // pass B: the packed words of this thread's photons, loaded up front
+        u32 pw[GEN_PPT];                                      // pass B: the packed words of this thread's bucket positions, loaded up front
         if (!COUNT) {
 #pragma unroll
-            for (int q = 0; q < GEN_PPT; q++) { const int pr = q * GEN_TPB + tid; pw[q] = pr < np ? a.ph_slot[p0 + pr] : 0u; }
+            for (int q = 0; q < GEN_PPT; q++) { const int i = q * GEN_TPB + tid; pw[q] = i < np ? a.ph_slot[p0 + i] : 0u; }
         }
         for (int c = tid; c < nch; c += GEN_TPB) {
-            hist[c] = 0;
-            if (COUNT) cdf[c] = a.cdf_table[(size_t)a.ins_cdfrow[ins_lo] * nch + c];
-            else { hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c]; }
+            if (COUNT) { hist[c] = 0; cdf[c] = a.cdf_table[(size_t)a.ins_cdfrow[ins_lo] * nch + c]; }
+            else { hist[c] = (i32)a.blk_cnt[vb * nch + c]; hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; }
         }
         for (int k = tid; k < nwin; k += GEN_TPB) {
-            if (COUNT) win[k] = (i32)(a.em_ph_off[e_lo + k] - p0);
-            else { win[k] = (i32)(a.em_ph_off[e_lo + k] - p0); wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] - itime : 0; }
+            win[k] = (i32)(a.em_ph_off[e_lo + k] - p0);
+            if (!COUNT) wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] - itime : 0;
         }
         __syncthreads();
         if (COUNT) {
@@ -1192,47 +1243,60 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
                 cguide[c] = (unsigned short)(lo < nch ? lo : nch - 1);
             }
             __syncthreads();
-        }
+            u32 word[GEN_PPT], cr[GEN_PPT];                  // packed word, channel << 16 | rank among the block's photons of that channel
 #pragma unroll 2
-        for (int q = 0; q < GEN_PPT; q++) {
-            const int pr = q * GEN_TPB + tid;
-            if (pr >= np) break;
-            if (COUNT) {
+            for (int q = 0; q < GEN_PPT; q++) {
+                const int pr = q * GEN_TPB + tid;
+                if (pr >= np) { cr[q] = 0xffffffffu; word[q] = 0; continue; }
                 int lo = 0, hi = nwin;                       // last k with win[k] <= pr
                 while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win[mid] <= pr) lo = mid; else hi = mid; }
                 const u32x4 A = philox4x32_10(jbase + (u32)lo, gid, (u32)(pr - win[lo]), SITE_PH_A, d.k0, d.k1);
                 const double uc = u53(A.x, A.y);
                 int ch = cguide[(int)(uc * CDF_G)];
                 while (ch < nch - 1 && uc >= cdf[ch]) ch++;
-                atomicAdd(&hist[ch], 1);
                 const u32 is_dpe = ((u64)A.z < d.thr_dpe) ? 1u : 0u, g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u;
-                a.ph_slot[p0 + pr] = (u32)ch | (is_dpe << 10) | (g1 << 11) | ((u32)lo << 22);
-            } else {
+                cr[q] = ((u32)ch << 16) | (u32)atomicAdd(&hist[ch], 1);
+                word[q] = (u32)pr | (is_dpe << 11) | (g1 << 12) | ((u32)lo << 23);
+            }
+            __syncthreads();
+            for (int c = tid; c < nch; c += GEN_TPB) a.blk_cnt[vb * nch + c] = (unsigned short)hist[c];     // -> k_block_ranges
+            if (tid == 0) a.blk_ins[vb] = ins_lo;
+            __syncthreads();
+            block_excl_scan(hist, nch, s_wtmp);
+#pragma unroll
+            for (int q = 0; q < GEN_PPT; q++) if (cr[q] != 0xffffffffu) stage[hist[cr[q] >> 16] + (cr[q] & 0xffffu)] = word[q];
+            __syncthreads();
+            for (int i = tid; i < np; i += GEN_TPB) a.ph_slot[p0 + i] = stage[i];
+        } else {
+            block_excl_scan(hist, nch, s_wtmp);
+            for (int c = tid; c < nch; c += GEN_TPB) {
+                const i32 b0 = hist[c], b1 = hist[c + 1];
+                hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c] - b0;
+                for (i32 k = b0; k < b1; k++) chmap[k] = (unsigned short)c;
+            }
+            __syncthreads();
+#pragma unroll 2
+            for (int q = 0; q < GEN_PPT; q++) {
+                const int i = q * GEN_TPB + tid;             // bucket position
+                if (i >= np) break;
                 const u32 w = pw[q];
-                const int ch = PW_CH(w), lo = PW_SLOT(w); const bool is_dpe = PW_DPE(w);
-                const u32 j = jbase + (u32)lo, m = (u32)(pr - win[lo]);
+                const int ch = chmap[i], lo = PW_SLOT(w); const bool is_dpe = PW_DPE(w);
+                const u32 j = jbase + (u32)lo, m = (u32)(PW_PR(w) - win[lo]);
                 const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
                 const u32 g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
                 // every delay term of the photon in one draw from the table of their sum, relative to the instruction time
                 i64 t = wtime[lo] + sample_disc(tab, u53(B.x, B.y));
                 if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
                 if (AP) ap_generate(d, a, ap, aps, j, gid, m, ins_lo, ch, is_dpe, itime, t);
-                const u32 rank = (u32)atomicAdd(&hist[ch], 1);
                 atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
-                a.ph[hbase[ch] + rank] = PhotonRec{(i32)t, PW_G1(w) | (is_dpe ? (g2 << 16) : 0u)};
+                a.ph[hbase[ch] + i] = PhotonRec{(i32)t, PW_G1(w) | (is_dpe ? (g2 << 16) : 0u)};
             }
-        }
-        __syncthreads();
-        for (int c = tid; c < nch; c += GEN_TPB) {
-            const i32 hc = hist[c];
-            if (COUNT) {
-                // reserve this block's range in every tile now; the fill pass then needs no returning global atomics
-                a.blk_base[vb * nch + c] = hc ? (u32)atomicAdd(&a.tile_count[tbase + c], hc) : 0u;
-            } else if (hc) {
-                atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]);
-            }
+            __syncthreads();
+            for (int c = tid; c < nch; c += GEN_TPB)
+                if (hist[c + 1] > hist[c]) { atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]); }
         }
     } else {
+        if (COUNT && tid == 0) a.blk_ins[vb] = -1;
         if (AP) __syncthreads();                             // s_apn
         for (int q = 0; q < GEN_PPT; q++) {
             const int pr = q * GEN_TPB + tid;
