@@ -427,6 +427,13 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             const double tr = (double)(r_ns[k] + rel0);
             acc[6] += tr; acc[7] += tr * tr;
         }
+        if (a.tile_truth) {      // the sums are complete: reduce and store them now, their registers are free for the tap loop
+#pragma unroll
+            for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+            if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
+            __syncthreads();
+            if (tid < 8) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + tid]; a.tile_truth[tile * 8 + tid] = sum; }
+        }
     }
 
     for (i64 w0 = (i64)win * (W - (tlen - 1)); w0 == 0 || w0 + (tlen - 1) < nb; w0 += (i64)a.n_win * (W - (tlen - 1))) {
@@ -547,7 +554,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         }
     }
 
-    if (a.tile_truth && win == 0) {
+    if (!RESIDENT && a.tile_truth && win == 0) {
 #pragma unroll
         for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
         __syncthreads();
