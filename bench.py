@@ -77,7 +77,7 @@ def main():
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--instructions', type=int, default=1000, help='S2 instructions per GPU per step')
-    ap.add_argument('--cpu-sample', type=int, default=12, help='S2 instructions timed on the CPU oracle (0: skip)')
+    ap.add_argument('--cpu-sample', type=int, default=60, help="S2 instructions timed on the CPU oracle, ~15 s (0: skip)")
     ap.add_argument('--no-gather', action='store_true', help='skip the RCCL gather of records (N > 1)')
     ap.add_argument('--sync-gather', action='store_true', help='do not overlap the gather with the next batch')
     args = ap.parse_args()
