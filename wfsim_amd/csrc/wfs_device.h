@@ -71,7 +71,9 @@ __device__ __forceinline__ void box_muller(u32x4 w, double &z0, double &z1)
 // inverse CDF from one uniform: cum[i] = P(X <= vmin + i), result = vmin + (first i with u < cum[i]).  The tables are
 // built on the host (wfs_engine.hip, build_time_tables) from erfc; the CPU oracle builds its own the same way.
 // (Exponential delays use the closed form trunc(-log(1-u) * tau).)
-#define DISC_G 1024
+#ifndef DISC_G
+#define DISC_G 4096
+#endif
 struct DiscTab { const double *cum; const unsigned short *guide; i32 vmin, n; };
 
 // Lookup in two steps so that several lookups of one photon can have their loads in flight together:

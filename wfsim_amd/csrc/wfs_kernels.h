@@ -1053,6 +1053,9 @@ __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double
 
 #define GEN_TPB 256
 #define GEN_PPT 8
+#ifndef GEN_GRP
+#define GEN_GRP 2                  // photons a thread carries through the fill pass together (4: 6.5 ms, 8: 8.2 ms, registers)
+#endif
 #define GEN_BLOCK (GEN_TPB * GEN_PPT)
 #define GEN_WIN 512                // emitter offsets staged in LDS per block
 #define CDF_G 512                  // guide cells of the per-block channel search
@@ -1282,21 +1285,45 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
                 for (i32 k = b0; k < b1; k++) chmap[k] = (unsigned short)c;
             }
             __syncthreads();
-#pragma unroll 2
-            for (int q = 0; q < GEN_PPT; q++) {
-                const int i = q * GEN_TPB + tid;             // bucket position
-                if (i >= np) break;
-                const u32 w = pw[q];
-                const int ch = chmap[i], lo = PW_SLOT(w); const bool is_dpe = PW_DPE(w);
-                const u32 j = jbase + (u32)lo, m = (u32)(PW_PR(w) - win[lo]);
-                const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
-                const u32 g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-                // every delay term of the photon in one draw from the table of their sum, relative to the instruction time
-                i64 t = wtime[lo] + sample_disc(tab, u53(B.x, B.y));
-                if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-                if (AP) ap_generate(d, a, ap, aps, j, gid, m, ins_lo, ch, is_dpe, itime, t);
-                atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
-                a.ph[hbase[ch] + i] = PhotonRec{(i32)t, PW_G1(w) | (is_dpe ? (g2 << 16) : 0u)};
+            // Groups of GEN_GRP photons per thread move through the steps together, so that the table gathers of a group
+            // (guide cells, then cumulative probabilities) are in flight at the same time: the pass is bound by their latency.
+#pragma unroll
+            for (int q0 = 0; q0 < GEN_PPT; q0 += GEN_GRP) {
+                if (q0 * GEN_TPB >= np) break;               // block-uniform
+                int lo[GEN_GRP], hi[GEN_GRP], slot[GEN_GRP]; double u[GEN_GRP]; u32 g2[GEN_GRP], j[GEN_GRP], m[GEN_GRP];
+#pragma unroll
+                for (int k = 0; k < GEN_GRP; k++) {
+                    const u32 w = pw[q0 + k];                // 0 past the end of the block: harmless values, nothing stored
+                    slot[k] = PW_SLOT(w);
+                    j[k] = jbase + (u32)slot[k]; m[k] = (u32)(PW_PR(w) - win[slot[k]]);
+                    const u32x4 B = philox4x32_10(j[k], gid, m[k], SITE_PH_B, d.k0, d.k1);
+                    g2[k] = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
+                    u[k] = u53(B.x, B.y);
+                    const int c = (int)(u[k] * DISC_G);
+                    lo[k] = tab.guide[c]; hi[k] = tab.guide[c + 1];          // the answer is in [lo, hi]
+                }
+#pragma unroll
+                for (int k = 0; k < GEN_GRP; k++)            // rare: a guide cell with more than 4 table entries (the far tail)
+                    while (hi[k] - lo[k] > 3) { const int mid = (lo[k] + hi[k]) >> 1; if (u[k] < tab.cum[mid]) hi[k] = mid; else lo[k] = mid + 1; }
+                double c0[GEN_GRP], c1[GEN_GRP], c2[GEN_GRP];
+                const int n1 = tab.n - 1;
+#pragma unroll
+                for (int k = 0; k < GEN_GRP; k++) {          // cum[n - 1] == 1 > u: clamped indices cannot change the outcome
+                    c0[k] = tab.cum[lo[k]]; c1[k] = tab.cum[lo[k] + 1 < n1 ? lo[k] + 1 : n1]; c2[k] = tab.cum[lo[k] + 2 < n1 ? lo[k] + 2 : n1];
+                }
+#pragma unroll
+                for (int k = 0; k < GEN_GRP; k++) {
+                    const int i = (q0 + k) * GEN_TPB + tid;  // bucket position
+                    if (i >= np) continue;
+                    const u32 w = pw[q0 + k];
+                    const int ch = chmap[i]; const bool is_dpe = PW_DPE(w);
+                    // every delay term of the photon in one draw from the table of their sum, relative to the instruction time
+                    i64 t = wtime[slot[k]] + (i64)tab.vmin + lo[k] + (u[k] < c0[k] ? 0 : (u[k] < c1[k] ? 1 : (u[k] < c2[k] ? 2 : 3)));
+                    if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
+                    if (AP) ap_generate(d, a, ap, aps, j[k], gid, m[k], ins_lo, ch, is_dpe, itime, t);
+                    atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
+                    a.ph[hbase[ch] + i] = PhotonRec{(i32)t, PW_G1(w) | (is_dpe ? (g2[k] << 16) : 0u)};
+                }
             }
             __syncthreads();
             for (int c = tid; c < nch; c += GEN_TPB)
