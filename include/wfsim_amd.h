@@ -143,6 +143,10 @@ typedef struct wfs_counts {
 } wfs_counts;
 int wfs_get_counts(wfs_handle *h, wfs_counts *out);
 
+/* Per-PMT truth (config 'per_pmt_truth', pulse.py:61-66, 268-269): acc6[set][channel][6] = n_photon, n_pe, n_photon_trigger,
+ * n_pe_trigger, raw_area, raw_area_trigger of every pulse set and TPC channel.  cap = sets the buffer holds. */
+int wfs_copy_truth_per_pmt(wfs_handle *h, double *acc6, int64_t cap);
+
 /* ---- results (host copies) ---------------------------------------------------------------------------- */
 /* raw_records, 244-byte packed strax layout, in the order the reference yields them (group, channel, interval,
  * fragment); dst may be a host or a device pointer (wfs_copy_records_dev). */

@@ -130,3 +130,40 @@ def test_truth_rows_against_oracle():
             assert r['t_first_electron'] == et.min() and abs(r['t_mean_electron'] - et.mean()) < 1e-3
         else:
             assert r['n_electron'] == 0 and np.isnan(r['t_mean_electron'])
+
+
+def test_per_pmt_truth_against_oracle():
+    """config per_pmt_truth (strax_interface.py:77-116, pulse.py:61-66, 268-269): per-channel truth arrays instead of the
+    total / bottom split; every channel's numbers against the oracle's photon list on the same Philox streams."""
+    cfg = dict(xenonnt_test_config(seed=17), per_pmt_truth=True)
+    ins = _mixed_instructions()
+    sim = wfsim_amd.ChunkRawRecords(cfg)
+    truth = np.concatenate([c['truth'] for c in sim(ins)])
+    assert len(truth) == len(ins)
+    assert 'n_photon_per_pmt' in truth.dtype.names and 'n_photon_bottom' not in truth.dtype.names
+    n_ch = truth['n_photon_per_pmt'].shape[1]
+    assert n_ch == cfg['n_tpc_pmts']
+    res = Resource(cfg)
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    orc = make_oracle(cfg)
+    orc.simulate(s_ins, order.astype(np.uint32), instruction_params(s_ins, cfg, res))
+    o = orc.results()
+    proc = processing_order(s_ins, np.arange(len(s_ins)), cluster)
+    gains = np.asarray(cfg['gains'], dtype=np.float64)
+    key_t = {(int(r['event_number']), int(r['type'])): r for r in truth}
+    for k, i in enumerate(proc):
+        r = key_t[(int(s_ins['event_number'][i]), int(s_ins['type'][i]))]
+        a, b = o['call_ph_off'][k], o['call_ph_off'][k + 1]
+        ch, dpe, g = o['ph_ch'][a:b].astype(np.int64), o['ph_dpe'][a:b].astype(np.int64), o['ph_gain'][a:b]
+        n_ph = np.bincount(ch, minlength=n_ch)
+        assert np.array_equal(r['n_photon_per_pmt'], n_ph)
+        assert np.array_equal(r['n_pe_per_pmt'], n_ph + np.bincount(ch, weights=dpe, minlength=n_ch).astype(np.int64))
+        area = np.bincount(ch, weights=g, minlength=n_ch) / np.where(gains[:n_ch] > 0, gains[:n_ch], 1.0)
+        assert np.allclose(r['raw_area_per_pmt'], area, rtol=1e-9, atol=1e-12)
+        # totals are the sums over the PMTs (pulse.py:267)
+        for f in ['n_photon', 'n_pe', 'n_photon_trigger']:
+            assert r[f] == r[f + '_per_pmt'].sum(), f
+        assert np.isclose(r['raw_area'], r['raw_area_per_pmt'].sum(), rtol=1e-9)
+        assert np.isclose(r['raw_area_trigger'], r['raw_area_trigger_per_pmt'].sum(), rtol=1e-9)
+        assert np.all(r['n_photon_trigger_per_pmt'] <= r['n_photon_per_pmt'])

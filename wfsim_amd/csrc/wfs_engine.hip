@@ -1056,6 +1056,24 @@ int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t cap)
     return WFS_OK;
 }
 
+int wfs_copy_truth_per_pmt(wfs_handle *h, double *acc6, int64_t cap)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    const i64 S = h->n_sets, nch = h->cfg.n_tpc, T = S * nch;
+    if (cap < S) return h->fail(WFS_E_CAPACITY, "per-PMT truth buffer too small");
+    std::vector<double> tt((size_t)T * 8); std::vector<i32> cnt((size_t)T); std::vector<double> gains((size_t)nch);
+    HIPCHK(hipMemcpy(tt.data(), h->tile_truth.p, tt.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt.data(), h->tile_count.p, cnt.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gains.data(), h->t_gains.p, gains.size() * 8, hipMemcpyDeviceToHost));
+    for (i64 t = 0; t < T; t++) {
+        double *o = acc6 + t * 6;
+        if (cnt[t] <= 0) { for (int q = 0; q < 6; q++) o[q] = 0.0; continue; }     // tiles without photons were never written
+        const double *p = tt.data() + t * 8, G = gains[t % nch];
+        o[0] = p[0]; o[1] = p[0] + p[1]; o[2] = p[2]; o[3] = p[2] + p[3]; o[4] = p[4] / G; o[5] = p[5] / G;       // pulse.py:259-271
+    }
+    return WFS_OK;
+}
+
 int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t cap)
 {
     if (!h || !h->ran) return WFS_E_STATE;

@@ -40,7 +40,7 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_load_instructions', 'wfs_load_photons', 'wfs_load_optical', 'wfs_run', 'wfs_get_counts', 'wfs_copy_records',
            'wfs_copy_records_dev', 'wfs_records_dev_ptr', 'wfs_copy_groups', 'wfs_copy_intervals',
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
-           'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
+           'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
            'wfs_kernel_times', 'wfs_set_profiling']
 
 
@@ -230,6 +230,14 @@ class Engine:
         acc, ts = np.zeros((s, 12)), np.zeros((s, 5))
         self._check(self.lib.wfs_copy_truth(self._h, _p(acc), _p(ts), C.c_int64(s)))
         return acc, ts
+
+    def truth_per_pmt(self):
+        """[pulse set][channel][n_photon, n_pe, n_photon_trigger, n_pe_trigger, raw_area, raw_area_trigger] (pulse.py:259-271)"""
+        s = self.counts['n_pulse_sets']
+        acc = np.zeros((s, int(self.params['n_tpc']), 6))
+        if s:
+            self._check(self.lib.wfs_copy_truth_per_pmt(self._h, _p(acc), C.c_int64(s)))
+        return acc
 
     def set_noise_offsets(self, ix_rand):
         a = _arr(ix_rand, np.int64)

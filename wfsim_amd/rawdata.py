@@ -134,7 +134,7 @@ class RawData:
     def _truth_rows(self, ins):
         acc, ts = self.engine.truth()
         es = self.engine.electron_stats()
-        cfg = self.config
+        per_pmt = self.engine.truth_per_pmt() if self.config.get('per_pmt_truth', False) else None      # pulse.py:62-66
         rows = []
         names = ['n_photon', 'n_pe', 'n_photon_trigger', 'n_pe_trigger', 'raw_area', 'raw_area_trigger']
         for i in range(len(ins)):
@@ -145,6 +145,8 @@ class RawData:
             for j, f in enumerate(names):
                 r[f] = acc[i, j]
                 r[f + '_bottom'] = acc[i, 6 + j]
+                if per_pmt is not None:
+                    r[f + '_per_pmt'] = per_pmt[i, :, j]
             r['instruction'] = ins[i]
             rows.append(r)
         return rows
@@ -175,8 +177,8 @@ class RawData:
             tb['endtime'] = tb['t_last_photon'] + (cfg['samples_before_pulse_center'] + cfg['samples_after_pulse_center']
                                                    + 1) * cfg['sample_duration']
         for f in ['n_pe', 'n_pe_trigger', 'n_photon', 'n_photon_trigger', 'raw_area', 'raw_area_trigger']:
-            for suffix in ['', '_bottom']:
-                if f + suffix in truth_buffer.dtype.names:
+            for suffix in ['', '_bottom', '_per_pmt']:          # rawdata.py:355-362: total + (bottom | per PMT)
+                if f + suffix in truth_buffer.dtype.names and f + suffix in r:
                     tb[f + suffix] = r[f + suffix]
         for f in ins.dtype.names:
             if f in truth_buffer.dtype.names:
