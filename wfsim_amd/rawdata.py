@@ -37,6 +37,9 @@ class RawData:
         if config.get('enable_electron_afterpulses', False) or config.get('enable_gate_afterpulses', False):
             raise NotImplementedError('electron afterpulses (secondary instructions, afterpulse.py:14-139) are not on '
                                       'the MI355X path yet (SURVEY.md 8f.1)')
+        if not config.get('save_full_truth', True):
+            raise NotImplementedError('save_full_truth=False (several instructions per Pulse call, rawdata.py:108-122) is not on '
+                                      'the MI355X path: every instruction is its own pulse set')
         self.resource = resource if resource is not None else Resource(config)
         self.engine = Engine(config, self.resource, device=device, seed=seed)
         self.source_finished = False
