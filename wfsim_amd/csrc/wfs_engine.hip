@@ -782,7 +782,7 @@ int wfs_run(wfs_handle *h)
         // registers; longer tiles: one workgroup per window (each re-reads the tile's photons)
         pd.n_win = (h->max_tile_dense <= (i64)tpb * DENSE_PPT) ? 1 : (int)std::min<i64>(NWIN_MAX, std::max<i64>(1, (h->max_nb_dense + step - 1) / step));
         TemplateArg tp;
-        memcpy(tp.t, h->h_templates, sizeof(tp.t));
+        for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
         size_t lds = (size_t)(W + 2 * DENSE_PAD) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
         lds = (lds + 15) / 16 * 16;
         const unsigned grid = (unsigned)(h->n_dense_tiles * pd.n_win);

@@ -325,7 +325,7 @@ struct PulseArgs {
 #define DENSE_SPT 1        // samples per thread carried through the tap loop (more costs registers, i.e. occupancy)
 #define DENSE_PAD 21       // zero start bins on either side of the window: no bounds checks in the tap loop
 
-struct TemplateArg { double t[WFS_DT * 22]; };    // kernarg segment -> scalar loads, the taps live in SGPRs
+struct TemplateArg { double t[22 * WFS_DT]; };    // t[k * dt + r] = templates[r][k]; kernarg segment -> scalar loads, the taps live in SGPRs
 
 template <int TPB, bool RESIDENT>
 __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateArg tp)
@@ -525,9 +525,8 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             for (int q = 0; q < DENSE_SPT; q++) wact[q] = __any(act[q]);
 #pragma unroll 2
             for (int k = tlen - 1; k >= 0; k--) {
-                const double T0 = tp.t[0 * tlen + k], T1 = tp.t[1 * tlen + k], T2 = tp.t[2 * tlen + k], T3 = tp.t[3 * tlen + k],
-                             T4 = tp.t[4 * tlen + k], T5 = tp.t[5 * tlen + k], T6 = tp.t[6 * tlen + k], T7 = tp.t[7 * tlen + k],
-                             T8 = tp.t[8 * tlen + k], T9 = tp.t[9 * tlen + k];
+                const double *Tk = tp.t + k * dt;            // the dt taps of one k are contiguous: two wide scalar loads
+                const double T0 = Tk[0], T1 = Tk[1], T2 = Tk[2], T3 = Tk[3], T4 = Tk[4], T5 = Tk[5], T6 = Tk[6], T7 = Tk[7], T8 = Tk[8], T9 = Tk[9];
 #pragma unroll
                 for (int q = 0; q < DENSE_SPT; q++) {
                     if (q >= nq || !wact[q]) continue;       // wave-uniform
