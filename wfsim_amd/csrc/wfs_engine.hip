@@ -46,7 +46,7 @@ struct wfs_handle {
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
-    DevBuf truth, tminmax, tile_truth, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
+    DevBuf truth, tminmax, tile_truth, tile_desc, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
     DevBuf scan_tmp, scal, noise_override; i64 n_noise_override = 0;
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
@@ -328,7 +328,7 @@ int wfs_destroy(wfs_handle *h)
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
-        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->currents, &h->cur_len, &h->cur_off,
+        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) { if (h->tt_cum[q].p) hipFree(h->tt_cum[q].p); if (h->tt_guide[q].p) hipFree(h->tt_guide[q].p); }
@@ -768,6 +768,14 @@ int wfs_run(wfs_handle *h)
     if (h->n_dense_tiles > 0) {
         PulseArgs pd = pa;
         pd.active_tiles = h->active_tiles.as<i32>() + h->n_sparse_tiles;
+        TRY(ensure(h, h->tile_desc, (size_t)h->n_dense_tiles * sizeof(TileDesc)));
+        {
+            DescArgs da{pd.active_tiles, h->n_dense_tiles, pa.tile_count, pa.tile_tmin, pa.tile_tmax, pa.tile_off, pa.set_cluster, pa.set_t0, pa.set_mode,
+                        pa.cl_group, pa.row_lo, pa.acc_off, h->tile_desc.as<TileDesc>()};
+            Timer t(h, "k_tile_desc");
+            hipLaunchKernelGGL(k_tile_desc, dim3(nblocks(h->n_dense_tiles, 256)), dim3(256), 0, h->stream, d, da);
+        }
+        pd.desc = h->tile_desc.as<TileDesc>();
         if (pd.cur_off) pd.cur_off += h->n_sparse_tiles;
         // windows of up to W_WIN start bins, one workgroup each: LDS per workgroup stays ~24 KB (6 workgroups per CU) and a
         // 10^6-PE tile is spread over three workgroups; very long tiles loop over further windows inside the kernel

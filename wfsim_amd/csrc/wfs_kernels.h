@@ -307,8 +307,20 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
 // contributions in ascending (j, r) = ascending time order with a separate multiply and add.  Adding a zero
 // contribution does not change a float sum, so the result equals the reference's current bit for bit (except for
 // the order in which three or more photons of the SAME ns are merged, which numpy's unstable argsort leaves open).
+// Everything a pulse workgroup needs to know about its tile, resolved once per tile by k_tile_desc (five levels of
+// dependent lookups otherwise: work list -> tile -> pulse set -> cluster -> window row).  64 bytes, read with scalar loads.
+struct TileDesc {
+    i64 off;              // first photon
+    i64 dst;              // index in raw[] of the tile's sample 0
+    i64 rel0;             // ns of the tile's first start bin relative to the set's t0
+    double G, thr;        // PMT gain, truth threshold of the channel
+    i32 n, nb, L, tile;   // photons, start bins, samples, tile id
+    i32 ch, mode, pad0, pad1;
+};
+
 struct PulseArgs {
     const i32 *active_tiles; i64 n_active;
+    const TileDesc *desc;   // per work-list entry (dense kernel)
     const i32 *tile_count, *tile_tmin, *tile_tmax; const i64 *tile_off;
     const i32 *set_cluster; const i64 *set_t0; const i32 *set_mode;       // mode 0: SPE codes, 1: explicit gains
     const PhotonRec *ph; const double *ph_gain;
@@ -326,6 +338,26 @@ struct PulseArgs {
 #define DENSE_PAD 21       // zero start bins on either side of the window: no bounds checks in the tap loop
 
 struct TemplateArg { double t[22 * WFS_DT]; };    // t[k * dt + r] = templates[r][k]; kernarg segment -> scalar loads, the taps live in SGPRs
+
+struct DescArgs { const i32 *list; i64 n; const i32 *tile_count, *tile_tmin, *tile_tmax; const i64 *tile_off; const i32 *set_cluster; const i64 *set_t0;
+                  const i32 *set_mode; const i32 *cl_group; const i64 *row_lo; const i64 *acc_off; TileDesc *desc; };
+__global__ void k_tile_desc(WfsDev d, DescArgs a)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const i64 tile = a.list[i];
+    const i64 set = tile / d.n_tpc; const i32 ch = (i32)(tile - set * d.n_tpc);
+    const i64 t0 = a.set_t0[set];
+    i64 left, right, bin0, nb;
+    tile_bounds(d, t0, a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+    const i64 ridx = (i64)a.cl_group[a.set_cluster[set]] * d.n_tpc + ch;
+    TileDesc t;
+    t.off = a.tile_off[tile]; t.dst = a.acc_off[ridx] + (left - (a.row_lo[ridx] - d.tw)); t.rel0 = bin0 * d.dt - t0;
+    t.G = d.gains[ch]; t.thr = d.thr_truth[ch];
+    t.n = a.tile_count[tile]; t.nb = (i32)nb; t.L = (i32)(right - left + 1); t.tile = (i32)tile;
+    t.ch = ch; t.mode = a.set_mode[set]; t.pad0 = 0; t.pad1 = 0;
+    a.desc[i] = t;
+}
 
 template <int TPB, bool RESIDENT>
 __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateArg tp)
@@ -345,23 +377,16 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     // consecutive windows overlap by tlen - 1 bins so that every sample sees all its taps inside one window)
     const i64 tidx = blockIdx.x / a.n_win;
     const int win = (int)(blockIdx.x - tidx * a.n_win);
-    const i64 tile = a.active_tiles[tidx];
-    const i32 n = a.tile_count[tile];
-    const i64 off = a.tile_off[tile];
-    const i64 set = tile / d.n_tpc; const i32 ch = (i32)(tile - set * d.n_tpc);
-    const i64 t0 = a.set_t0[set];
-    i64 left, right, bin0, nb;
-    tile_bounds(d, t0, a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
-    const i64 L = right - left + 1;
+    const TileDesc td = a.desc[tidx];                     // block-uniform: scalar loads
+    const i64 tile = td.tile; const i32 n = td.n; const i64 off = td.off; const i32 ch = td.ch;
+    const i64 nb = td.nb, L = td.L;
     const int lead = d.store_before + d.samples_before;
-    const i64 g = a.cl_group[a.set_cluster[set]];
-    const i64 ridx = g * d.n_tpc + ch;
-    i32 *dst = a.raw + a.acc_off[ridx] + (left - (a.row_lo[ridx] - d.tw));
-    const int mode = a.set_mode[set];
-    const double G = d.gains[ch];
+    i32 *dst = a.raw + td.dst;
+    const int mode = td.mode;
+    const double G = td.G;
     const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? ch : 0) * 2001;
-    const double thr = d.thr_truth[ch];
-    const i64 rel0 = bin0 * dt - t0;                      // ns of the tile's first start bin relative to t0
+    const double thr = td.thr;
+    const i64 rel0 = td.rel0;                             // ns of the tile's first start bin relative to t0
 
     // window w exists iff it is the first or the previous one did not already reach the last start bin (block-uniform)
     if (win > 0 && (i64)win * (W - (tlen - 1)) + (tlen - 1) >= nb) return;
@@ -417,22 +442,43 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 r_gain[k] = gk;
             }
         }
+        // truth sums of the tile (pulse.py:229-271).  The four counts need no vector reduction (tile_count, the DPE count
+        // above, wave ballots); the four float sums go through LDS (H is still free) and one shuffle tree per quantity.
+        u32 c_trig = 0, c_trig_dpe = 0;                   // wave-uniform
+        double sg = 0, sgt = 0, st = 0, st2 = 0;
 #pragma unroll
         for (int k = 0; k < DENSE_PPT; k++) {
-            if (r_ns[k] < 0) continue;
-            const int r = r_ns[k] % dt;
-            const bool above = r_gain[k] * s_cmax[r] * d.c2a > thr;
-            acc[0] += 1; acc[1] += (code[k] >> 16) != 0; acc[4] += r_gain[k];
-            if (above) { acc[2] += 1; acc[5] += r_gain[k]; if (tid + k * TPB < n_dpe_tile) acc[3] += 1; }
-            const double tr = (double)(r_ns[k] + rel0);
-            acc[6] += tr; acc[7] += tr * tr;
+            const bool v = r_ns[k] >= 0;
+            const int r = v ? r_ns[k] % dt : 0;
+            const bool above = v && (r_gain[k] * s_cmax[r] * d.c2a > thr);
+            c_trig += (u32)__popcll(__ballot(above));
+            c_trig_dpe += (u32)__popcll(__ballot(above && tid + k * TPB < n_dpe_tile));
+            if (v) {
+                sg += r_gain[k];
+                if (above) sgt += r_gain[k];
+                const double tr = (double)(r_ns[k] + rel0);
+                st += tr; st2 += tr * tr;
+            }
         }
-        if (a.tile_truth) {      // the sums are complete: reduce and store them now, their registers are free for the tap loop
-#pragma unroll
-            for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
-            if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
+        if (a.tile_truth) {
+            constexpr int NW = TPB / 64;
+            double *S = H;                                 // [4][TPB]
+            S[0 * TPB + tid] = sg; S[1 * TPB + tid] = sgt; S[2 * TPB + tid] = st; S[3 * TPB + tid] = st2;
+            if (lane == 0) { wsum[NW + wid * 2] = c_trig; wsum[NW + wid * 2 + 1] = c_trig_dpe; }
             __syncthreads();
-            if (tid < 8) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + tid]; a.tile_truth[tile * 8 + tid] = sum; }
+            for (int q = wid; q < 4; q += NW) {
+                double x = 0;
+#pragma unroll
+                for (int j = 0; j < NW; j++) x += S[q * TPB + j * 64 + lane];
+                for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+                if (lane == 0) a.tile_truth[tile * 8 + 4 + q] = x;
+            }
+            if (tid == 0) {
+                u32 t2 = 0, t3 = 0;
+                for (int w = 0; w < NW; w++) { t2 += wsum[NW + w * 2]; t3 += wsum[NW + w * 2 + 1]; }
+                double *o = a.tile_truth + tile * 8;
+                o[0] = (double)n; o[1] = (double)n_dpe_tile; o[2] = (double)t2; o[3] = (double)t3;
+            }
         }
     }
 
