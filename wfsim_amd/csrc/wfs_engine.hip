@@ -777,9 +777,9 @@ int wfs_run(wfs_handle *h)
         }
         pd.desc = h->tile_desc.as<TileDesc>();
         if (pd.cur_off) pd.cur_off += h->n_sparse_tiles;
-        // windows of up to W_WIN start bins, one workgroup each: LDS per workgroup stays ~24 KB (6 workgroups per CU) and a
+        // windows of up to W_WIN start bins: LDS per workgroup stays below 160 KB / 7 and a
         // 10^6-PE tile is spread over three workgroups; very long tiles loop over further windows inside the kernel
-        const int W_WIN = 256, NWIN_MAX = 8;
+        const int W_WIN = 240, NWIN_MAX = 8;      // 240 start bins + padding = 22.9 KB of LDS: 7 workgroups per CU (256: 6; measured 6.9 vs 7.25 ms)
         int W = (int)std::min<i64>(std::max<i64>(h->max_nb_dense, d.tlen + 1), W_WIN);
         W = (W + 7) / 8 * 8;
         pd.W = W;
