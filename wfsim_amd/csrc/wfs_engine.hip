@@ -38,7 +38,7 @@ struct wfs_handle {
     ApElem ap[WFS_MAX_AP];
     // instructions
     i64 n_ins = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
-    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, em_off;
+    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, ph_slot;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, dense_tiles;
@@ -323,7 +323,7 @@ int wfs_destroy(wfs_handle *h)
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
-        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table,
+        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
@@ -468,6 +468,19 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     TRY(upload(h, h->ins_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_p, p_hit, (size_t)n * 8)); TRY(upload(h, h->ins_dm, drift_mean, (size_t)n * 8));
     TRY(upload(h, h->ins_ds, drift_spread, (size_t)n * 8)); TRY(upload(h, h->ins_sc, sc_gain, (size_t)n * 8));
     TRY(upload(h, h->ins_cdfrow, cdf_row, (size_t)n * 4)); TRY(upload(h, h->cdf_table, cdf_table, (size_t)n_cdf * h->cfg.n_tpc * 8));
+    {   // guide table of every channel-CDF row: guide[c] = first channel whose cumulative probability exceeds c / CDF_G
+        const int nch = h->cfg.n_tpc;
+        std::vector<unsigned short> guide((size_t)n_cdf * (CDF_G + 2));
+        for (int r = 0; r < n_cdf; r++) {
+            const double *row = cdf_table + (size_t)r * nch; int ch = 0;
+            for (int c = 0; c <= CDF_G + 1; c++) {
+                const double x = (double)c / CDF_G;
+                while (ch < nch - 1 && row[ch] <= x) ch++;
+                guide[(size_t)r * (CDF_G + 2) + c] = (unsigned short)ch;
+            }
+        }
+        TRY(upload(h, h->cdf_guide, guide.data(), guide.size() * 2));
+    }
     TRY(upload(h, h->em_off, em_off.data(), em_off.size() * 8));
     {
         std::vector<i32> sc((size_t)S), sm((size_t)S, 0); std::vector<i64> st((size_t)S);
@@ -596,7 +609,7 @@ static int run_generation(wfs_handle *h)
     g.n_ins = N; g.n_emitters = E;
     g.ins_type = h->ins_type.as<int8_t>(); g.ins_time = h->ins_time.as<i64>(); g.ins_amp = h->ins_amp.as<i32>(); g.ins_gid = h->ins_gid.as<u32>();
     g.ins_p = h->ins_p.as<double>(); g.ins_dm = h->ins_dm.as<double>(); g.ins_ds = h->ins_ds.as<double>(); g.ins_sc = h->ins_sc.as<double>();
-    g.ins_cdfrow = h->ins_cdfrow.as<i32>(); g.cdf_table = h->cdf_table.as<double>(); g.em_off = h->em_off.as<i64>();
+    g.ins_cdfrow = h->ins_cdfrow.as<i32>(); g.cdf_table = h->cdf_table.as<double>(); g.cdf_guide = h->cdf_guide.as<unsigned short>(); g.em_off = h->em_off.as<i64>();
     g.em_time = h->em_time.as<i64>(); g.em_nph = h->em_nph.as<i32>(); g.em_ins = h->em_ins.as<i32>();
     g.el_stat = h->el_stat.as<double>(); g.el_minmax = h->el_minmax.as<i64>(); g.scal = h->scal.as<i64>();
     { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }

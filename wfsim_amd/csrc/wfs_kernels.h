@@ -972,6 +972,7 @@ struct GenArgs {
     i64 n_ins, n_emitters, n_photons;
     const int8_t *ins_type; const i64 *ins_time; const i32 *ins_amp; const u32 *ins_gid;
     const double *ins_p, *ins_dm, *ins_ds, *ins_sc; const i32 *ins_cdfrow; const double *cdf_table;
+    const unsigned short *cdf_guide;      // [n_cdf][CDF_G + 2] guide table of every CDF row (host)
     const i64 *em_off;            // [n_ins + 1] first emitter of each instruction
     i64 *em_time; i32 *em_nph; i32 *em_ins; const i64 *em_ph_off;
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
@@ -1225,10 +1226,17 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
     const i64 pa = a.em_ph_off[a.em_off[ins]], pb = a.em_ph_off[a.em_off[ins + 1]];     // photons [pa, pb) of the instruction
     if (pb <= pa) return;
     u32 run = (u32)a.tile_count[idx];
-    for (i64 b = pa / GEN_BLOCK; b <= (pb - 1) / GEN_BLOCK; b++) {
-        if (a.blk_ins[b] != ins) continue;
-        a.blk_base[b * nch + c] = run;
-        run += a.blk_cnt[b * nch + c];
+    const i64 b1 = (pb - 1) / GEN_BLOCK;
+    for (i64 b0 = pa / GEN_BLOCK; b0 <= b1; b0 += 8) {       // eight blocks at a time: their loads are in flight together
+        u32 cnt[8]; bool mine[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const i64 b = b0 + k < b1 ? b0 + k : b1;
+            mine[k] = b0 + k <= b1 && a.blk_ins[b] == ins;
+            cnt[k] = a.blk_cnt[b * nch + c];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) if (mine[k]) { a.blk_base[(b0 + k) * nch + c] = run; run += cnt[k]; }
     }
     a.tile_count[idx] = (i32)run;
 }
@@ -1290,12 +1298,27 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         }
         __syncthreads();
         if (COUNT) {
-            // guide[c] = first channel whose cumulative probability exceeds c / CDF_G (searchsorted side='right')
-            for (int c = tid; c <= CDF_G; c += GEN_TPB) {
-                const double x = (double)c / CDF_G;
-                int lo = 0, hi = nch;
-                while (lo < hi) { int mid = (lo + hi) >> 1; if (x < cdf[mid]) hi = mid; else lo = mid + 1; }
-                cguide[c] = (unsigned short)(lo < nch ? lo : nch - 1);
+            // guide[c] = first channel whose cumulative probability exceeds c / CDF_G (searchsorted side='right'), built on the host
+            for (int c = tid; c <= CDF_G; c += GEN_TPB) cguide[c] = a.cdf_guide[(size_t)a.ins_cdfrow[ins_lo] * (CDF_G + 2) + c];
+            // photon -> emitter slot (last k with win[k] <= pr) for the whole block at once: every emitter marks its first
+            // photon, a running maximum over the photon index fills the gaps (stage[] is free until the bucketing step)
+            i32 *emap = (i32 *)stage;
+            for (int i = tid; i < GEN_BLOCK; i += GEN_TPB) emap[i] = 0;
+            __syncthreads();
+            for (int k = tid; k < nwin; k += GEN_TPB) { const i32 w0 = win[k]; if (w0 > 0 && w0 < GEN_BLOCK) atomicMax(&emap[w0], k); }
+            __syncthreads();
+            {
+                i32 v[GEN_PPT]; i32 mx = 0;
+#pragma unroll
+                for (int k = 0; k < GEN_PPT; k++) { const i32 x = emap[tid * GEN_PPT + k]; mx = x > mx ? x : mx; v[k] = mx; }
+                i32 inc = mx;                                // inclusive running maximum over the threads of the wave
+                for (int o = 1; o < 64; o <<= 1) { const i32 y = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc = y > inc ? y : inc; }
+                if ((tid & 63) == 63) s_wtmp[tid >> 6] = inc;
+                i32 carry = __shfl_up(inc, 1, 64); if ((tid & 63) == 0) carry = 0;
+                __syncthreads();
+                for (int w = 0; w < (tid >> 6); w++) carry = s_wtmp[w] > carry ? s_wtmp[w] : carry;
+#pragma unroll
+                for (int k = 0; k < GEN_PPT; k++) emap[tid * GEN_PPT + k] = v[k] > carry ? v[k] : carry;
             }
             __syncthreads();
             u32 word[GEN_PPT], cr[GEN_PPT];                  // packed word, channel << 16 | rank among the block's photons of that channel
@@ -1303,8 +1326,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             for (int q = 0; q < GEN_PPT; q++) {
                 const int pr = q * GEN_TPB + tid;
                 if (pr >= np) { cr[q] = 0xffffffffu; word[q] = 0; continue; }
-                int lo = 0, hi = nwin;                       // last k with win[k] <= pr
-                while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (win[mid] <= pr) lo = mid; else hi = mid; }
+                const int lo = emap[pr];
                 const u32x4 A = philox4x32_10(jbase + (u32)lo, gid, (u32)(pr - win[lo]), SITE_PH_A, d.k0, d.k1);
                 const double uc = u53(A.x, A.y);
                 int ch = cguide[(int)(uc * CDF_G)];
