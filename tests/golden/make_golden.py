@@ -411,6 +411,30 @@ def fixture_chains(ref):
                         **run_chain(ref, base_config(), make_instructions(rows), 505, pat, ap=ap))
 
 
+def params_overrides():
+    """chain F: everything the digitiser / ZLE / pulse window code reads from the config at non-default values,
+    non-uniform gains and three turned-off PMTs (shared with the tests through chain_params_config.json)"""
+    rng = np.random.default_rng(77)
+    gains = np.round(rng.uniform(1.0e6, 3.0e6, N_TPC))
+    off = [5, 200, 300]
+    gains[off] = 0
+    return dict(gains=gains, turned_off_pmts=np.array(off), trigger_window=30, samples_to_store_before=20,
+                samples_to_store_after=70, zle_threshold=25, special_thresholds={'7': 40, '310': 5},
+                digitizer_reference_baseline=15000, right_raw_extension=30000)
+
+
+def fixture_chain_params(ref):
+    pat = dict(s1=SyntheticPatternMap(14e-5, 30.0, 18.0, 0.15), s2=SyntheticPatternMap(30e-5, 9.0, 25.0, 0.02))
+    MS = 1_000_000
+    ov = params_overrides()
+    rows = [dict(type=1, time=MS, x=0, y=0, z=-40, amp=4000), dict(type=2, time=MS, x=4, y=-3, z=-40, amp=250),
+            dict(type=1, time=MS + 50_000, x=-20, y=5, z=-70, amp=900),           # same cluster only with the default rext
+            dict(type=1, time=3 * MS, x=20, y=0, z=-5, amp=12000), dict(type=2, time=4 * MS, x=-12, y=30, z=-80, amp=60)]
+    np.savez_compressed(HERE + '/chain_params.npz', **run_chain(ref, base_config(**ov), make_instructions(rows), 606, pat))
+    with open(HERE + '/chain_params_config.json', 'w') as f:
+        json.dump({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in ov.items()}, f)
+
+
 def hist(x):
     v, c = np.unique(np.asarray(x, dtype=np.int64), return_counts=True)
     return v.astype(np.int64), c.astype(np.int64)
@@ -496,6 +520,8 @@ if __name__ == '__main__':
         fixture_add_current(ref, p)
     if 'chains' in which:
         fixture_chains(ref)
+    if 'chains' in which or 'params' in which:
+        fixture_chain_params(ref)
     if 'dists' in which:
         fixture_distributions(ref)
     if 'stats' in which:

@@ -3,6 +3,8 @@ import os
 
 import numpy as np
 
+from wfsim_amd.config import xenonnt_test_config  # noqa: F401
+
 from wfsim_amd import tables as T
 from wfsim_amd.config import kernel_params, N_ROWS
 from wfsim_amd.resource import Resource
@@ -12,6 +14,16 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 def golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def params_chain_config():
+    """the config of golden chain F (tests/golden/make_golden.py: params_overrides): non-default digitiser / ZLE / pulse
+    window settings, non-uniform gains, three turned-off PMTs"""
+    import json
+    ov = json.load(open(os.path.join(GOLDEN, 'chain_params_config.json')))
+    ov['gains'] = np.asarray(ov['gains'], dtype=np.float64)
+    ov['turned_off_pmts'] = np.asarray(ov['turned_off_pmts'])
+    return xenonnt_test_config(**ov)
 
 
 def host_tables(config, resource=None):

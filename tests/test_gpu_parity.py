@@ -63,7 +63,7 @@ def _check_chain(name, config, force_dense=False, noise_offsets=False):
     if max(x[1] for x in rows) < 500:
         # int(high_energy_deamplification_factor) == 0 and no HE noise: the reference keeps flat baseline rows for the
         # high-energy channels (rawdata.py:242-249) that can never produce a ZLE interval; the HIP path skips them
-        flat = np.full(1, 16000, dtype=np.int64)
+        flat = np.full(1, int(config['digitizer_reference_baseline']), dtype=np.int64)
         assert all(np.all(np.frombuffer(x[4], dtype=np.int64) == flat) for x in ref_rows if x[1] >= 500)
         ref_rows = [x for x in ref_rows if x[1] < 500]
     assert len(rows) == len(ref_rows)
@@ -108,6 +108,13 @@ def test_chain_he_channels():
 
 def test_chain_pmt_afterpulse_pulses():
     _check_chain('chain_pmt_ap.npz', xenonnt_test_config())
+
+
+@pytest.mark.parametrize('force_dense', [False, True])
+def test_chain_nondefault_parameters(force_dense):
+    """chain F: non-default trigger window / stored samples / thresholds / baseline / rext, non-uniform gains, dead PMTs"""
+    from tests.helpers import params_chain_config
+    _check_chain('chain_params.npz', params_chain_config(), force_dense=force_dense)
 
 
 def test_chain_noise():

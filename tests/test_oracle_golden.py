@@ -84,6 +84,19 @@ def test_chain_he_channels():
         assert np.array_equal(r['zl_' + k], d['zle_' + k]), k
 
 
+def test_chain_nondefault_parameters():
+    """chain F: trigger window 30, store 20/70 samples, zle_threshold 25 + special thresholds, baseline 15000,
+    rext 30000, non-uniform gains with three turned-off PMTs"""
+    from tests.helpers import params_chain_config
+    cfg = params_chain_config()
+    d, r, orc = _check_chain('chain_params.npz', cfg)
+    assert not np.isin(d['ph_ch'], cfg['turned_off_pmts']).any()          # s1.py / s2.py zero the pattern of turned-off PMTs
+    assert len(d['dg_left']) == 5                                         # rext 30000: the S1 50 us later gets a window of its own
+    assert np.array_equal(r['row_data'], d['row_data'])
+    for k in ['ch', 'left', 'right', 'data']:
+        assert np.array_equal(r['zl_' + k], d['zle_' + k]), k
+
+
 def test_chain_pmt_afterpulse_pulses():
     # afterpulse photons are injected with their pre-assigned gains (Pulse.__call__ branch pulse.py:105-107)
     d, r, orc = _check_chain('chain_pmt_ap.npz', xenonnt_test_config())
