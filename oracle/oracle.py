@@ -212,3 +212,21 @@ def philox(ctr, key):
     out = np.zeros(4, dtype=np.uint32)
     lib().orc_philox(_p(c), _p(k), _p(out))
     return out
+
+
+def add_noise(data, mask, left, right, noise, ix_rand):
+    """rawdata.py:398-437 after the ix_rand draw: in place on int64 data[n_ch, L]; returns nothing"""
+    data_c = np.ascontiguousarray(data, dtype=np.int64)
+    assert data_c is data or data.size == 0 or np.shares_memory(data_c, data)
+    m, l, r = _arr(mask, np.uint8), _arr(left, np.int64), _arr(right, np.int64)
+    nz = _arr(noise, np.int16)
+    lib().orc_add_noise(_p(data_c), C.c_int64(data.shape[0]), C.c_int64(data.shape[1]), _p(m), _p(l), _p(r), _p(nz),
+                        C.c_int64(nz.shape[0]), C.c_int64(nz.shape[1]), C.c_int64(int(ix_rand)))
+
+
+def noise_high(mask, left, right, noise_len):
+    """upper bound of np.random.randint(0, high) for the noise start index (rawdata.py:407-417); -1: no masked channel"""
+    m, l, r = _arr(mask, np.uint8), _arr(left, np.int64), _arr(right, np.int64)
+    f = lib().orc_noise_high
+    f.restype = C.c_int64
+    return int(f(C.c_int64(len(m)), _p(m), _p(l), _p(r), C.c_int64(int(noise_len))))

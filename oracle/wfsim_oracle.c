@@ -347,6 +347,36 @@ i64 orc_find_intervals_below_threshold(const i64 *w, i64 n, i64 threshold, i64 h
     return cur;
 }
 
+/* rawdata.py:398-437 add_noise, the part after ix_rand is drawn: per masked channel noise[(ix_rand + ix - ch_left) mod N, ch]
+ * is added to the samples ch_left..ch_right that exist (the reference guards against ix >= row length), channels past the
+ * noise columns are skipped. */
+static void add_noise_rows(i64 *raw, i64 R, i64 L, const uint8_t *mask, const i64 *ml, const i64 *mr,
+                           const int16_t *noise, i64 N, i64 noise_channels, i64 ix_rand)
+{
+    for (i64 ch = 0; ch < R; ch++) {
+        if (ch >= noise_channels || !mask[ch]) continue;
+        for (i64 ix = ml[ch]; ix <= mr[ch]; ix++) {
+            if (ix >= L) continue;
+            i64 in = ix_rand + ix - ml[ch];
+            if (in >= N) in -= N * (in / N);
+            raw[ch * L + ix] += noise[in * noise_channels + ch];
+        }
+    }
+}
+/* upper bound of np.random.randint(0, high) for ix_rand (rawdata.py:407-417); <= 0 means ix_rand = 0 */
+i64 orc_noise_high(i64 R, const uint8_t *mask, const i64 *ml, const i64 *mr, i64 N)
+{
+    i64 nl = INT64_MAX, nr = INT64_MIN; int any = 0;
+    for (i64 r = 0; r < R; r++) if (mask[r]) { any = 1; if (ml[r] < nl) nl = ml[r]; if (mr[r] > nr) nr = mr[r]; }
+    if (!any) return -1;
+    return (N - nr + nl - 1 < 0) ? N - 1 : N - nr + nl - 1;
+}
+void orc_add_noise(i64 *raw, i64 R, i64 L, const uint8_t *mask, const i64 *ml, const i64 *mr, const int16_t *noise, i64 N,
+                   i64 noise_channels, i64 ix_rand)
+{
+    add_noise_rows(raw, R, L, mask, ml, mr, noise, N, noise_channels, ix_rand);
+}
+
 /* rawdata.py:204-272 digitize_pulse_cache + :398-458 add_noise/add_baseline/digitizer_saturation, then
  * rawdata.py:274-311 ZLE over the same window.  Consumes all pulses cached since the previous digitise. */
 void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
@@ -392,15 +422,7 @@ void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
             if (high <= 0) ix_rand = 0;
             else { u32 w[4]; draw(s, 0, noise_gid, 0, SITE_NOISE, w); ix_rand = (i64)(u53(w[0], w[1]) * (double)high); }
             if (s->noise_override && s->dg_left.n < s->n_noise_override && s->noise_override[s->dg_left.n] >= 0) ix_rand = s->noise_override[s->dg_left.n];
-            for (i64 ch = 0; ch < R; ch++) {
-                if (ch >= c->noise_channels || !mask[ch]) continue;
-                for (i64 ix = ml[ch]; ix <= mr[ch]; ix++) {
-                    if (ix >= L) continue;
-                    i64 in = ix_rand + ix - ml[ch];
-                    if (in >= N) in -= N * (in / N);
-                    raw[ch * L + ix] += s->noise[in * c->noise_channels + ch];
-                }
-            }
+            add_noise_rows(raw, R, L, mask, ml, mr, s->noise, N, c->noise_channels, ix_rand);
         }
     }
     i64 dg = s->dg_left.n;
