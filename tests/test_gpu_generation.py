@@ -113,6 +113,24 @@ def test_mixed_clusters_and_large_s2():
     _compare(*_run_both(xenonnt_test_config(s2_secondary_sc_gain=100.0), _instructions(rows)))
 
 
+def test_tiles_above_one_register_batch():
+    """an S2 of ~4x10^6 PE: ~6000 photons per PMT, more than the 2048 the resident pulse kernel keeps in registers ->
+    the dense kernel runs one workgroup per (tile, window), and a second, small S2 rides along in the same launch"""
+    cfg = xenonnt_test_config(s2_secondary_sc_gain=100.0)
+    rows = [dict(type=2, time=MS, x=2, y=-1, z=-12, amp=40000), dict(type=2, time=3 * MS, x=0, y=0, z=-30, amp=200),
+            dict(type=1, time=5 * MS, x=0, y=0, z=-30, amp=900)]
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows), seed=21)
+    assert np.diff(eng.photons()['set_off']).max() > 2048 * 494
+    _compare(orc, o, eng, counts, s_ins)
+    # truth of the big S2 through the windowed kernel's own reduction path
+    acc, ts = eng.truth()
+    tr = o['truth'].reshape(-1, 12)
+    big = int(np.argmax(acc[:, 0]))
+    kbig = int(np.argmax(tr[:, 0]))
+    for j in (0, 1, 2, 4, 5, 6, 7, 8, 10, 11):          # all but n_pe_trigger(_bottom): order dependent (pulse.py:255)
+        assert np.isclose(acc[big, j], tr[kbig, j], rtol=1e-9), j
+
+
 def test_small_poisson_mean_and_gain_spread():
     rows = [dict(type=2, time=MS * (i + 1), x=0, y=0, z=-20, amp=300) for i in range(5)]
     _compare(*_run_both(xenonnt_test_config(s2_secondary_sc_gain=7.0, s2_gain_spread=2.5, s2_time_spread=30.0),
