@@ -41,7 +41,7 @@ struct wfs_handle {
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, ph_slot;
-    DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, dense_tiles;
+    DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles;
     DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
@@ -51,8 +51,8 @@ struct wfs_handle {
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
-    i64 h_scal[16] = {0};
-    i64 n_active_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
+    i64 h_scal[32] = {0};
+    i64 n_active_tiles = 0, n_tiny_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
     double h_templates[WFS_DT * 22] = {0};
@@ -326,7 +326,7 @@ int wfs_destroy(wfs_handle *h)
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
-        &h->active_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
+        &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
@@ -686,7 +686,7 @@ int wfs_run(wfs_handle *h)
     h->times.clear();
     const WfsDev &d = h->dev;
     const i64 T = h->n_tiles, S = h->n_sets, C = h->n_clusters;
-    HIPCHK(hipMemsetAsync(h->scal.p, 0, 128, h->stream));
+    HIPCHK(hipMemsetAsync(h->scal.p, 0, 256, h->stream));
     if (h->optical) {
         OpticalArgs oa{T, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_gid.as<u32>(),
                        h->opt_t.as<i32>(), h->opt_item.as<u32>(), h->ph.as<PhotonRec>(), h->scal.as<i64>()};
@@ -705,7 +705,7 @@ int wfs_run(wfs_handle *h)
     TRY(fill64(h, h->row_lo, CG * d.n_tpc, I64_MAX)); TRY(fill64(h, h->row_hi, CG * d.n_tpc, I64_MIN));
     TRY(ensure(h, h->acc_len, (size_t)CG * d.n_tpc * 4)); HIPCHK(hipMemsetAsync(h->acc_len.p, 0, (size_t)CG * d.n_tpc * 4, h->stream));
     TRY(ensure(h, h->itv_cap, (size_t)CG * d.row_slots * 4)); TRY(ensure(h, h->active_rows, (size_t)CG * d.row_slots * 4));
-    TRY(ensure(h, h->active_tiles, (size_t)T * 4)); TRY(ensure(h, h->dense_tiles, (size_t)T * 4));
+    TRY(ensure(h, h->active_tiles, (size_t)T * 4)); TRY(ensure(h, h->sparse_tiles, (size_t)T * 4)); TRY(ensure(h, h->dense_tiles, (size_t)T * 4));
     GeomArgs ga{};
     ga.n_sets = S; ga.n_tiles = T; ga.n_clusters = C; ga.n_gslots = CG;
     ga.tile_count = h->tile_count.as<i32>(); ga.tile_tmin = h->tile_tmin.as<i32>(); ga.tile_tmax = h->tile_tmax.as<i32>();
@@ -713,7 +713,7 @@ int wfs_run(wfs_handle *h)
     ga.cl_end = h->cl_end.as<i64>(); ga.cl_group = h->cl_group.as<i32>(); ga.grp_lo = h->grp_lo.as<i64>(); ga.grp_hi = h->grp_hi.as<i64>();
     ga.grp_left = h->grp_left.as<i64>(); ga.grp_right = h->grp_right.as<i64>(); ga.grp_ixrand = h->grp_ixrand.as<i64>(); ga.grp_gid = h->grp_gid.as<u32>();
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
-    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
+    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.sparse_tiles = h->sparse_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
     ga.noise_override = h->n_noise_override ? h->noise_override.as<i64>() : nullptr; ga.n_noise_override = h->n_noise_override;
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 1024)), dim3(1024), 0, h->stream, d, ga); }
     { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(GROUPS_TPB), 0, h->stream, d, ga); }
@@ -726,9 +726,13 @@ int wfs_run(wfs_handle *h)
     if (h->h_scal[1] == 1) return h->fail(WFS_E_CAPACITY, "Pulse cache too long (digitise window of 10^6 samples or more, rawdata.py:219)");
     if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
     h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5]; h->max_tile_dense = h->h_scal[15];
-    h->n_dense_tiles = h->h_scal[11]; h->max_nb_dense = h->h_scal[12]; h->n_active_tiles = h->n_sparse_tiles + h->n_dense_tiles;
-    if (h->n_dense_tiles > 0)       // one work list: sparse tiles first, dense tiles behind them
-        HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_sparse_tiles, h->dense_tiles.p, (size_t)h->n_dense_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
+    h->n_dense_tiles = h->h_scal[11]; h->max_nb_dense = h->h_scal[12]; h->n_tiny_tiles = h->h_scal[16];
+    h->n_active_tiles = h->n_tiny_tiles + h->n_sparse_tiles + h->n_dense_tiles;
+    // one work list: tiny tiles, then sparse, then dense
+    if (h->n_sparse_tiles > 0)
+        HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_tiny_tiles, h->sparse_tiles.p, (size_t)h->n_sparse_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (h->n_dense_tiles > 0)
+        HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles, h->dense_tiles.p, (size_t)h->n_dense_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
     h->s_raw = h->h_scal[8]; h->n_itv_slots = h->h_scal[9];
     // deterministic processing order of the work lists (they were appended with atomics)
     // (results do not depend on it; sorting keeps profiles and debug dumps reproducible)
@@ -767,8 +771,23 @@ int wfs_run(wfs_handle *h)
         HIPCHK(hipStreamSynchronize(h->stream));
         pa.currents = h->currents.as<double>(); pa.cur_off = h->cur_off.as<i64>();
     }
+    if (h->n_active_tiles > 0) {        // tile descriptors of the whole work list (used by the tiny and the dense kernel)
+        TRY(ensure(h, h->tile_desc, (size_t)h->n_active_tiles * sizeof(TileDesc)));
+        DescArgs da{pa.active_tiles, h->n_active_tiles, pa.tile_count, pa.tile_tmin, pa.tile_tmax, pa.tile_off, pa.set_cluster, pa.set_t0, pa.set_mode,
+                    pa.cl_group, pa.row_lo, pa.acc_off, h->tile_desc.as<TileDesc>()};
+        Timer t(h, "k_tile_desc");
+        hipLaunchKernelGGL(k_tile_desc, dim3(nblocks(h->n_active_tiles, 256)), dim3(256), 0, h->stream, d, da);
+    }
+    if (h->n_tiny_tiles > 0) {
+        PulseArgs pt = pa;
+        pt.desc = h->tile_desc.as<TileDesc>();
+        Timer t(h, "k_pulse_tiny");
+        hipLaunchKernelGGL(k_pulse_tiny, dim3(nblocks(h->n_tiny_tiles, 256)), dim3(256), 0, h->stream, d, pt, h->n_tiny_tiles);
+    }
     if (h->n_sparse_tiles > 0) {
         PulseArgs ps = pa;
+        ps.active_tiles = h->active_tiles.as<i32>() + h->n_tiny_tiles;
+        if (ps.cur_off) ps.cur_off += h->n_tiny_tiles;
         ps.W = (int)((h->max_nb + 7) / 8 * 8); ps.NP = (int)((h->max_tile + 7) / 8 * 8);
         const bool small = h->max_tile <= 256 && h->max_nb <= 256;
         const int tpb = small ? 64 : 256;
@@ -780,16 +799,9 @@ int wfs_run(wfs_handle *h)
     }
     if (h->n_dense_tiles > 0) {
         PulseArgs pd = pa;
-        pd.active_tiles = h->active_tiles.as<i32>() + h->n_sparse_tiles;
-        TRY(ensure(h, h->tile_desc, (size_t)h->n_dense_tiles * sizeof(TileDesc)));
-        {
-            DescArgs da{pd.active_tiles, h->n_dense_tiles, pa.tile_count, pa.tile_tmin, pa.tile_tmax, pa.tile_off, pa.set_cluster, pa.set_t0, pa.set_mode,
-                        pa.cl_group, pa.row_lo, pa.acc_off, h->tile_desc.as<TileDesc>()};
-            Timer t(h, "k_tile_desc");
-            hipLaunchKernelGGL(k_tile_desc, dim3(nblocks(h->n_dense_tiles, 256)), dim3(256), 0, h->stream, d, da);
-        }
-        pd.desc = h->tile_desc.as<TileDesc>();
-        if (pd.cur_off) pd.cur_off += h->n_sparse_tiles;
+        pd.active_tiles = h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles;
+        pd.desc = h->tile_desc.as<TileDesc>() + h->n_tiny_tiles + h->n_sparse_tiles;
+        if (pd.cur_off) pd.cur_off += h->n_tiny_tiles + h->n_sparse_tiles;
         // windows of up to W_WIN start bins: LDS per workgroup stays below 160 KB / 7 and a
         // 10^6-PE tile is spread over three workgroups; very long tiles loop over further windows inside the kernel
         const int W_WIN = 240, NWIN_MAX = 8;      // 240 start bins + padding = 22.9 KB of LDS: 7 workgroups per CU (256: 6; measured 6.9 vs 7.25 ms)

@@ -105,7 +105,8 @@ struct GeomArgs {
     i32 *acc_len, *itv_cap; i32 *active_rows;
     i64 *scal;           // [0] n_groups [1] error flag [2] n_active_rows [3] n sparse tiles [4] their max start bins
                          // [5] their max photons [11] n dense tiles [12] their max start bins
-    i32 *active_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
+    i32 *active_tiles;   // tiny tiles (thread per tile); the other two lists are copied behind them by the host side
+    i32 *sparse_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
     i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
     i32 force_dense;     // debug: send every tile to the dense kernel
     i32 init_has; i64 init_runmax;      // last_pulse_end_time carried in from earlier batches
@@ -114,6 +115,8 @@ struct GeomArgs {
 
 #define SPARSE_MAX_PHOTONS 32      // tiles with a handful of photons (S1-like) go to the sorted-list kernel
 #define SPARSE_MAX_BINS 64
+#define TINY_MAX_PHOTONS 4         // tiles of a few photons in a few start bins (the bulk of an S1): one THREAD per tile
+#define TINY_MAX_BINS 32
 
 __device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i32 tmax, i64 &left, i64 &right, i64 &bin0, i64 &nb)
 {
@@ -132,14 +135,14 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = tile < a.n_tiles && a.tile_count[tile] > 0;
-    bool sparse = false; i64 nb = 0; i32 cnt = 0; i32 cl = -1; i64 end = I64_MIN;
+    int cls = 2; i64 nb = 0; i32 cnt = 0; i32 cl = -1; i64 end = I64_MIN;      // class 0 tiny, 1 sparse, 2 dense
     if (live) {
         const i64 set = tile / d.n_tpc;
         i64 left, right, bin0;
         tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
         cl = a.set_cluster[set]; end = right * d.dt;
         cnt = a.tile_count[tile];
-        sparse = !a.force_dense && cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS;
+        if (!a.force_dense) cls = (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1 : 2);
     }
     {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
         const u64 ml = __ballot(live);
@@ -154,26 +157,26 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     }
     // work lists and maxima: aggregated per workgroup in LDS, then one global atomic per workgroup and counter
     // (76k wave-level atomics on one cache line cost ~3 ms; the counters all live in the same line of scal[])
-    __shared__ i32 s_ns, s_nd; __shared__ i64 s_bs, s_bd, s_mx[4];
-    if (threadIdx.x == 0) { s_ns = 0; s_nd = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; s_mx[3] = 0; }
+    __shared__ i32 s_n[3]; __shared__ i64 s_b[3], s_mx[4];
+    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; s_mx[3] = 0; }
     __syncthreads();
     i32 rk = 0;
     if (live) {
-        rk = atomicAdd(sparse ? &s_ns : &s_nd, 1);
-        if (sparse) { atomicMax(&s_mx[0], nb); atomicMax(&s_mx[1], (i64)cnt); } else { atomicMax(&s_mx[2], nb); atomicMax(&s_mx[3], (i64)cnt); }
+        rk = atomicAdd(&s_n[cls], 1);
+        if (cls == 1) { atomicMax(&s_mx[0], nb); atomicMax(&s_mx[1], (i64)cnt); } else if (cls == 2) { atomicMax(&s_mx[2], nb); atomicMax(&s_mx[3], (i64)cnt); }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s_bs = s_ns ? (i64)atomicAdd((u64 *)&a.scal[3], (u64)s_ns) : 0;
-        s_bd = s_nd ? (i64)atomicAdd((u64 *)&a.scal[11], (u64)s_nd) : 0;
+        s_b[0] = s_n[0] ? (i64)atomicAdd((u64 *)&a.scal[16], (u64)s_n[0]) : 0;
+        s_b[1] = s_n[1] ? (i64)atomicAdd((u64 *)&a.scal[3], (u64)s_n[1]) : 0;
+        s_b[2] = s_n[2] ? (i64)atomicAdd((u64 *)&a.scal[11], (u64)s_n[2]) : 0;
         if (s_mx[0]) atomicMax(&a.scal[4], s_mx[0]);
         if (s_mx[1]) atomicMax(&a.scal[5], s_mx[1]);
         if (s_mx[2]) atomicMax(&a.scal[12], s_mx[2]);
         if (s_mx[3]) atomicMax(&a.scal[15], s_mx[3]);
     }
     __syncthreads();
-    if (live && sparse) a.active_tiles[s_bs + rk] = (i32)tile;
-    if (live && !sparse) a.dense_tiles[s_bd + rk] = (i32)tile;
+    if (live) (cls == 0 ? a.active_tiles : (cls == 1 ? a.sparse_tiles : a.dense_tiles))[s_b[cls] + rk] = (i32)tile;
 }
 
 // Digitise groups.  The cache is digitised before cluster k when min(instruction key of k) - last_pulse_end_time > rext
@@ -606,6 +609,95 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
         __syncthreads();
         if (tid < 8) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + tid]; a.tile_truth[tile * 8 + tid] = sum; }
+    }
+}
+
+// Tiny tiles (a few photons in a few start bins: almost every tile of an S1): one THREAD per tile.  The photons are
+// sorted by time in registers, equal-ns photons merged (first of the run carries the summed gain), and every sample in
+// reach of a photon adds templates[r][k] * gain in ascending time with a separate multiply and add: the arithmetic of
+// add_current (pulse.py:276-318), hence the same bits as the other two kernels.  Truth sums need no reduction.
+__global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n_tiny)
+{
+    constexpr int dt = WFS_DT, tlen = 22, NP = TINY_MAX_PHOTONS;
+    __shared__ double sT[dt * tlen];                      // templates[r][k]
+    __shared__ double s_cmax[dt];
+    for (int i = threadIdx.x; i < dt * tlen; i += blockDim.x) sT[i] = d.templates[i];
+    if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
+    __syncthreads();
+    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_tiny) return;
+    const TileDesc td = a.desc[idx];
+    const int n = td.n, L = td.L;
+    const int lead = d.store_before + d.samples_before;
+    const double G = td.G;
+    const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? td.ch : 0) * 2001;
+    i32 ns[NP]; double g[NP]; u32 code[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        const bool v = k < n;
+        const PhotonRec rec = a.ph[td.off + (v ? k : 0)];
+        ns[k] = v ? (i32)(rec.t - td.rel0) : 0x7fffffff;
+        code[k] = v ? rec.code : 0u;
+        g[k] = 0.0;
+        if (v) {
+            if (td.mode != 0) g[k] = a.ph_gain[td.off + k];
+            else { g[k] = G * spe_row[code[k] & 0xffffu]; if (code[k] >> 16) g[k] += G * spe_row[code[k] >> 16]; }      // pulse.py:97-103
+        }
+    }
+    if (a.tile_truth) {        // pulse.py:229-271, photons in their order in the channel slice
+        i32 n_dpe = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) n_dpe += (code[k] >> 16) != 0;
+        double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            if (k >= n) continue;
+            const bool above = g[k] * s_cmax[ns[k] % dt] * d.c2a > td.thr;
+            v[0] += 1; v[1] += (code[k] >> 16) != 0; v[4] += g[k];
+            if (above) { v[2] += 1; v[5] += g[k]; if (k < n_dpe) v[3] += 1; }
+            const double tr = (double)(ns[k] + td.rel0);
+            v[6] += tr; v[7] += tr * tr;
+        }
+        for (int q = 0; q < 8; q++) a.tile_truth[(i64)td.tile * 8 + q] = v[q];
+    }
+    // ---- ascending time (stable: equal ns keep their order), then merge runs of equal ns
+#pragma unroll
+    for (int i = 1; i < NP; i++)
+#pragma unroll
+        for (int j = i; j > 0; j--)
+            if (ns[j] < ns[j - 1]) { const i32 t = ns[j]; ns[j] = ns[j - 1]; ns[j - 1] = t; const double x = g[j]; g[j] = g[j - 1]; g[j - 1] = x; }
+    // run heads collect the gains of their run in order; the others become 0.0 (adding 0.0 changes nothing)
+    {
+        int head = 0;
+#pragma unroll
+        for (int k = 1; k < NP; k++) {
+            if (k < n && ns[k] == ns[k - 1]) {
+#pragma unroll
+                for (int q = 0; q < NP; q++) if (q == head) g[q] += g[k];
+                g[k] = 0.0;
+            } else head = k;
+        }
+    }
+    int jb[NP], rr[NP];
+#pragma unroll
+    for (int k = 0; k < NP; k++) { jb[k] = (k < n) ? ns[k] / dt : 0x3fffffff; rr[k] = (k < n) ? ns[k] - jb[k] * dt : 0; }
+    i32 *dst = a.raw + td.dst;
+    // samples in reach of a photon: start bin j touches samples j + lead .. j + lead + tlen - 1
+    const int s_first = a.currents ? 0 : jb[0] + lead;
+    int jmax = 0;
+#pragma unroll
+    for (int k = 0; k < NP; k++) if (k < n) jmax = jb[k] > jmax ? jb[k] : jmax;
+    const int s_last = a.currents ? L - 1 : (jmax + lead + tlen - 1 < L - 1 ? jmax + lead + tlen - 1 : L - 1);
+    for (int s = s_first; s <= s_last; s++) {
+        double cur = 0.0;
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int kk = s - lead - jb[k];
+            if (k < n && kk >= 0 && kk < tlen) { const double prod = sT[rr[k] * tlen + kk] * g[k]; cur = cur + prod; }
+        }
+        if (a.currents) a.currents[a.cur_off[idx] + s] = cur;
+        const i64 adc = -(i64)rint(cur * d.c2a);                 // rawdata.py:236
+        if (adc != 0) atomicAdd(&dst[s], (i32)adc);
     }
 }
 
