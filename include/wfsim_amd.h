@@ -104,11 +104,16 @@ int wfs_set_ap_element(wfs_handle *h, int32_t element, int32_t n_bins_delay, int
  *   p_hit f64                                S1: light yield (s1.py:125-131); S2: electron survival (s2.py:241-252)
  *   drift_mean/drift_spread f64              s2.py:158-179
  *   sc_gain f64                              s2.py:182-209
- *   cdf_row i32, cdf_table f64[n_cdf][n_tpc] cumulative channel probabilities (np.random.choice, s1.py:154, s2.py:673) */
+ *   cdf_row i32, cdf_table f64[n_cdf][n_tpc] cumulative channel probabilities (np.random.choice, s1.py:154, s2.py:673)
+ *   run_set i32 (or NULL), n_run_sets       pulse set of every instruction: the instructions the reference hands to ONE
+ *                                           Pulse call (rawdata.py:108-127; save_full_truth=False groups S1s within 100 ns
+ *                                           and S2s within 2 mm).  Sets are numbered 0..n_run_sets-1; their instructions
+ *                                           share cluster and type.  NULL: one set per instruction (the default). */
 int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const int64_t *time, const int32_t *amp,
                           const uint32_t *gid, const int32_t *cluster, const int64_t *tmin,
                           const double *p_hit, const double *drift_mean, const double *drift_spread,
-                          const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf);
+                          const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf,
+                          const int32_t *run_set, int64_t n_run_sets);
 
 /* Parity entry: photons supplied instead of generated -- what RawDataOptical.sim_primary hands to Pulse
  * (rawdata.py:475-493) and what the golden vectors inject.  One "pulse set" = one Pulse.__call__ (pulse.py:39).

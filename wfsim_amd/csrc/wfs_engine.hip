@@ -37,8 +37,8 @@ struct wfs_handle {
     DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise;
     ApElem ap[WFS_MAX_AP];
     // instructions
-    i64 n_ins = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
-    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off;
+    i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
+    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, ph_slot;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles;
@@ -323,7 +323,7 @@ int wfs_destroy(wfs_handle *h)
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
-        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide,
+        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
@@ -443,7 +443,8 @@ static int load_clusters(wfs_handle *h, i64 n, const int32_t *cluster, const int
 
 int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const int64_t *time, const int32_t *amp, const uint32_t *gid,
                           const int32_t *cluster, const int64_t *tmin, const double *p_hit, const double *drift_mean,
-                          const double *drift_spread, const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf)
+                          const double *drift_spread, const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf,
+                          const int32_t *run_set, int64_t n_run_sets)
 {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
@@ -459,10 +460,26 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         if (type[i] == 2 && h->dev.n_lum < 2) return h->fail(WFS_E_STATE, "S2 instructions need the luminescence table");
         em_off[i + 1] = em_off[i] + (type[i] == 1 ? 1 : (i64)amp[i]);
     }
-    // PMT afterpulses are a second pulse set per instruction (rawdata.py:176-178): set n + i belongs to instruction i
+    // pulse sets (one Pulse.__call__ each, rawdata.py:108-127): the caller's run sets, by default one per instruction
+    std::vector<i32> ins_set((size_t)n);
+    i64 PS = n;
+    if (run_set) {
+        if (n_run_sets <= 0 || n_run_sets > n) return h->fail(WFS_E_INVALID, "wfs_load_instructions: bad number of run sets");
+        PS = n_run_sets;
+        for (i64 i = 0; i < n; i++) { if (run_set[i] < 0 || run_set[i] >= PS) return h->fail(WFS_E_INVALID, "run set index out of range"); ins_set[i] = run_set[i]; }
+    } else for (i64 i = 0; i < n; i++) ins_set[i] = (i32)i;
+    std::vector<i64> set_off((size_t)PS + 1, 0); std::vector<i32> set_list((size_t)n);        // set -> its instructions (CSR)
+    for (i64 i = 0; i < n; i++) set_off[ins_set[i] + 1]++;
+    for (i64 q = 0; q < PS; q++) { if (set_off[q + 1] == 0) return h->fail(WFS_E_INVALID, "empty run set"); set_off[q + 1] += set_off[q]; }
+    { std::vector<i64> cur(set_off.begin(), set_off.end() - 1); for (i64 i = 0; i < n; i++) set_list[cur[ins_set[i]]++] = (i32)i; }
+    for (i64 q = 0; q < PS; q++)
+        for (i64 k = set_off[q] + 1; k < set_off[q + 1]; k++)
+            if (cluster[set_list[k]] != cluster[set_list[set_off[q]]] || type[set_list[k]] != type[set_list[set_off[q]]])
+                return h->fail(WFS_E_INVALID, "the instructions of a run set must share cluster and type");
+    // PMT afterpulses are a second pulse set per primary set (rawdata.py:176-178): set PS + q belongs to set q
     h->ap_active = h->cfg.enable_pmt_ap && h->dev.n_ap > 0;
-    const i64 S = h->ap_active ? 2 * n : n;
-    h->n_ins = n; h->n_sets = S; h->n_emitters = em_off[n]; h->n_tiles = S * h->cfg.n_tpc;
+    const i64 S = h->ap_active ? 2 * PS : PS;
+    h->n_ins = n; h->n_psets = PS; h->n_sets = S; h->n_emitters = em_off[n]; h->n_tiles = S * h->cfg.n_tpc;
     if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
     TRY(upload(h, h->ins_type, type, (size_t)n)); TRY(upload(h, h->ins_time, time, (size_t)n * 8)); TRY(upload(h, h->ins_amp, amp, (size_t)n * 4));
     TRY(upload(h, h->ins_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_p, p_hit, (size_t)n * 8)); TRY(upload(h, h->ins_dm, drift_mean, (size_t)n * 8));
@@ -484,7 +501,14 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     TRY(upload(h, h->em_off, em_off.data(), em_off.size() * 8));
     {
         std::vector<i32> sc((size_t)S), sm((size_t)S, 0); std::vector<i64> st((size_t)S);
-        for (i64 i = 0; i < S; i++) { sc[i] = cluster[i % n]; st[i] = time[i % n]; sm[i] = i >= n ? 1 : 0; }
+        for (i64 q = 0; q < S; q++) {
+            const i64 ps = q % PS;
+            i64 t0 = time[set_list[set_off[ps]]];
+            for (i64 k = set_off[ps]; k < set_off[ps + 1]; k++) t0 = std::min<i64>(t0, time[set_list[k]]);
+            sc[q] = cluster[set_list[set_off[ps]]]; st[q] = t0; sm[q] = q >= PS ? 1 : 0;
+        }
+        TRY(upload(h, h->ins_set, ins_set.data(), (size_t)n * 4)); TRY(upload(h, h->set_ins_off, set_off.data(), set_off.size() * 8));
+        TRY(upload(h, h->set_ins_list, set_list.data(), (size_t)n * 4));
         TRY(upload(h, h->set_cluster, sc.data(), (size_t)S * 4)); TRY(upload(h, h->set_t0, st.data(), (size_t)S * 8));
         TRY(upload(h, h->set_mode, sm.data(), (size_t)S * 4));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -606,7 +630,8 @@ static int run_generation(wfs_handle *h)
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     GenArgs g{};
-    g.n_ins = N; g.n_emitters = E;
+    g.n_ins = N; g.n_psets = h->n_psets; g.n_emitters = E;
+    g.ins_set = h->ins_set.as<i32>(); g.set_ins_off = h->set_ins_off.as<i64>(); g.set_ins_list = h->set_ins_list.as<i32>(); g.set_t0 = h->set_t0.as<i64>();
     g.ins_type = h->ins_type.as<int8_t>(); g.ins_time = h->ins_time.as<i64>(); g.ins_amp = h->ins_amp.as<i32>(); g.ins_gid = h->ins_gid.as<u32>();
     g.ins_p = h->ins_p.as<double>(); g.ins_dm = h->ins_dm.as<double>(); g.ins_ds = h->ins_ds.as<double>(); g.ins_sc = h->ins_sc.as<double>();
     g.ins_cdfrow = h->ins_cdfrow.as<i32>(); g.cdf_table = h->cdf_table.as<double>(); g.cdf_guide = h->cdf_guide.as<unsigned short>(); g.em_off = h->em_off.as<i64>();
@@ -619,7 +644,7 @@ static int run_generation(wfs_handle *h)
     const i64 P = h->h_scal[6];
     h->n_photons = P; h->n_ap_photons = 0;
     g.em_ph_off = h->em_ph_off.as<i64>(); g.n_photons = P;
-    const i64 TP = N * d.n_tpc;                 // primary tiles; afterpulse tiles follow
+    const i64 TP = h->n_psets * d.n_tpc;        // primary tiles; afterpulse tiles follow
     const bool ap_on = h->ap_active;
     const i64 ap_cap = ap_on ? P / 8 + 65536 : 0;
     TRY(ensure(h, h->tile_count, (size_t)T * 4)); TRY(ensure(h, h->tile_cursor, (size_t)T * 4));
@@ -657,7 +682,7 @@ static int run_generation(wfs_handle *h)
         g.xcd_chunk = (nb + 7) / 8;
         const unsigned nbx = (unsigned)(g.xcd_chunk * 8);
         { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true, false>), dim3(nbx), dim3(GEN_TPB), gen_lds_count, h->stream, d, g, ap); }
-        { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(N * d.n_tpc, 256)), dim3(256), 0, h->stream, d, g); }
+        { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
         { Timer t(h, "k_photons_fill");
           if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
@@ -888,7 +913,7 @@ int wfs_get_counts(wfs_handle *h, wfs_counts *out)
     // n_pe and n_intervals need device reductions: sum the per-set truth (cheap)
     std::vector<double> tr((size_t)h->n_sets * 16);
     HIPCHK(hipMemcpy(tr.data(), h->truth.p, tr.size() * 8, hipMemcpyDeviceToHost));
-    const i64 n_prim = (!h->injected && h->ap_active) ? h->n_ins : h->n_sets;       // afterpulse sets carry no truth (rawdata.py:322-323)
+    const i64 n_prim = (!h->injected && h->ap_active) ? h->n_psets : h->n_sets;       // afterpulse sets carry no truth (rawdata.py:322-323)
     double npe = 0; for (i64 s = 0; s < n_prim; s++) npe += tr[s * 16 + 1];
     c.n_pe = (i64)(npe + 0.5);
     std::vector<i32> n((size_t)(h->n_clusters + 1) * h->dev.row_slots);

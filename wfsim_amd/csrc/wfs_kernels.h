@@ -1061,7 +1061,10 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
 
 // ------------------------------------------------------------------------------------------------ generation
 struct GenArgs {
-    i64 n_ins, n_emitters, n_photons;
+    i64 n_ins, n_psets, n_emitters, n_photons;
+    const i32 *ins_set;           // [n_ins] pulse set (one Pulse.__call__, rawdata.py:108-127) of every instruction; tiles are (set, channel)
+    const i64 *set_ins_off; const i32 *set_ins_list;      // set -> its instructions (CSR)
+    const i64 *set_t0;            // [n_sets] time origin of the set's photon times
     const int8_t *ins_type; const i64 *ins_time; const i32 *ins_amp; const u32 *ins_gid;
     const double *ins_p, *ins_dm, *ins_ds, *ins_sc; const i32 *ins_cdfrow; const double *cdf_table;
     const unsigned short *cdf_guide;      // [n_cdf][CDF_G + 2] guide table of every CDF row (host)
@@ -1313,22 +1316,25 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
 {
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int nch = d.n_tpc;
-    if (idx >= a.n_ins * nch) return;
-    const i32 ins = (i32)(idx / nch); const int c = (int)(idx - (i64)ins * nch);
-    const i64 pa = a.em_ph_off[a.em_off[ins]], pb = a.em_ph_off[a.em_off[ins + 1]];     // photons [pa, pb) of the instruction
-    if (pb <= pa) return;
+    if (idx >= a.n_psets * nch) return;
+    const i32 set = (i32)(idx / nch); const int c = (int)(idx - (i64)set * nch);
     u32 run = (u32)a.tile_count[idx];
-    const i64 b1 = (pb - 1) / GEN_BLOCK;
-    for (i64 b0 = pa / GEN_BLOCK; b0 <= b1; b0 += 8) {       // eight blocks at a time: their loads are in flight together
-        u32 cnt[8]; bool mine[8];
+    for (i64 q = a.set_ins_off[set]; q < a.set_ins_off[set + 1]; q++) {      // the set's instructions, in order
+        const i32 ins = a.set_ins_list[q];
+        const i64 pa = a.em_ph_off[a.em_off[ins]], pb = a.em_ph_off[a.em_off[ins + 1]];     // photons [pa, pb) of the instruction
+        if (pb <= pa) continue;
+        const i64 b1 = (pb - 1) / GEN_BLOCK;
+        for (i64 b0 = pa / GEN_BLOCK; b0 <= b1; b0 += 8) {       // eight blocks at a time: their loads are in flight together
+            u32 cnt[8]; bool mine[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const i64 b = b0 + k < b1 ? b0 + k : b1;
-            mine[k] = b0 + k <= b1 && a.blk_ins[b] == ins;
-            cnt[k] = a.blk_cnt[b * nch + c];
+            for (int k = 0; k < 8; k++) {
+                const i64 b = b0 + k < b1 ? b0 + k : b1;
+                mine[k] = b0 + k <= b1 && a.blk_ins[b] == ins;
+                cnt[k] = a.blk_cnt[b * nch + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (mine[k]) { a.blk_base[(b0 + k) * nch + c] = run; run += cnt[k]; }
         }
-#pragma unroll
-        for (int k = 0; k < 8; k++) if (mine[k]) { a.blk_base[(b0 + k) * nch + c] = run; run += cnt[k]; }
     }
     a.tile_count[idx] = (i32)run;
 }
@@ -1371,9 +1377,10 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
     const bool single = nwin > 0 && ins_lo == a.em_ins[e_hi];      // all photons of the block in one pulse set
 
     if (single) {
-        const u32 gid = a.ins_gid[ins_lo]; const i64 emoff = a.em_off[ins_lo]; const i64 itime = a.ins_time[ins_lo];
+        const u32 gid = a.ins_gid[ins_lo]; const i64 emoff = a.em_off[ins_lo];
+        const i32 set_lo = a.ins_set[ins_lo]; const i64 itime = a.set_t0[set_lo];       // photon times are relative to the pulse set's origin
         const DiscTab &tab = (a.ins_type[ins_lo] == 2) ? d.tab_s2 : d.tab_s1;
-        const i64 tbase = (i64)ins_lo * nch;
+        const i64 tbase = (i64)set_lo * nch;
         const u32 jbase = (u32)(e_lo - emoff);
         u32 pw[GEN_PPT];                                      // pass B: the packed words of this thread's bucket positions, loaded up front
         if (!COUNT) {
@@ -1479,7 +1486,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
                     // every delay term of the photon in one draw from the table of their sum, relative to the instruction time
                     i64 t = wtime[slot[k]] + (i64)tab.vmin + lo[k] + (u[k] < c0[k] ? 0 : (u[k] < c1[k] ? 1 : (u[k] < c2[k] ? 2 : 3)));
                     if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-                    if (AP) ap_generate(d, a, ap, aps, j[k], gid, m[k], ins_lo, ch, is_dpe, itime, t);
+                    if (AP) ap_generate(d, a, ap, aps, j[k], gid, m[k], set_lo, ch, is_dpe, itime, t);
                     atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
                     a.ph[hbase[ch] + i] = PhotonRec{(i32)t, PW_G1(w) | (is_dpe ? (g2[k] << 16) : 0u)};
                 }
@@ -1502,15 +1509,16 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             const u32 gid = a.ins_gid[ins], j = (u32)(lo - a.em_off[ins]);
             const u32x4 A = philox4x32_10(j, gid, m, SITE_PH_A, d.k0, d.k1);
             const int ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * nch, nch, u53(A.x, A.y));
-            const i64 tile = (i64)ins * nch + ch;
+            const i32 set = a.ins_set[ins];
+            const i64 tile = (i64)set * nch + ch;
             if (COUNT) { a.ph_slot[p] = (u32)atomicAdd(&a.tile_count[tile], 1); continue; }      // the photon's slot in its tile
-            const i64 itime = a.ins_time[ins];
+            const i64 itime = a.set_t0[set];
             const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
             const bool is_dpe = (u64)A.z < d.thr_dpe;
             const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
             i64 t = a.em_time[lo] - itime + sample_disc(a.ins_type[ins] == 2 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-            if (AP) ap_generate(d, a, ap, aps, j, gid, m, ins, ch, is_dpe, itime, t);
+            if (AP) ap_generate(d, a, ap, aps, j, gid, m, set, ch, is_dpe, itime, t);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
             a.ph[a.tile_off[tile] + a.ph_slot[p]] = PhotonRec{(i32)t, g1 | (is_dpe ? (g2 << 16) : 0u)};
         }
@@ -1527,13 +1535,13 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
     }
 }
 
-// afterpulse photons -> tiles of the afterpulse pulse set of their instruction (set n_ins + ins): count, then place
+// afterpulse photons -> tiles of the afterpulse pulse set of their primary set (set n_psets + set): count, then place
 __global__ void k_ap_count(WfsDev d, GenArgs a, ApArgs ap)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
     if (i >= n) return;
-    atomicAdd(&a.tile_count[((i64)a.n_ins + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i]], 1);
+    atomicAdd(&a.tile_count[((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i]], 1);
 }
 
 __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
@@ -1541,7 +1549,7 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
     if (i >= n) return;
-    const i64 tile = ((i64)a.n_ins + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i];
+    const i64 tile = ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i];
     const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
     a.ph[pos] = PhotonRec{ap.ap_t[i], 0u}; ph_gain_base[pos] = ap.ap_gain[i];
     atomicMin(&a.tile_tmin[tile], ap.ap_t[i]); atomicMax(&a.tile_tmax[tile], ap.ap_t[i]);

@@ -130,14 +130,17 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------------------------------
-    def load_instructions(self, ins, gid, cluster, tmin, ip):
-        """ins: instruction array sorted by the scheduler key; ip: dict from physics.instruction_params."""
+    def load_instructions(self, ins, gid, cluster, tmin, ip, run_set=None):
+        """ins: instruction array sorted by the scheduler key; ip: dict from physics.instruction_params;
+        run_set: pulse set of every instruction (scheduler.run_sets), None = one set per instruction."""
         n = len(ins)
         a = [_arr(ins['type'], np.int8), _arr(ins['time'], np.int64), _arr(ins['amp'], np.int32), _arr(gid, np.uint32),
              _arr(cluster, np.int32), _arr(tmin, np.int64), _arr(ip['p_hit'], np.float64), _arr(ip['drift_mean'], np.float64),
              _arr(ip['drift_spread'], np.float64), _arr(ip['sc_gain'], np.float64), _arr(ip['cdf_row'], np.int32),
              _arr(ip['cdf_table'], np.float64)]
-        self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0])))
+        rs = _arr(run_set, np.int32) if run_set is not None else None
+        self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
+                                                   _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0)))
 
     def load_optical(self, ins, gid, cluster, tmin, channels, timings, time_cutoff):
         """ins: optical instructions (with _first/_last) sorted by time; channels/timings: the flat photon arrays"""
