@@ -180,8 +180,9 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
 /* truth accumulators per pulse set: 12 f64 (n_photon n_pe n_photon_trigger n_pe_trigger raw_area raw_area_trigger,
  * then the same for the bottom array; pulse.py:229-271) + photon time stats (n, mean, min, max, std; rawdata.py:325-332) */
 int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t capacity_sets);
-/* electron arrival-time statistics per instruction (n, mean, min, max, std; rawdata.py:325-332; NaN when there are none) */
-int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t capacity_instructions);
+/* electron arrival-time statistics per run set (= per instruction by default): n, mean, min, max, std over the electrons of
+ * all its instructions (rawdata.py:325-341; NaN when there are none) */
+int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t capacity_sets);
 
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 /* flags: bit 0 keep f64 tile currents and finished rows for wfs_copy_currents / wfs_copy_rows; bit 1 send every tile

@@ -152,6 +152,10 @@ class Oracle:
         self._noise_override = _arr(ix_rand, np.int64)
         lib().orc_set_noise_override(self._s, _p(self._noise_override), C.c_int64(len(self._noise_override)))
 
+    def set_save_full_truth(self, on):
+        """rawdata.py:42: False groups S1s within 100 ns / S2s within 2 mm into one Pulse call"""
+        lib().orc_set_save_full_truth(self._s, C.c_int(int(bool(on))))
+
     def digitize_and_zle(self, noise_gid=0):
         lib().orc_digitize_and_zle(self._s, C.c_uint32(noise_gid))
 

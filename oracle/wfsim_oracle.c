@@ -89,6 +89,7 @@ typedef struct orc_session_s {
     vec_f64 truth;
     i64 n_pe_total;
     const i64 *noise_override; i64 n_noise_override;
+    int save_full_truth;         /* rawdata.py:42: 1 (default) = every instruction is its own Pulse call */
     struct { double *cum; i64 n; i64 vmin; } tab[9];   /* trunc()-ed delay variates: the individual terms and their sums, see TAB_* */    /* tests: ix_rand per digitise call instead of the Philox draw */
 } orc_session;
 
@@ -172,7 +173,7 @@ orc_session *orc_new(const orc_config *c, const double *templates, const double 
 {
     orc_session *s = (orc_session *)calloc(1, sizeof(orc_session));
     s->c = *c; s->templates = templates; s->spe = spe; s->gains = gains; s->thr_truth = thr_truth; s->thr_zle = thr_zle;
-    s->lum_x = lum_x; s->lum_t = lum_t; s->noise = noise;
+    s->lum_x = lum_x; s->lum_t = lum_t; s->noise = noise; s->save_full_truth = 1;
     tab_normal(s, TAB_TTS, c->tts_mean, c->tts_sigma); tab_exp(s, TAB_S1_EXP, c->s1_decay_time); tab_normal(s, TAB_S1_SPREAD, 0.0, c->s1_decay_spread);
     tab_exp(s, TAB_T1, c->t1_gas); tab_exp(s, TAB_T3, c->t3_gas); tab_normal(s, TAB_S2_SPREAD, 0.0, c->s2_time_spread);
     tab_totals(s);
@@ -195,6 +196,7 @@ void orc_set_ap_element(orc_session *s, int e, int n_bins_delay, int n_bins_amp,
 }
 
 void orc_set_noise_override(orc_session *s, const i64 *ix, i64 n) { s->noise_override = ix; s->n_noise_override = n; }
+void orc_set_save_full_truth(orc_session *s, int on) { s->save_full_truth = on; }
 
 void orc_free(orc_session *s)
 {
@@ -631,7 +633,7 @@ static void sort_by_channel_and_call(orc_session *s, int kind, int runset, photo
 }
 
 /* afterpulse.py:172-249 PMT_Afterpulse.photon_afterpulse for the photons of the pulse call just made */
-static void pmt_afterpulse_call(orc_session *s, int runset, u32 gid, i64 call_index, const u32 *emitter_of, const u32 *item_of)
+static void pmt_afterpulse_call(orc_session *s, int runset, const u32 *gid_of, i64 call_index, const u32 *emitter_of, const u32 *item_of)
 {
     const orc_config *c = &s->c;
     i64 a = s->call_ph_off.p[call_index], b = s->call_ph_off.p[call_index + 1];
@@ -641,7 +643,7 @@ static void pmt_afterpulse_call(orc_session *s, int runset, u32 gid, i64 call_in
         const orc_ap_element *ap = &s->ap[e];
         for (i64 i = a; i < b; i++) {
             int ch = s->ph_ch.p[i]; u32 w[4];
-            draw(s, emitter_of[i - a], gid, item_of[i - a], SITE_AP + (u32)e, w);
+            draw(s, emitter_of[i - a], gid_of[i - a], item_of[i - a], SITE_AP + (u32)e, w);
             double rU0 = 1.0 - u53(w[0], w[1]), rU1 = 1.0 - u53(w[2], w[3]);
             const double *dc = ap->delay_cdf + (i64)ch * ap->n_bins_delay;
             double prob = dc[ap->n_bins_delay - 1];
@@ -650,7 +652,7 @@ static void pmt_afterpulse_call(orc_session *s, int runset, u32 gid, i64 call_in
             if (!(rU0 <= prob)) continue;
             double delay, amp;
             if (ap->is_uniform) {
-                u32 x[4]; draw(s, emitter_of[i - a], gid, item_of[i - a], SITE_AP_X + (u32)e, x);
+                u32 x[4]; draw(s, emitter_of[i - a], gid_of[i - a], item_of[i - a], SITE_AP_X + (u32)e, x);
                 double lo = dc[0], hi = dc[1];
                 delay = (lo + (hi - lo) * u53(x[0], x[1])) * ap->delay_bin; amp = 1.0;
             } else {
@@ -673,43 +675,38 @@ static void pmt_afterpulse_call(orc_session *s, int runset, u32 gid, i64 call_in
     free(pb.t.p); free(pb.ch.p); free(pb.dpe.p); free(pb.gain.p);
 }
 
-/* s1.py:60-114 S1.__call__ (model 'simple'), one instruction = one run-set.  Returns photons generated. */
-i64 orc_s1(orc_session *s, u32 gid, int runset, i64 time, i64 amp, double p_hit, const double *cdf)
+/* One Pulse call can cover several instructions (save_full_truth=False groups them, rawdata.py:108-127): the photons of
+ * the instructions are appended in instruction order (s1.py:95-103 / s2.py:107-136 loop over the instruction array) and
+ * every photon remembers its Philox coordinates (gid, emitter, item) for the afterpulse stage. */
+typedef struct { photon_buf pb; vec_i64 gid, em, it; } call_ctx;
+static void ctx_push(call_ctx *x, i64 t, int ch, int dpe, double g, u32 gid, i64 em, i64 it)
+{
+    VEC_PUSH(x->pb.t, i64, t); VEC_PUSH(x->pb.ch, int16_t, (int16_t)ch); VEC_PUSH(x->pb.dpe, uint8_t, (uint8_t)dpe); VEC_PUSH(x->pb.gain, double, g);
+    VEC_PUSH(x->gid, i64, (i64)gid); VEC_PUSH(x->em, i64, em); VEC_PUSH(x->it, i64, it);
+}
+/* s1.py:117-238 for one instruction: Binomial(amp, ly) hits as Bernoulli trials, then one_photon() each */
+static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, double p_hit, const double *cdf)
 {
     u64 T = bern_threshold(p_hit); i64 n_hits = 0; u32 w[4];
     for (i64 j = 0; j < amp; j++) {                   /* s1.py:133 Binomial(amp, ly) as a sum of Bernoulli trials */
         if ((j & 3) == 0) draw(s, 0, gid, (u32)(j >> 2), SITE_S1_HIT, w);
         n_hits += (u64)w[j & 3] < T;
     }
-    photon_buf pb; memset(&pb, 0, sizeof pb);
-    u32 *em = (u32 *)malloc((size_t)(n_hits ? n_hits : 1) * 4), *it = (u32 *)malloc((size_t)(n_hits ? n_hits : 1) * 4);
     for (i64 k = 0; k < n_hits; k++) {
         i64 t; int ch, dpe; double g;
         one_photon(s, 0, 0, gid, (u32)k, time, cdf, &t, &ch, &dpe, &g);
-        VEC_PUSH(pb.t, i64, t); VEC_PUSH(pb.ch, int16_t, (int16_t)ch); VEC_PUSH(pb.dpe, uint8_t, (uint8_t)dpe); VEC_PUSH(pb.gain, double, g);
+        ctx_push(x, t, ch, dpe, g, gid, 0, k);
     }
-    /* remember (emitter,item) in channel-sorted order for the afterpulse stage */
-    i64 n = n_hits; i64 *key = (i64 *)malloc((size_t)(n ? n : 1) * 8);
-    for (i64 i = 0; i < n; i++) key[i] = ((i64)pb.ch.p[i] << 40) | i;
-    qsort(key, (size_t)n, 8, cmp_ch_stable);
-    for (i64 i = 0; i < n; i++) { em[i] = 0; it[i] = (u32)(key[i] & ((1ll << 40) - 1)); }
-    i64 call = s->call_kind.n;
-    sort_by_channel_and_call(s, 1, runset, &pb, 0);
-    if (s->c.enable_pmt_ap) pmt_afterpulse_call(s, runset, gid, call, em, it);
-    free(key); free(em); free(it); free(pb.t.p); free(pb.ch.p); free(pb.dpe.p); free(pb.gain.p);
     return n_hits;
 }
-
-/* s2.py:73-136 S2.__call__ (luminescence 'simple'), one instruction.  Candidate electron j < amp survives with
+/* s2.py:73-136 S2.__call__ (luminescence 'simple') for one instruction.  Candidate electron j < amp survives with
  * probability cy (s2.py:254 Binomial as Bernoulli trials); survivors draw s2.py:280-282 arrival time and
  * s2.py:308-310 photon count; photons as one_photon(). */
-i64 orc_s2(orc_session *s, u32 gid, int runset, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
-           double sc_gain, const double *cdf)
+static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
+                  double sc_gain, const double *cdf)
 {
     const orc_config *c = &s->c;
-    u64 T = bern_threshold(cy); u32 w[4];
-    photon_buf pb; memset(&pb, 0, sizeof pb);
-    vec_i64 em = {0}, it = {0};
+    u64 T = bern_threshold(cy); u32 w[4]; i64 n0 = x->pb.t.n;
     for (i64 j = 0; j < amp; j++) {
         if ((j & 3) == 0) draw(s, 0, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);
         if (!((u64)w[j & 3] < T)) continue;
@@ -727,20 +724,25 @@ i64 orc_s2(orc_session *s, u32 gid, int runset, i64 time, i64 amp, double cy, do
         for (i64 m = 0; m < nph; m++) {
             i64 t; int ch, dpe; double g;
             one_photon(s, 1, (u32)j, gid, (u32)m, et, cdf, &t, &ch, &dpe, &g);
-            VEC_PUSH(pb.t, i64, t); VEC_PUSH(pb.ch, int16_t, (int16_t)ch); VEC_PUSH(pb.dpe, uint8_t, (uint8_t)dpe); VEC_PUSH(pb.gain, double, g);
-            VEC_PUSH(em, i64, j); VEC_PUSH(it, i64, m);
+            ctx_push(x, t, ch, dpe, g, gid, j, m);
         }
     }
-    i64 n = pb.t.n; i64 *key = (i64 *)malloc((size_t)(n ? n : 1) * 8);
-    u32 *em2 = (u32 *)malloc((size_t)(n ? n : 1) * 4), *it2 = (u32 *)malloc((size_t)(n ? n : 1) * 4);
-    for (i64 i = 0; i < n; i++) key[i] = ((i64)pb.ch.p[i] << 40) | i;
-    qsort(key, (size_t)n, 8, cmp_ch_stable);
-    for (i64 i = 0; i < n; i++) { i64 q = key[i] & ((1ll << 40) - 1); em2[i] = (u32)em.p[q]; it2[i] = (u32)it.p[q]; }
+    return x->pb.t.n - n0;
+}
+/* the Pulse call over the collected photons (+ its PMT afterpulse call, rawdata.py:176-178) */
+static void finish_call(orc_session *s, int kind, int runset, call_ctx *x)
+{
+    i64 n = x->pb.t.n; i64 *key = (i64 *)malloc((size_t)(n ? n : 1) * 8);
+    u32 *g2 = (u32 *)malloc((size_t)(n ? n : 1) * 4), *em2 = (u32 *)malloc((size_t)(n ? n : 1) * 4), *it2 = (u32 *)malloc((size_t)(n ? n : 1) * 4);
+    for (i64 i = 0; i < n; i++) key[i] = ((i64)x->pb.ch.p[i] << 40) | i;
+    qsort(key, (size_t)n, 8, cmp_ch_stable);            /* channel-sorted order, as Pulse.__call__ sees the photons */
+    for (i64 i = 0; i < n; i++) { i64 q = key[i] & ((1ll << 40) - 1); g2[i] = (u32)x->gid.p[q]; em2[i] = (u32)x->em.p[q]; it2[i] = (u32)x->it.p[q]; }
     i64 call = s->call_kind.n;
-    sort_by_channel_and_call(s, 2, runset, &pb, 0);
-    if (c->enable_pmt_ap) pmt_afterpulse_call(s, runset, gid, call, em2, it2);
-    free(key); free(em2); free(it2); free(em.p); free(it.p); free(pb.t.p); free(pb.ch.p); free(pb.dpe.p); free(pb.gain.p);
-    return n;
+    sort_by_channel_and_call(s, kind, runset, &x->pb, 0);
+    if (s->c.enable_pmt_ap) pmt_afterpulse_call(s, runset, g2, call, em2, it2);
+    free(key); free(g2); free(em2); free(it2);
+    free(x->pb.t.p); free(x->pb.ch.p); free(x->pb.dpe.p); free(x->pb.gain.p); free(x->gid.p); free(x->em.p); free(x->it.p);
+    memset(x, 0, sizeof *x);
 }
 
 /* rawdata.py:475-493 RawDataOptical.sim_primary for one instruction: supplied photons (ns relative to the instruction,
@@ -824,13 +826,21 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
             orc_digitize_and_zle(s, gid[ord[group_start].i]);    /* rawdata.py:96-98 */
             group_start = a;
         }
-        for (int ptype = 1; ptype <= 2; ptype++)
+        for (int ptype = 1; ptype <= 2; ptype++) {
+            /* run sets (rawdata.py:108-122): every instruction on its own, or -- save_full_truth off -- S1s whose keys are
+             * at most 100 ns apart / S2s at most int(0.2 / v) ns apart in one Pulse call */
+            const i64 gap = ptype == 1 ? 100 : (i64)(0.2 / c->drift_velocity);
+            call_ctx x; memset(&x, 0, sizeof x); int open = 0; i64 last_key = 0;
             for (i64 k = a; k < b; k++) {
                 i64 i = ord[k].i; if (type[i] != ptype) continue;
+                if (open && (s->save_full_truth || ord[k].t - last_key > gap)) { finish_call(s, ptype, runset++, &x); open = 0; }
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
-                if (ptype == 1) orc_s1(s, gid[i], runset++, time[i], amp[i], p_hit[i], cdf);
-                else orc_s2(s, gid[i], runset++, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+                if (ptype == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
+                else gen_s2(s, &x, gid[i], time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+                open = 1; last_key = ord[k].t;
             }
+            if (open) finish_call(s, ptype, runset++, &x);
+        }
         a = b;
     }
     orc_digitize_and_zle(s, gid[ord[group_start].i]);         /* rawdata.py:154-155 */

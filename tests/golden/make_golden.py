@@ -435,6 +435,20 @@ def fixture_chain_params(ref):
         json.dump({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in ov.items()}, f)
 
 
+def fixture_chain_runsets(ref):
+    """chain G: save_full_truth=False -- S1s within 100 ns and S2s within int(0.2 / v) ns of each other share one
+    Pulse call and one truth row (rawdata.py:106-127, 364-372)"""
+    pat = dict(s1=SyntheticPatternMap(14e-5, 30.0, 18.0, 0.15), s2=SyntheticPatternMap(30e-5, 9.0, 25.0, 0.02))
+    MS = 1_000_000
+    rows = [dict(type=1, time=MS, x=1, y=2, z=-10, amp=900), dict(type=1, time=MS + 50, x=3, y=-2, z=-12, amp=700),
+            dict(type=1, time=MS + 120, x=-5, y=0, z=-11, amp=500), dict(type=1, time=MS + 400, x=9, y=9, z=-10, amp=1100),
+            dict(type=2, time=MS, x=1, y=2, z=-10.0, amp=60), dict(type=2, time=MS + 50, x=3, y=-2, z=-10.1, amp=40),
+            dict(type=2, time=MS + 120, x=-5, y=0, z=-10.5, amp=30),
+            dict(type=1, time=3 * MS, x=0, y=0, z=-30, amp=2000), dict(type=2, time=3 * MS, x=0, y=0, z=-30, amp=100)]
+    np.savez_compressed(HERE + '/chain_runsets.npz',
+                        **run_chain(ref, base_config(save_full_truth=False), make_instructions(rows), 707, pat))
+
+
 def hist(x):
     v, c = np.unique(np.asarray(x, dtype=np.int64), return_counts=True)
     return v.astype(np.int64), c.astype(np.int64)
@@ -522,6 +536,8 @@ if __name__ == '__main__':
         fixture_chains(ref)
     if 'chains' in which or 'params' in which:
         fixture_chain_params(ref)
+    if 'chains' in which or 'runsets' in which:
+        fixture_chain_runsets(ref)
     if 'dists' in which:
         fixture_distributions(ref)
     if 'stats' in which:

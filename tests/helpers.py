@@ -47,7 +47,9 @@ def ap_tables_from_golden():
 
 def make_oracle(config, ap_tables=None):
     from oracle.oracle import Oracle
-    return Oracle(kernel_params(config), host_tables(config), ap_tables)
+    orc = Oracle(kernel_params(config), host_tables(config), ap_tables)
+    orc.set_save_full_truth(config.get('save_full_truth', True))
+    return orc
 
 
 def replay_chain_on_oracle(orc, d):

@@ -42,7 +42,9 @@ def _run_both(cfg, ins, seed=7, ap=None):
     orc.simulate(s_ins, gid, ip)
     o = orc.results()
     eng = make_engine(cfg)
-    eng.load_instructions(s_ins, gid, cluster, key, ip)
+    from wfsim_amd.scheduler import run_sets
+    rs = None if cfg.get('save_full_truth', True) else run_sets(s_ins, key, cluster, cfg)[0]
+    eng.load_instructions(s_ins, gid, cluster, key, ip, run_set=rs)
     counts = eng.run()
     return orc, o, eng, counts, s_ins
 
@@ -129,6 +131,52 @@ def test_tiles_above_one_register_batch():
     kbig = int(np.argmax(tr[:, 0]))
     for j in (0, 1, 2, 4, 5, 6, 7, 8, 10, 11):          # all but n_pe_trigger(_bottom): order dependent (pulse.py:255)
         assert np.isclose(acc[big, j], tr[kbig, j], rtol=1e-9), j
+
+
+def test_run_sets_several_instructions_per_pulse_call():
+    """save_full_truth=False: S1s within 100 ns / S2s within 2 mm share one Pulse call (rawdata.py:106-127): tiles are
+    per (run set, channel), photons of the grouped instructions merge into the same pulses; PMT afterpulses follow the set"""
+    from tests.helpers import golden, ap_tables_from_golden
+    from wfsim_amd.scheduler import run_sets
+    cfg = xenonnt_test_config(save_full_truth=False)
+    rows = [dict(type=1, time=MS, x=1, y=2, z=-10, amp=900), dict(type=1, time=MS + 50, x=3, y=-2, z=-12, amp=700),
+            dict(type=1, time=MS + 120, x=-5, y=0, z=-11, amp=500), dict(type=1, time=MS + 400, x=9, y=9, z=-10, amp=1100),
+            dict(type=2, time=MS, x=1, y=2, z=-10.0, amp=160), dict(type=2, time=MS + 50, x=3, y=-2, z=-10.1, amp=140),
+            dict(type=2, time=MS + 120, x=-5, y=0, z=-10.5, amp=130),
+            dict(type=1, time=3 * MS, x=0, y=0, z=-30, amp=2000), dict(type=2, time=3 * MS, x=0, y=0, z=-30, amp=100),
+            dict(type=2, time=3 * MS + 700, x=4, y=0, z=-30, amp=5000)]        # a big S2 sharing its set with a small one
+    for ap in (None, ap_tables_from_golden()):
+        orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows), seed=9, ap=ap)
+        order, key, cluster = schedule(s_ins, cfg)
+        rs, n_sets = run_sets(s_ins, key, cluster, cfg)
+        assert n_sets == 6 and counts['n_pulse_sets'] == (12 if ap else 6)
+        prim = o['call_kind'] != 3
+        assert prim.sum() == n_sets
+        # photons per pulse set: oracle calls are in processing order = set numbering
+        ph = eng.photons()
+        k_set = 0
+        for k, kind in enumerate(o['call_kind']):
+            i = (n_sets + k_set - 1) if kind == 3 else k_set
+            if kind != 3:
+                k_set += 1
+            a, b = o['call_ph_off'][k], o['call_ph_off'][k + 1]
+            c, e = ph['set_off'][i], ph['set_off'][i + 1]
+            assert b - a == e - c
+            ko = np.lexsort((o['ph_gain'][a:b], o['ph_t'][a:b], o['ph_ch'][a:b]))
+            kg = np.lexsort((ph['gain'][c:e], ph['t'][c:e], ph['ch'][c:e]))
+            assert np.array_equal(o['ph_t'][a:b][ko], ph['t'][c:e][kg]) and np.array_equal(o['ph_ch'][a:b][ko], ph['ch'][c:e][kg])
+            assert np.array_equal(o['ph_gain'][a:b][ko], ph['gain'][c:e][kg])
+        assert eng.records().tobytes() == orc.pack_records().tobytes()
+        assert counts['n_pe'] == orc.n_pe
+        # electron statistics per run set
+        es = eng.electron_stats()
+        assert len(es) == n_sets
+        ks = [k for k, kind in enumerate(o['call_kind']) if kind != 3]
+        for q, k in enumerate(ks):
+            et = o['e_t'][o['call_e_off'][k]:o['call_e_off'][k + 1]]
+            if o['call_kind'][k] == 2:
+                assert es[q, 0] == len(et) and es[q, 2] == et.min() and es[q, 3] == et.max()
+                assert abs(es[q, 1] - et.mean()) < 1e-3 and abs(es[q, 4] - et.std()) < 1e-3
 
 
 def test_small_poisson_mean_and_gain_spread():

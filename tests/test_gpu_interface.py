@@ -167,3 +167,28 @@ def test_per_pmt_truth_against_oracle():
         assert np.isclose(r['raw_area'], r['raw_area_per_pmt'].sum(), rtol=1e-9)
         assert np.isclose(r['raw_area_trigger'], r['raw_area_trigger_per_pmt'].sum(), rtol=1e-9)
         assert np.all(r['n_photon_trigger_per_pmt'] <= r['n_photon_per_pmt'])
+
+
+def test_truth_rows_of_run_sets_match_reference_summary():
+    """save_full_truth=False through ChunkRawRecords: one truth row per run set with the reference's summary of the
+    grouped instructions (rawdata.py:364-372: mean x/y/z, summed amp, the rest from the first instruction) --
+    against the truth rows the reference wrote for the same instructions (golden chain G)"""
+    from tests.helpers import golden
+    d = golden('chain_runsets.npz')
+    cfg = xenonnt_test_config(seed=3, save_full_truth=False)
+    sim = wfsim_amd.ChunkRawRecords(cfg)
+    truth = np.concatenate([c['truth'] for c in sim(d['instructions'])])
+    ref = d['truth']
+    assert len(truth) == len(ref) == 6
+    for f in ['type', 'amp', 'event_number', 'recoil', 'g4id' if 'g4id' in ref.dtype.names else 'type']:
+        assert np.array_equal(np.sort(truth[f]), np.sort(ref[f])), f
+    key = lambda r: (int(r['type']), int(r['amp']), int(r['event_number']))
+    got = {key(r): r for r in truth}
+    for r in ref:
+        g = got[key(r)]
+        for f in ['x', 'y', 'z']:
+            assert np.isclose(g[f], r[f]), f
+        # photon / electron counts are random variates: same distribution (Poisson-ish), compared loosely
+        assert abs(g['n_photon'] - r['n_photon']) < 6 * np.sqrt(r['n_photon'] + 25)
+        if r['type'] == 2:
+            assert abs(g['n_electron'] - r['n_electron']) < 6 * np.sqrt(r['n_electron'] + 9)

@@ -132,3 +132,42 @@ def test_chain_noise():
     assert np.array_equal(r['row_data'], d['row_data'])
     for k in ['ch', 'left', 'right', 'data']:
         assert np.array_equal(r['zl_' + k], d['zle_' + k]), k
+
+
+def test_run_sets_grouping_matches_reference():
+    """save_full_truth=False (rawdata.py:106-127): golden chain G.  The host scheduler's run sets and the oracle's own
+    scheduler group the instructions as the reference did (one Pulse call and one truth row per group); the merged
+    calls replay bit-exact."""
+    from wfsim_amd.scheduler import schedule, run_sets
+    from wfsim_amd.physics import instruction_params
+    from wfsim_amd.resource import Resource
+    cfg = xenonnt_test_config(save_full_truth=False)
+    d, r, orc = _check_chain('chain_runsets.npz', cfg)
+    assert np.array_equal(r['row_data'], d['row_data'])
+    ins = d['instructions']
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    rs, n_sets = run_sets(s_ins, key, cluster, cfg)
+    assert n_sets == len(d['call_kind']) == 6
+    ref_truth = d['truth']
+    for q in range(n_sets):
+        m = np.where(rs == q)[0]
+        row = ref_truth[q]                                   # the reference fills truth rows in processing order
+        assert s_ins['type'][m[0]] == d['call_kind'][q] == row['type']
+        assert row['amp'] == s_ins['amp'][m].sum()
+        assert np.isclose(row['x'], s_ins['x'][m].mean()) and np.isclose(row['z'], s_ins['z'][m].mean())
+        assert row['time'] == s_ins['time'][m[0]] and row['event_number'] == s_ins['event_number'][m[0]]
+    assert [int((rs == q).sum()) for q in range(n_sets)] == [3, 1, 2, 1, 1, 1]
+    # with save_full_truth every instruction is a set of its own, numbered in processing order
+    rs1, n1 = run_sets(s_ins, key, cluster, xenonnt_test_config())
+    assert n1 == len(ins) and sorted(rs1.tolist()) == list(range(len(ins)))
+    # the oracle's own scheduler makes the same calls
+    o2 = make_oracle(cfg)
+    o2.simulate(s_ins, order.astype(np.uint32), instruction_params(s_ins, cfg, Resource(cfg)))
+    res = o2.results()
+    assert np.array_equal(res['call_kind'], d['call_kind'])
+    o3 = make_oracle(xenonnt_test_config())
+    o3.simulate(s_ins, order.astype(np.uint32), instruction_params(s_ins, xenonnt_test_config(), Resource(xenonnt_test_config())))
+    assert len(o3.results()['call_kind']) == len(ins)
+    # grouping does not change the photons (same Philox coordinates), only which call they belong to
+    assert len(res['ph_t']) == len(o3.results()['ph_t'])

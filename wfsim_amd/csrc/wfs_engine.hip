@@ -59,6 +59,7 @@ struct wfs_handle {
     std::vector<double> h_gains;
     i64 zero64 = 0;
     DevBuf tt_cum[6], tt_guide[6];
+    std::vector<i64> h_rs_off; std::vector<i32> h_rs_list;        // run set -> instructions (host copy)
     std::vector<double> h_lum_x, h_lum_t;          // luminescence table (host copy, enters the S2 delay table)
     DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
 
@@ -480,6 +481,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     h->ap_active = h->cfg.enable_pmt_ap && h->dev.n_ap > 0;
     const i64 S = h->ap_active ? 2 * PS : PS;
     h->n_ins = n; h->n_psets = PS; h->n_sets = S; h->n_emitters = em_off[n]; h->n_tiles = S * h->cfg.n_tpc;
+    h->h_rs_off = set_off; h->h_rs_list = set_list;
     if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
     TRY(upload(h, h->ins_type, type, (size_t)n)); TRY(upload(h, h->ins_time, time, (size_t)n * 8)); TRY(upload(h, h->ins_amp, amp, (size_t)n * 4));
     TRY(upload(h, h->ins_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_p, p_hit, (size_t)n * 8)); TRY(upload(h, h->ins_dm, drift_mean, (size_t)n * 8));
@@ -1137,18 +1139,28 @@ int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t cap)
     if (!h || !h->ran) return WFS_E_STATE;
     const i64 N = h->n_ins;
     if (h->optical) { for (i64 i = 0; i < N && i < cap; i++) { estat5[i * 5] = 0; for (int q = 1; q < 5; q++) estat5[i * 5 + q] = NAN; } return WFS_OK; }
-    if (cap < N) return h->fail(WFS_E_CAPACITY, "electron stats buffer too small");
+    const i64 PS = h->n_psets;
+    if (cap < PS) return h->fail(WFS_E_CAPACITY, "electron stats buffer too small");
     if (N == 0) return WFS_OK;
     std::vector<double> st((size_t)N * 4); std::vector<i64> mm((size_t)N * 2), t0((size_t)N);
     HIPCHK(hipMemcpy(st.data(), h->el_stat.p, st.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(mm.data(), h->el_minmax.p, mm.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(t0.data(), h->ins_time.p, t0.size() * 8, hipMemcpyDeviceToHost));
-    for (i64 i = 0; i < N; i++) {
-        double n = st[i * 4], s1 = st[i * 4 + 1], s2 = st[i * 4 + 2];
+    for (i64 q = 0; q < PS; q++) {
+        // moments of the electrons of all instructions of the run set (rawdata.py:334-341), about the first instruction's time
+        const i64 ref = t0[h->h_rs_list[h->h_rs_off[q]]];
+        double n = 0, s1 = 0, s2 = 0; i64 lo = I64_MAX, hi = I64_MIN;
+        for (i64 k = h->h_rs_off[q]; k < h->h_rs_off[q + 1]; k++) {
+            const i64 i = h->h_rs_list[k];
+            const double ni = st[i * 4], a1 = st[i * 4 + 1], a2 = st[i * 4 + 2], dlt = (double)(t0[i] - ref);
+            if (!(ni > 0)) continue;
+            n += ni; s1 += a1 + ni * dlt; s2 += a2 + 2 * dlt * a1 + ni * dlt * dlt;
+            lo = std::min(lo, mm[2 * i]); hi = std::max(hi, mm[2 * i + 1]);
+        }
         double mean = n > 0 ? s1 / n : 0, var = n > 0 ? s2 / n - mean * mean : 0;
-        estat5[i * 5 + 0] = n; estat5[i * 5 + 1] = n > 0 ? (double)t0[i] + mean : NAN;
-        estat5[i * 5 + 2] = n > 0 ? (double)mm[2 * i] : NAN; estat5[i * 5 + 3] = n > 0 ? (double)mm[2 * i + 1] : NAN;
-        estat5[i * 5 + 4] = n > 0 ? sqrt(var > 0 ? var : 0) : NAN;
+        estat5[q * 5 + 0] = n; estat5[q * 5 + 1] = n > 0 ? (double)ref + mean : NAN;
+        estat5[q * 5 + 2] = n > 0 ? (double)lo : NAN; estat5[q * 5 + 3] = n > 0 ? (double)hi : NAN;
+        estat5[q * 5 + 4] = n > 0 ? sqrt(var > 0 ? var : 0) : NAN;
     }
     return WFS_OK;
 }

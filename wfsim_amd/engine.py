@@ -139,6 +139,7 @@ class Engine:
              _arr(ip['drift_spread'], np.float64), _arr(ip['sc_gain'], np.float64), _arr(ip['cdf_row'], np.int32),
              _arr(ip['cdf_table'], np.float64)]
         rs = _arr(run_set, np.int32) if run_set is not None else None
+        self._n_run_sets = (int(rs.max()) + 1 if len(rs) else 0) if rs is not None else n
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
                                                    _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0)))
 
@@ -256,7 +257,10 @@ class Engine:
         return g
 
     def electron_stats(self):
-        n = self.counts['n_instructions']
+        """per run set (= per instruction unless run sets were given): n, mean, min, max, std of the electron times"""
+        n = getattr(self, '_n_run_sets', None)
+        if n is None or self.counts['n_instructions'] == 0:
+            n = self.counts['n_instructions']
         es = np.zeros((n, 5))
         if n:
             self._check(self.lib.wfs_copy_electron_stats(self._h, _p(es), C.c_int64(n)))

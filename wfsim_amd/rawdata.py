@@ -21,7 +21,7 @@ from .dtypes import raw_record_dtype
 from .engine import Engine
 from .physics import instruction_params
 from .resource import Resource
-from .scheduler import schedule, processing_order
+from .scheduler import schedule, processing_order, run_sets
 
 log = logging.getLogger('wfsim_amd.core')
 
@@ -37,9 +37,6 @@ class RawData:
         if config.get('enable_electron_afterpulses', False) or config.get('enable_gate_afterpulses', False):
             raise NotImplementedError('electron afterpulses (secondary instructions, afterpulse.py:14-139) are not on '
                                       'the MI355X path yet (SURVEY.md 8f.1)')
-        if not config.get('save_full_truth', True):
-            raise NotImplementedError('save_full_truth=False (several instructions per Pulse call, rawdata.py:108-122) is not on '
-                                      'the MI355X path: every instruction is its own pulse set')
         self.resource = resource if resource is not None else Resource(config)
         self.engine = Engine(config, self.resource, device=device, seed=seed)
         self.source_finished = False
@@ -109,12 +106,12 @@ class RawData:
                         scale *= 2
                         continue
                     n_emit, b = g_last, restart
-            proc = processing_order(ins, np.arange(len(ins)), cl)
-            truth_rows = self._truth_rows(ins) if len(truth_buffer) else None
+            truth_rows = self._truth_rows(ins, cl) if len(truth_buffer) else None      # one per run set, in processing order
             for g in range(n_emit):
                 if truth_rows is not None:
-                    for i in proc[ins_group[proc] == g]:
-                        self._write_truth(truth_rows[i], truth_buffer)
+                    for r in truth_rows:
+                        if ins_group[r['first']] == g:
+                            self._write_truth(r, truth_buffer)
                 if not nonempty[g]:
                     continue
                 has_pulse, runmax = True, (max(runmax, int(ends[g])) if has_pulse else int(ends[g]))
@@ -131,26 +128,43 @@ class RawData:
 
     def _load_batch(self, ins, gid, cl, key):
         ip = instruction_params(ins, self.config, self.resource)
-        self.engine.load_instructions(ins, gid, cl, key, ip)
+        # one pulse set per instruction, or -- save_full_truth off -- per group of nearby S1s / S2s (rawdata.py:106-127)
+        self._run_set = None if self.config.get('save_full_truth', True) else run_sets(ins, key, cl, self.config)[0]
+        self.engine.load_instructions(ins, gid, cl, key, ip, run_set=self._run_set)
 
     # ---- truth (rawdata.py:313-375) ----------------------------------------------------------------
-    def _truth_rows(self, ins):
+    def _truth_rows(self, ins, cl):
         acc, ts = self.engine.truth()
         es = self.engine.electron_stats()
         per_pmt = self.engine.truth_per_pmt() if self.config.get('per_pmt_truth', False) else None      # pulse.py:62-66
-        rows = []
         names = ['n_photon', 'n_pe', 'n_photon_trigger', 'n_pe_trigger', 'raw_area', 'raw_area_trigger']
-        for i in range(len(ins)):
-            r = {}
-            n_ph = ts[i, 0]
-            r['n_photon_t'] = (n_ph, ts[i, 1], ts[i, 2], ts[i, 3], ts[i, 4])
-            r['electron'] = tuple(es[i]) if ins['type'][i] == 2 else (0, np.nan, np.nan, np.nan, np.nan)
+        run_set = getattr(self, '_run_set', None)
+        if run_set is None:
+            # every instruction is its own pulse set (set index = position in the sorted batch); rows in processing order
+            members = [[int(i)] for i in processing_order(ins, np.arange(len(ins)), cl)]
+            set_ids = [m[0] for m in members]
+        else:
+            order = np.argsort(run_set, kind='stable')
+            cuts = np.where(np.diff(run_set[order]) != 0)[0] + 1
+            members = [m.tolist() for m in np.split(order, cuts)] if len(order) else []
+            set_ids = [int(run_set[m[0]]) for m in members]
+        rows = []
+        for q, m in zip(set_ids, members):
+            r = {'first': m[0]}
+            r['n_photon_t'] = (ts[q, 0], ts[q, 1], ts[q, 2], ts[q, 3], ts[q, 4])
+            r['electron'] = tuple(es[q]) if ins['type'][m[0]] % 2 == 0 else (0, np.nan, np.nan, np.nan, np.nan)
             for j, f in enumerate(names):
-                r[f] = acc[i, j]
-                r[f + '_bottom'] = acc[i, 6 + j]
+                r[f] = acc[q, j]
+                r[f + '_bottom'] = acc[q, 6 + j]
                 if per_pmt is not None:
-                    r[f + '_per_pmt'] = per_pmt[i, :, j]
-            r['instruction'] = ins[i]
+                    r[f + '_per_pmt'] = per_pmt[q, :, j]
+            # rawdata.py:364-372: the run set in one row -- mean position, summed amp, everything else from its first instruction
+            row = ins[m[0]].copy()
+            if len(m) > 1:
+                for f in ('x', 'y', 'z'):
+                    row[f] = np.mean(ins[f][m])
+                row['amp'] = np.sum(ins['amp'][m])
+            r['instruction'] = row
             rows.append(r)
         return rows
 

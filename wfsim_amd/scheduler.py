@@ -33,3 +33,29 @@ def processing_order(instructions, order, cluster):
         for ptype in (1, 2, 4, 6):
             out.extend(idx[typ[idx] == ptype].tolist())
     return np.asarray(out, dtype=np.int64)
+
+
+def run_sets(s_ins, key, cluster, config):
+    """Pulse set ("run set") of every sorted instruction: the instructions the reference hands to one Pulse call
+    (rawdata.py:106-127).  With ``save_full_truth`` (the default) every instruction is its own set; without it S1s
+    whose keys are at most 100 ns apart and S2s at most ``int(0.2 / v)`` ns apart (2 mm of drift) share a set.
+    Sets are numbered in processing order (cluster, S1 sets, then S2 sets).  Returns (run_set int32[n], n_sets)."""
+    n = len(s_ins)
+    out = np.zeros(n, dtype=np.int32)
+    full = config.get('save_full_truth', True)
+    gaps = {1: 100, 2: int(0.2 / config['drift_velocity_liquid'])}
+    typ = s_ins['type']
+    k = 0
+    bounds = np.concatenate([[0], np.where(np.diff(cluster) != 0)[0] + 1, [n]]) if n else np.zeros(1, dtype=np.int64)
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        for ptype in (1, 2, 4, 6):
+            idx = np.arange(a, b)[typ[a:b] == ptype]
+            if len(idx) == 0:
+                continue
+            if full or ptype not in gaps:
+                new = np.ones(len(idx), dtype=bool) if ptype in gaps else np.concatenate([[True], np.zeros(len(idx) - 1, dtype=bool)])
+            else:
+                new = np.concatenate([[True], np.diff(key[idx]) > gaps[ptype]])
+            out[idx] = k + np.cumsum(new) - 1
+            k += int(new.sum())
+    return out, k
