@@ -108,12 +108,15 @@ int wfs_set_ap_element(wfs_handle *h, int32_t element, int32_t n_bins_delay, int
  *   run_set i32 (or NULL), n_run_sets       pulse set of every instruction: the instructions the reference hands to ONE
  *                                           Pulse call (rawdata.py:108-127; save_full_truth=False groups S1s within 100 ns
  *                                           and S2s within 2 mm).  Sets are numbered 0..n_run_sets-1; their instructions
- *                                           share cluster and type.  NULL: one set per instruction (the default). */
+ *                                           share cluster and type.  NULL: one set per instruction (the default).
+ *   em_base u32 (or NULL)                   offset of the instruction's emitter ids in the Philox counters: an electron-
+ *                                           afterpulse instruction carries its parent's gid and (k + 1) << 20 for the k-th
+ *                                           secondary of that parent (streams independent of batching / sharding) */
 int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const int64_t *time, const int32_t *amp,
                           const uint32_t *gid, const int32_t *cluster, const int64_t *tmin,
                           const double *p_hit, const double *drift_mean, const double *drift_spread,
                           const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf,
-                          const int32_t *run_set, int64_t n_run_sets);
+                          const int32_t *run_set, int64_t n_run_sets, const uint32_t *em_base);
 
 /* Parity entry: photons supplied instead of generated -- what RawDataOptical.sim_primary hands to Pulse
  * (rawdata.py:475-493) and what the golden vectors inject.  One "pulse set" = one Pulse.__call__ (pulse.py:39).
@@ -147,6 +150,14 @@ typedef struct wfs_counts {
             n_raw_samples, n_intervals, n_records;
 } wfs_counts;
 int wfs_get_counts(wfs_handle *h, wfs_counts *out);
+
+/* Electron afterpulses need, per parent S2, the number of detected photons and the arrival times of randomly chosen ones
+ * (afterpulse.py:37-47, 106-121: len(signal_pulse._photon_timings), _photon_timings[randint]).
+ * off[n + 1]: first generated photon of every instruction (generation order: instruction by instruction, emitter by
+ * emitter); index: photons in that numbering, t_out: their arrival times in ns (recomputed from the photon's own draws,
+ * so the answer does not depend on the order inside the channel buckets).  After wfs_run (also with debug bit 2). */
+int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t capacity);
+int wfs_gather_photon_times(wfs_handle *h, int64_t n, const int64_t *index, int64_t *t_out);
 
 /* Per-PMT truth (config 'per_pmt_truth', pulse.py:61-66, 268-269): acc6[set][channel][6] = n_photon, n_pe, n_photon_trigger,
  * n_pe_trigger, raw_area, raw_area_trigger of every pulse set and TPC channel.  cap = sets the buffer holds. */
@@ -186,7 +197,8 @@ int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t capacity_sets
 
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 /* flags: bit 0 keep f64 tile currents and finished rows for wfs_copy_currents / wfs_copy_rows; bit 1 send every tile
- * to the dense pulse kernel (both kernels give the same bits; used by the parity tests) */
+ * to the dense pulse kernel (both kernels give the same bits; used by the parity tests); bit 2 wfs_run stops after the
+ * photon generation (enough for wfs_copy_set_photon_counts / wfs_gather_photon_times: the electron-afterpulse pre-pass) */
 int wfs_set_debug(wfs_handle *h, int32_t flags);
 /* parity tests: noise start index per digitise window (rawdata.py:417) instead of the Philox draw; entries < 0 keep the draw.
  * Indexed by the window number of wfs_copy_groups (host pointer, copied). n = 0 clears the override. */

@@ -159,7 +159,7 @@ class Oracle:
     def digitize_and_zle(self, noise_gid=0):
         lib().orc_digitize_and_zle(self._s, C.c_uint32(noise_gid))
 
-    def simulate(self, instructions, gid, ip):
+    def simulate(self, instructions, gid, ip, em_base=None):
         n = len(instructions)
         a = dict(type=_arr(instructions['type'], np.int8), time=_arr(instructions['time'], np.int64),
                  z=_arr(instructions['z'], np.float32), amp=_arr(instructions['amp'], np.int32),
@@ -169,7 +169,7 @@ class Oracle:
                  cdf_table=_arr(ip['cdf_table'], np.float64))
         lib().orc_simulate(self._s, C.c_int64(n), *[_p(a[k]) for k in
                            ['type', 'time', 'z', 'amp', 'gid', 'p_hit', 'drift_mean', 'drift_spread', 'sc_gain',
-                            'cdf_row', 'cdf_table']])
+                            'cdf_row', 'cdf_table']], _p(_arr(em_base, np.uint32) if em_base is not None else None))
 
     def simulate_optical(self, instructions, gid, channels, timings, cutoff):
         a = dict(time=_arr(instructions['time'], np.int64), gid=_arr(gid, np.uint32), first=_arr(instructions['_first'], np.int32),

@@ -702,29 +702,30 @@ static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, doubl
 /* s2.py:73-136 S2.__call__ (luminescence 'simple') for one instruction.  Candidate electron j < amp survives with
  * probability cy (s2.py:254 Binomial as Bernoulli trials); survivors draw s2.py:280-282 arrival time and
  * s2.py:308-310 photon count; photons as one_photon(). */
-static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
+static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
                   double sc_gain, const double *cdf)
 {
     const orc_config *c = &s->c;
     u64 T = bern_threshold(cy); u32 w[4]; i64 n0 = x->pb.t.n;
     for (i64 j = 0; j < amp; j++) {
-        if ((j & 3) == 0) draw(s, 0, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);
+        if ((j & 3) == 0) draw(s, em_base, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);
         if (!((u64)w[j & 3] < T)) continue;
         u32 A[4], B[4]; double z_drift, z_gain;
-        draw(s, (u32)j, gid, 0, SITE_EL_A, A);
-        draw(s, (u32)j, gid, 0, SITE_EL_B, B);
+        const u32 je = em_base + (u32)j;            /* emitter id in the Philox counters */
+        draw(s, je, gid, 0, SITE_EL_A, A);
+        draw(s, je, gid, 0, SITE_EL_B, B);
         box_muller(B, &z_drift, &z_gain);
         double timing = -log(1.0 - u53(A[0], A[1])) * c->trap_time;
         timing += drift_mean + drift_spread * z_drift;
         i64 et = time + (i64)timing;
-        i64 nph = poisson_draw(s, (u32)j, gid, sc_gain);
+        i64 nph = poisson_draw(s, je, gid, sc_gain);
         nph += (i64)(0.0 + c->gain_spread * z_gain);
         if (nph < 0) nph = 0;
         VEC_PUSH(s->e_t, i64, et);
         for (i64 m = 0; m < nph; m++) {
             i64 t; int ch, dpe; double g;
-            one_photon(s, 1, (u32)j, gid, (u32)m, et, cdf, &t, &ch, &dpe, &g);
-            ctx_push(x, t, ch, dpe, g, gid, j, m);
+            one_photon(s, 1, je, gid, (u32)m, et, cdf, &t, &ch, &dpe, &g);
+            ctx_push(x, t, ch, dpe, g, gid, (i64)je, m);
         }
     }
     return x->pb.t.n - n0;
@@ -803,7 +804,7 @@ void orc_simulate_optical(orc_session *s, i64 n, const i64 *time, const u32 *gid
  * after the end of the last pulse (rawdata.py:96-98) and at the end (rawdata.py:154-155). */
 void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, const float *z, const i32 *amp,
                   const u32 *gid, const double *p_hit, const double *drift_mean, const double *drift_spread,
-                  const double *sc_gain, const i32 *cdf_row, const double *cdf_table)
+                  const double *sc_gain, const i32 *cdf_row, const double *cdf_table, const u32 *em_base)
 {
     const orc_config *c = &s->c;
     if (n == 0) return;
@@ -826,20 +827,22 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
             orc_digitize_and_zle(s, gid[ord[group_start].i]);    /* rawdata.py:96-98 */
             group_start = a;
         }
-        for (int ptype = 1; ptype <= 2; ptype++) {
-            /* run sets (rawdata.py:108-122): every instruction on its own, or -- save_full_truth off -- S1s whose keys are
-             * at most 100 ns apart / S2s at most int(0.2 / v) ns apart in one Pulse call */
+        static const int ptypes[4] = {1, 2, 4, 6};              /* rawdata.py:102: S1, S2, photo-ionisation electrons, gate electrons */
+        for (int pq = 0; pq < 4; pq++) {
+            const int ptype = ptypes[pq];
+            /* run sets (rawdata.py:106-127): every S1 / S2 on its own, or -- save_full_truth off -- S1s whose keys are at most
+             * 100 ns apart / S2s at most int(0.2 / v) ns apart in one Pulse call; electron afterpulses: one call per cluster */
             const i64 gap = ptype == 1 ? 100 : (i64)(0.2 / c->drift_velocity);
             call_ctx x; memset(&x, 0, sizeof x); int open = 0; i64 last_key = 0;
             for (i64 k = a; k < b; k++) {
                 i64 i = ord[k].i; if (type[i] != ptype) continue;
-                if (open && (s->save_full_truth || ord[k].t - last_key > gap)) { finish_call(s, ptype, runset++, &x); open = 0; }
+                if (open && ptype <= 2 && (s->save_full_truth || ord[k].t - last_key > gap)) { finish_call(s, ptype, runset++, &x); open = 0; }
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
                 if (ptype == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
-                else gen_s2(s, &x, gid[i], time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+                else gen_s2(s, &x, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
                 open = 1; last_key = ord[k].t;
             }
-            if (open) finish_call(s, ptype, runset++, &x);
+            if (open) finish_call(s, ptype == 6 ? 5 : ptype, runset++, &x);      /* call kinds: 1 S1, 2 S2, 3 PMT afterpulse, 4 PI electrons, 5 gate electrons */
         }
         a = b;
     }

@@ -208,7 +208,7 @@ class Recorder:
         return sum(len(c['pulses']) for c in self.calls)
 
 
-def run_chain(ref, config, instructions, seed, pattern_maps=None, noise=None, ap=None, store_currents=False):
+def run_chain(ref, config, instructions, seed, pattern_maps=None, noise=None, ap=None, store_currents=False, ele_ap=None):
     """Run reference RawData over instructions; return flat dict of arrays for np.savez."""
     config = dict(config)
     # the reference caches Resources keyed on file names only; clear so per-case patches do not leak
@@ -227,7 +227,27 @@ def run_chain(ref, config, instructions, seed, pattern_maps=None, noise=None, ap
         np.savez(path, arr_0=noise)
         config['noise_file'] = path
         config['enable_noise'] = True
-    rd = ref.rawdata.RawData(config)
+    if ele_ap is not None:
+        config['enable_electron_afterpulses'] = True
+        config['ele_ap_pdfs'] = ''
+        orig_get = ref.load_resource.straxen.get_resource
+        ref.load_resource.straxen.get_resource = lambda path, fmt='text': (ele_ap if fmt in ('dill', 'pkl.gz') else orig_get(path, fmt=fmt))
+    try:
+        rd = ref.rawdata.RawData(config)
+    finally:
+        if ele_ap is not None:
+            ref.load_resource.straxen.get_resource = orig_get
+    secondaries = []
+    if ele_ap is not None:
+        rd.resource.uniform_to_ele_ap = ele_ap
+        gen = rd.pulses['pi_el'].generate_instruction
+
+        def generate_instruction(signal_pulse, signal_pulse_instruction):
+            out = gen(signal_pulse, signal_pulse_instruction)
+            if len(out):
+                secondaries.append(np.array(out))
+            return out
+        rd.pulses['pi_el'].generate_instruction = generate_instruction
     if pattern_maps is not None:
         rd.resource.s1_pattern_map = pattern_maps['s1']
         rd.resource.s2_pattern_map = pattern_maps['s2']
@@ -243,6 +263,8 @@ def run_chain(ref, config, instructions, seed, pattern_maps=None, noise=None, ap
         rec.uninstall()
 
     out = dict(instructions=instructions, seed=np.int64(seed))
+    if ele_ap is not None:
+        out['secondaries'] = np.concatenate(secondaries) if secondaries else np.zeros(0, dtype=instructions.dtype)
     calls = rec.calls
     kinds = ['Pulse', 'S1', 'S2', 'PMT_Afterpulse', 'PhotoIonization_Electron', 'PhotoElectric_Electron']
     out['call_kind'] = np.array([kinds.index(c['kind']) for c in calls], dtype=np.int8)
@@ -449,6 +471,36 @@ def fixture_chain_runsets(ref):
                         **run_chain(ref, base_config(save_full_truth=False), make_instructions(rows), 707, pat))
 
 
+class StubDelayHist:
+    """stand-in for the multihist.Hist1d the reference loads as uniform_to_ele_ap (private resource): the members
+    afterpulse.py touches -- n, bin_centers, get_random (bin by content, uniform inside the bin)"""
+
+    def __init__(self, histogram, bin_edges):
+        self.histogram, self.bin_edges = np.asarray(histogram, float), np.asarray(bin_edges, float)
+        self.bin_centers = 0.5 * (self.bin_edges[1:] + self.bin_edges[:-1])
+        self.n = self.histogram.sum()
+
+    def get_random(self, size):
+        i = np.random.choice(len(self.bin_centers), size=size, p=self.histogram / self.n)
+        return self.bin_centers[i] + np.random.uniform(-0.5, 0.5, size) * np.diff(self.bin_edges)[i]
+
+
+def fixture_chain_electron_ap(ref):
+    """chain H: enable_electron_afterpulses -- every S2 queues photo-ionisation electron instructions (type 4,
+    afterpulse.py:14-91) that the scheduler feeds back (rawdata.py:133-145); all type-4 instructions of a cluster
+    share one Pulse call.  The generated secondaries are stored with the chain."""
+    pat = dict(s1=SyntheticPatternMap(14e-5, 30.0, 18.0, 0.15), s2=SyntheticPatternMap(30e-5, 9.0, 25.0, 0.02))
+    MS = 1_000_000
+    edges = np.linspace(0, 700e3, 141)
+    h = np.exp(-np.arange(140) / 30.0); h *= 4e-3 / h.sum()
+    np.savez_compressed(HERE + '/ele_ap_hist.npz', histogram=h, bin_edges=edges)
+    rows = [dict(type=1, time=MS, x=0, y=0, z=-20, amp=2000), dict(type=2, time=MS, x=0, y=0, z=-20, amp=300),
+            dict(type=2, time=MS + 450_000, x=5, y=-3, z=-60, amp=400),      # inside the first S2's afterpulse range
+            dict(type=1, time=4 * MS, x=5, y=-3, z=-61, amp=900), dict(type=2, time=6 * MS, x=-9, y=4, z=-5, amp=150)]
+    np.savez_compressed(HERE + '/chain_ele_ap.npz',
+                        **run_chain(ref, base_config(), make_instructions(rows), 808, pat, ele_ap=StubDelayHist(h, edges)))
+
+
 def hist(x):
     v, c = np.unique(np.asarray(x, dtype=np.int64), return_counts=True)
     return v.astype(np.int64), c.astype(np.int64)
@@ -538,6 +590,8 @@ if __name__ == '__main__':
         fixture_chain_params(ref)
     if 'chains' in which or 'runsets' in which:
         fixture_chain_runsets(ref)
+    if 'chains' in which or 'ele_ap' in which:
+        fixture_chain_electron_ap(ref)
     if 'dists' in which:
         fixture_distributions(ref)
     if 'stats' in which:

@@ -192,3 +192,54 @@ def test_truth_rows_of_run_sets_match_reference_summary():
         assert abs(g['n_photon'] - r['n_photon']) < 6 * np.sqrt(r['n_photon'] + 25)
         if r['type'] == 2:
             assert abs(g['n_electron'] - r['n_electron']) < 6 * np.sqrt(r['n_electron'] + 9)
+
+
+def _ele_ap_config(**kw):
+    # a synthetic delay-time histogram (the real x1t_se_afterpulse_delaytime.pkl.gz is a private resource):
+    # ~2e-3 electrons per detected photon, delays up to 700 us
+    edges = np.linspace(0, 700e3, 141)
+    hist = 2e-3 * np.exp(-np.arange(140) / 30.0); hist *= 2e-3 / hist.sum()
+    return xenonnt_test_config(enable_electron_afterpulses=True, uniform_to_ele_ap=(hist, edges), **kw)
+
+
+def test_electron_afterpulses_against_oracle():
+    """enable_electron_afterpulses (+ gate afterpulses): every S2 queues type-4 / type-6 secondary instructions
+    (afterpulse.py:14-139) that are simulated like S2s; all type-4 instructions of a cluster share one Pulse call.
+    The secondaries come from the host pre-pass; primaries + secondaries: GPU against the oracle, record for record."""
+    from wfsim_amd import electron_afterpulse as ea
+    from wfsim_amd.scheduler import run_sets
+    cfg = _ele_ap_config(seed=23, enable_gate_afterpulses=True, photoelectric_p=2e-3)
+    MS = 1_000_000
+    ins = np.zeros(5, dtype=instruction_dtype)
+    ins['type'] = [1, 2, 2, 1, 2]
+    ins['time'] = [MS, MS, 3 * MS, 3 * MS + 50_000, 6 * MS]
+    ins['x'], ins['y'], ins['z'] = [0, 0, 5, 5, -9], [0, 0, -3, -3, 4], [-20, -20, -60, -61, -5]
+    ins['amp'] = [2000, 800, 1500, 900, 300]
+    ins['recoil'], ins['event_number'] = 7, np.arange(5)
+    rd = wfsim_amd.RawData(cfg)
+    truth = np.zeros(400, dtype=instruction_dtype + truth_extra_dtype + [('fill', bool)])
+    windows = list(rd.iter_windows(ins, truth_buffer=truth))
+    rec = np.concatenate([w['records'] for w in windows])
+    # the secondaries, regenerated: deterministic in (seed, parent gid), independent of batching
+    sec, sec_gid, sec_base = rd.electron_afterpulse_instructions(ins, np.arange(5))
+    assert len(sec) > 20 and set(np.unique(sec['type'])) == {4, 6}
+    assert np.all(np.isin(sec_gid, [1, 2, 4])) and np.all(sec['z'] <= 0)          # parents are the three S2s
+    assert np.all(sec['amp'][sec['type'] == 6] == 1) and np.all(sec['amp'] >= 1)
+    for g in (1, 2, 4):                                                            # later than the parent, by at most the histogram's range
+        tz = sec['time'][(sec_gid == g) & (sec['type'] == 4)] + 1700
+        assert np.all(tz >= ins['time'][g]) and np.all(tz < ins['time'][g] + 800_000)
+    # oracle on the union with the same stream ids
+    allins = np.concatenate([ins, sec]); gids = np.concatenate([np.arange(5), sec_gid]); base = np.concatenate([np.zeros(5, np.uint32), sec_base])
+    order, key, cluster = schedule(allins, cfg)
+    s_ins = allins[order]
+    orc = make_oracle(cfg)
+    orc.simulate(s_ins, gids[order].astype(np.uint32), instruction_params(s_ins, cfg, Resource(cfg)), em_base=base[order])
+    o = orc.results()
+    assert rec.tobytes() == orc.pack_records().tobytes()
+    assert len(windows) == len(o['dg_left']) and np.array_equal([w['left'] for w in windows], o['dg_left'])
+    # call structure: per cluster S1s, S2s, then ONE type-4 call and ONE type-6 call (rawdata.py:102-127)
+    rs, n_sets = run_sets(s_ins, key, cluster, cfg)
+    assert n_sets == len(o['call_kind']) and set(o['call_kind']) == {1, 2, 4, 5}
+    t = truth[truth['fill']]
+    assert len(t) == n_sets and (t['type'] == 4).sum() == (o['call_kind'] == 4).sum() >= 3
+    assert np.all(t['n_electron'][t['type'] == 2] > 0) and t['n_electron'][t['type'] == 4].sum() > 10      # a lone secondary electron may be lost on the way

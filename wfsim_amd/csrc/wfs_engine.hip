@@ -32,13 +32,15 @@ struct wfs_handle {
     bool tables_set = false, batch_loaded = false, injected = false, optical = false, ran = false;
     DevBuf set_gid, opt_t, opt_item;
     int keep_currents = 0, profiling = 0;
+    bool gen_done = false;
+    GenArgs gen_args{};           // the generator's view of the batch (kept for wfs_gather_photon_times)
     int carry_has = 0; i64 carry_runmax = 0;
     // tables
     DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise;
     ApElem ap[WFS_MAX_AP];
     // instructions
     i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
-    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_set, set_ins_off, set_ins_list;
+    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_embase, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, ph_slot;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles;
@@ -46,7 +48,7 @@ struct wfs_handle {
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
-    DevBuf truth, tminmax, tile_truth, tile_desc, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
+    DevBuf truth, tminmax, tile_truth, tile_desc, gather_idx, gather_out, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
     DevBuf scan_tmp, scal, noise_override; i64 n_noise_override = 0;
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
@@ -324,12 +326,12 @@ int wfs_destroy(wfs_handle *h)
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
-        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
+        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
-        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->currents, &h->cur_len, &h->cur_off,
+        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) { if (h->tt_cum[q].p) hipFree(h->tt_cum[q].p); if (h->tt_guide[q].p) hipFree(h->tt_guide[q].p); }
@@ -445,7 +447,7 @@ static int load_clusters(wfs_handle *h, i64 n, const int32_t *cluster, const int
 int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const int64_t *time, const int32_t *amp, const uint32_t *gid,
                           const int32_t *cluster, const int64_t *tmin, const double *p_hit, const double *drift_mean,
                           const double *drift_spread, const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf,
-                          const int32_t *run_set, int64_t n_run_sets)
+                          const int32_t *run_set, int64_t n_run_sets, const uint32_t *em_base)
 {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
@@ -455,10 +457,11 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     std::vector<i64> em_off((size_t)n + 1);
     em_off[0] = 0;
     for (i64 i = 0; i < n; i++) {
-        if (type[i] != 1 && type[i] != 2) return h->fail(WFS_E_INVALID, "only instruction types 1 (S1) and 2 (S2) are supported");
+        if (type[i] != 1 && type[i] != 2 && type[i] != 4 && type[i] != 6)      // 4 / 6: electron afterpulses, simulated like an S2 (afterpulse.py:14, 94)
+            return h->fail(WFS_E_INVALID, "instruction types: 1 (S1), 2 (S2), 4 / 6 (photo-ionisation / photo-electric electrons)");
         if (amp[i] < 0) return h->fail(WFS_E_INVALID, "negative amp");
         if (cdf_row[i] < 0 || cdf_row[i] >= n_cdf) return h->fail(WFS_E_INVALID, "cdf_row out of range");
-        if (type[i] == 2 && h->dev.n_lum < 2) return h->fail(WFS_E_STATE, "S2 instructions need the luminescence table");
+        if (type[i] != 1 && h->dev.n_lum < 2) return h->fail(WFS_E_STATE, "S2 instructions need the luminescence table");
         em_off[i + 1] = em_off[i] + (type[i] == 1 ? 1 : (i64)amp[i]);
     }
     // pulse sets (one Pulse.__call__ each, rawdata.py:108-127): the caller's run sets, by default one per instruction
@@ -484,6 +487,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     h->h_rs_off = set_off; h->h_rs_list = set_list;
     if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
     TRY(upload(h, h->ins_type, type, (size_t)n)); TRY(upload(h, h->ins_time, time, (size_t)n * 8)); TRY(upload(h, h->ins_amp, amp, (size_t)n * 4));
+    { std::vector<u32> eb((size_t)n, 0u); if (em_base) eb.assign(em_base, em_base + n); TRY(upload(h, h->ins_embase, eb.data(), (size_t)n * 4)); HIPCHK(hipStreamSynchronize(h->stream)); }
     TRY(upload(h, h->ins_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_p, p_hit, (size_t)n * 8)); TRY(upload(h, h->ins_dm, drift_mean, (size_t)n * 8));
     TRY(upload(h, h->ins_ds, drift_spread, (size_t)n * 8)); TRY(upload(h, h->ins_sc, sc_gain, (size_t)n * 8));
     TRY(upload(h, h->ins_cdfrow, cdf_row, (size_t)n * 4)); TRY(upload(h, h->cdf_table, cdf_table, (size_t)n_cdf * h->cfg.n_tpc * 8));
@@ -516,7 +520,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     TRY(load_clusters(h, n, cluster, tmin, gid));
-    h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false;
+    h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false;
     return WFS_OK;
 }
 
@@ -565,7 +569,7 @@ int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, 
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     TRY(load_clusters(h, n_sets, set_cluster, set_tmin, nullptr));
-    h->injected = true; h->optical = false; h->batch_loaded = true; h->ran = false;
+    h->injected = true; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false;
     return WFS_OK;
 }
 
@@ -613,7 +617,7 @@ int wfs_load_optical(wfs_handle *h, int64_t n, const int64_t *time, const uint32
     HIPCHK(hipMemsetAsync(h->el_stat.p, 0, (size_t)n * 32, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     TRY(load_clusters(h, n, cluster, tmin, gid));
-    h->injected = false; h->optical = true; h->batch_loaded = true; h->ran = false;
+    h->injected = false; h->optical = true; h->batch_loaded = true; h->ran = false; h->gen_done = false;
     return WFS_OK;
 }
 
@@ -633,7 +637,7 @@ static int run_generation(wfs_handle *h)
     }
     GenArgs g{};
     g.n_ins = N; g.n_psets = h->n_psets; g.n_emitters = E;
-    g.ins_set = h->ins_set.as<i32>(); g.set_ins_off = h->set_ins_off.as<i64>(); g.set_ins_list = h->set_ins_list.as<i32>(); g.set_t0 = h->set_t0.as<i64>();
+    g.ins_embase = h->ins_embase.as<u32>(); g.ins_set = h->ins_set.as<i32>(); g.set_ins_off = h->set_ins_off.as<i64>(); g.set_ins_list = h->set_ins_list.as<i32>(); g.set_t0 = h->set_t0.as<i64>();
     g.ins_type = h->ins_type.as<int8_t>(); g.ins_time = h->ins_time.as<i64>(); g.ins_amp = h->ins_amp.as<i32>(); g.ins_gid = h->ins_gid.as<u32>();
     g.ins_p = h->ins_p.as<double>(); g.ins_dm = h->ins_dm.as<double>(); g.ins_ds = h->ins_ds.as<double>(); g.ins_sc = h->ins_sc.as<double>();
     g.ins_cdfrow = h->ins_cdfrow.as<i32>(); g.cdf_table = h->cdf_table.as<double>(); g.cdf_guide = h->cdf_guide.as<unsigned short>(); g.em_off = h->em_off.as<i64>();
@@ -701,6 +705,7 @@ static int run_generation(wfs_handle *h)
         if (h->h_scal[13] > ap_cap) return h->fail(WFS_E_CAPACITY, "more PMT afterpulse photons than 1/8 of the primary photons: afterpulse probability unreasonably high");
         h->n_ap_photons = h->h_scal[13];
     }
+    h->gen_args = g;
     return WFS_OK;
 }
 
@@ -708,6 +713,7 @@ int wfs_run(wfs_handle *h)
 {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded) return h->fail(WFS_E_STATE, "no batch loaded");
+    h->ran = false; h->gen_done = false;
     HIPCHK(hipSetDevice(h->device));
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     h->times.clear();
@@ -722,6 +728,8 @@ int wfs_run(wfs_handle *h)
     }
     else if (!h->injected) TRY(run_generation(h));
     else { h->ap_active = false; TRY(scan(h, h->tile_count.as<i32>(), T, h->tile_off, 7)); }
+    h->gen_done = true;
+    if (h->keep_currents & 4) { HIPCHK(hipStreamSynchronize(h->stream)); return WFS_OK; }      // wfs_set_debug bit 2: photon generation only
 
     // ---- geometry: tiles -> clusters -> groups -> rows
     const i64 CG = C + 1;         // group slots
@@ -1082,6 +1090,7 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
     HIPCHK(hipMemcpy(spe.data(), h->t_spe.p, spe.size() * 8, hipMemcpyDeviceToHost));
     const i64 gain_first = h->injected ? 0 : h->n_photons;         // ph_gain covers the explicit-gain photons only
     if (P - gain_first > 0 && (h->injected || h->ap_active)) { pg.resize((size_t)(P - gain_first)); HIPCHK(hipMemcpy(pg.data(), h->ph_gain.p, pg.size() * 8, hipMemcpyDeviceToHost)); }
+    if (off[(size_t)T] != P) { char msg[160]; snprintf(msg, sizeof msg, "wfs_copy_photons: tile offsets end at %lld, %lld photons (T %lld, sets %lld)", (long long)off[(size_t)T], (long long)P, (long long)T, (long long)h->n_sets); return h->fail(WFS_E_STATE, msg); }
     for (i64 s = 0; s <= h->n_sets; s++) set_off[s] = off[(size_t)s * d.n_tpc];
     for (i64 tile = 0; tile < T; tile++) {
         i64 s = tile / d.n_tpc; int c = (int)(tile - s * d.n_tpc);
@@ -1093,6 +1102,32 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
             else { double g = gains[c] * row[g1]; if (g2) g += gains[c] * row[g2]; gain[p] = g; dpe[p] = g2 != 0; }
         }
     }
+    return WFS_OK;
+}
+
+int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t cap)
+{
+    if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
+    const i64 N = h->n_ins;
+    if (cap < N + 1) return h->fail(WFS_E_CAPACITY, "offset buffer too small");
+    std::vector<i64> emo((size_t)N + 1), epo((size_t)h->n_emitters + 1);
+    HIPCHK(hipMemcpy(emo.data(), h->em_off.p, emo.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(epo.data(), h->em_ph_off.p, epo.size() * 8, hipMemcpyDeviceToHost));
+    for (i64 i = 0; i <= N; i++) off[i] = epo[(size_t)emo[i]];
+    return WFS_OK;
+}
+
+int wfs_gather_photon_times(wfs_handle *h, int64_t n, const int64_t *index, int64_t *t_out)
+{
+    if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
+    if (n <= 0) return WFS_OK;
+    if (!index || !t_out) return h->fail(WFS_E_INVALID, "wfs_gather_photon_times: null argument");
+    for (i64 i = 0; i < n; i++) if (index[i] < 0 || index[i] >= h->n_photons) return h->fail(WFS_E_INVALID, "photon index out of range");
+    HIPCHK(hipSetDevice(h->device));
+    TRY(upload(h, h->gather_idx, index, (size_t)n * 8)); TRY(ensure(h, h->gather_out, (size_t)n * 8));
+    hipLaunchKernelGGL(k_photon_times, dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->dev, h->gen_args, n, h->gather_idx.as<i64>(), h->gather_out.as<i64>());
+    HIPCHK(hipMemcpyAsync(t_out, h->gather_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
 }
 

@@ -1062,6 +1062,8 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
 // ------------------------------------------------------------------------------------------------ generation
 struct GenArgs {
     i64 n_ins, n_psets, n_emitters, n_photons;
+    const u32 *ins_embase;        // [n_ins] offset of the instruction's emitter ids in the Philox counters (0 for primaries; the k-th
+                                  // electron-afterpulse instruction of a parent shares the parent's gid and uses (k + 1) << 20)
     const i32 *ins_set;           // [n_ins] pulse set (one Pulse.__call__, rawdata.py:108-127) of every instruction; tiles are (set, channel)
     const i64 *set_ins_off; const i32 *set_ins_list;      // set -> its instructions (CSR)
     const i64 *set_t0;            // [n_sets] time origin of the set's photon times
@@ -1142,14 +1144,14 @@ __global__ __launch_bounds__(256) void k_s2_electrons(WfsDev d, GenArgs a)
     if (e < a.n_emitters) {
         i64 lo = 0, hi = a.n_ins;                   // instruction of emitter e: em_off[lo] <= e < em_off[lo+1]
         while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_off[mid] <= e) lo = mid; else hi = mid; }
-        i = lo; is_s2 = a.ins_type[i] == 2;
+        i = lo; is_s2 = a.ins_type[i] != 1;          // types 2, 4, 6 are S2-like (electrons drifting to the gas gap)
     }
     double st_n = 0, st_t = 0, st_t2 = 0; i64 st_min = I64_MAX, st_max = I64_MIN;
     if (is_s2) {
-        const u32 j = (u32)(e - a.em_off[i]); const u32 gid = a.ins_gid[i];
+        const u32 j0 = (u32)(e - a.em_off[i]), jb = a.ins_embase[i], j = jb + j0; const u32 gid = a.ins_gid[i];
         a.em_ins[e] = (i32)i;
-        u32x4 sv = philox4x32_10(0, gid, j >> 2, SITE_S2_SURVIVE, d.k0, d.k1);
-        u32 word = (j & 3) == 0 ? sv.x : (j & 3) == 1 ? sv.y : (j & 3) == 2 ? sv.z : sv.w;
+        u32x4 sv = philox4x32_10(jb, gid, j0 >> 2, SITE_S2_SURVIVE, d.k0, d.k1);
+        u32 word = (j0 & 3) == 0 ? sv.x : (j0 & 3) == 1 ? sv.y : (j0 & 3) == 2 ? sv.z : sv.w;
         if (!((u64)word < bern_threshold(a.ins_p[i]))) { a.em_nph[e] = 0; a.em_time[e] = I64_MIN; }
         else {
             u32x4 A = philox4x32_10(j, gid, 0, SITE_EL_A, d.k0, d.k1);
@@ -1379,9 +1381,9 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
     if (single) {
         const u32 gid = a.ins_gid[ins_lo]; const i64 emoff = a.em_off[ins_lo];
         const i32 set_lo = a.ins_set[ins_lo]; const i64 itime = a.set_t0[set_lo];       // photon times are relative to the pulse set's origin
-        const DiscTab &tab = (a.ins_type[ins_lo] == 2) ? d.tab_s2 : d.tab_s1;
+        const DiscTab &tab = (a.ins_type[ins_lo] != 1) ? d.tab_s2 : d.tab_s1;
         const i64 tbase = (i64)set_lo * nch;
-        const u32 jbase = (u32)(e_lo - emoff);
+        const u32 jbase = (u32)(e_lo - emoff) + a.ins_embase[ins_lo];
         u32 pw[GEN_PPT];                                      // pass B: the packed words of this thread's bucket positions, loaded up front
         if (!COUNT) {
 #pragma unroll
@@ -1506,7 +1508,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
             const u32 m = (u32)(p - a.em_ph_off[lo]);
             const i32 ins = a.em_ins[lo];
-            const u32 gid = a.ins_gid[ins], j = (u32)(lo - a.em_off[ins]);
+            const u32 gid = a.ins_gid[ins], j = (u32)(lo - a.em_off[ins]) + a.ins_embase[ins];
             const u32x4 A = philox4x32_10(j, gid, m, SITE_PH_A, d.k0, d.k1);
             const int ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * nch, nch, u53(A.x, A.y));
             const i32 set = a.ins_set[ins];
@@ -1516,7 +1518,7 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
             const bool is_dpe = (u64)A.z < d.thr_dpe;
             const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-            i64 t = a.em_time[lo] - itime + sample_disc(a.ins_type[ins] == 2 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
+            i64 t = a.em_time[lo] - itime + sample_disc(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
             if (AP) ap_generate(d, a, ap, aps, j, gid, m, set, ch, is_dpe, itime, t);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
@@ -1553,6 +1555,23 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
     const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
     a.ph[pos] = PhotonRec{ap.ap_t[i], 0u}; ph_gain_base[pos] = ap.ap_gain[i];
     atomicMin(&a.tile_tmin[tile], ap.ap_t[i]); atomicMax(&a.tile_tmax[tile], ap.ap_t[i]);
+}
+
+// Arrival times of chosen photons, addressed by their index in GENERATION order (emitter by emitter, the order of
+// em_ph_off): electron afterpulses pick random detected photons of their parent S2 as time zeros (afterpulse.py:44-47).
+// The time is recomputed from the photon's own Philox draw (site B), so the choice does not depend on where the
+// bucketing put the photon.
+__global__ void k_photon_times(WfsDev d, GenArgs a, i64 n, const i64 *index, i64 *out)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const i64 p = index[i];
+    i64 lo = 0, hi = a.n_emitters;
+    while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
+    const i32 ins = a.em_ins[lo];
+    const u32 j = (u32)(lo - a.em_off[ins]) + a.ins_embase[ins], m = (u32)(p - a.em_ph_off[lo]);
+    const u32x4 B = philox4x32_10(j, a.ins_gid[ins], m, SITE_PH_B, d.k0, d.k1);
+    out[i] = a.em_time[lo] + sample_disc(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
 }
 
 // Optical input (RawDataOptical.sim_primary, rawdata.py:475-493): photons are supplied, already bucketed by the host

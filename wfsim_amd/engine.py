@@ -40,7 +40,7 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_load_instructions', 'wfs_load_photons', 'wfs_load_optical', 'wfs_run', 'wfs_get_counts', 'wfs_copy_records',
            'wfs_copy_records_dev', 'wfs_records_dev_ptr', 'wfs_copy_groups', 'wfs_copy_intervals',
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
-           'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
+           'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_instruction_photon_offsets', 'wfs_gather_photon_times', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
            'wfs_kernel_times', 'wfs_set_profiling']
 
 
@@ -130,7 +130,7 @@ class Engine:
             pass
 
     # ------------------------------------------------------------------------------------------
-    def load_instructions(self, ins, gid, cluster, tmin, ip, run_set=None):
+    def load_instructions(self, ins, gid, cluster, tmin, ip, run_set=None, em_base=None):
         """ins: instruction array sorted by the scheduler key; ip: dict from physics.instruction_params;
         run_set: pulse set of every instruction (scheduler.run_sets), None = one set per instruction."""
         n = len(ins)
@@ -139,9 +139,11 @@ class Engine:
              _arr(ip['drift_spread'], np.float64), _arr(ip['sc_gain'], np.float64), _arr(ip['cdf_row'], np.int32),
              _arr(ip['cdf_table'], np.float64)]
         rs = _arr(run_set, np.int32) if run_set is not None else None
+        self._n_loaded = n
         self._n_run_sets = (int(rs.max()) + 1 if len(rs) else 0) if rs is not None else n
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
-                                                   _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0)))
+                                                   _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0),
+                                                   _p(_arr(em_base, np.uint32) if em_base is not None else None)))
 
     def load_optical(self, ins, gid, cluster, tmin, channels, timings, time_cutoff):
         """ins: optical instructions (with _first/_last) sorted by time; channels/timings: the flat photon arrays"""
@@ -162,8 +164,31 @@ class Engine:
         self.counts = {n: getattr(c, n) for n, _ in WfsCounts._fields_}
         return self.counts
 
-    def set_debug(self, on=True, force_dense=False):
-        self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(bool(on)) | (2 if force_dense else 0))))
+    def set_debug(self, on=True, force_dense=False, generate_only=False):
+        self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(bool(on)) | (2 if force_dense else 0) | (4 if generate_only else 0))))
+
+    def generate(self):
+        """photon generation only (no pulses / records): the pre-pass of the electron afterpulses"""
+        self.set_debug(False, generate_only=True)
+        try:
+            self._check(self.lib.wfs_run(self._h))
+        finally:
+            self.set_debug(False)
+
+    def instruction_photon_offsets(self):
+        """first generated photon of every instruction of the batch (+ the total): generation order"""
+        n = getattr(self, '_n_loaded', 0)
+        out = np.zeros(n + 1, dtype=np.int64)
+        self._check(self.lib.wfs_copy_instruction_photon_offsets(self._h, _p(out), C.c_int64(n + 1)))
+        return out
+
+    def gather_photon_times(self, index):
+        """arrival times [ns] of photons given by their index in generation order"""
+        i = _arr(index, np.int64)
+        out = np.zeros(len(i), dtype=np.int64)
+        if len(i):
+            self._check(self.lib.wfs_gather_photon_times(self._h, C.c_int64(len(i)), _p(i), _p(out)))
+        return out
 
     def set_profiling(self, on=True):
         self._check(self.lib.wfs_set_profiling(self._h, C.c_int32(int(on))))

@@ -119,9 +119,10 @@ def instruction_params(instructions, config, resource):
     cumulative channel table of every instruction (rows de-duplicated)."""
     n = len(instructions)
     is_s1 = instructions['type'] == 1
-    is_s2 = instructions['type'] == 2
+    # types 4 (photo-ionisation electrons) and 6 (photo-electric electrons) are simulated by S2.__call__ (afterpulse.py:14, 94)
+    is_s2 = np.isin(instructions['type'], (2, 4, 6))
     if not np.all(is_s1 | is_s2):
-        raise NotImplementedError('only primary S1 (type 1) and S2 (type 2) instructions are on the MI355X path')
+        raise NotImplementedError('instruction types on the MI355X path: 1 (S1), 2 (S2), 4 / 6 (electron afterpulses)')
     p_hit = np.zeros(n)
     drift_mean = np.zeros(n)
     drift_spread = np.zeros(n)

@@ -21,6 +21,7 @@ from .dtypes import raw_record_dtype
 from .engine import Engine
 from .physics import instruction_params
 from .resource import Resource
+from . import electron_afterpulse as ea
 from .scheduler import schedule, processing_order, run_sets
 
 log = logging.getLogger('wfsim_amd.core')
@@ -34,11 +35,15 @@ class RawData:
 
     def __init__(self, config, device=0, resource=None, seed=None):
         self.config = config
-        if config.get('enable_electron_afterpulses', False) or config.get('enable_gate_afterpulses', False):
-            raise NotImplementedError('electron afterpulses (secondary instructions, afterpulse.py:14-139) are not on '
-                                      'the MI355X path yet (SURVEY.md 8f.1)')
         self.resource = resource if resource is not None else Resource(config)
         self.engine = Engine(config, self.resource, device=device, seed=seed)
+        # electron afterpulses (afterpulse.py:14-139): secondaries are made in a pre-pass over the primaries
+        self._pi_hist = self._pi_grid = None
+        if config.get('enable_electron_afterpulses', False):
+            if not hasattr(self.resource, 'uniform_to_ele_ap'):
+                raise ValueError('enable_electron_afterpulses needs resource.uniform_to_ele_ap (delay-time histogram, load_resource.py:233)')
+            self._pi_hist = ea.DelayHistogram.wrap(self.resource.uniform_to_ele_ap)
+            self._pi_grid = ea.coarse_delay_grid(self._pi_hist, config)
         self.source_finished = False
         self.left = self.right = 0
         #: run-wide index of every instruction passed to __call__ (RNG stream ids); None: position in the input
@@ -70,6 +75,13 @@ class RawData:
             return
         cfg = self.config
         dt, tw, rext = cfg['sample_duration'], cfg['trigger_window'], cfg['right_raw_extension']
+        gids = np.arange(len(instructions)) if self.global_ids is None else np.asarray(self.global_ids)
+        em_base = np.zeros(len(instructions), dtype=np.uint32)
+        if self._has_electron_afterpulses():
+            # pre-pass: the secondaries of every S2 (type 4 / 6 instructions), then everything through the normal path
+            sec, sec_gid, sec_base = self.electron_afterpulse_instructions(instructions, gids)
+            instructions = np.concatenate([instructions, sec])
+            gids, em_base = np.concatenate([gids, sec_gid]), np.concatenate([em_base, sec_base])
         order, key, cluster = schedule(instructions, cfg)
         s_ins = instructions[order]
         n = len(s_ins)
@@ -81,9 +93,10 @@ class RawData:
         while a < n:
             b = self._batch_end(a, est_csum, cluster, scale)
             ins = s_ins[a:b]
-            gid = (order[a:b] if self.global_ids is None else np.asarray(self.global_ids)[order[a:b]]).astype(np.uint32)
+            gid = gids[order[a:b]].astype(np.uint32)
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)
             self.engine.set_window_carry(has_pulse, runmax)
+            self._batch_em_base = em_base[order[a:b]]
             self._load_batch(ins, gid, cl, key[a:b])
             self.engine.run()
             groups = self.engine.groups()
@@ -124,13 +137,69 @@ class RawData:
 
     def _expected_quanta(self, s_ins):
         return np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15,
-                        s_ins['amp'] * float(self.config.get('s2_secondary_sc_gain', 30)))
+                        s_ins['amp'] * float(self.config.get('s2_secondary_sc_gain', 30)))     # types 2, 4, 6: electrons
 
     def _load_batch(self, ins, gid, cl, key):
         ip = instruction_params(ins, self.config, self.resource)
         # one pulse set per instruction, or -- save_full_truth off -- per group of nearby S1s / S2s (rawdata.py:106-127)
-        self._run_set = None if self.config.get('save_full_truth', True) else run_sets(ins, key, cl, self.config)[0]
-        self.engine.load_instructions(ins, gid, cl, key, ip, run_set=self._run_set)
+        # ...; electron-afterpulse instructions (types 4 / 6) of a cluster always share one call
+        plain = self.config.get('save_full_truth', True) and bool(np.all(ins['type'] <= 2))
+        self._run_set = None if plain else run_sets(ins, key, cl, self.config)[0]
+        self.engine.load_instructions(ins, gid, cl, key, ip, run_set=self._run_set, em_base=getattr(self, '_batch_em_base', None))
+
+    # ---- electron afterpulses (afterpulse.py:14-139, rawdata.py:192-202) ------------------------------
+    def _has_electron_afterpulses(self):
+        return bool(self.config.get('enable_electron_afterpulses', False) or self.config.get('enable_gate_afterpulses', False))
+
+    def electron_afterpulse_instructions(self, instructions, gids):
+        """Pre-pass: photons of the primaries only (no pulses), then for every S2 pulse set its secondary instructions
+        (type 4 photo-ionisation / type 6 gate electrons).  Returns (secondaries, their gid, their emitter offsets)."""
+        cfg = self.config
+        order, key, cluster = schedule(instructions, cfg)
+        s_ins, s_gid = instructions[order], np.asarray(gids)[order]
+        n = len(s_ins)
+        est_csum = np.cumsum(self._expected_quanta(s_ins))
+        out, out_gid, out_base = [], [], []
+        a = 0
+        while a < n:
+            b = self._batch_end(a, est_csum, cluster)
+            ins, gid = s_ins[a:b], s_gid[a:b]
+            cl = (cluster[a:b] - cluster[a]).astype(np.int32)
+            self._batch_em_base = None
+            self._load_batch(ins, gid.astype(np.uint32), cl, key[a:b])
+            self.engine.generate()
+            ph_off = self.engine.instruction_photon_offsets()           # generation order: instruction by instruction
+            rs = np.arange(len(ins)) if self._run_set is None else self._run_set
+            members = {}
+            for i, q in enumerate(rs):
+                members.setdefault(int(q), []).append(i)
+            plans, req_idx = [], []
+            for q, m in sorted(members.items()):
+                i = m[0]                                                 # signal_pulse_instruction[0] (afterpulse.py:49)
+                if ins['type'][i] != 2:                                  # only S2s make electron afterpulses (rawdata.py:194-200)
+                    continue
+                n_ph = np.array([ph_off[k + 1] - ph_off[k] for k in m])  # the call's photons: its instructions one after the other
+                p = ea.plan_secondaries(ins[i:i + 1], int(gid[i]), int(n_ph.sum()), cfg, self._pi_hist, self._pi_grid)
+                starts = np.concatenate([[0], np.cumsum(n_ph)])
+                for pl in p:
+                    which = np.searchsorted(starts, pl[1], side='right') - 1          # picked photon -> instruction of the set
+                    req_idx.append(ph_off[np.asarray(m)[which]] + (pl[1] - starts[which]))
+                if p:
+                    plans.append((i, p))
+            t_all = self.engine.gather_photon_times(np.concatenate(req_idx)) if req_idx else np.zeros(0, np.int64)
+            pos = 0
+            for i, p in plans:
+                tz = []
+                for pl in p:
+                    tz.append(t_all[pos:pos + len(pl[1])]); pos += len(pl[1])
+                sec = ea.build_instructions(ins[i:i + 1], p, tz, cfg)
+                if len(sec) > ea.MAX_SECONDARIES_PER_PARENT:
+                    raise ValueError(f'{len(sec)} electron-afterpulse instructions from one S2: more than the stream ids allow')
+                out.append(sec); out_gid.append(np.full(len(sec), gid[i])); out_base.append(((np.arange(len(sec)) + 1) << 20).astype(np.uint32))
+            a = b
+        if not out:
+            return np.zeros(0, dtype=instructions.dtype), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.uint32)
+        return np.concatenate(out), np.concatenate(out_gid).astype(np.int64), np.concatenate(out_base)
 
     # ---- truth (rawdata.py:313-375) ----------------------------------------------------------------
     def _truth_rows(self, ins, cl):

@@ -89,3 +89,11 @@ class Resource:
             self.noise_data = np.ascontiguousarray(c['noise_data'])
         if c.get('enable_pmt_afterpulses', False):
             self.uniform_to_pmt_ap = c['uniform_to_pmt_ap']
+        if c.get('enable_electron_afterpulses', False):
+            # delay-time histogram of the photo-ionisation electrons (load_resource.py:233, a multihist.Hist1d in the
+            # reference): any object with ``histogram`` and ``bin_edges``, or a (histogram, bin_edges) pair
+            h = c['uniform_to_ele_ap']
+            if isinstance(h, (tuple, list)):
+                from .electron_afterpulse import DelayHistogram
+                h = DelayHistogram(h[0], h[1])
+            self.uniform_to_ele_ap = h
