@@ -171,6 +171,15 @@ class Oracle:
                            ['type', 'time', 'z', 'amp', 'gid', 'p_hit', 'drift_mean', 'drift_spread', 'sc_gain',
                             'cdf_row', 'cdf_table']], _p(_arr(em_base, np.uint32) if em_base is not None else None))
 
+    def simulate_scheduled(self, instructions, gid, ip, em_base, cluster, tmin, run_set):
+        """instructions in processing order with their clusters, window-rule keys and pulse sets (feedback_schedule)"""
+        n = len(instructions)
+        a = [_arr(instructions['type'], np.int8), _arr(instructions['time'], np.int64), _arr(instructions['amp'], np.int32),
+             _arr(gid, np.uint32), _arr(ip['p_hit'], np.float64), _arr(ip['drift_mean'], np.float64), _arr(ip['drift_spread'], np.float64),
+             _arr(ip['sc_gain'], np.float64), _arr(ip['cdf_row'], np.int32), _arr(ip['cdf_table'], np.float64), _arr(em_base, np.uint32),
+             _arr(cluster, np.int32), _arr(tmin, np.int64), _arr(run_set, np.int32)]
+        lib().orc_simulate_scheduled(self._s, C.c_int64(n), *[_p(x) for x in a])
+
     def simulate_optical(self, instructions, gid, channels, timings, cutoff):
         a = dict(time=_arr(instructions['time'], np.int64), gid=_arr(gid, np.uint32), first=_arr(instructions['_first'], np.int32),
                  last=_arr(instructions['_last'], np.int32), channels=_arr(channels, np.int32), timings=_arr(timings, np.int64))

@@ -850,6 +850,40 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
     free(it); free(ord);
 }
 
+/* The same with the schedule given: instructions in processing order, cluster[] non-decreasing, tmin[] the key the
+ * window rule sees (rawdata.py:96-98; the host raises it for clusters that are always preceded by a digitisation,
+ * rawdata.py:148-149), run_set[] non-decreasing inside a cluster.  Used for runs with electron afterpulses, whose
+ * order comes from the host's replay of the feedback loop (wfsim_amd/scheduler.py: feedback_schedule). */
+void orc_simulate_scheduled(orc_session *s, i64 n, const int8_t *type, const i64 *time, const i32 *amp, const u32 *gid,
+                            const double *p_hit, const double *drift_mean, const double *drift_spread, const double *sc_gain,
+                            const i32 *cdf_row, const double *cdf_table, const u32 *em_base, const i32 *cluster, const i64 *tmin,
+                            const i32 *run_set)
+{
+    const orc_config *c = &s->c;
+    if (n == 0) return;
+    i64 a = 0, group_start = 0;
+    while (a < n) {
+        i64 b = a + 1, cmin = tmin[a];
+        while (b < n && cluster[b] == cluster[a]) { if (tmin[b] < cmin) cmin = tmin[b]; b++; }
+        if (s->has_pulse && (double)(cmin - s->last_end) > c->rext) { orc_digitize_and_zle(s, gid[group_start]); group_start = a; }
+        i64 k = a;
+        while (k < b) {
+            i64 e = k + 1;
+            while (e < b && run_set[e] == run_set[k]) e++;
+            call_ctx x; memset(&x, 0, sizeof x);
+            for (i64 i = k; i < e; i++) {
+                const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
+                if (type[i] == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
+                else gen_s2(s, &x, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+            }
+            finish_call(s, type[k] == 6 ? 5 : type[k], run_set[k], &x);
+            k = e;
+        }
+        a = b;
+    }
+    orc_digitize_and_zle(s, gid[group_start]);
+}
+
 /* ---------------------------------------------------------------- record packing ----------------- */
 /* strax_interface.py:391-436: one ZLE interval -> ceil(len/110) raw_records (244-byte packed layout). */
 i64 orc_pack_records(const orc_session *s, i64 samples_per_record, uint8_t *out, i64 capacity)

@@ -74,20 +74,36 @@ def make_engine(config, seed=None, resource=None):
     return Engine(config, resource or Resource(config), device=0, seed=seed)
 
 
+def chain_union(d):
+    """primaries + recorded secondaries of a golden chain and, per instruction, its parent (-1 for primaries): the
+    reference copies the parent S2's fields into its secondaries (afterpulse.py:49), event_number identifies it"""
+    prim = d['instructions']
+    if 'secondaries' not in d.files or len(d['secondaries']) == 0:
+        return prim, np.full(len(prim), -1, dtype=np.int64)
+    sec = d['secondaries']
+    parent = np.full(len(prim) + len(sec), -1, dtype=np.int64)
+    for k in range(len(sec)):
+        parent[len(prim) + k] = int(np.where((prim['type'] == 2) & (prim['event_number'] == sec['event_number'][k]))[0][0])
+    return np.concatenate([prim, sec]), parent
+
+
 def chain_sets(d, config):
-    """Pulse sets of a golden chain: (set_cluster, set_tmin) per recorded Pulse.__call__."""
-    from wfsim_amd.scheduler import schedule, processing_order
-    ins = d['instructions']
-    order, key, cluster = schedule(ins, config)
-    proc = processing_order(ins, order, cluster)
+    """Pulse sets of a golden chain: (set_cluster, set_tmin) per recorded Pulse.__call__ -- the host scheduler's clusters,
+    window-rule keys and run sets for the chain's instructions, matched to the recorded calls in processing order."""
+    from wfsim_amd.scheduler import feedback_schedule
+    ins, parent = chain_union(d)
+    order, key, cluster, rs = feedback_schedule(ins, parent, config)
+    n_sets = int(rs.max()) + 1
+    cl_of = np.array([cluster[np.where(rs == q)[0][0]] for q in range(n_sets)])
+    tmin_of = np.array([key[rs == q].min() for q in range(n_sets)])
     set_cluster, set_tmin = [], []
     k = -1
     for kind in d['call_kind']:
         if kind != 3:          # a primary Pulse call; kind 3 = PMT afterpulses of the previous primary
             k += 1
-        set_cluster.append(cluster[proc[k]])
-        set_tmin.append(key[proc[k]])
-    assert k == len(ins) - 1
+        set_cluster.append(cl_of[k])
+        set_tmin.append(tmin_of[k])
+    assert k == n_sets - 1, (k, n_sets)
     return np.asarray(set_cluster, np.int32), np.asarray(set_tmin, np.int64)
 
 

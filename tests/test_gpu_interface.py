@@ -228,17 +228,21 @@ def test_electron_afterpulses_against_oracle():
     for g in (1, 2, 4):                                                            # later than the parent, by at most the histogram's range
         tz = sec['time'][(sec_gid == g) & (sec['type'] == 4)] + 1700
         assert np.all(tz >= ins['time'][g]) and np.all(tz < ins['time'][g] + 800_000)
-    # oracle on the union with the same stream ids
+    # oracle on the union with the same stream ids, in the order / clusters / pulse sets of the reference's feedback loop
+    from wfsim_amd.scheduler import feedback_schedule
+    sec2, sec_gid2, sec_base2, sec_parent = rd.electron_afterpulse_instructions(ins, np.arange(5), with_parent=True)
+    assert np.array_equal(sec2, sec)                                               # reproducible
     allins = np.concatenate([ins, sec]); gids = np.concatenate([np.arange(5), sec_gid]); base = np.concatenate([np.zeros(5, np.uint32), sec_base])
-    order, key, cluster = schedule(allins, cfg)
+    parent = np.concatenate([np.full(5, -1), sec_parent])
+    order, key, cluster, rs = feedback_schedule(allins, parent, cfg)
     s_ins = allins[order]
     orc = make_oracle(cfg)
-    orc.simulate(s_ins, gids[order].astype(np.uint32), instruction_params(s_ins, cfg, Resource(cfg)), em_base=base[order])
+    orc.simulate_scheduled(s_ins, gids[order].astype(np.uint32), instruction_params(s_ins, cfg, Resource(cfg)), base[order], cluster, key, rs)
     o = orc.results()
     assert rec.tobytes() == orc.pack_records().tobytes()
     assert len(windows) == len(o['dg_left']) and np.array_equal([w['left'] for w in windows], o['dg_left'])
-    # call structure: per cluster S1s, S2s, then ONE type-4 call and ONE type-6 call (rawdata.py:102-127)
-    rs, n_sets = run_sets(s_ins, key, cluster, cfg)
+    # call structure: per dynamic cluster S1s, S2s, then ONE type-4 call and ONE type-6 call (rawdata.py:102-127)
+    n_sets = int(rs.max()) + 1
     assert n_sets == len(o['call_kind']) and set(o['call_kind']) == {1, 2, 4, 5}
     t = truth[truth['fill']]
     assert len(t) == n_sets and (t['type'] == 4).sum() == (o['call_kind'] == 4).sum() >= 3

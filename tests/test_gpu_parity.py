@@ -117,6 +117,14 @@ def test_chain_nondefault_parameters(force_dense):
     _check_chain('chain_params.npz', params_chain_config(), force_dense=force_dense)
 
 
+def test_chain_run_sets_and_electron_afterpulses():
+    """golden chains G (save_full_truth=False: several instructions per Pulse call) and H (electron afterpulses: type-4
+    calls, windows closed right after a cluster of secondaries, rawdata.py:148-149): clusters, window-rule keys and pulse
+    sets from the host scheduler, photons of the reference's calls injected -> windows, rows, ZLE, records bit-exact"""
+    _check_chain('chain_runsets.npz', xenonnt_test_config(save_full_truth=False))
+    _check_chain('chain_ele_ap.npz', xenonnt_test_config())
+
+
 def test_chain_noise():
     cfg = xenonnt_test_config(enable_noise=True, noise_data=golden('noise.npz')['noise'])
     _check_chain('chain_noise.npz', cfg, noise_offsets=True)

@@ -171,3 +171,28 @@ def test_run_sets_grouping_matches_reference():
     assert len(o3.results()['call_kind']) == len(ins)
     # grouping does not change the photons (same Philox coordinates), only which call they belong to
     assert len(res['ph_t']) == len(o3.results()['ph_t'])
+
+
+def test_electron_afterpulse_feedback_schedule_matches_reference():
+    """golden chain H (enable_electron_afterpulses, secondaries recorded from the reference): the host's replay of the
+    scheduler feedback loop (rawdata.py:70-151) makes the same Pulse calls in the same order -- type-4 instructions are
+    seen one pass after their parent, grouped per residual cluster -- and the recorded calls replay bit-exact"""
+    from tests.helpers import chain_union
+    from wfsim_amd.scheduler import feedback_schedule
+    cfg = xenonnt_test_config()
+    d, r, orc = _check_chain('chain_ele_ap.npz', cfg)
+    assert np.array_equal(r['row_data'], d['row_data'])
+    for k in ['ch', 'left', 'right', 'data']:
+        assert np.array_equal(r['zl_' + k], d['zle_' + k]), k
+    ins, parent = chain_union(d)
+    assert (parent >= 0).sum() == len(d['secondaries']) > 10 and np.all(d['secondaries']['type'] == 4)
+    order, key, cluster, rs = feedback_schedule(ins, parent, cfg)
+    s_ins = ins[order]
+    n_sets = int(rs.max()) + 1
+    kinds = np.array([s_ins['type'][np.where(rs == q)[0][0]] for q in range(n_sets)])
+    assert np.array_equal(kinds, d['call_kind'])
+    # the reference's truth rows of the calls that made photons carry the summed amp of their instructions
+    amps = np.array([s_ins['amp'][rs == q].sum() for q in range(n_sets)])
+    with_photons = np.diff(d['call_ph_off']) > 0
+    assert np.array_equal(amps[with_photons], d['truth']['amp'])
+    assert np.all(np.diff(cluster) >= 0) and np.all(np.diff(rs) >= 0)

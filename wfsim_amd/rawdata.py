@@ -22,7 +22,7 @@ from .engine import Engine
 from .physics import instruction_params
 from .resource import Resource
 from . import electron_afterpulse as ea
-from .scheduler import schedule, processing_order, run_sets
+from .scheduler import schedule, processing_order, run_sets, feedback_schedule
 
 log = logging.getLogger('wfsim_amd.core')
 
@@ -77,12 +77,17 @@ class RawData:
         dt, tw, rext = cfg['sample_duration'], cfg['trigger_window'], cfg['right_raw_extension']
         gids = np.arange(len(instructions)) if self.global_ids is None else np.asarray(self.global_ids)
         em_base = np.zeros(len(instructions), dtype=np.uint32)
+        self._all_run_sets = None
         if self._has_electron_afterpulses():
-            # pre-pass: the secondaries of every S2 (type 4 / 6 instructions), then everything through the normal path
-            sec, sec_gid, sec_base = self.electron_afterpulse_instructions(instructions, gids)
+            # pre-pass: the secondaries of every S2 (type 4 / 6 instructions); then primaries and secondaries go through the
+            # normal path in the order, clusters and pulse sets of the reference's feedback loop (rawdata.py:70-151)
+            sec, sec_gid, sec_base, sec_parent = self.electron_afterpulse_instructions(instructions, gids, with_parent=True)
+            parent = np.concatenate([np.full(len(instructions), -1, dtype=np.int64), sec_parent])
             instructions = np.concatenate([instructions, sec])
             gids, em_base = np.concatenate([gids, sec_gid]), np.concatenate([em_base, sec_base])
-        order, key, cluster = schedule(instructions, cfg)
+            order, key, cluster, self._all_run_sets = feedback_schedule(instructions, parent, cfg)
+        else:
+            order, key, cluster = schedule(instructions, cfg)
         s_ins = instructions[order]
         n = len(s_ins)
         self.instruction_event_number = np.min(instructions['event_number'])
@@ -97,6 +102,7 @@ class RawData:
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)
             self.engine.set_window_carry(has_pulse, runmax)
             self._batch_em_base = em_base[order[a:b]]
+            self._batch_run_set = None if self._all_run_sets is None else self._all_run_sets[a:b] - self._all_run_sets[a]
             self._load_batch(ins, gid, cl, key[a:b])
             self.engine.run()
             groups = self.engine.groups()
@@ -144,14 +150,15 @@ class RawData:
         # one pulse set per instruction, or -- save_full_truth off -- per group of nearby S1s / S2s (rawdata.py:106-127)
         # ...; electron-afterpulse instructions (types 4 / 6) of a cluster always share one call
         plain = self.config.get('save_full_truth', True) and bool(np.all(ins['type'] <= 2))
-        self._run_set = None if plain else run_sets(ins, key, cl, self.config)[0]
+        given = getattr(self, '_batch_run_set', None)                   # electron afterpulses: from the feedback schedule
+        self._run_set = given if given is not None else (None if plain else run_sets(ins, key, cl, self.config)[0])
         self.engine.load_instructions(ins, gid, cl, key, ip, run_set=self._run_set, em_base=getattr(self, '_batch_em_base', None))
 
     # ---- electron afterpulses (afterpulse.py:14-139, rawdata.py:192-202) ------------------------------
     def _has_electron_afterpulses(self):
         return bool(self.config.get('enable_electron_afterpulses', False) or self.config.get('enable_gate_afterpulses', False))
 
-    def electron_afterpulse_instructions(self, instructions, gids):
+    def electron_afterpulse_instructions(self, instructions, gids, with_parent=False):
         """Pre-pass: photons of the primaries only (no pulses), then for every S2 pulse set its secondary instructions
         (type 4 photo-ionisation / type 6 gate electrons).  Returns (secondaries, their gid, their emitter offsets)."""
         cfg = self.config
@@ -159,13 +166,13 @@ class RawData:
         s_ins, s_gid = instructions[order], np.asarray(gids)[order]
         n = len(s_ins)
         est_csum = np.cumsum(self._expected_quanta(s_ins))
-        out, out_gid, out_base = [], [], []
+        out, out_gid, out_base, out_parent = [], [], [], []
         a = 0
         while a < n:
             b = self._batch_end(a, est_csum, cluster)
             ins, gid = s_ins[a:b], s_gid[a:b]
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)
-            self._batch_em_base = None
+            self._batch_em_base = self._batch_run_set = None
             self._load_batch(ins, gid.astype(np.uint32), cl, key[a:b])
             self.engine.generate()
             ph_off = self.engine.instruction_photon_offsets()           # generation order: instruction by instruction
@@ -196,10 +203,13 @@ class RawData:
                 if len(sec) > ea.MAX_SECONDARIES_PER_PARENT:
                     raise ValueError(f'{len(sec)} electron-afterpulse instructions from one S2: more than the stream ids allow')
                 out.append(sec); out_gid.append(np.full(len(sec), gid[i])); out_base.append(((np.arange(len(sec)) + 1) << 20).astype(np.uint32))
+                out_parent.append(np.full(len(sec), order[a + i]))       # index of the parent (first instruction of its set) in the input
             a = b
         if not out:
-            return np.zeros(0, dtype=instructions.dtype), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.uint32)
-        return np.concatenate(out), np.concatenate(out_gid).astype(np.int64), np.concatenate(out_base)
+            res = (np.zeros(0, dtype=instructions.dtype), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.uint32), np.zeros(0, dtype=np.int64))
+        else:
+            res = (np.concatenate(out), np.concatenate(out_gid).astype(np.int64), np.concatenate(out_base), np.concatenate(out_parent).astype(np.int64))
+        return res if with_parent else res[:3]
 
     # ---- truth (rawdata.py:313-375) ----------------------------------------------------------------
     def _truth_rows(self, ins, cl):

@@ -59,3 +59,75 @@ def run_sets(s_ins, key, cluster, config):
             out[idx] = k + np.cumsum(new) - 1
             k += int(new.sum())
     return out, k
+
+
+FORCED_BREAK_KEY = np.int64(2 ** 62)
+
+
+def feedback_schedule(instructions, parent, config):
+    """The reference's scheduler loop with electron-afterpulse feedback (rawdata.py:70-151), replayed on the host for a
+    run whose secondaries are already known.
+
+    ``instructions``: primaries followed by secondaries; ``parent[i]``: for a secondary the index of the instruction
+    whose pulse set produced it (the first instruction of that set), -1 for primaries.  The loop: one cluster of
+    primaries is added to the buffer per pass, the buffer is re-clustered (gap > rext), clusters are simulated in time
+    order up to and including the first one that holds a primary; a secondary enters the buffer when its parent's set
+    has been simulated, i.e. it is seen from the NEXT pass on.  A cluster without primaries is digitised right after
+    it was simulated (rawdata.py:148-149), the others when the next pass starts and finds a gap (rawdata.py:96-98).
+
+    Returns (order, key, cluster, run_set): ``instructions[order]`` in processing order (cluster by cluster, key
+    order inside), ``cluster`` the non-decreasing dynamic cluster index, ``key`` the scheduler key except that the
+    members of a cluster that is always preceded by a digitisation carry FORCED_BREAK_KEY (the device's window rule
+    ``min key - last pulse end > rext`` then fires whenever a pulse exists), ``run_set`` the pulse set of every
+    instruction (numbered in processing order)."""
+    from .physics import instruction_time
+    n = len(instructions)
+    key = instruction_time(instructions, config).astype(np.int64)
+    rext = config['right_raw_extension']
+    typ = instructions['type']
+    prim = np.where(parent < 0)[0]
+    prim = prim[np.argsort(key[prim], kind='stable')]
+    cuts = np.where(np.diff(key[prim]) > rext)[0] + 1
+    queue = [q for q in np.split(prim, cuts)] if len(prim) else []
+    children = {}
+    for i in np.where(parent >= 0)[0]:
+        children.setdefault(int(parent[i]), []).append(int(i))
+    full = config.get('save_full_truth', True)
+    gaps = {1: 100, 2: int(0.2 / config['drift_velocity_liquid'])}
+    buf = []
+    order, cluster, eff_key, run_set = [], [], [], []
+    n_cl = n_set = 0
+    while queue or buf:
+        if queue:
+            buf.extend(queue.pop(0).tolist())
+        b = np.asarray(buf, dtype=np.int64)
+        b = b[np.argsort(key[b], kind='stable')]
+        cls = np.split(b, np.where(np.diff(key[b]) > rext)[0] + 1)
+        first = True
+        for cl in cls:
+            has_prim = bool(np.any(typ[cl] <= 2))
+            released = []
+            for ptype in (1, 2, 4, 6):
+                idx = cl[typ[cl] == ptype]
+                if len(idx) == 0:
+                    continue
+                if ptype in gaps:
+                    new = np.ones(len(idx), dtype=bool) if full else np.concatenate([[True], np.diff(key[idx]) > gaps[ptype]])
+                else:
+                    new = np.concatenate([[True], np.zeros(len(idx) - 1, dtype=bool)])
+                sid = n_set + np.cumsum(new) - 1
+                n_set += int(new.sum())
+                order.extend(idx.tolist()); run_set.extend(sid.tolist()); cluster.extend([n_cl] * len(idx))
+                eff_key.extend((key[idx] if first else np.full(len(idx), FORCED_BREAK_KEY)).tolist())
+                if ptype == 2:                           # secondaries hang on the first instruction of their parent set
+                    for i0 in idx[new]:
+                        released.extend(children.get(int(i0), []))
+            members = set(cl.tolist())
+            buf = [i for i in buf if i not in members] + released
+            n_cl += 1
+            first = False
+            if has_prim:
+                break
+    assert len(order) == n, 'every instruction is scheduled exactly once'
+    return (np.asarray(order, dtype=np.int64), np.asarray(eff_key, dtype=np.int64), np.asarray(cluster, dtype=np.int32),
+            np.asarray(run_set, dtype=np.int32))
