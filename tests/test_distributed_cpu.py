@@ -25,6 +25,11 @@ def test_shard_clusters_whole_clusters_balanced():
         assert loads.max() < 1.25 * loads.mean() + weight.max() * 6
     assert np.array_equal(shard_clusters(np.zeros(0, int), np.zeros(0), 4), np.zeros(5))
     assert np.array_equal(shard_clusters(np.zeros(3, int), np.ones(3), 2), [0, 3, 3])   # one cluster cannot be split
+    # electron afterpulses: cuts only where the key jumps by more than rext + the longest delay
+    cluster = np.arange(10); key = np.array([0, 1, 2, 3, 50, 51, 52, 53, 54, 55]) * 1_000_000
+    b = shard_clusters(cluster, np.ones(10), 4, key=key, min_gap=5_000_000)
+    assert set(b[1:-1].tolist()) <= {4, 10} and b[0] == 0 and b[-1] == 10 and np.all(np.diff(b) >= 0)
+    assert np.array_equal(shard_clusters(cluster, np.ones(10), 2, key=key, min_gap=5_000_000), [0, 4, 10])
 
 
 def _fake_records(rank, n):

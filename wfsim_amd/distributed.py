@@ -11,17 +11,24 @@ Concatenating the shards in rank order gives the globally time-ordered stream.
 import numpy as np
 
 
-def shard_clusters(cluster, weight, world_size):
+def shard_clusters(cluster, weight, world_size, key=None, min_gap=None):
     """Contiguous ranges of whole clusters, balanced by ``weight`` (e.g. expected quanta per instruction).
 
     ``cluster``: non-decreasing cluster index of every (sorted) instruction.  Returns ``bounds`` with
-    ``world_size + 1`` instruction indices: rank r owns ``[bounds[r], bounds[r + 1])``."""
+    ``world_size + 1`` instruction indices: rank r owns ``[bounds[r], bounds[r + 1])``.
+    With ``key`` and ``min_gap`` a range may only start where the scheduler key jumps by more than ``min_gap`` ns:
+    electron afterpulses land up to the longest delay after their S2 and merge into the clusters that follow
+    (rawdata.py:133-140), so shards are cut only at gaps larger than rext + that delay."""
     n = len(cluster)
     if n == 0:
         return np.zeros(world_size + 1, dtype=np.int64)
     w = np.cumsum(np.asarray(weight, dtype=np.float64))
     total = w[-1]
     starts = np.concatenate([[0], np.where(np.diff(cluster) != 0)[0] + 1])      # first instruction of every cluster
+    if key is not None and min_gap is not None:
+        key = np.asarray(key)
+        ok = np.concatenate([[True], (key[starts[1:]] - key[starts[1:] - 1]) > min_gap])
+        starts = starts[ok]
     bounds = [0]
     for r in range(1, world_size):
         target = total * r / world_size
@@ -78,7 +85,17 @@ def simulate_sharded(config, instructions, device=None, dst=0):
     order, key, cluster = schedule(instructions, config)
     s_ins = instructions[order]
     weight = np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15, s_ins['amp'] * float(config.get('s2_secondary_sc_gain', 30)))
-    b = shard_clusters(cluster, weight, world)
+    min_gap = None
+    if config.get('enable_electron_afterpulses', False) or config.get('enable_gate_afterpulses', False):
+        # the secondaries of an S2 reach this far behind it: drift of the longest delay + the gate offset
+        delay = 0.0
+        if config.get('enable_electron_afterpulses', False):
+            h = config['uniform_to_ele_ap']
+            delay = float(h[1][-1]) if isinstance(h, (tuple, list)) else float(h.bin_edges[-1])
+        if config.get('enable_gate_afterpulses', False):
+            delay = max(delay, config['photoelectric_t_center'] + config['drift_time_gate'] + 6 * config['photoelectric_t_spread'])
+        min_gap = config['right_raw_extension'] + delay + 2 * config['drift_time_gate'] + 10_000
+    b = shard_clusters(cluster, weight, world, key=key, min_gap=min_gap)
     mine = s_ins[b[rank]:b[rank + 1]]
     rd = RawData(config, device=device)
     # run-wide instruction ids keep the RNG streams independent of the sharding
