@@ -30,7 +30,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from _ref_stubs import import_reference, REFERENCE_ROOT   # noqa: E402
-from wfsim_amd.dtypes import instruction_dtype, truth_extra_dtype   # noqa: E402
+from wfsim_amd.dtypes import instruction_dtype, truth_extra_dtype, optical_extra_dtype   # noqa: E402
 
 TMP = '/tmp/wfsim_golden_tmp'
 os.makedirs(TMP, exist_ok=True)
@@ -501,6 +501,28 @@ def fixture_chain_electron_ap(ref):
                         **run_chain(ref, base_config(), make_instructions(rows), 808, pat, ele_ap=StubDelayHist(h, edges)))
 
 
+def fixture_optical_adjustment(ref):
+    """utils.optical_adjustment (host preparation of optical input): random photon lists, a third of the entries longer
+    than PULSE_MAX_DURATION, some empty"""
+    rng = np.random.default_rng(11)
+    n = 60
+    ins = np.zeros(n, dtype=instruction_dtype + optical_extra_dtype)
+    nph = rng.integers(0, 25, n); nph[::7] = 0
+    ins['_first'] = np.cumsum(nph) - nph
+    ins['_last'] = np.cumsum(nph)
+    ins['time'] = 1_000_000 * np.arange(n)
+    ins['type'], ins['event_number'] = 1, np.arange(n)
+    tot = int(nph.sum())
+    timings = rng.integers(0, 400, tot).astype(np.int64)
+    tail = rng.random(tot) < 0.08
+    timings[tail] += rng.integers(900, 5000, tail.sum())
+    channels = rng.integers(0, 120, tot).astype(np.int64)
+    t_in, c_in = timings.copy(), channels.copy()
+    out = ref.utils.optical_adjustment(ins.copy(), timings, channels)
+    np.savez_compressed(HERE + '/optical_adjustment.npz', ins_in=ins, timings_in=t_in, channels_in=c_in,
+                        ins_out=out, timings_out=timings, channels_out=channels)
+
+
 def hist(x):
     v, c = np.unique(np.asarray(x, dtype=np.int64), return_counts=True)
     return v.astype(np.int64), c.astype(np.int64)
@@ -592,6 +614,8 @@ if __name__ == '__main__':
         fixture_chain_runsets(ref)
     if 'chains' in which or 'ele_ap' in which:
         fixture_chain_electron_ap(ref)
+    if 'optical' in which or 'tables' in which:
+        fixture_optical_adjustment(ref)
     if 'dists' in which:
         fixture_distributions(ref)
     if 'stats' in which:

@@ -120,3 +120,24 @@ def test_empty_instructions():
     sim = ChunkRawRecords(cfg, rawdata_generator=FakeRawData)
     assert list(sim(_instructions([]))) == []
     assert sim.source_finished()
+
+
+def test_optical_adjustment_matches_reference():
+    """host preparation of optical input (utils.py:122-165) against the reference's own output on the same arrays:
+    entry times moved to their first photon, long entries split into an early and a late instruction"""
+    from tests.helpers import golden
+    from wfsim_amd.optical import optical_adjustment, PULSE_MAX_DURATION
+    d = golden('optical_adjustment.npz')
+    t, c = d['timings_in'].copy(), d['channels_in'].copy()
+    out = optical_adjustment(d['ins_in'], t, c)
+    assert len(out) == len(d['ins_out']) > len(d['ins_in'])
+    for f in out.dtype.names:
+        assert np.array_equal(out[f], d['ins_out'][f]), f
+    assert np.array_equal(t, d['timings_out']) and np.array_equal(c, d['channels_out'])
+    # the entries kept by the original rows now fit the pulse length; the appended rows hold the late photons
+    n0 = len(d['ins_in'])
+    for r in out[:n0]:
+        if r['_last'] > r['_first']:
+            assert t[r['_first']:r['_last']].max() <= PULSE_MAX_DURATION and t[r['_first']:r['_last']].min() >= 0
+    for r in out[n0:]:
+        assert t[r['_first']:r['_last']].min() > PULSE_MAX_DURATION
