@@ -198,7 +198,7 @@ def main():
                       pipeline_frac=b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       kernels_ms={k: round(v[0], 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}),
     )
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and world == 1:          # the CPU baseline is timed on rank 0 of the 1-GPU run only
         out['cpu_baseline'], _ = cpu_baseline(cfg, args.cpu_sample)
     print(json.dumps(out))
     if world > 1:
