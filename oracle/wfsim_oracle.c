@@ -6,7 +6,8 @@
  *
  * Parity status: PINNED.  Every deterministic stage below is checked bit-for-bit against vectors produced by
  * running the reference itself (tests/golden/make_golden.py, WFSim v1.2.2 imported from /root/reference in the
- * build container): add_current currents, pulse bounds, digitised rows, channel masks, ZLE tuples.  The random
+ * build container): add_current currents, pulse bounds, digitised rows, channel masks, ZLE tuples, add_noise, the
+ * Pulse-call structure of run sets and of the electron-afterpulse feedback loop (golden chains A-H).  The random
  * stages cannot be stream-compatible with numpy's legacy generator; they follow the reference's arithmetic
  * (same truncations, term by term) on a counter-based Philox4x32-10 stream (layout in DESIGN.md "RNG streams")
  * and are pinned statistically against histograms of the reference's own draws (tests/golden/dists.npz).
