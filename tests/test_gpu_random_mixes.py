@@ -1,0 +1,68 @@
+"""Randomised end-to-end runs on the GPU against the CPU oracle: instruction mixes, secondary gains, run sets, PMT
+afterpulses and noise drawn at random (fixed seeds); records must agree byte for byte every time.  Aimed at the seams:
+photon blocks that straddle instructions, blocks with more emitters than the LDS window, empty instructions, tiles on
+either side of the tiny / sparse / dense classes."""
+import numpy as np
+import pytest
+
+from tests.helpers import make_engine, make_oracle, ap_tables_from_golden, golden
+from wfsim_amd.config import xenonnt_test_config
+from wfsim_amd.dtypes import instruction_dtype
+from wfsim_amd.physics import instruction_params
+from wfsim_amd.resource import Resource
+from wfsim_amd.scheduler import schedule, run_sets
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_case(seed):
+    rng = np.random.default_rng(seed)
+    kw = dict(s2_secondary_sc_gain=float(rng.choice([1.5, 4.0, 21.3, 100.0])), seed=int(rng.integers(1, 10 ** 6)))
+    if rng.random() < 0.4:
+        kw['save_full_truth'] = False
+    if rng.random() < 0.3:
+        kw['s2_time_spread'] = float(rng.choice([0.0, 30.0]))
+    ap = ap_tables_from_golden() if rng.random() < 0.35 else None
+    if ap is not None:
+        kw.update(enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap)
+    if rng.random() < 0.3:
+        kw.update(enable_noise=True, noise_data=golden('noise.npz')['noise'])
+    cfg = xenonnt_test_config(**kw)
+    n = int(rng.integers(3, 60))
+    ins = np.zeros(n, dtype=instruction_dtype)
+    ins['type'] = rng.choice([1, 2], n, p=[0.5, 0.5])
+    # clusters of instructions: a few within ns..us of each other, the rest far apart
+    base = np.cumsum(rng.choice([200, 3_000, 40_000, 500_000, 3_000_000], n)).astype(np.int64) + 1_000_000
+    ins['time'] = base
+    ins['x'], ins['y'] = rng.uniform(-30, 30, n), rng.uniform(-30, 30, n)
+    ins['z'] = -rng.uniform(0.5, 95, n)
+    s1 = ins['type'] == 1
+    ins['amp'] = np.where(s1, rng.choice([0, 1, 40, 700, 5000, 30000], n), rng.choice([0, 1, 7, 60, 400, 2500, 9000], n, p=[.1, .15, .2, .2, .2, .1, .05]))
+    ins['recoil'], ins['event_number'] = 7, np.arange(n)
+    return cfg, ins, ap
+
+
+import os
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES', 12)))))
+def test_random_mix_matches_oracle(seed):
+    cfg, ins, ap = _random_case(1000 + seed)
+    res = Resource(cfg)
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    gid = order.astype(np.uint32)
+    ip = instruction_params(s_ins, cfg, res)
+    orc = make_oracle(cfg, ap)
+    orc.simulate(s_ins, gid, ip)
+    eng = make_engine(cfg)
+    rs = None if cfg.get('save_full_truth', True) else run_sets(s_ins, key, cluster, cfg)[0]
+    eng.load_instructions(s_ins, gid, cluster, key, ip, run_set=rs)
+    counts = eng.run()
+    o = orc.results()
+    assert counts['n_photons'] == len(o['ph_t'])
+    g = eng.groups()
+    keep = g['right'] >= g['left']
+    assert np.array_equal(g['left'][keep], o['dg_left']) and np.array_equal(g['right'][keep], o['dg_right'])
+    assert eng.records().tobytes() == orc.pack_records().tobytes()
+    assert counts['n_pe'] == orc.n_pe
