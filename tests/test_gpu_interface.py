@@ -244,6 +244,11 @@ def test_electron_afterpulses_against_oracle():
     # call structure: per dynamic cluster S1s, S2s, then ONE type-4 call and ONE type-6 call (rawdata.py:102-127)
     n_sets = int(rs.max()) + 1
     assert n_sets == len(o['call_kind']) and set(o['call_kind']) == {1, 2, 4, 5}
+    # small batches (pre-pass and main pass): same windows, same bytes
+    rd3 = wfsim_amd.RawData(cfg)
+    rd3.max_batch_quanta = 20000
+    got = [(w['left'], w['right'], w['records'].tobytes()) for w in rd3.iter_windows(ins)]
+    assert got == [(w['left'], w['right'], w['records'].tobytes()) for w in windows]
     t = truth[truth['fill']]
     assert len(t) == n_sets and (t['type'] == 4).sum() == (o['call_kind'] == 4).sum() >= 3
     assert np.all(t['n_electron'][t['type'] == 2] > 0) and t['n_electron'][t['type'] == 4].sum() > 10      # a lone secondary electron may be lost on the way
