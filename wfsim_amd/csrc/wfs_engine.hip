@@ -42,7 +42,7 @@ struct wfs_handle {
     i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_embase, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
-    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, ph_slot;
+    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ph_slot;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles;
     DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
@@ -325,7 +325,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -644,7 +644,12 @@ static int run_generation(wfs_handle *h)
     g.em_time = h->em_time.as<i64>(); g.em_nph = h->em_nph.as<i32>(); g.em_ins = h->em_ins.as<i32>();
     g.el_stat = h->el_stat.as<double>(); g.el_minmax = h->el_minmax.as<i64>(); g.scal = h->scal.as<i64>();
     { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }
-    { Timer t(h, "k_s2_electrons"); hipLaunchKernelGGL(k_s2_electrons, dim3(nblocks(E, 256)), dim3(256), 0, h->stream, d, g); }
+    {
+        const i64 neb = (E + 255) / 256;
+        TRY(ensure(h, h->eblk_ins, (size_t)(neb + 1) * 4)); g.eblk_ins = h->eblk_ins.as<i32>();
+        { Timer t(h, "k_emitter_blocks"); hipLaunchKernelGGL(k_emitter_blocks, dim3(nblocks(neb + 1, 256)), dim3(256), 0, h->stream, g, neb); }
+        Timer t(h, "k_s2_electrons"); hipLaunchKernelGGL(k_s2_electrons, dim3(nblocks(E, 256)), dim3(256), 0, h->stream, d, g);
+    }
     TRY(scan(h, h->em_nph.as<i32>(), E, h->em_ph_off, 6));
     TRY(read_scal(h));
     const i64 P = h->h_scal[6];

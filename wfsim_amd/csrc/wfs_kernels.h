@@ -1076,6 +1076,7 @@ struct GenArgs {
     PhotonRec *ph;
     i64 n_blocks;
     i64 xcd_chunk;                // XCD x (workgroup id % 8) walks the photon blocks [x * xcd_chunk, (x + 1) * xcd_chunk) in order
+    i32 *eblk_ins;                // [ceil(n_emitters / 256) + 1] instruction of the first emitter of every block of k_s2_electrons
     i64 *blk_e;                   // [n_blocks][2] first / last emitter of every photon block
     u32 *blk_base;                // [n_blocks][n_tpc] start of the block's photons inside each tile (written by the count pass)
     unsigned short *blk_cnt;      // [n_blocks][n_tpc] the block's photons per channel (count pass, single-instruction blocks)
@@ -1137,12 +1138,27 @@ __global__ __launch_bounds__(256) void k_s1_hits(WfsDev d, GenArgs a)
 }
 
 // S2: one thread per candidate electron (s2.py:254, 258-286, 308-310)
+// instruction of the first emitter of every 256-emitter block of k_s2_electrons (+ a sentinel: the last instruction)
+__global__ void k_emitter_blocks(GenArgs a, i64 n_blocks)
+{
+    const i64 b = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_blocks) return;
+    if (b == n_blocks) { a.eblk_ins[b] = (i32)(a.n_ins - 1); return; }
+    const i64 e = b * 256;
+    i64 lo = 0, hi = a.n_ins;
+    while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_off[mid] <= e) lo = mid; else hi = mid; }
+    a.eblk_ins[b] = (i32)lo;
+}
+
 __global__ __launch_bounds__(256) void k_s2_electrons(WfsDev d, GenArgs a)
 {
     const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     i64 i = -1; bool is_s2 = false;
+    // instruction of emitter e: em_off[i] <= e < em_off[i+1].  The instruction of every block's first emitter comes from
+    // k_emitter_blocks (all those searches in flight at once); inside the block the search runs over what is left,
+    // usually nothing (10^4 candidate electrons per S2).
     if (e < a.n_emitters) {
-        i64 lo = 0, hi = a.n_ins;                   // instruction of emitter e: em_off[lo] <= e < em_off[lo+1]
+        i64 lo = a.eblk_ins[blockIdx.x], hi = a.eblk_ins[blockIdx.x + 1] + 1;
         while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_off[mid] <= e) lo = mid; else hi = mid; }
         i = lo; is_s2 = a.ins_type[i] != 1;          // types 2, 4, 6 are S2-like (electrons drifting to the gas gap)
     }
