@@ -74,8 +74,8 @@ def cpu_baseline(cfg, n_sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--instructions', type=int, default=1000, help='S2 instructions per GPU per step')
     ap.add_argument('--cpu-sample', type=int, default=60, help="S2 instructions timed on the CPU oracle, ~15 s (0: skip)")
     ap.add_argument('--no-gather', action='store_true', help='skip the RCCL gather of records (N > 1)')
