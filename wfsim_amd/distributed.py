@@ -53,12 +53,15 @@ def gather_records(records, dst=0, group=None, async_op=False):
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
-    bufs, reqs = None, []
+    bufs, ops = None, []
     if rank == dst:
         bufs = [records if r == dst else torch.empty(sizes[r], dtype=records.dtype, device=records.device) for r in range(world)]
-        reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(world) if r != dst and sizes[r] > 0]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r, group) for r in range(world) if r != dst and sizes[r] > 0]
     elif sizes[rank] > 0:
-        reqs = [dist.isend(records, dst=dst, group=group)]
+        ops = [dist.P2POp(dist.isend, records, dst, group)]
+    # ONE grouped call (ncclGroupStart/End under RCCL): the root's receives run concurrently over all its xGMI links;
+    # separate irecv calls would queue behind each other on the communicator's stream
+    reqs = dist.batch_isend_irecv(ops) if ops else []
     if async_op:
         return bufs, (reqs, records)          # keep the send buffer alive until the transfer is done
     wait_gather(reqs)
