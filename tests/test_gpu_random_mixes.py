@@ -66,3 +66,42 @@ def test_random_mix_matches_oracle(seed):
     assert np.array_equal(g['left'][keep], o['dg_left']) and np.array_equal(g['right'][keep], o['dg_right'])
     assert eng.records().tobytes() == orc.pack_records().tobytes()
     assert counts['n_pe'] == orc.n_pe
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_EAP', 8)))))
+def test_random_mix_with_electron_afterpulses(seed):
+    """the same with electron afterpulses (and, half of the time, gate afterpulses / run sets): RawData end to end
+    against the oracle fed with the same secondaries in the order of the feedback schedule"""
+    import wfsim_amd
+    from wfsim_amd.scheduler import feedback_schedule
+    rng = np.random.default_rng(5000 + seed)
+    edges = np.linspace(0, float(rng.choice([150e3, 700e3])), 141)
+    hist = np.exp(-np.arange(140) / 30.0); hist *= float(rng.choice([5e-4, 3e-3])) / hist.sum()
+    kw = dict(enable_electron_afterpulses=True, uniform_to_ele_ap=(hist, edges), seed=int(rng.integers(1, 10 ** 6)),
+              s2_secondary_sc_gain=float(rng.choice([21.3, 60.0])))
+    if rng.random() < 0.5:
+        kw.update(enable_gate_afterpulses=True, photoelectric_p=float(rng.choice([1e-4, 2e-3])))
+    if rng.random() < 0.5:
+        kw['save_full_truth'] = False
+    cfg = xenonnt_test_config(**kw)
+    n = int(rng.integers(3, 25))
+    ins = np.zeros(n, dtype=instruction_dtype)
+    ins['type'] = rng.choice([1, 2], n)
+    ins['time'] = np.cumsum(rng.choice([300, 30_000, 250_000, 2_000_000], n)).astype(np.int64) + 1_000_000
+    ins['x'], ins['y'], ins['z'] = rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), -rng.uniform(0.5, 95, n)
+    ins['amp'] = np.where(ins['type'] == 1, rng.choice([0, 50, 900, 6000], n), rng.choice([0, 5, 80, 600, 2000], n))
+    ins['recoil'], ins['event_number'] = 7, np.arange(n)
+    rd = wfsim_amd.RawData(cfg)
+    rd.max_batch_quanta = int(rng.choice([30_000, 2_000_000_000]))
+    windows = list(rd.iter_windows(ins))
+    rec = np.concatenate([w['records'] for w in windows]) if windows else np.zeros(0)
+    sec, sec_gid, sec_base, sec_parent = rd.electron_afterpulse_instructions(ins, np.arange(n), with_parent=True)
+    allins = np.concatenate([ins, sec]); gids = np.concatenate([np.arange(n), sec_gid])
+    base = np.concatenate([np.zeros(n, np.uint32), sec_base]); parent = np.concatenate([np.full(n, -1), sec_parent])
+    order, key, cluster, rs = feedback_schedule(allins, parent, cfg)
+    s_ins = allins[order]
+    orc = make_oracle(cfg)
+    orc.simulate_scheduled(s_ins, gids[order].astype(np.uint32), instruction_params(s_ins, cfg, Resource(cfg)), base[order], cluster, key, rs)
+    o = orc.results()
+    assert len(windows) == len(o['dg_left']) and np.array_equal([w['left'] for w in windows], o['dg_left'])
+    assert (rec.tobytes() if len(rec) else b'') == orc.pack_records().tobytes()

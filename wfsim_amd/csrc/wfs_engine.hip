@@ -107,7 +107,8 @@ struct Timer {
     ~Timer() { if (on) hipEventRecord(h->times.back().b, h->stream); }
 };
 
-inline unsigned nblocks(i64 n, int tpb) { return (unsigned)((n + tpb - 1) / tpb); }
+// grid size for n items; never 0 (a launch with an empty grid is an error, every kernel bounds-checks its index)
+inline unsigned nblocks(i64 n, int tpb) { return n > 0 ? (unsigned)((n + tpb - 1) / tpb) : 1u; }
 
 int fill64(wfs_handle *h, DevBuf &b, i64 n, i64 v)
 {

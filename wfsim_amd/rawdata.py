@@ -118,7 +118,10 @@ class RawData:
                 # would the next cluster have been simulated before this batch's last window was digitised
                 # (rawdata.py:96-98)?  then that window is not complete: simulate it again with the next batch
                 run_all = max(int(ends.max()), runmax) if has_pulse else int(ends.max())
-                if not (key[b] - run_all > rext):
+                # (the key the rule looks at is the smallest of the next CLUSTER: in feedback order its first instruction
+                # need not carry it)
+                nxt = cluster == cluster[b]
+                if not (int(key[nxt].min()) - run_all > rext):
                     g_last = int(np.where(nonempty)[0][-1])
                     restart = a + int(np.argmax(ins_group >= g_last))
                     if restart == a:            # the whole batch is one open window: take a bigger batch
