@@ -90,6 +90,7 @@ typedef struct orc_session_s {
     vec_f64 truth;
     i64 n_pe_total;
     const i64 *noise_override; i64 n_noise_override;
+    u32 win_gid; int win_gid_set; /* noise stream of the open window: gid of the first instruction of its first cluster that made a pulse */
     int save_full_truth;         /* rawdata.py:42: 1 (default) = every instruction is its own Pulse call */
     struct { double *cum; i64 n; i64 vmin; } tab[9];   /* trunc()-ed delay variates: the individual terms and their sums, see TAB_* */    /* tests: ix_rand per digitise call instead of the Philox draw */
 } orc_session;
@@ -462,6 +463,15 @@ void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
     s->first_uncommitted_pulse = p1;
 }
 
+/* schedulers: digitise the open window with its noise stream; note_cluster() names the stream after the first cluster
+ * of the window that produced a pulse (clusters without pulses must not matter: the answer would otherwise depend on
+ * how a run is cut into batches) */
+static void digitize_window(orc_session *s) { orc_digitize_and_zle(s, s->win_gid); s->win_gid_set = 0; }
+static void note_cluster(orc_session *s, i64 pulses_before, u32 first_gid)
+{
+    if (!s->win_gid_set && s->pl_ch.n > pulses_before) { s->win_gid = first_gid; s->win_gid_set = 1; }
+}
+
 /* ---------------------------------------------------------------- integer delay variates --------- */
 /* The reference draws a float variate and truncates it to int64 (pulse.py:54-56 normal, s1.py:193-194 exponential and
  * normal, pulse.py:339-341 exponential * lifetime, s2.py:550 normal).  trunc(Y) is sampled here directly: from one
@@ -783,18 +793,20 @@ void orc_simulate_optical(orc_session *s, i64 n, const i64 *time, const u32 *gid
     tkey *ord = (tkey *)malloc((size_t)n * sizeof(tkey));
     for (i64 i = 0; i < n; i++) { ord[i].t = time[i]; ord[i].i = i; }
     qsort(ord, (size_t)n, sizeof(tkey), tkey_cmp);
-    i64 a = 0, group_start = 0; int runset = 0;
+    i64 a = 0; int runset = 0;
     while (a < n) {
         i64 b = a + 1;
         while (b < n && !((double)(ord[b].t - ord[b - 1].t) > c->rext)) b++;
-        if (s->has_pulse && (double)(ord[a].t - s->last_end) > c->rext) { orc_digitize_and_zle(s, gid[ord[group_start].i]); group_start = a; }
+        if (s->has_pulse && (double)(ord[a].t - s->last_end) > c->rext) digitize_window(s);
+        const i64 np0 = s->pl_ch.n;
         for (i64 k = a; k < b; k++) {
             i64 i = ord[k].i;
             orc_optical(s, gid[i], runset++, time[i], last[i] - first[i], timings + first[i], channels + first[i], cutoff);
         }
+        note_cluster(s, np0, gid[ord[a].i]);
         a = b;
     }
-    orc_digitize_and_zle(s, gid[ord[group_start].i]);
+    digitize_window(s);
     free(ord);
 }
 
@@ -820,14 +832,12 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
         ord[i].t = it[i]; ord[i].i = i;
     }
     qsort(ord, (size_t)n, sizeof(tkey), tkey_cmp);
-    i64 a = 0, group_start = 0; int runset = 0;
+    i64 a = 0; int runset = 0;
     while (a < n) {
         i64 b = a + 1;
         while (b < n && !((double)(ord[b].t - ord[b - 1].t) > c->rext)) b++;
-        if (s->has_pulse && (double)(ord[a].t - s->last_end) > c->rext) {
-            orc_digitize_and_zle(s, gid[ord[group_start].i]);    /* rawdata.py:96-98 */
-            group_start = a;
-        }
+        if (s->has_pulse && (double)(ord[a].t - s->last_end) > c->rext) digitize_window(s);    /* rawdata.py:96-98 */
+        const i64 np0 = s->pl_ch.n;
         static const int ptypes[4] = {1, 2, 4, 6};              /* rawdata.py:102: S1, S2, photo-ionisation electrons, gate electrons */
         for (int pq = 0; pq < 4; pq++) {
             const int ptype = ptypes[pq];
@@ -845,9 +855,10 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
             }
             if (open) finish_call(s, ptype == 6 ? 5 : ptype, runset++, &x);      /* call kinds: 1 S1, 2 S2, 3 PMT afterpulse, 4 PI electrons, 5 gate electrons */
         }
+        note_cluster(s, np0, gid[ord[a].i]);
         a = b;
     }
-    orc_digitize_and_zle(s, gid[ord[group_start].i]);         /* rawdata.py:154-155 */
+    digitize_window(s);                                       /* rawdata.py:154-155 */
     free(it); free(ord);
 }
 
@@ -862,11 +873,12 @@ void orc_simulate_scheduled(orc_session *s, i64 n, const int8_t *type, const i64
 {
     const orc_config *c = &s->c;
     if (n == 0) return;
-    i64 a = 0, group_start = 0;
+    i64 a = 0;
     while (a < n) {
         i64 b = a + 1, cmin = tmin[a];
         while (b < n && cluster[b] == cluster[a]) { if (tmin[b] < cmin) cmin = tmin[b]; b++; }
-        if (s->has_pulse && (double)(cmin - s->last_end) > c->rext) { orc_digitize_and_zle(s, gid[group_start]); group_start = a; }
+        if (s->has_pulse && (double)(cmin - s->last_end) > c->rext) digitize_window(s);
+        const i64 np0 = s->pl_ch.n;
         i64 k = a;
         while (k < b) {
             i64 e = k + 1;
@@ -880,9 +892,10 @@ void orc_simulate_scheduled(orc_session *s, i64 n, const int8_t *type, const i64
             finish_call(s, type[k] == 6 ? 5 : type[k], run_set[k], &x);
             k = e;
         }
+        note_cluster(s, np0, gid[a]);
         a = b;
     }
-    orc_digitize_and_zle(s, gid[group_start]);
+    digitize_window(s);
 }
 
 /* ---------------------------------------------------------------- record packing ----------------- */

@@ -105,3 +105,28 @@ def test_random_mix_with_electron_afterpulses(seed):
     o = orc.results()
     assert len(windows) == len(o['dg_left']) and np.array_equal([w['left'] for w in windows], o['dg_left'])
     assert (rec.tobytes() if len(rec) else b'') == orc.pack_records().tobytes()
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_BATCH', 10)))))
+def test_random_mix_small_batches_equal_one_batch(seed):
+    """RawData.iter_windows: windows and record bytes do not depend on how the run is cut into GPU batches
+    (window carry across batches, re-run of an open window, truth rows) -- random mixes incl. afterpulses, noise, run sets"""
+    import wfsim_amd
+    from wfsim_amd.dtypes import truth_extra_dtype
+    cfg, ins, ap = _random_case(9000 + seed)
+    rng = np.random.default_rng(seed)
+
+    def run(mbq):
+        rd = wfsim_amd.RawData(cfg)
+        rd.max_batch_quanta = mbq
+        truth = np.zeros(4 * len(ins) + 10, dtype=instruction_dtype + truth_extra_dtype + [('fill', bool)])
+        w = [(x['left'], x['right'], x['records'].tobytes()) for x in rd.iter_windows(ins, truth_buffer=truth)]
+        t = truth[truth['fill']]
+        return w, t
+    w1, t1 = run(2_000_000_000)
+    w2, t2 = run(int(rng.choice([500, 5_000, 60_000])))
+    assert w1 == w2
+    assert len(t1) == len(t2)
+    for f in ('n_photon', 'n_pe', 't_first_photon', 't_last_photon', 'n_electron', 'amp', 'time', 'event_number'):
+        assert np.array_equal(t1[f], t2[f], equal_nan=True), f
+    assert np.allclose(t1['raw_area'], t2['raw_area'], rtol=1e-12)        # float sum over the photons of a tile: order dependent

@@ -222,7 +222,8 @@ __global__ __launch_bounds__(GROUPS_TPB) void k_groups(WfsDev d, GeomArgs a)
         ssum[tid] += t;
         __syncthreads();
     }
-    // 4) group of every cluster; the first cluster of a group names its noise stream
+    // 4) group of every cluster; the first cluster of a group that made a pulse names its noise stream (grp_gid holds its
+    //    index here; clusters without pulses must not matter, or the stream would depend on how a run is cut into batches)
     i32 g = ssum[tid] - nflag;
     {
         i64 r = run; i32 h = has;
@@ -230,9 +231,8 @@ __global__ __launch_bounds__(GROUPS_TPB) void k_groups(WfsDev d, GeomArgs a)
             const bool flag = h && (double)(a.cl_tmin[k] - r) > d.rext;
             if (flag) g++;
             a.cl_group[k] = g;
-            if (flag || k == 0) a.grp_gid[g] = a.cl_gid[k];
             const i64 e = a.cl_end[k];
-            if (e != I64_MIN) { r = h ? (e > r ? e : r) : e; h = 1; }
+            if (e != I64_MIN) { atomicMin(&a.grp_gid[g], (u32)k); r = h ? (e > r ? e : r) : e; h = 1; }     // first cluster of the group with a pulse
         }
     }
     if (tid == GROUPS_TPB - 1) a.scal[0] = ssum[tid] + 1;
@@ -265,7 +265,7 @@ __global__ void k_group_final(WfsDev d, GeomArgs a)
         i64 nl = a.grp_lo[g] - left - d.tw, nr = a.grp_hi[g] - left + d.tw;
         i64 N = d.noise_len, high = (N - nr + nl - 1 < 0) ? N - 1 : N - nr + nl - 1;
         if (high <= 0) ix = 0;
-        else { u32x4 w = philox4x32_10(0, a.grp_gid[g], 0, SITE_NOISE, d.k0, d.k1); ix = (i64)(u53(w.x, w.y) * (double)high); }
+        else { u32x4 w = philox4x32_10(0, a.cl_gid[a.grp_gid[g]], 0, SITE_NOISE, d.k0, d.k1); ix = (i64)(u53(w.x, w.y) * (double)high); }
         if (a.noise_override && g < a.n_noise_override && a.noise_override[g] >= 0) ix = a.noise_override[g];
     }
     a.grp_ixrand[g] = ix;
