@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def nveto_config(**kw):
-    c = xenonnt_test_config(detector='XENONnT_neutron_veto', right_raw_extension=2000, **kw)
+    kw.setdefault('right_raw_extension', 2000)
+    c = xenonnt_test_config(detector='XENONnT_neutron_veto', **kw)
     n = 120
     c['gains'] = np.full(n, 2e6)
     c['gains'][7] = 0.0                       # one dead PMT

@@ -130,3 +130,45 @@ def test_random_mix_small_batches_equal_one_batch(seed):
     for f in ('n_photon', 'n_pe', 't_first_photon', 't_last_photon', 'n_electron', 'amp', 'time', 'event_number'):
         assert np.array_equal(t1[f], t2[f], equal_nan=True), f
     assert np.allclose(t1['raw_area'], t2['raw_area'], rtol=1e-12)        # float sum over the photons of a tile: order dependent
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_SHARD', 6)))))
+def test_random_mix_sharded_equals_single(seed):
+    """what every rank of a multi-GPU run would compute (contiguous cluster ranges from shard_clusters, run-wide
+    instruction ids), one after the other on this GPU: the concatenation equals the single-GPU run byte for byte"""
+    import wfsim_amd
+    from wfsim_amd.distributed import shard_clusters, safe_cut_gap
+    cfg, ins, ap = _random_case(12000 + seed)
+    world = int(np.random.default_rng(seed).choice([2, 3, 8]))
+    single = b''.join(w['records'].tobytes() for w in wfsim_amd.RawData(cfg).iter_windows(ins))
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    b = shard_clusters(cluster, np.maximum(s_ins['amp'], 1), world, key=key, min_gap=safe_cut_gap(cfg))
+    parts = []
+    for r in range(world):
+        mine = s_ins[b[r]:b[r + 1]]
+        if len(mine) == 0:
+            continue
+        rd = wfsim_amd.RawData(cfg)
+        rd.global_ids = order[b[r]:b[r + 1]]
+        parts.append(b''.join(w['records'].tobytes() for w in rd.iter_windows(mine)))
+    assert b''.join(parts) == single
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_OPT', 6)))))
+def test_random_optical_matches_oracle(seed):
+    """RawDataOptical at random rates / batch sizes against the oracle's optical scheduler"""
+    import wfsim_amd
+    from tests.test_gpu_optical import nveto_config, optical_instructions
+    rng = np.random.default_rng(15000 + seed)
+    cfg = nveto_config(seed=int(rng.integers(1, 10 ** 6)), right_raw_extension=int(rng.choice([500, 2000, 20000])))
+    ins, channels, timings = optical_instructions(int(rng.integers(50, 1500)), float(rng.choice([300.0, 1000.0, 30000.0])), int(rng.integers(1, 1000)))
+    rd = wfsim_amd.RawDataOptical(cfg, channels=channels, timings=timings)
+    rd.max_batch_quanta = int(rng.choice([200, 5000, 2_000_000_000]))
+    windows = list(rd.iter_windows(ins))
+    rec = b''.join(w['records'].tobytes() for w in windows)
+    orc = make_oracle(cfg)
+    orc.simulate_optical(ins, np.arange(len(ins), dtype=np.uint32), channels, timings, int(1e6))
+    o = orc.results()
+    assert len(windows) == len(o['dg_left']) and np.array_equal([w['left'] for w in windows], o['dg_left'])
+    assert rec == orc.pack_records().tobytes()

@@ -39,6 +39,24 @@ def shard_clusters(cluster, weight, world_size, key=None, min_gap=None):
     return np.asarray(bounds, dtype=np.int64)
 
 
+def safe_cut_gap(config):
+    """Gap of the scheduler key behind which a new shard may start.  Consecutive clusters (gap > rext) still share a
+    digitise window when a pulse of the earlier one is not over ``rext`` before the next one starts
+    (``min key - last_pulse_end_time > rext``, rawdata.py:96-98), so a cut needs rext plus the longest a signal lasts past
+    its key: the S1 / S2 photon delays (tables end below ~40 lifetimes: 10 us), PMT afterpulse delays, and the reach of
+    the electron afterpulses.  ``simulate_sharded`` verifies afterwards that no window crossed a cut."""
+    reach = 20_000.0
+    if config.get('enable_pmt_afterpulses', False):
+        for el in config['uniform_to_pmt_ap'].values():
+            reach = max(reach, 20_000.0 + float(el['delaytime_bin_size']) * np.asarray(el['delaytime_cdf']).shape[-1])
+    if config.get('enable_electron_afterpulses', False):
+        h = config['uniform_to_ele_ap']
+        reach += (float(h[1][-1]) if isinstance(h, (tuple, list)) else float(h.bin_edges[-1])) + 2 * config['drift_time_gate']
+    if config.get('enable_gate_afterpulses', False):
+        reach += config['photoelectric_t_center'] + 2 * config['drift_time_gate'] + 6 * config['photoelectric_t_spread']
+    return float(config['right_raw_extension']) + reach
+
+
 def gather_records(records, dst=0, group=None, async_op=False):
     """Variable-length gather of packed records (uint8 tensor of n * 244 bytes per rank, on the backend's device).
 
@@ -88,23 +106,25 @@ def simulate_sharded(config, instructions, device=None, dst=0):
     order, key, cluster = schedule(instructions, config)
     s_ins = instructions[order]
     weight = np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15, s_ins['amp'] * float(config.get('s2_secondary_sc_gain', 30)))
-    min_gap = None
-    if config.get('enable_electron_afterpulses', False) or config.get('enable_gate_afterpulses', False):
-        # the secondaries of an S2 reach this far behind it: drift of the longest delay + the gate offset
-        delay = 0.0
-        if config.get('enable_electron_afterpulses', False):
-            h = config['uniform_to_ele_ap']
-            delay = float(h[1][-1]) if isinstance(h, (tuple, list)) else float(h.bin_edges[-1])
-        if config.get('enable_gate_afterpulses', False):
-            delay = max(delay, config['photoelectric_t_center'] + config['drift_time_gate'] + 6 * config['photoelectric_t_spread'])
-        min_gap = config['right_raw_extension'] + delay + 2 * config['drift_time_gate'] + 10_000
+    min_gap = safe_cut_gap(config)
     b = shard_clusters(cluster, weight, world, key=key, min_gap=min_gap)
     mine = s_ins[b[rank]:b[rank + 1]]
     rd = RawData(config, device=device)
     # run-wide instruction ids keep the RNG streams independent of the sharding
     rd.global_ids = order[b[rank]:b[rank + 1]]
-    recs = [w['records'] for w in rd.iter_windows(mine)]
+    recs, last_end = [], np.iinfo(np.int64).min
+    for w in rd.iter_windows(mine):
+        recs.append(w['records'])
+        last_end = max(last_end, (int(w['right']) - config['trigger_window']) * config['sample_duration'])
     local = np.concatenate(recs) if recs else np.zeros(0, dtype=raw_record_dtype())
+    # no digitise window may reach into the next shard (rawdata.py:96-98 applied across the cut)
+    ends = [None] * world
+    dist.all_gather_object(ends, int(last_end))
+    run_end = np.iinfo(np.int64).min
+    for r in range(world - 1):
+        run_end = max(run_end, ends[r])
+        if b[r + 1] < len(key) and b[r + 1] > b[r] and not (key[b[r + 1]] - run_end > config['right_raw_extension']):
+            raise RuntimeError(f'a digitise window of shard {r} reaches into shard {r + 1}: the result would depend on the sharding')
     dev = torch.device('cuda', device) if dist.get_backend() == 'nccl' else torch.device('cpu')
     t = torch.from_numpy(local.view(np.uint8).copy()).to(dev)
     bufs = gather_records(t, dst=dst)
