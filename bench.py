@@ -90,10 +90,19 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     import torch
     import torch.distributed as dist
+    # WFS_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with ONE card (all ranks on device 0, the
+    # collectives on host tensors); the driver's runs use RCCL, one rank per GPU
+    backend = os.environ.get('WFS_BENCH_BACKEND', 'nccl')
+    if backend != 'nccl':
+        local_rank = 0
+    coll = 'cuda' if backend == 'nccl' else 'cpu'
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from wfsim_amd.engine import Engine
     cfg = bench_config(seed=3)
@@ -119,7 +128,7 @@ def main():
                 wait_gather(pending[1])
             mine = torch.empty(counts['n_records'] * 244, dtype=torch.uint8, device='cuda')
             eng.copy_records_to_device(mine.data_ptr(), counts['n_records'])
-            pending = gather_records(mine, dst=0, async_op=not args.sync_gather)
+            pending = gather_records(mine if coll == 'cuda' else mine.cpu(), dst=0, async_op=not args.sync_gather)
             if args.sync_gather:
                 pending = None
         return counts
@@ -146,10 +155,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        t = torch.tensor([elapsed], device=coll, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([counts['n_pe'], counts['n_records'], counts['n_photons']], device='cuda', dtype=torch.int64)
+        tot = torch.tensor([counts['n_pe'], counts['n_records'], counts['n_photons']], device=coll, dtype=torch.int64)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_pe, total_rec, total_ph = (int(x) for x in tot.tolist())
     else:
@@ -191,7 +200,7 @@ def main():
         config=dict(workload=f'{M} S2 instructions per GPU, 1e4 electrons each (~1e6 PE), 494 PMTs, z=-10 cm, '
                              f's2_secondary_sc_gain=100, noise/afterpulses off (BASELINE configs[2])',
                     instructions_per_gpu=M, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
-                    gather='none' if (world == 1 or args.no_gather) else ('rccl send/recv to rank 0' + ('' if args.sync_gather else ', overlapped with the next batch')),
+                    gather='none' if (world == 1 or args.no_gather) else (('rccl' if backend == 'nccl' else backend) + ' send/recv to rank 0' + ('' if args.sync_gather else ', overlapped with the next batch')),
                     ms_per_step_incl_d2h_of_records=pcie_ms),
         roofline=dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                       traffic=traffic, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,
