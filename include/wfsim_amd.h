@@ -118,6 +118,27 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
                           const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf,
                           const int32_t *run_set, int64_t n_run_sets, const uint32_t *em_base);
 
+/* ---- model variants of the photon delays ---------------------------------------------------------------
+ * S1.photon_timings (s1.py:162-238: 'custom' recoil models er / nr / alpha / led, s1.py:262-337) and S2.photon_timings
+ * (s2.py:504-557: 'garfield' luminescence s2.py:380-411, optical propagation s2.py:486-502) add one more independent,
+ * integer-truncated delay term per photon.  The host hands over that term's probability mass function; table k is the
+ * convolution of pmf k (support vmin[k] .. vmin[k] + len - 1, pmf[pmf_off[k] .. pmf_off[k + 1])) with base[k]:
+ *   0 transit time only, 1 the S1 terms of wfs_config, 2 the S2 terms, 3 the S2 terms without the 'simple' luminescence.
+ * Call after wfs_set_tables; n_tables = 0 drops the tables. */
+int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, const int64_t *pmf_off, const double *pmf,
+                         const int32_t *vmin);
+
+/* S1 optical propagation (S1.optical_propagation, s1.py:241-260; the spline is a RegularGridInterpolator over (z, u),
+ * load_resource.py:356-357): node values [nz][nu] for top- and bottom-array channels, the uniform u grid u0 + k * du.
+ * The delay of a photon is trunc(multilinear interpolation at (z of the instruction, u)), u from the photon's stream. */
+int wfs_set_s1_propagation(wfs_handle *h, int32_t nz, int32_t nu, double u0, double du, const double *top, const double *bottom);
+
+/* Per instruction of the batch just loaded (wfs_load_instructions resets them): delay table of its photons on top-array
+ * and on bottom-array channels (-1: the default table of the instruction type; tab_bottom NULL: same as tab), and for
+ * S1 propagation the z cell of the spline grid and the normalised distance inside it (prop_zi -1 / NULL: none). */
+int wfs_set_instruction_models(wfs_handle *h, int64_t n, const int32_t *tab, const int32_t *tab_bottom,
+                               const int32_t *prop_zi, const double *prop_zf);
+
 /* Parity entry: photons supplied instead of generated -- what RawDataOptical.sim_primary hands to Pulse
  * (rawdata.py:475-493) and what the golden vectors inject.  One "pulse set" = one Pulse.__call__ (pulse.py:39).
  *   set_cluster i32[n_sets], set_tmin i64[n_sets]   cluster id and scheduler key of the set's instruction

@@ -159,8 +159,28 @@ class Oracle:
     def digitize_and_zle(self, noise_gid=0):
         lib().orc_digitize_and_zle(self._s, C.c_uint32(noise_gid))
 
+    def set_delay_models(self, models):
+        """models: wfsim_amd.delay_models.DelayModels (the extra delay terms as probability mass functions + spline nodes)"""
+        self._models = models if models is not None and models.active else None
+        if self._models is None:
+            return
+        base, off, pmf, vmin = models.table_arrays()
+        lib().orc_set_delay_models(self._s, C.c_int32(len(base)), _p(base), _p(off), _p(pmf), _p(vmin))
+        sp = models.s1_prop
+        if sp is not None:
+            lib().orc_set_s1_propagation(self._s, C.c_int32(len(sp['z'])), C.c_int32(sp['nu']), C.c_double(sp['u0']), C.c_double(sp['du']),
+                                         _p(sp['top']), _p(sp['bottom']))
+
+    def _instruction_models(self, instructions, gid):
+        if getattr(self, '_models', None) is None:
+            lib().orc_set_instruction_models(self._s, C.c_int64(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
+            return
+        self._im = self._models.instruction_tables(instructions, gid)       # kept alive: the C side keeps the pointers
+        lib().orc_set_instruction_models(self._s, C.c_int64(len(instructions)), *[_p(x) for x in self._im])
+
     def simulate(self, instructions, gid, ip, em_base=None):
         n = len(instructions)
+        self._instruction_models(instructions, gid)
         a = dict(type=_arr(instructions['type'], np.int8), time=_arr(instructions['time'], np.int64),
                  z=_arr(instructions['z'], np.float32), amp=_arr(instructions['amp'], np.int32),
                  gid=_arr(gid, np.uint32), p_hit=_arr(ip['p_hit'], np.float64),
@@ -174,6 +194,7 @@ class Oracle:
     def simulate_scheduled(self, instructions, gid, ip, em_base, cluster, tmin, run_set):
         """instructions in processing order with their clusters, window-rule keys and pulse sets (feedback_schedule)"""
         n = len(instructions)
+        self._instruction_models(instructions, gid)
         a = [_arr(instructions['type'], np.int8), _arr(instructions['time'], np.int64), _arr(instructions['amp'], np.int32),
              _arr(gid, np.uint32), _arr(ip['p_hit'], np.float64), _arr(ip['drift_mean'], np.float64), _arr(ip['drift_spread'], np.float64),
              _arr(ip['sc_gain'], np.float64), _arr(ip['cdf_row'], np.int32), _arr(ip['cdf_table'], np.float64), _arr(em_base, np.uint32),
@@ -195,6 +216,12 @@ class Oracle:
     def sample_term(self, kind, n, p0=0.0, p1=0.0):
         out = np.zeros(n, dtype=np.int64)
         lib().orc_sample_term(self._s, C.c_int(kind), C.c_int64(n), C.c_double(p0), C.c_double(p1), _p(out))
+        return out
+
+    def sample_delay(self, n, is_s2, tab=-1, bottom=False, pzi=-1, pzf=0.0):
+        out = np.zeros(n, dtype=np.int64)
+        lib().orc_sample_delay(self._s, C.c_int64(n), C.c_int(int(is_s2)), C.c_int32(tab), C.c_int(int(bottom)), C.c_int32(pzi),
+                               C.c_double(pzf), _p(out))
         return out
 
     def sample_poisson(self, lam, n):

@@ -92,7 +92,12 @@ typedef struct orc_session_s {
     const i64 *noise_override; i64 n_noise_override;
     u32 win_gid; int win_gid_set; /* noise stream of the open window: gid of the first instruction of its first cluster that made a pulse */
     int save_full_truth;         /* rawdata.py:42: 1 (default) = every instruction is its own Pulse call */
-    struct { double *cum; i64 n; i64 vmin; } tab[9];   /* trunc()-ed delay variates: the individual terms and their sums, see TAB_* */    /* tests: ix_rand per digitise call instead of the Philox draw */
+    struct { double *cum; i64 n; i64 vmin; } tab[10];
+    /* model variants of the photon delays (orc_set_delay_models ...): extra tables, per-instruction choice, S1 propagation */
+    struct { double *cum; i64 n; i64 vmin; } *xtab; i32 n_xtab;
+    const i32 *ins_tab, *ins_tabb, *ins_pzi; const double *ins_pzf; i64 n_ins_models;
+    double *prop_top, *prop_bot; i32 prop_nz, prop_nu; double prop_u0, prop_du;
+    i32 cur_tab, cur_tabb, cur_pzi; double cur_pzf;   /* trunc()-ed delay variates: the individual terms and their sums, see TAB_* */    /* tests: ix_rand per digitise call instead of the Philox draw */
 } orc_session;
 
 /* ---------------------------------------------------------------- Philox4x32-10 ------------------ */
@@ -163,7 +168,7 @@ static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam)
     }
 }
 
-enum { TAB_TTS = 0, TAB_S1_EXP, TAB_S1_SPREAD, TAB_T1, TAB_T3, TAB_S2_SPREAD, TAB_LUM, TAB_S1_TOTAL, TAB_S2_TOTAL, TAB_N };
+enum { TAB_TTS = 0, TAB_S1_EXP, TAB_S1_SPREAD, TAB_T1, TAB_T3, TAB_S2_SPREAD, TAB_LUM, TAB_S1_TOTAL, TAB_S2_TOTAL, TAB_S2_NOLUM, TAB_N };
 static void tab_exp(struct orc_session_s *s, int slot, double tau);
 static void tab_totals(struct orc_session_s *s);
 static void tab_normal(struct orc_session_s *s, int slot, double mu, double sigma);
@@ -174,6 +179,7 @@ orc_session *orc_new(const orc_config *c, const double *templates, const double 
                      const int16_t *noise)
 {
     orc_session *s = (orc_session *)calloc(1, sizeof(orc_session));
+    s->cur_tab = s->cur_tabb = s->cur_pzi = -1;
     s->c = *c; s->templates = templates; s->spe = spe; s->gains = gains; s->thr_truth = thr_truth; s->thr_zle = thr_zle;
     s->lum_x = lum_x; s->lum_t = lum_t; s->noise = noise; s->save_full_truth = 1;
     tab_normal(s, TAB_TTS, c->tts_mean, c->tts_sigma); tab_exp(s, TAB_S1_EXP, c->s1_decay_time); tab_normal(s, TAB_S1_SPREAD, 0.0, c->s1_decay_spread);
@@ -213,6 +219,8 @@ void orc_free(orc_session *s)
         (void **)&s->truth.p };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
     for (int q = 0; q < TAB_N; q++) free(s->tab[q].cum);
+    for (i32 k = 0; k < s->n_xtab; k++) free(s->xtab[k].cum);
+    free(s->xtab); free(s->prop_top); free(s->prop_bot);
     free(s);
 }
 
@@ -575,7 +583,80 @@ static void tab_totals(orc_session *s)
     pmf_t b = pmf_conv(st, lum);
     if (c->s2_time_model == 1 && c->s2_time_spread != 0) { pmf_t sp = pmf_of_tab(s, TAB_S2_SPREAD), r = pmf_conv(b, sp); free(b.p); free(sp.p); b = r; }
     { pmf_t r = pmf_conv(b, tts); tab_from_pmf(s, TAB_S2_TOTAL, r); free(r.p); }
+    {   /* the same without the 'simple' luminescence term: base of the garfield tables (s2.py:512-528) */
+        pmf_t nb = pmf_conv(st, tts);
+        if (c->s2_time_model == 1 && c->s2_time_spread != 0) { pmf_t sp = pmf_of_tab(s, TAB_S2_SPREAD), r = pmf_conv(nb, sp); free(nb.p); free(sp.p); nb = r; }
+        tab_from_pmf(s, TAB_S2_NOLUM, nb); free(nb.p);
+    }
     free(t1.p); free(t3.p); free(lum.p); free(st.p); free(b.p); free(tts.p);
+}
+
+/* Model variants of S1.photon_timings (s1.py:162-238: 'custom' recoil models, optical propagation) and
+ * S2.photon_timings (s2.py:504-557: garfield luminescence, optical propagation): every one of them adds one more independent
+ * integer-truncated term.  Table k = base[k] (*) extra pmf k with base 0: transit time only, 1: the S1 terms of wfs_config,
+ * 2: the S2 terms, 3: the S2 terms without the 'simple' luminescence.  An instruction names the table of its photons on
+ * top-array channels and the one for bottom-array channels (the S2 propagation spline differs, s2.py:496-500). */
+void orc_set_delay_models(orc_session *s, i32 n_tables, const i32 *base, const i64 *pmf_off, const double *pmf, const i32 *vmin)
+{
+    static const int slot_of_base[4] = {TAB_TTS, TAB_S1_TOTAL, TAB_S2_TOTAL, TAB_S2_NOLUM};
+    for (i32 k = 0; k < s->n_xtab; k++) free(s->xtab[k].cum);
+    free(s->xtab); s->xtab = NULL; s->n_xtab = n_tables;
+    if (n_tables <= 0) return;
+    s->xtab = calloc((size_t)n_tables, sizeof *s->xtab);
+    for (i32 k = 0; k < n_tables; k++) {
+        pmf_t e; e.n = pmf_off[k + 1] - pmf_off[k]; e.vmin = vmin[k]; e.p = (double *)(pmf + pmf_off[k]);
+        pmf_t b = pmf_of_tab(s, slot_of_base[base[k]]), r = pmf_conv(b, e);
+        /* tab_from_pmf writes s->tab[slot]: build in a scratch slot-shaped struct */
+        i64 first = 0; while (first < r.n - 1 && r.p[first] == 0.0) first++;
+        double *c = (double *)malloc((size_t)(r.n - first) * 8); double acc = 0; i64 n = 0;
+        for (i64 i = first; i < r.n; i++) { acc += r.p[i]; c[n++] = acc; if (acc >= 1.0) break; }
+        while (n > 1 && c[n - 2] >= 1.0) n--;
+        c[n - 1] = 1.0;
+        s->xtab[k].cum = c; s->xtab[k].n = n; s->xtab[k].vmin = r.vmin + first;
+        free(b.p); free(r.p);
+    }
+}
+/* S1 optical propagation (s1.py:241-260): spline([z, u]) per photon, a RegularGridInterpolator (load_resource.py:356-357:
+ * multilinear, extrapolating) over (z, u) for the top and the bottom array.  The host hands over the node values
+ * [nz][nu], the u grid (u0, du) and per instruction the z cell and the normalised distance in it. */
+void orc_set_s1_propagation(orc_session *s, i32 nz, i32 nu, double u0, double du, const double *top, const double *bot)
+{
+    free(s->prop_top); free(s->prop_bot); s->prop_top = s->prop_bot = NULL; s->prop_nz = nz; s->prop_nu = nu; s->prop_u0 = u0; s->prop_du = du;
+    if (nz <= 0) return;
+    s->prop_top = (double *)malloc((size_t)nz * nu * 8); memcpy(s->prop_top, top, (size_t)nz * nu * 8);
+    s->prop_bot = (double *)malloc((size_t)nz * nu * 8); memcpy(s->prop_bot, bot, (size_t)nz * nu * 8);
+}
+/* per instruction (same indexing as the arrays of the next orc_simulate* call; the caller keeps them alive):
+ * tab / tabb: delay table for top / bottom channels (-1: the default table of the type); pzi, pzf: z cell and fraction */
+void orc_set_instruction_models(orc_session *s, i64 n, const i32 *tab, const i32 *tabb, const i32 *pzi, const double *pzf)
+{
+    s->n_ins_models = n; s->ins_tab = tab; s->ins_tabb = tabb; s->ins_pzi = pzi; s->ins_pzf = pzf;
+}
+static void set_cur(orc_session *s, i64 i)
+{
+    const int on = i < s->n_ins_models;
+    s->cur_tab = on && s->ins_tab ? s->ins_tab[i] : -1; s->cur_tabb = on && s->ins_tabb ? s->ins_tabb[i] : s->cur_tab;
+    s->cur_pzi = on && s->ins_pzi ? s->ins_pzi[i] : -1; s->cur_pzf = on && s->ins_pzf ? s->ins_pzf[i] : 0.0;
+}
+static i64 sample_cum(const double *c, i64 n, i64 vmin, double u)
+{
+    i64 lo = 0, hi = n - 1;
+    while (lo < hi) { i64 mid = (lo + hi) >> 1; if (u < c[mid]) hi = mid; else lo = mid + 1; }
+    return vmin + lo;
+}
+/* multilinear interpolation as scipy's RegularGridInterpolator evaluates it: sum over the cell's corners of value * weights */
+static double s1_propagation(const orc_session *s, int bottom, i32 zi, double zf, double u)
+{
+    const double *T = bottom ? s->prop_bot : s->prop_top; const i32 nu = s->prop_nu;
+    i32 ui = (i32)floor((u - s->prop_u0) / s->prop_du);
+    if (ui < 0) ui = 0; if (ui > nu - 2) ui = nu - 2;
+    const double uf = (u - (s->prop_u0 + (double)ui * s->prop_du)) / s->prop_du;
+    const double *r0 = T + (i64)zi * nu + ui, *r1 = r0 + nu;
+    double v = r0[0] * ((1.0 - zf) * (1.0 - uf));
+    v += r0[1] * ((1.0 - zf) * uf);
+    v += r1[0] * (zf * (1.0 - uf));
+    v += r1[1] * (zf * uf);
+    return v;
 }
 
 /* ---------------------------------------------------------------- photon generation -------------- */
@@ -622,7 +703,11 @@ static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u3
     int ch = channel_from_cdf(cdf, c->n_tpc, u53(A[0], A[1]));
     int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
     int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
-    i64 t = t0 + sample_tab(s, is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL, u53(B[0], B[1]));     /* all delay terms, see tab_totals */
+    i64 t;                                                /* all delay terms from one table, see tab_totals / orc_set_delay_models */
+    if (s->cur_tab >= 0) { const i32 k = ch >= c->n_top ? s->cur_tabb : s->cur_tab; t = t0 + sample_cum(s->xtab[k].cum, s->xtab[k].n, s->xtab[k].vmin, u53(B[0], B[1])); }
+    else t = t0 + sample_tab(s, is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL, u53(B[0], B[1]));
+    if (!is_s2 && s->prop_top && s->cur_pzi >= 0)         /* s1.py:185-188; prop_time is an int64 array: the assignment truncates */
+        t += (i64)s1_propagation(s, ch >= c->n_top, s->cur_pzi, s->cur_pzf, ((double)B[3] + 0.5) * (1.0 / 4294967296.0));
     int sc = c->n_spe_channels > ch ? ch : 0;
     const double *row = s->spe + (i64)sc * 2001;
     double G = s->gains[ch], gain = G * row[g1];
@@ -849,6 +934,7 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
                 i64 i = ord[k].i; if (type[i] != ptype) continue;
                 if (open && ptype <= 2 && (s->save_full_truth || ord[k].t - last_key > gap)) { finish_call(s, ptype, runset++, &x); open = 0; }
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
+                set_cur(s, i);
                 if (ptype == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
                 else gen_s2(s, &x, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
                 open = 1; last_key = ord[k].t;
@@ -886,6 +972,7 @@ void orc_simulate_scheduled(orc_session *s, i64 n, const int8_t *type, const i64
             call_ctx x; memset(&x, 0, sizeof x);
             for (i64 i = k; i < e; i++) {
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
+                set_cur(s, i);
                 if (type[i] == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
                 else gen_s2(s, &x, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
             }
@@ -970,4 +1057,15 @@ void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 
     }
 }
 
+/* the delay of a photon exactly as one_photon() adds it: table `tab` (-1: the default of the type), S1 propagation cell */
+void orc_sample_delay(orc_session *s, i64 n, int is_s2, i32 tab, int bottom, i32 pzi, double pzf, i64 *out)
+{
+    for (i64 i = 0; i < n; i++) {
+        u32 B[4]; draw(s, 0, 424242u, (u32)i, SITE_PH_B, B);
+        i64 t = tab >= 0 ? sample_cum(s->xtab[tab].cum, s->xtab[tab].n, s->xtab[tab].vmin, u53(B[0], B[1]))
+                         : sample_tab(s, is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL, u53(B[0], B[1]));
+        if (!is_s2 && s->prop_top && pzi >= 0) t += (i64)s1_propagation(s, bottom, pzi, pzf, ((double)B[3] + 0.5) * (1.0 / 4294967296.0));
+        out[i] = t;
+    }
+}
 void orc_sample_poisson(orc_session *s, double lam, i64 n, i64 *out) { for (i64 i = 0; i < n; i++) out[i] = poisson_draw(s, (u32)i, 12345u, lam); }

@@ -576,6 +576,74 @@ def fixture_distributions(ref):
     np.savez_compressed(HERE + '/dists.npz', **out)
 
 
+def model_fixture_inputs():
+    """synthetic resources of the model variants (the real splines / garfield tables are private files)"""
+    rng = np.random.default_rng(4242)
+    zg, ug = np.linspace(-100.0, 0.0, 11), np.linspace(0.0, 1.0, 21)
+    shape_u = -np.log(1 - 0.97 * ug)                                 # a propagation-time quantile function
+    s1_top = (4.0 + 0.05 * (zg[:, None] + 100.0)) * shape_u[None, :] + 1.5
+    s1_bot = (9.0 - 0.04 * (zg[:, None] + 100.0)) * shape_u[None, :] + 0.5
+    u2 = np.linspace(0.0, 1.0, 33)
+    s2_top = 12.0 * -np.log(1 - 0.95 * u2)
+    s2_bot = 3.0 + 25.0 * u2 ** 2
+    gx = np.linspace(-0.25, 0.25, 11)
+    gt = np.stack([rng.gamma(3.0 + 8 * abs(x), 60.0, 4000) + 900 for x in gx])          # ns, [rows, samples]
+    return dict(s1_z=zg, s1_u=ug, s1_top=s1_top, s1_bottom=s1_bot, s2_u=u2, s2_top=s2_top, s2_bottom=s2_bot,
+                garfield_x=gx, garfield_t=gt)
+
+
+def fixture_model_distributions(ref):
+    """Delay of a photon (all terms + transit time, pulse.py:53-56) under the model variants of S1.photon_timings
+    (s1.py:162-238) and S2.photon_timings (s2.py:504-557), as histograms of the reference's own draws."""
+    from wfsim_amd.itp_map import InterpolatingMap          # stands in for straxen.InterpolatingMap (the resource object)
+    m = model_fixture_inputs()
+    out = {k: v for k, v in m.items()}
+    n = 2_000_000
+    s1_spline = InterpolatingMap(dict(coordinate_system=[['z', [-100.0, 0.0, 11]], ['u', [0.0, 1.0, 21]]],
+                                      top=m['s1_top'].tolist(), bottom=m['s1_bottom'].tolist()), method='RegularGridInterpolator')
+    s2_spline = InterpolatingMap(dict(coordinate_system=[['u', [0.0, 1.0, 33]]], top=m['s2_top'].tolist(), bottom=m['s2_bottom'].tolist()))
+
+    def tts(cfg, k):
+        return np.random.normal(cfg['pmt_transit_time_mean'], cfg['pmt_transit_time_spread'] / 2.35482, k).astype(np.int64)
+
+    # S1: custom recoil models, with and without the 'simple' terms.  S1.er reads `units`, which s1.py never imports (as
+    # shipped the ER branch ends in a NameError): the module is handed the reference's own units module to pin what the
+    # code computes once that import exists
+    if not hasattr(ref.s1, 'units'):
+        ref.s1.units = ref.units
+    for tag, model, recoil in [('er', 'custom', 7), ('nr', 'custom', 0), ('alpha', 'custom', 6), ('led', 'custom', 20), ('er_simple', 'simple+custom', 7)]:
+        cfg = base_config(s1_model_type=model, led_pulse_length=33.3)
+        ref.load_resource._cached_configs.clear()
+        s1 = ref.s1.S1(cfg)
+        np.random.seed(9100 + recoil)
+        t = s1.photon_timings(t=np.array([0]), n_photon_hits=np.array([n]), recoil_type=np.array([recoil]), config=cfg, phase='liquid')
+        out[f's1_{tag}_v'], out[f's1_{tag}_c'] = hist(t + tts(cfg, n))
+    # S1: optical propagation at a z between two grid nodes, top and bottom array channels
+    cfg = base_config(s1_model_type='simple+optical_propagation')
+    ref.load_resource._cached_configs.clear()
+    s1 = ref.s1.S1(cfg)
+    s1.resource.s1_optical_propagation_spline = s1_spline
+    for tag, ch in [('top', 5), ('bottom', 300)]:
+        np.random.seed(9200 + ch)
+        t = s1.photon_timings(t=np.array([0]), n_photon_hits=np.array([n]), recoil_type=np.array([7]), config=cfg, phase='liquid',
+                              channels=np.full(n, ch), positions=np.array([[0.0, 0.0, -33.3]]), resource=s1.resource)
+        out[f's1_prop_{tag}_v'], out[f's1_prop_{tag}_c'] = hist(t + tts(cfg, n))
+    # S2: optical propagation (simple luminescence), garfield luminescence (zero_delay), both
+    gar = dict(t=m['garfield_t'], x=m['garfield_x'])
+    for tag, lum, tm in [('prop', 'simple', 'optical_propagation'), ('garfield', 'garfield', 'zero_delay'), ('garfield_prop', 'garfield', 'optical_propagation')]:
+        cfg = base_config(s2_luminescence_model=lum, s2_time_model=tm)
+        ref.load_resource._cached_configs.clear()
+        s2 = ref.s2.S2(base_config())          # the garfield table is attached below instead of being read from a private file
+        s2.resource.s2_optical_propagation_spline = s2_spline
+        s2.resource.s2_luminescence = gar
+        xy = np.array([[0.21, 0.0]])
+        for side, ch in [('top', 5), ('bottom', 300)]:
+            np.random.seed(9300 + ch)
+            t = s2.photon_timings(xy, np.array([n]), np.zeros(1, dtype=np.int64), np.array([n]), np.full(n, ch), 'gas', cfg, s2.resource)
+            out[f's2_{tag}_{side}_v'], out[f's2_{tag}_{side}_c'] = hist(t + tts(cfg, n))
+    np.savez_compressed(HERE + '/dists_models.npz', **out)
+
+
 def fixture_chain_stats(ref):
     """Per-instruction summary statistics of full reference runs (statistical end-to-end pins)."""
     MS = 1_000_000
@@ -602,7 +670,7 @@ def fixture_chain_stats(ref):
 
 if __name__ == '__main__':
     ref = import_reference()
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'stats']
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats']
     p = fixture_tables(ref)
     if 'add_current' in which:
         fixture_add_current(ref, p)
@@ -618,6 +686,8 @@ if __name__ == '__main__':
         fixture_optical_adjustment(ref)
     if 'dists' in which:
         fixture_distributions(ref)
+    if 'models' in which:
+        fixture_model_distributions(ref)
     if 'stats' in which:
         fixture_chain_stats(ref)
     for f in sorted(os.listdir(HERE)):

@@ -45,10 +45,12 @@ def ap_tables_from_golden():
     return out
 
 
-def make_oracle(config, ap_tables=None):
+def make_oracle(config, ap_tables=None, resource=None):
     from oracle.oracle import Oracle
     orc = Oracle(kernel_params(config), host_tables(config), ap_tables)
     orc.set_save_full_truth(config.get('save_full_truth', True))
+    from wfsim_amd.delay_models import DelayModels
+    orc.set_delay_models(DelayModels(config, resource or Resource(config)))
     return orc
 
 

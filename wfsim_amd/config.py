@@ -50,28 +50,26 @@ def current_2_adc(config):
             / (config['digitizer_voltage_range'] / 2 ** (config['digitizer_bits'])))
 
 
-_S2_TIME_MODELS = {'zero_delay': 0, 's2_time_spread around zero': 1}
-
-
 def kernel_params(config):
     """Scalars of the hot path, named as the fields of ``wfs_config`` (include/wfsim_amd.h)."""
     c = config
     detector_nt = c['detector'] == 'XENONnT'
     s1_model = c.get('s1_model_type', 'simple')
     for part in re.split(r'[+ ,]+', s1_model):
-        if part not in ('', 'simple'):
-            # /root/reference/wfsim/core/s1.py:50 lists simple, custom, optical_propagation, nest
-            raise NotImplementedError(f's1_model_type "{part}" is outside the MI355X hot path (SURVEY.md 2.1 row 2)')
-    if c.get('s2_luminescence_model', 'simple') != 'simple':
-        raise NotImplementedError('only s2_luminescence_model "simple" is on the MI355X hot path (SURVEY.md 2.1 row 3)')
-    s2_time_model = None
-    for name, code in _S2_TIME_MODELS.items():       # same substring tests as s2.py:542-552
-        if name in c['s2_time_model']:
-            s2_time_model = code
-            break
-    if s2_time_model is None:
-        if 'optical_propagation' in c['s2_time_model']:
-            raise NotImplementedError('s2 optical propagation splines are outside the MI355X hot path')
+        # /root/reference/wfsim/core/s1.py:50 lists simple, custom, optical_propagation, nest
+        assert part in ('', 'simple', 'custom', 'optical_propagation', 'nest'), f'Model type "{part}" not in the valid S1 model types'
+        if part == 'nest':
+            raise NotImplementedError('s1_model_type "nest" needs nestpy and is outside the MI355X hot path (SURVEY.md 2.1 row 2)')
+    if c.get('s2_luminescence_model', 'simple') not in ('simple', 'garfield'):
+        if c.get('s2_luminescence_model') == 'garfield_gas_gap':
+            raise NotImplementedError('s2_luminescence_model "garfield_gas_gap" is outside the MI355X hot path (delay_models.py)')
+        raise KeyError(f"{c['s2_luminescence_model']} is not valid! Use 'simple' or 'garfield' or 'garfield_gas_gap'")
+    # same substring tests, in the same order, as s2.py:539-552; the propagation term itself is a delay table (delay_models.py)
+    if 'optical_propagation' in c['s2_time_model'] or 'zero_delay' in c['s2_time_model']:
+        s2_time_model = 0
+    elif 's2_time_spread around zero' in c['s2_time_model']:
+        s2_time_model = 1
+    else:
         raise KeyError(f"{c['s2_time_model']} is not in any of the valid s2 time models")
     he = c.get('channel_map', {}).get('he', (500, 752))
     bottom = np.asarray(c.get('channels_bottom', []))

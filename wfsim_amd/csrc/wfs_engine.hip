@@ -16,6 +16,7 @@ struct DevBuf {
     void *p = nullptr; size_t cap = 0;
     template <class T> T *as() const { return (T *)p; }
 };
+struct Pmf { std::vector<double> p; long vmin = 0; };      // probability mass function of an integer delay term
 
 struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf; };
 
@@ -64,6 +65,11 @@ struct wfs_handle {
     std::vector<i64> h_rs_off; std::vector<i32> h_rs_list;        // run set -> instructions (host copy)
     std::vector<double> h_lum_x, h_lum_t;          // luminescence table (host copy, enters the S2 delay table)
     DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
+    // model variants of the photon delays
+    std::vector<DevBuf> x_cum, x_guide; std::vector<DiscTab> h_tabs; DevBuf d_tabs; i32 n_user_tabs = 0;
+    std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
+    DevBuf prop_top, prop_bot; i32 prop_nz = 0, prop_nu = 0; double prop_u0 = 0, prop_du = 1;
+    DevBuf ins_tab, ins_tabb, ins_pzi, ins_pzf; bool ins_models = false;
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
@@ -185,7 +191,6 @@ static int upload_disc(wfs_handle *h, int slot, const std::vector<double> &cum, 
 
 // ---- delay of a photon = sum of independent, separately truncated terms: sampled from ONE uniform through
 // the convolution of the terms' probability mass functions (same distribution as adding separately drawn terms)
-struct Pmf { std::vector<double> p; long vmin = 0; };
 
 static Pmf pmf_from_cum(const std::vector<double> &cum, long vmin)
 {
@@ -256,9 +261,12 @@ int build_time_tables(wfs_handle *h)
     Pmf s1; s1.p = {1.0};
     if (c.s1_simple) { s1 = pmf_exp(c.s1_decay_time); if (c.s1_decay_spread != 0.0) s1 = pmf_conv(s1, pmf_normal(0.0, c.s1_decay_spread)); }
     TRY(upload_pmf(h, 1, pmf_conv(s1, tts), d.tab_s1));
-    Pmf s2 = pmf_conv(pmf_mix(pmf_exp(c.t1_gas), c.sf_gas, pmf_exp(c.t3_gas), 1.0 - c.sf_gas), pmf_luminescence(h->h_lum_x, h->h_lum_t));
-    if (c.s2_time_model == 1 && c.s2_time_spread != 0.0) s2 = pmf_conv(s2, pmf_normal(0.0, c.s2_time_spread));
+    const Pmf st = pmf_mix(pmf_exp(c.t1_gas), c.sf_gas, pmf_exp(c.t3_gas), 1.0 - c.sf_gas);
+    Pmf s2 = pmf_conv(st, pmf_luminescence(h->h_lum_x, h->h_lum_t)), s2n = st;
+    if (c.s2_time_model == 1 && c.s2_time_spread != 0.0) { s2 = pmf_conv(s2, pmf_normal(0.0, c.s2_time_spread)); s2n = pmf_conv(s2n, pmf_normal(0.0, c.s2_time_spread)); }
     TRY(upload_pmf(h, 2, pmf_conv(s2, tts), d.tab_s2));
+    // bases of the model-variant tables (wfs_set_delay_models): 0 transit time, 1 S1 terms, 2 S2 terms, 3 S2 without luminescence
+    h->base_pmf = {tts, pmf_conv(s1, tts), pmf_conv(s2, tts), pmf_conv(s2n, tts)};
     return WFS_OK;
 }
 
@@ -315,6 +323,8 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     hipFuncSetAttribute((const void *)k_photons<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photons<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photons<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photons<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photons<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
@@ -326,7 +336,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -336,6 +346,8 @@ int wfs_destroy(wfs_handle *h)
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) { if (h->tt_cum[q].p) hipFree(h->tt_cum[q].p); if (h->tt_guide[q].p) hipFree(h->tt_guide[q].p); }
+    for (auto &b : h->x_cum) if (b.p) hipFree(b.p);
+    for (auto &b : h->x_guide) if (b.p) hipFree(b.p);
     for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); }
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -521,7 +533,82 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     TRY(load_clusters(h, n, cluster, tmin, gid));
-    h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false;
+    h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false; h->ins_models = false;
+    return WFS_OK;
+}
+
+// ---- model variants of the photon delays: S1 'custom' recoil models and optical propagation (s1.py:162-260), S2 garfield
+// luminescence and optical propagation (s2.py:380-557).  Each adds one independent integer-truncated term; the host builds
+// its probability mass function, the table of the sum is the convolution with the terms wfs_config describes.
+int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, const int64_t *pmf_off, const double *pmf, const int32_t *vmin)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
+    if (n_tables < 0 || n_tables > 4096 || (n_tables > 0 && (!base || !pmf_off || !pmf || !vmin))) return h->fail(WFS_E_INVALID, "wfs_set_delay_models: bad arguments");
+    HIPCHK(hipSetDevice(h->device));
+    for (auto &b : h->x_cum) if (b.p) hipFree(b.p);
+    for (auto &b : h->x_guide) if (b.p) hipFree(b.p);
+    h->x_cum.assign((size_t)n_tables, DevBuf{}); h->x_guide.assign((size_t)n_tables, DevBuf{});
+    h->h_tabs.assign((size_t)n_tables + 2, DiscTab{});
+    h->n_user_tabs = n_tables; h->ins_models = false;
+    for (int k = 0; k < n_tables; k++) {
+        if (base[k] < 0 || base[k] > 3 || pmf_off[k + 1] <= pmf_off[k]) return h->fail(WFS_E_INVALID, "wfs_set_delay_models: bad base or empty pmf");
+        Pmf e; e.vmin = vmin[k]; e.p.assign(pmf + pmf_off[k], pmf + pmf_off[k + 1]);
+        const Pmf a = pmf_conv(h->base_pmf[base[k]], e);
+        size_t first = 0; while (first + 1 < a.p.size() && a.p[first] == 0.0) first++;
+        std::vector<double> cum; double acc = 0;
+        for (size_t i = first; i < a.p.size(); i++) { acc += a.p[i]; cum.push_back(acc); if (acc >= 1.0) break; }
+        while (cum.size() > 1 && cum[cum.size() - 2] >= 1.0) cum.pop_back();
+        cum.back() = 1.0;
+        if (cum.size() > 65000) return h->fail(WFS_E_CAPACITY, "delay table too long");
+        std::vector<unsigned short> guide(DISC_G + 2);
+        size_t idx = 0;
+        for (int c = 0; c <= DISC_G + 1; c++) { const double x = (double)c / DISC_G; while (idx + 1 < cum.size() && cum[idx] <= x) idx++; guide[c] = (unsigned short)idx; }
+        TRY(upload(h, h->x_cum[k], cum.data(), cum.size() * 8)); TRY(upload(h, h->x_guide[k], guide.data(), guide.size() * 2));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        h->h_tabs[k] = DiscTab{h->x_cum[k].as<double>(), h->x_guide[k].as<unsigned short>(), (i32)(a.vmin + (long)first), (i32)cum.size()};
+    }
+    h->h_tabs[n_tables] = h->dev.tab_s1; h->h_tabs[n_tables + 1] = h->dev.tab_s2;       // "-1": the default table of the type
+    TRY(upload(h, h->d_tabs, h->h_tabs.data(), h->h_tabs.size() * sizeof(DiscTab)));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return WFS_OK;
+}
+
+int wfs_set_s1_propagation(wfs_handle *h, int32_t nz, int32_t nu, double u0, double du, const double *top, const double *bottom)
+{
+    if (!h) return WFS_E_INVALID;
+    if (nz == 0) { h->prop_nz = 0; return WFS_OK; }
+    if (nz < 2 || nu < 2 || !(du > 0) || !top || !bottom) return h->fail(WFS_E_INVALID, "wfs_set_s1_propagation: needs a grid of at least 2 x 2 nodes");
+    HIPCHK(hipSetDevice(h->device));
+    TRY(upload(h, h->prop_top, top, (size_t)nz * nu * 8)); TRY(upload(h, h->prop_bot, bottom, (size_t)nz * nu * 8));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->prop_nz = nz; h->prop_nu = nu; h->prop_u0 = u0; h->prop_du = du;
+    return WFS_OK;
+}
+
+int wfs_set_instruction_models(wfs_handle *h, int64_t n, const int32_t *tab, const int32_t *tab_bottom, const int32_t *prop_zi, const double *prop_zf)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins) return h->fail(WFS_E_STATE, "wfs_set_instruction_models follows wfs_load_instructions of the same batch");
+    if (h->d_tabs.p == nullptr) TRY(wfs_set_delay_models(h, 0, nullptr, nullptr, nullptr, nullptr));
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<int8_t> type((size_t)n);
+    HIPCHK(hipMemcpy(type.data(), h->ins_type.p, (size_t)n, hipMemcpyDeviceToHost));
+    std::vector<i32> t((size_t)n), tb((size_t)n), zi((size_t)n, -1); std::vector<double> zf((size_t)n, 0.0);
+    for (i64 i = 0; i < n; i++) {
+        const i32 dflt = h->n_user_tabs + (type[i] == 1 ? 0 : 1);
+        const i32 a = tab ? tab[i] : -1, b = tab_bottom ? tab_bottom[i] : a;
+        if (a < -1 || a >= h->n_user_tabs || b < -1 || b >= h->n_user_tabs) return h->fail(WFS_E_INVALID, "delay table index out of range");
+        t[i] = a < 0 ? dflt : a; tb[i] = b < 0 ? dflt : b;
+        if (prop_zi && prop_zi[i] >= 0) {
+            if (h->prop_nz < 2 || prop_zi[i] > h->prop_nz - 2 || !prop_zf) return h->fail(WFS_E_INVALID, "S1 propagation cell out of range (wfs_set_s1_propagation first)");
+            zi[i] = prop_zi[i]; zf[i] = prop_zf[i];
+        }
+    }
+    TRY(upload(h, h->ins_tab, t.data(), (size_t)n * 4)); TRY(upload(h, h->ins_tabb, tb.data(), (size_t)n * 4));
+    TRY(upload(h, h->ins_pzi, zi.data(), (size_t)n * 4)); TRY(upload(h, h->ins_pzf, zf.data(), (size_t)n * 8));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->ins_models = true; h->gen_done = false;
     return WFS_OK;
 }
 
@@ -644,6 +731,12 @@ static int run_generation(wfs_handle *h)
     g.ins_cdfrow = h->ins_cdfrow.as<i32>(); g.cdf_table = h->cdf_table.as<double>(); g.cdf_guide = h->cdf_guide.as<unsigned short>(); g.em_off = h->em_off.as<i64>();
     g.em_time = h->em_time.as<i64>(); g.em_nph = h->em_nph.as<i32>(); g.em_ins = h->em_ins.as<i32>();
     g.el_stat = h->el_stat.as<double>(); g.el_minmax = h->el_minmax.as<i64>(); g.scal = h->scal.as<i64>();
+    const bool ext = h->ins_models;
+    if (ext) {
+        g.tabs = h->d_tabs.as<DiscTab>(); g.ins_tab = h->ins_tab.as<i32>(); g.ins_tabb = h->ins_tabb.as<i32>();
+        g.ins_pzi = h->ins_pzi.as<i32>(); g.ins_pzf = h->ins_pzf.as<double>();
+        if (h->prop_nz >= 2) { g.prop_top = h->prop_top.as<double>(); g.prop_bot = h->prop_bot.as<double>(); g.prop_nu = h->prop_nu; g.prop_u0 = h->prop_u0; g.prop_du = h->prop_du; }
+    }
     { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }
     {
         const i64 neb = (E + 255) / 256;
@@ -697,7 +790,9 @@ static int run_generation(wfs_handle *h)
         { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
         { Timer t(h, "k_photons_fill");
-          if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          else if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
           else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, false>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap); }
     } else {
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));

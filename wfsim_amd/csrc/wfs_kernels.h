@@ -1085,7 +1085,29 @@ struct GenArgs {
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
     i64 *scal;
+    // model variants of the photon delays (wfs_set_delay_models / wfs_set_instruction_models); tabs == nullptr: the two default tables
+    const DiscTab *tabs;          // [n_tables + 2] user tables, then the default S1 and S2 tables
+    const i32 *ins_tab, *ins_tabb;        // [n_ins] table of the instruction's photons on top / bottom array channels
+    const i32 *ins_pzi; const double *ins_pzf;    // [n_ins] S1 optical propagation: z cell of the spline grid and normalised distance in it (-1: none)
+    const double *prop_top, *prop_bot; i32 prop_nu; double prop_u0, prop_du;      // spline node values [nz][nu], u grid
 };
+
+// S1 optical propagation delay (s1.py:241-260): multilinear interpolation of the spline nodes, evaluated as scipy's
+// RegularGridInterpolator does (sum over the cell's corners of value * weights); same operation order as the oracle
+__device__ __forceinline__ double s1_propagation(const GenArgs &a, bool bottom, i32 zi, double zf, u32 w)
+{
+    const double u = ((double)w + 0.5) * (1.0 / 4294967296.0);
+    const double *T = bottom ? a.prop_bot : a.prop_top; const i32 nu = a.prop_nu;
+    i32 ui = (i32)floor((u - a.prop_u0) / a.prop_du);
+    ui = ui < 0 ? 0 : (ui > nu - 2 ? nu - 2 : ui);
+    const double uf = (u - (a.prop_u0 + (double)ui * a.prop_du)) / a.prop_du;
+    const double *r0 = T + (i64)zi * nu + ui, *r1 = r0 + nu;
+    double v = r0[0] * ((1.0 - zf) * (1.0 - uf));
+    v += r0[1] * ((1.0 - zf) * uf);
+    v += r1[0] * (zf * (1.0 - uf));
+    v += r1[1] * (zf * uf);
+    return v;
+}
 
 // Poisson: PTRS (Hoermann 1993) for lam >= 10, multiplication method below; same algorithm and uniforms as the oracle
 __device__ i64 poisson_draw(const WfsDev &d, u32 emitter, u32 gid, double lam)
@@ -1357,7 +1379,8 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
     a.tile_count[idx] = (i32)run;
 }
 
-template <bool COUNT, bool AP>
+// EXT: delay tables per instruction and array (model variants), S1 optical propagation term
+template <bool COUNT, bool AP, bool EXT = false>
 __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs ap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1398,6 +1421,12 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         const u32 gid = a.ins_gid[ins_lo]; const i64 emoff = a.em_off[ins_lo];
         const i32 set_lo = a.ins_set[ins_lo]; const i64 itime = a.set_t0[set_lo];       // photon times are relative to the pulse set's origin
         const DiscTab &tab = (a.ins_type[ins_lo] != 1) ? d.tab_s2 : d.tab_s1;
+        DiscTab tab_t = tab, tab_b = tab; i32 pzi = -1; double pzf = 0.0;
+        if (EXT && !COUNT) {
+            tab_t = a.tabs[a.ins_tab[ins_lo]]; tab_b = a.tabs[a.ins_tabb[ins_lo]];
+            if (a.prop_top && a.ins_type[ins_lo] == 1) { pzi = a.ins_pzi[ins_lo]; pzf = a.ins_pzf[ins_lo]; }
+        }
+#define TAB_OF(k) (EXT ? (bot[k] ? tab_b : tab_t) : tab)
         const i64 tbase = (i64)set_lo * nch;
         const u32 jbase = (u32)(e_lo - emoff) + a.ins_embase[ins_lo];
         u32 pw[GEN_PPT];                                      // pass B: the packed words of this thread's bucket positions, loaded up front
@@ -1474,26 +1503,28 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
 #pragma unroll
             for (int q0 = 0; q0 < GEN_PPT; q0 += GEN_GRP) {
                 if (q0 * GEN_TPB >= np) break;               // block-uniform
-                int lo[GEN_GRP], hi[GEN_GRP], slot[GEN_GRP]; double u[GEN_GRP]; u32 g2[GEN_GRP], j[GEN_GRP], m[GEN_GRP];
+                int lo[GEN_GRP], hi[GEN_GRP], slot[GEN_GRP]; double u[GEN_GRP]; u32 g2[GEN_GRP], j[GEN_GRP], m[GEN_GRP], bw[GEN_GRP]; bool bot[GEN_GRP];
 #pragma unroll
                 for (int k = 0; k < GEN_GRP; k++) {
                     const u32 w = pw[q0 + k];                // 0 past the end of the block: harmless values, nothing stored
                     slot[k] = PW_SLOT(w);
                     j[k] = jbase + (u32)slot[k]; m[k] = (u32)(PW_PR(w) - win[slot[k]]);
                     const u32x4 B = philox4x32_10(j[k], gid, m[k], SITE_PH_B, d.k0, d.k1);
-                    g2[k] = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
+                    g2[k] = (u32)(((u64)B.z * 2000u) >> 32) + 1u; bw[k] = B.w;
                     u[k] = u53(B.x, B.y);
                     const int c = (int)(u[k] * DISC_G);
-                    lo[k] = tab.guide[c]; hi[k] = tab.guide[c + 1];          // the answer is in [lo, hi]
+                    const int ib = (q0 + k) * GEN_TPB + tid;
+                    bot[k] = EXT && ib < np && chmap[ib] >= d.n_top;
+                    lo[k] = TAB_OF(k).guide[c]; hi[k] = TAB_OF(k).guide[c + 1];          // the answer is in [lo, hi]
                 }
 #pragma unroll
                 for (int k = 0; k < GEN_GRP; k++)            // rare: a guide cell with more than 4 table entries (the far tail)
-                    while (hi[k] - lo[k] > 3) { const int mid = (lo[k] + hi[k]) >> 1; if (u[k] < tab.cum[mid]) hi[k] = mid; else lo[k] = mid + 1; }
+                    while (hi[k] - lo[k] > 3) { const int mid = (lo[k] + hi[k]) >> 1; if (u[k] < TAB_OF(k).cum[mid]) hi[k] = mid; else lo[k] = mid + 1; }
                 double c0[GEN_GRP], c1[GEN_GRP], c2[GEN_GRP];
-                const int n1 = tab.n - 1;
 #pragma unroll
                 for (int k = 0; k < GEN_GRP; k++) {          // cum[n - 1] == 1 > u: clamped indices cannot change the outcome
-                    c0[k] = tab.cum[lo[k]]; c1[k] = tab.cum[lo[k] + 1 < n1 ? lo[k] + 1 : n1]; c2[k] = tab.cum[lo[k] + 2 < n1 ? lo[k] + 2 : n1];
+                    const int n1 = TAB_OF(k).n - 1;
+                    c0[k] = TAB_OF(k).cum[lo[k]]; c1[k] = TAB_OF(k).cum[lo[k] + 1 < n1 ? lo[k] + 1 : n1]; c2[k] = TAB_OF(k).cum[lo[k] + 2 < n1 ? lo[k] + 2 : n1];
                 }
 #pragma unroll
                 for (int k = 0; k < GEN_GRP; k++) {
@@ -1502,7 +1533,8 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
                     const u32 w = pw[q0 + k];
                     const int ch = chmap[i]; const bool is_dpe = PW_DPE(w);
                     // every delay term of the photon in one draw from the table of their sum, relative to the instruction time
-                    i64 t = wtime[slot[k]] + (i64)tab.vmin + lo[k] + (u[k] < c0[k] ? 0 : (u[k] < c1[k] ? 1 : (u[k] < c2[k] ? 2 : 3)));
+                    i64 t = wtime[slot[k]] + (i64)TAB_OF(k).vmin + lo[k] + (u[k] < c0[k] ? 0 : (u[k] < c1[k] ? 1 : (u[k] < c2[k] ? 2 : 3)));
+                    if (EXT && pzi >= 0) t += (i64)s1_propagation(a, bot[k], pzi, pzf, bw[k]);     // s1.py:185-188: int64 array, the assignment truncates
                     if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
                     if (AP) ap_generate(d, a, ap, aps, j[k], gid, m[k], set_lo, ch, is_dpe, itime, t);
                     atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
@@ -1534,7 +1566,11 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
             const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
             const bool is_dpe = (u64)A.z < d.thr_dpe;
             const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-            i64 t = a.em_time[lo] - itime + sample_disc(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
+            i64 t = a.em_time[lo] - itime;
+            if (EXT) {
+                t += sample_disc(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], u53(B.x, B.y));
+                if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], B.w);
+            } else t += sample_disc(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
             if (AP) ap_generate(d, a, ap, aps, j, gid, m, set, ch, is_dpe, itime, t);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
@@ -1552,6 +1588,8 @@ __global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs
         }
     }
 }
+
+#undef TAB_OF
 
 // afterpulse photons -> tiles of the afterpulse pulse set of their primary set (set n_psets + set): count, then place
 __global__ void k_ap_count(WfsDev d, GenArgs a, ApArgs ap)
@@ -1587,6 +1625,14 @@ __global__ void k_photon_times(WfsDev d, GenArgs a, i64 n, const i64 *index, i64
     const i32 ins = a.em_ins[lo];
     const u32 j = (u32)(lo - a.em_off[ins]) + a.ins_embase[ins], m = (u32)(p - a.em_ph_off[lo]);
     const u32x4 B = philox4x32_10(j, a.ins_gid[ins], m, SITE_PH_B, d.k0, d.k1);
+    if (a.tabs) {                                            // model variants: the table depends on the photon's array
+        const u32x4 A = philox4x32_10(j, a.ins_gid[ins], m, SITE_PH_A, d.k0, d.k1);
+        const int ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * d.n_tpc, d.n_tpc, u53(A.x, A.y));
+        i64 t = a.em_time[lo] + sample_disc(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], u53(B.x, B.y));
+        if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], B.w);
+        out[i] = t;
+        return;
+    }
     out[i] = a.em_time[lo] + sample_disc(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
 }
 

@@ -41,7 +41,7 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_copy_records_dev', 'wfs_records_dev_ptr', 'wfs_copy_groups', 'wfs_copy_intervals',
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
            'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_instruction_photon_offsets', 'wfs_gather_photon_times', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
-           'wfs_kernel_times', 'wfs_set_profiling']
+           'wfs_kernel_times', 'wfs_set_profiling', 'wfs_set_delay_models', 'wfs_set_s1_propagation', 'wfs_set_instruction_models']
 
 
 def load_library():
@@ -112,6 +112,17 @@ class Engine:
                     self._h, C.c_int32(e), C.c_int32(dc.shape[1]), C.c_int32(ac.shape[-1]), C.c_int32(ac.ndim == 2),
                     C.c_int32('Uniform' in name), C.c_double(d['delaytime_bin_size']), C.c_double(d['amplitude_bin_size']), _p(dc), _p(ac)))
 
+        # model variants of the photon delays (S1 custom / optical propagation, S2 garfield / optical propagation)
+        from .delay_models import DelayModels
+        self.models = DelayModels(config, resource)
+        if self.models.active:
+            base, off, pmf, vmin = self.models.table_arrays()
+            self._check(self.lib.wfs_set_delay_models(self._h, C.c_int32(len(base)), _p(base), _p(off), _p(pmf), _p(vmin)))
+            sp = self.models.s1_prop
+            if sp is not None:
+                self._check(self.lib.wfs_set_s1_propagation(self._h, C.c_int32(len(sp['z'])), C.c_int32(sp['nu']), C.c_double(sp['u0']),
+                                                            C.c_double(sp['du']), _p(sp['top']), _p(sp['bottom'])))
+
     # ------------------------------------------------------------------------------------------
     def _check(self, rc):
         if rc != 0:
@@ -144,6 +155,9 @@ class Engine:
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
                                                    _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0),
                                                    _p(_arr(em_base, np.uint32) if em_base is not None else None)))
+        if self.models.active:
+            tab, tabb, zi, zf = self.models.instruction_tables(ins, gid)
+            self._check(self.lib.wfs_set_instruction_models(self._h, C.c_int64(n), _p(tab), _p(tabb), _p(zi), _p(zf)))
 
     def load_optical(self, ins, gid, cluster, tmin, channels, timings, time_cutoff):
         """ins: optical instructions (with _first/_last) sorted by time; channels/timings: the flat photon arrays"""

@@ -34,20 +34,51 @@ class DummyMap:
 
 
 def make_map(map_file, fmt=None, method='WeightedNearestNeighbors'):
-    """``["constant dummy", const, shape]`` -> DummyMap; a callable is returned as is.
-
-    File-backed interpolating maps need straxen and are not available here (load_resource.py:393-399).
-    """
+    """``["constant dummy", const, shape]`` -> DummyMap; a callable is returned as is; a dict (the map data) or the
+    path of a json / json.gz / pkl file of it -> ``itp_map.InterpolatingMap`` (load_resource.py:383-401; the reference
+    resolves file NAMES through straxen's downloader, here the path is opened as given)."""
     if isinstance(map_file, (list, tuple)):
         assert map_file[0] == 'constant dummy', ('Alternative file input can only be '
                                                  '("constant dummy", constant: int, shape: list')
         return DummyMap(map_file[1], map_file[2])
     if callable(map_file):
         return map_file
+    if isinstance(map_file, dict):
+        from .itp_map import InterpolatingMap
+        return InterpolatingMap(map_file, method=method)
     if isinstance(map_file, str):
-        raise NotImplementedError(
-            f'map file {map_file!r}: file-backed InterpolatingMaps need straxen; pass a callable or a dummy map')
+        from .itp_map import InterpolatingMap, load_map_data
+        return InterpolatingMap(load_map_data(map_file, fmt), method=method)
     raise TypeError("Can't handle map_file except a string or a list")
+
+
+def make_patternmap(map_file, fmt=None, method='WeightedNearestNeighbors', pmt_mask=None):
+    """Pattern maps with the PMT mask applied and the compressed / quantised storage undone (load_resource.py:403-435).
+    Compression codecs: the ones python ships (bz2, zlib, lzma); strax's blosc / zstd / lz4 are not installed here."""
+    if isinstance(map_file, (list, tuple)) or callable(map_file):
+        return make_map(map_file)
+    from copy import deepcopy
+    from .itp_map import InterpolatingMap, load_map_data
+    map_data = deepcopy(map_file) if isinstance(map_file, dict) else load_map_data(map_file, fmt)
+    if 'compressed' in map_data:
+        import bz2
+        import lzma
+        import zlib
+        codecs = dict(bz2=bz2.decompress, zlib=zlib.decompress, lzma=lzma.decompress)
+        compressor, dtype, shape = map_data['compressed']
+        if compressor not in codecs:
+            raise NotImplementedError(f'map compressor {compressor!r}: only {sorted(codecs)} are available offline')
+        map_data['map'] = np.frombuffer(codecs[compressor](map_data['map']), dtype=dtype).reshape(*shape)
+        del map_data['compressed']
+    if 'quantized' in map_data:
+        map_data['map'] = map_data['quantized'] * np.asarray(map_data['map']).astype(np.float32)
+        del map_data['quantized']
+    if pmt_mask is not None:
+        m = np.array(map_data['map'])
+        assert m.shape[-1] == pmt_mask.shape[0], 'Error! Pattern map and PMT gains must have same dimensions!'
+        m[..., ~pmt_mask] = 0.0
+        map_data['map'] = m
+    return InterpolatingMap(map_data, method=method)
 
 
 class Resource:
@@ -55,8 +86,9 @@ class Resource:
 
     def __init__(self, config):
         c = config
-        self.s1_pattern_map = make_map(c['s1_pattern_map'])
-        self.s2_pattern_map = make_map(c['s2_pattern_map'])
+        pmt_mask = np.asarray(c['gains']) > 0
+        self.s1_pattern_map = make_patternmap(c['s1_pattern_map'], pmt_mask=pmt_mask)
+        self.s2_pattern_map = make_patternmap(c['s2_pattern_map'], pmt_mask=pmt_mask)
         self.s1_lce_correction_map = make_map(c.get('s1_lce_correction_map', ['constant dummy', 1, []]))
         self.s2_correction_map = make_map(c.get('s2_correction_map', ['constant dummy', 1, []]))
         self.se_gain_map = make_map(c.get('se_gain_map', ['constant dummy', 1, []]))
@@ -69,6 +101,22 @@ class Resource:
                 r = np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
                 return fmap(np.array([r, z]).T, **kwargs)
             self.field_dependencies_map = rz_map
+        # photon propagation splines (load_resource.py:354-365) and the garfield luminescence table (load_resource.py:293-309)
+        if c.get('s1_time_spline', False):
+            self.s1_optical_propagation_spline = make_map(c['s1_time_spline'], method='RegularGridInterpolator')
+        if c.get('s2_time_spline', False):
+            self.s2_optical_propagation_spline = make_map(c['s2_time_spline'])
+        if c.get('s2_luminescence_model', 'simple') == 'garfield':
+            lum = c['s2_luminescence']
+            if isinstance(lum, str):
+                lum = np.load(lum, allow_pickle=False)
+                lum = lum['arr_0'] if hasattr(lum, 'files') and 'arr_0' in lum.files else lum
+            if getattr(lum, 'dtype', None) is not None and lum.dtype.names and 'll' in lum.dtype.names:
+                # several liquid levels in one file: take the simulated one (load_resource.py:303-307)
+                levels = np.unique(lum['ll'])
+                level = min(levels, key=lambda x: abs(x - (c['gate_to_anode_distance'] - c['elr_gas_gap_length'])))
+                lum = lum[lum['ll'] == level]
+            self.s2_luminescence = dict(t=np.asarray(lum['t']), x=np.asarray(lum['x']))
         if c.get('enable_gas_gap_warping', False):
             self.gas_gap_length = make_map(c['gas_gap_map'])
         # SPE area distributions: dict(charge, pdf[, n_channels]) or dict(charge, pdfs[n_ch, n_bins]) or a CSV path
