@@ -1,0 +1,95 @@
+"""Host-side per-instruction physics (wfsim_amd/physics.py): the S2 pattern variants of S2.photon_channels
+(/root/reference/wfsim/core/s2.py:616-682) and the map resource formats.  CPU only."""
+import bz2
+
+import numpy as np
+import pytest
+
+from wfsim_amd.config import xenonnt_test_config
+from wfsim_amd.dtypes import instruction_dtype
+from wfsim_amd.physics import instruction_params, s2_channel_probabilities
+from wfsim_amd.resource import Resource, make_patternmap
+
+
+def _s2(n, seed=0):
+    rng = np.random.default_rng(seed)
+    ins = np.zeros(n, dtype=instruction_dtype)
+    ins['type'], ins['z'], ins['amp'] = 2, -10.0, 100
+    ins['x'], ins['y'] = rng.uniform(-30, 30, n), rng.uniform(-30, 30, n)
+    return ins
+
+
+def test_transverse_diffusion_constant_is_the_reference_noop():
+    """s2.py:581 reads the constant with getattr() on a dict -> 0: the 'diffused' pattern is the pattern at xy; only
+    instructions outside tpc_radius lose their pattern (s2.py:598)"""
+    ins = _s2(5)
+    ins['x'][2] = 60.0
+    a = instruction_params(ins, xenonnt_test_config(diffusion_constant_transverse=0), Resource(xenonnt_test_config()))
+    cfg = xenonnt_test_config(diffusion_constant_transverse=2e-8)
+    b = instruction_params(ins, cfg, Resource(cfg))
+    keep = np.arange(5) != 2
+    assert np.array_equal(a['cdf_table'][a['cdf_row'][keep]], b['cdf_table'][b['cdf_row'][keep]])
+    assert np.array_equal(a['p_hit'][keep], b['p_hit'][keep]) and b['p_hit'][2] == 0.0
+    cfg = xenonnt_test_config(diffusion_constant_transverse=2e-8, enable_field_dependencies=dict(diffusion_transverse_map=True))
+    with pytest.raises(NotImplementedError):
+        s2_channel_probabilities(np.zeros((1, 2)), cfg, Resource(xenonnt_test_config()))
+
+
+def test_aft_smearing_follows_the_skew_normal_and_the_instruction_id():
+    from scipy.stats import skewnorm
+    n = 4000
+    cfg = xenonnt_test_config(s2_aft_sigma=0.08, s2_aft_skewness=1.5, seed=9)
+    res = Resource(cfg)
+    pos = np.zeros((n, 2))
+    p0 = s2_channel_probabilities(pos[:1], dict(cfg, s2_aft_sigma=0.0), res)[0]
+    top = np.arange(cfg['n_top_pmts'])
+    aft0 = p0[top].sum()
+    p = s2_channel_probabilities(pos, cfg, res, gids=np.arange(n))
+    assert np.allclose(p.sum(axis=1), 1.0)
+    ratio = p[:, top].sum(axis=1) / aft0
+    m, v = skewnorm.stats(a=1.5, loc=1.0, scale=0.08, moments='mv')
+    assert abs(ratio.mean() - m) < 5 * np.sqrt(v / n) and abs(ratio.std() / np.sqrt(v) - 1) < 0.05
+    # inside one array the pattern keeps its shape
+    assert np.allclose(p[7, top] / p[7, top].sum(), p0[top] / p0[top].sum())
+    # keyed by the run-wide instruction id: independent of how the run is cut into batches
+    q = s2_channel_probabilities(pos[:10], cfg, res, gids=np.arange(100, 110))
+    assert np.array_equal(q, p[100:110])
+    ip = instruction_params(_s2(6), cfg, res, gids=np.arange(6))
+    assert len(np.unique(ip['cdf_row'])) == 6
+
+
+def test_pattern_map_formats_mask_quantised_compressed():
+    """make_patternmap (load_resource.py:403-435): PMT mask, quantised storage, compressed storage"""
+    rng = np.random.default_rng(4)
+    m = rng.random((5, 6, 8)).astype(np.float32)
+    csys = [['x', [-1, 1, 5]], ['y', [-1, 1, 6]]]
+    mask = np.ones(8, dtype=bool); mask[3] = False
+    plain = make_patternmap(dict(coordinate_system=csys, map=m), pmt_mask=mask)
+    pts = np.array([[0.13, -0.4], [0.9, 0.9]])
+    out = plain(pts)
+    assert out.shape == (2, 8) and np.all(out[:, 3] == 0) and np.all(out[:, 0] > 0)
+    q = np.round(m / 0.001).astype(np.uint16)
+    quant = make_patternmap(dict(coordinate_system=csys, map=q, quantized=0.001), pmt_mask=mask)
+    assert np.allclose(quant(pts), out, atol=1e-3)
+    comp = make_patternmap(dict(coordinate_system=csys, map=bz2.compress(q.tobytes()), compressed=('bz2', 'uint16', q.shape), quantized=0.001), pmt_mask=mask)
+    assert np.array_equal(comp(pts), quant(pts))
+    with pytest.raises(NotImplementedError):
+        make_patternmap(dict(coordinate_system=csys, map=b'', compressed=('blosc', 'uint16', q.shape)))
+
+
+def test_interpolated_pattern_maps_feed_the_channel_tables():
+    """a position dependent (InterpolatingMap) S1 and S2 pattern through instruction_params: one CDF row per instruction"""
+    rng = np.random.default_rng(6)
+    s2map = dict(coordinate_system=[['x', [-50, 50, 11]], ['y', [-50, 50, 11]]], map=rng.random((11, 11, 494)))
+    s1map = dict(coordinate_system=[['x', [-50, 50, 5]], ['y', [-50, 50, 5]], ['z', [-100, 0, 6]]], map=rng.random((5, 5, 6, 494)))
+    cfg = xenonnt_test_config(s1_pattern_map=s1map, s2_pattern_map=s2map)
+    cfg['gains'] = np.array(cfg['gains'], dtype=np.float64); cfg['gains'][[5, 300]] = 0
+    res = Resource(cfg)
+    ins = _s2(7)
+    ins['type'][:3] = 1
+    ip = instruction_params(ins, cfg, res)
+    cdf = ip['cdf_table'][ip['cdf_row']]
+    assert cdf.shape == (7, 494) and np.allclose(cdf[:, -1], 1.0) and np.all(np.diff(cdf, axis=1) >= 0)
+    p = np.diff(cdf, axis=1, prepend=0.0)
+    assert np.all(p[:, [5, 300]] == 0)                       # turned-off PMTs never fire
+    assert len(np.unique(ip['cdf_row'])) == 7

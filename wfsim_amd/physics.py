@@ -91,20 +91,43 @@ def s2_secondary_gain(positions, config, resource):
     return sc_gain
 
 
-def s2_channel_probabilities(positions, config, resource):
-    if config.get('diffusion_constant_transverse', 0) > 0:
-        raise NotImplementedError('transverse-diffusion averaged S2 patterns (s2.py:560-613) are not on the MI355X path')
-    if config.get('s2_aft_sigma', 0.0) != 0:
-        raise NotImplementedError('s2_aft_sigma smearing (s2.py:660-665) is not on the MI355X path')
+def s2_channel_probabilities(positions, config, resource, gids=None):
+    """S2.photon_channels up to the categorical draw, /root/reference/wfsim/core/s2.py:616-682.
+
+    ``diffusion_constant_transverse > 0`` sends the reference through s2_pattern_map_diffuse (s2.py:560-613), which reads
+    the constant with ``getattr(config, ...)`` on a dict and therefore always diffuses by 0: every electron sits at the
+    instruction's xy and the averaged pattern IS the pattern at xy (instructions outside ``tpc_radius`` get no pattern).
+    Only with the private ``diffusion_transverse_map`` field maps is there a real spread; that branch is not provided.
+    ``s2_aft_sigma``: the top-array fraction of every instruction's pattern is rescaled by a skew-normal factor
+    (s2.py:660-665); the draw comes from a host Philox stream keyed by (seed, run-wide instruction id)."""
     channels = np.arange(config['n_tpc_pmts']).astype(np.int64)
     bottom_index = np.array(config['channels_bottom'])
     pattern = np.array(resource.s2_pattern_map(positions), dtype=np.float64)
+    if config.get('diffusion_constant_transverse', 0) > 0:
+        if config.get('enable_field_dependencies', {}).get('diffusion_transverse_map', False):
+            raise NotImplementedError('diffusion_transverse_map (private field maps, s2.py:575-579) is not on the MI355X path')
+        outside = np.sum(np.asarray(positions, dtype=np.float64) ** 2, axis=1) > config['tpc_radius'] ** 2     # s2.py:598
+        pattern[outside] = 0
     if pattern.shape[1] - 1 not in bottom_index:
         pattern = np.pad(pattern, [[0, 0], [0, len(bottom_index)]], 'constant', constant_values=1)
     pattern[:, np.isin(channels, _turned_off(config))] = 0
     sum_pat = np.sum(pattern, axis=1).reshape(-1, 1)
     pattern = np.divide(pattern, sum_pat, out=np.zeros_like(pattern), where=sum_pat != 0)
     assert pattern.shape[1] == len(channels)
+    aft_sigma = config.get('s2_aft_sigma', 0.0)
+    if aft_sigma != 0:
+        from numpy.random import Generator, Philox
+        from scipy.stats import skewnorm
+        top_index = np.arange(config['n_top_pmts'])
+        g = np.arange(len(pattern)) if gids is None else np.asarray(gids)
+        for i, pat in enumerate(pattern):
+            if pat.sum() == 0:
+                continue
+            rs = Generator(Philox(key=[int(config.get('seed', 0) or 0), (int(g[i]) << 8) | 0x41]))
+            cur_aft = np.sum(pat[top_index]) / np.sum(pat)
+            new_aft = np.clip(cur_aft * skewnorm.rvs(loc=1.0, scale=aft_sigma, a=config.get('s2_aft_skewness', 0.0), random_state=rs), 0, 1)
+            pat[top_index] *= (new_aft / cur_aft)
+            pat[bottom_index] *= (1 - new_aft) / (1 - cur_aft)
     return pattern
 
 
@@ -114,7 +137,7 @@ def instruction_time(instructions, config):
     return instructions['time'] + (instructions['z'] / v * (instructions['type'] % 2 - 1)).astype(np.int64)
 
 
-def instruction_params(instructions, config, resource):
+def instruction_params(instructions, config, resource, gids=None):
     """Batch arrays for the device: hit/survival probability, drift parameters, secondary gain and the
     cumulative channel table of every instruction (rows de-duplicated)."""
     n = len(instructions)
@@ -149,14 +172,22 @@ def instruction_params(instructions, config, resource):
             drift_mean[sel], drift_spread[sel] = m, s
             sc_gain[sel] = s2_secondary_gain(xy, config, resource)
             pmap = resource.s2_pattern_map
-            probs = (lambda q: s2_channel_probabilities(np.array([q['x'], q['y']]).T, config, resource))
+            sel_gids = None if gids is None else np.asarray(gids)[sel]
+            probs = (lambda q: s2_channel_probabilities(np.array([q['x'], q['y']]).T, config, resource, sel_gids))
         idx = np.where(sel)[0]
-        if isinstance(pmap, DummyMap):
+        per_instruction = kind == 's2' and (config.get('s2_aft_sigma', 0.0) != 0 or (
+            config.get('diffusion_constant_transverse', 0) > 0 and np.any(ins['x'].astype(np.float64) ** 2 + ins['y'].astype(np.float64) ** 2 > config['tpc_radius'] ** 2)))
+        if isinstance(pmap, DummyMap) and not per_instruction:
             const_rows[kind] = len(rows)
             rows.append(choice_cdf(probs(ins[:1]))[0])
             cdf_row[idx] = const_rows[kind]
         else:
-            cdf = choice_cdf(probs(ins))
+            p = probs(ins)
+            empty = p.sum(axis=1) == 0          # no pattern (all PMTs off / outside the TPC): the instruction makes no photons
+            if empty.any():
+                p[empty] = 1.0
+                p_hit[idx[empty]] = 0.0
+            cdf = choice_cdf(p)
             cdf_row[idx] = len(rows) + np.arange(len(idx))
             rows.extend(list(cdf))
     cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.zeros((1, n_ch))
