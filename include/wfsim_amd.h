@@ -139,6 +139,21 @@ int wfs_set_s1_propagation(wfs_handle *h, int32_t nz, int32_t nu, double u0, dou
 int wfs_set_instruction_models(wfs_handle *h, int64_t n, const int32_t *tab, const int32_t *tab_bottom,
                                const int32_t *prop_zi, const double *prop_zf);
 
+/* ---- pattern maps evaluated on the device ----------------------------------------------------------------
+ * The hit pattern of an instruction is resource.s1_pattern_map(x, y, z) / s2_pattern_map(x, y) (s1.py:148, s2.py:640):
+ * straxen InterpolatingMaps on a regular grid, method WeightedNearestNeighbors (load_resource.make_patternmap,
+ * load_resource.py:403-435): inverse-distance weighted average of the 2 * dims nearest nodes, distances clipped at 1e-6.
+ * which: 1 S1 map (3-D), 2 S2 map (2-D); nodes per axis, first / last node per axis; values f32[nodes][n_map_channels]
+ * (row-major over the axes, PMT mask already applied).  n_map_channels < n_tpc: the missing (bottom) channels count 1
+ * (s2.py:648-650).  Turned-off PMTs (gain 0) are removed on the device (s1.py:150, s2.py:653).  dims = 0 drops the map.
+ * An instruction loaded with cdf_row = -1 takes its channel CDF from the map of its type: call wfs_eval_pattern_rows
+ * with the positions (float32 as in instruction_dtype; z unused for S2) after wfs_load_instructions, before wfs_run.
+ * wfs_copy_cdf_rows returns the rows the generator uses (parity tests feed them to the oracle). */
+int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
+                        const float *values, int32_t n_map_channels);
+int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float *y, const float *z);
+int wfs_copy_cdf_rows(wfs_handle *h, int32_t *cdf_row, double *cdf_table, int64_t cap_rows);
+
 /* Parity entry: photons supplied instead of generated -- what RawDataOptical.sim_primary hands to Pulse
  * (rawdata.py:475-493) and what the golden vectors inject.  One "pulse set" = one Pulse.__call__ (pulse.py:39).
  *   set_cluster i32[n_sets], set_tmin i64[n_sets]   cluster id and scheduler key of the set's instruction

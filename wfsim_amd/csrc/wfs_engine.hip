@@ -70,6 +70,10 @@ struct wfs_handle {
     std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
     DevBuf prop_top, prop_bot; i32 prop_nz = 0, prop_nu = 0; double prop_u0 = 0, prop_du = 1;
     DevBuf ins_tab, ins_tabb, ins_pzi, ins_pzf; bool ins_models = false;
+    // pattern maps evaluated on the device
+    struct PatternMap { bool set = false; i32 dims = 0, n[3] = {1, 1, 1}, w[3] = {0, 0, 0}, n_map_ch = 0; double lo[3] = {0, 0, 0}, hgrid[3] = {1, 1, 1}; DevBuf values; } pmap[2];
+    std::vector<i32> dev_row_ins; std::vector<int8_t> h_ins_type; i64 n_host_rows = 0; bool dev_rows_pending = false;
+    DevBuf map_row_ins[2], map_row_id[2], map_x, map_y, map_z, map_nb_idx[2], map_nb_w[2];
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
@@ -336,7 +340,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -473,7 +477,8 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         if (type[i] != 1 && type[i] != 2 && type[i] != 4 && type[i] != 6)      // 4 / 6: electron afterpulses, simulated like an S2 (afterpulse.py:14, 94)
             return h->fail(WFS_E_INVALID, "instruction types: 1 (S1), 2 (S2), 4 / 6 (photo-ionisation / photo-electric electrons)");
         if (amp[i] < 0) return h->fail(WFS_E_INVALID, "negative amp");
-        if (cdf_row[i] < 0 || cdf_row[i] >= n_cdf) return h->fail(WFS_E_INVALID, "cdf_row out of range");
+        if (cdf_row[i] < -1 || cdf_row[i] >= n_cdf) return h->fail(WFS_E_INVALID, "cdf_row out of range");
+        if (cdf_row[i] == -1 && !h->pmap[type[i] == 1 ? 0 : 1].set) return h->fail(WFS_E_STATE, "cdf_row -1 needs wfs_set_pattern_map for the instruction type");
         if (type[i] != 1 && h->dev.n_lum < 2) return h->fail(WFS_E_STATE, "S2 instructions need the luminescence table");
         em_off[i + 1] = em_off[i] + (type[i] == 1 ? 1 : (i64)amp[i]);
     }
@@ -503,7 +508,17 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     { std::vector<u32> eb((size_t)n, 0u); if (em_base) eb.assign(em_base, em_base + n); TRY(upload(h, h->ins_embase, eb.data(), (size_t)n * 4)); HIPCHK(hipStreamSynchronize(h->stream)); }
     TRY(upload(h, h->ins_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_p, p_hit, (size_t)n * 8)); TRY(upload(h, h->ins_dm, drift_mean, (size_t)n * 8));
     TRY(upload(h, h->ins_ds, drift_spread, (size_t)n * 8)); TRY(upload(h, h->ins_sc, sc_gain, (size_t)n * 8));
-    TRY(upload(h, h->ins_cdfrow, cdf_row, (size_t)n * 4)); TRY(upload(h, h->cdf_table, cdf_table, (size_t)n_cdf * h->cfg.n_tpc * 8));
+    // rows -1: the channel CDF of the instruction comes from the device pattern map (wfs_eval_pattern_rows), stored behind the host rows
+    h->dev_row_ins.clear(); h->h_ins_type.assign(type, type + n); h->n_host_rows = n_cdf;
+    {
+        std::vector<i32> rows(cdf_row, cdf_row + n);
+        for (i64 i = 0; i < n; i++) if (rows[i] < 0) { rows[i] = (i32)(n_cdf + (i64)h->dev_row_ins.size()); h->dev_row_ins.push_back((i32)i); }
+        h->dev_rows_pending = !h->dev_row_ins.empty();
+        const size_t total = (size_t)n_cdf + h->dev_row_ins.size();
+        TRY(ensure(h, h->cdf_table, total * h->cfg.n_tpc * 8)); TRY(ensure(h, h->cdf_guide, total * (CDF_G + 2) * 2));
+        TRY(upload(h, h->ins_cdfrow, rows.data(), (size_t)n * 4)); HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    TRY(upload(h, h->cdf_table, cdf_table, (size_t)n_cdf * h->cfg.n_tpc * 8));
     {   // guide table of every channel-CDF row: guide[c] = first channel whose cumulative probability exceeds c / CDF_G
         const int nch = h->cfg.n_tpc;
         std::vector<unsigned short> guide((size_t)n_cdf * (CDF_G + 2));
@@ -571,6 +586,79 @@ int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, c
     h->h_tabs[n_tables] = h->dev.tab_s1; h->h_tabs[n_tables + 1] = h->dev.tab_s2;       // "-1": the default table of the type
     TRY(upload(h, h->d_tabs, h->h_tabs.data(), h->h_tabs.size() * sizeof(DiscTab)));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return WFS_OK;
+}
+
+// ---- pattern maps evaluated on the device (make_patternmap, load_resource.py:403-435; WeightedNearestNeighbors) ----
+int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
+                        const float *values, int32_t n_map_channels)
+{
+    if (!h) return WFS_E_INVALID;
+    if (which != 1 && which != 2) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: which = 1 (S1 map) or 2 (S2 map)");
+    auto &m = h->pmap[which - 1];
+    if (dims == 0) { m.set = false; return WFS_OK; }
+    if (dims < 2 || dims > 3 || !n_nodes || !lo || !hi || !values || n_map_channels <= 0 || n_map_channels > h->cfg.n_tpc)
+        return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: 2 or 3 dimensions, at most n_tpc channels");
+    HIPCHK(hipSetDevice(h->device));
+    size_t nodes = 1; double diag2 = 0;
+    for (int a = 0; a < 3; a++) { m.n[a] = 1; m.lo[a] = 0; m.hgrid[a] = 1; m.w[a] = 0; }
+    for (int a = 0; a < dims; a++) {
+        if (n_nodes[a] < 2 || !(hi[a] > lo[a])) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: every axis needs at least 2 nodes and hi > lo");
+        m.n[a] = n_nodes[a]; m.lo[a] = lo[a]; m.hgrid[a] = (hi[a] - lo[a]) / (n_nodes[a] - 1); nodes *= (size_t)n_nodes[a];
+        diag2 += m.hgrid[a] * m.hgrid[a];
+    }
+    // the 2 * dims nearest nodes lie within one cell diagonal (a cell has 2^dims >= 2 * dims corners): candidate block per axis
+    for (int a = 0; a < dims; a++) m.w[a] = (i32)ceil(sqrt(diag2) / m.hgrid[a]) + 1;
+    m.dims = dims; m.n_map_ch = n_map_channels;
+    TRY(upload(h, m.values, values, nodes * (size_t)n_map_channels * 4));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    m.set = true;
+    return WFS_OK;
+}
+
+int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float *y, const float *z)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins || !x || !y || !z) return h->fail(WFS_E_STATE, "wfs_eval_pattern_rows follows wfs_load_instructions of the same batch");
+    if (h->dev_row_ins.empty()) return WFS_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const int nch = h->cfg.n_tpc;
+    TRY(upload(h, h->map_x, x, (size_t)n * 4)); TRY(upload(h, h->map_y, y, (size_t)n * 4)); TRY(upload(h, h->map_z, z, (size_t)n * 4));
+    i64 first = h->n_host_rows;
+    // rows were numbered in instruction order; evaluate them map by map, each over its own (ordered) subset
+    std::vector<i32> rows_of[2]; std::vector<i64> row_id[2];
+    for (size_t k = 0; k < h->dev_row_ins.size(); k++) { const int w = h->h_ins_type[h->dev_row_ins[k]] == 1 ? 0 : 1; rows_of[w].push_back(h->dev_row_ins[k]); row_id[w].push_back(first + (i64)k); }
+    for (int w = 0; w < 2; w++) {
+        if (rows_of[w].empty()) continue;
+        const auto &pm = h->pmap[w];
+        const i64 nr = (i64)rows_of[w].size();
+        TRY(upload(h, h->map_row_ins[w], rows_of[w].data(), (size_t)nr * 4)); TRY(upload(h, h->map_row_id[w], row_id[w].data(), (size_t)nr * 8));
+        TRY(ensure(h, h->map_nb_idx[w], (size_t)nr * MAP_K * 8)); TRY(ensure(h, h->map_nb_w[w], (size_t)nr * MAP_K * 8));
+        MapArgs m{};
+        m.dims = pm.dims; for (int q = 0; q < 3; q++) { m.n[q] = pm.n[q]; m.w[q] = pm.w[q]; m.lo[q] = pm.lo[q]; m.h[q] = pm.hgrid[q]; }
+        m.values = pm.values.as<float>(); m.n_map_ch = pm.n_map_ch; m.n_rows = nr; m.row_ins = h->map_row_ins[w].as<i32>(); m.row_id = h->map_row_id[w].as<i64>();
+        m.x = h->map_x.as<float>(); m.y = h->map_y.as<float>(); m.z = h->map_z.as<float>();
+        m.nb_idx = h->map_nb_idx[w].as<i64>(); m.nb_w = h->map_nb_w[w].as<double>();
+        m.cdf_table = h->cdf_table.as<double>(); m.cdf_guide = h->cdf_guide.as<unsigned short>(); m.gains = h->t_gains.as<double>();
+        { Timer t(h, "k_map_neighbours"); hipLaunchKernelGGL(k_map_neighbours, dim3(nblocks(nr, 128)), dim3(128), 0, h->stream, m); }
+        { Timer t(h, "k_map_rows"); hipLaunchKernelGGL(k_map_rows, dim3((unsigned)nr), dim3(256), (size_t)nch * 8, h->stream, m, nch); }
+    }
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
+    h->dev_rows_pending = false; h->gen_done = false;
+    return WFS_OK;
+}
+
+// channel CDF rows of the loaded batch as the generator sees them (host rows followed by the device-evaluated ones)
+int wfs_copy_cdf_rows(wfs_handle *h, int32_t *cdf_row, double *cdf_table, int64_t cap_rows)
+{
+    if (!h || !h->batch_loaded || h->injected || h->optical) return WFS_E_STATE;
+    if (h->dev_rows_pending) return h->fail(WFS_E_STATE, "wfs_eval_pattern_rows has not been called for this batch");
+    const i64 total = h->n_host_rows + (i64)h->dev_row_ins.size();
+    if (cap_rows < total) return h->fail(WFS_E_CAPACITY, "cdf row buffer too small");
+    HIPCHK(hipSetDevice(h->device));
+    if (cdf_row) HIPCHK(hipMemcpy(cdf_row, h->ins_cdfrow.p, (size_t)h->n_ins * 4, hipMemcpyDeviceToHost));
+    if (cdf_table) HIPCHK(hipMemcpy(cdf_table, h->cdf_table.p, (size_t)total * h->cfg.n_tpc * 8, hipMemcpyDeviceToHost));
     return WFS_OK;
 }
 
@@ -814,6 +902,7 @@ int wfs_run(wfs_handle *h)
 {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded) return h->fail(WFS_E_STATE, "no batch loaded");
+    if (h->dev_rows_pending && !h->injected && !h->optical) return h->fail(WFS_E_STATE, "instructions with cdf_row -1: call wfs_eval_pattern_rows before wfs_run");
     h->ran = false; h->gen_done = false;
     HIPCHK(hipSetDevice(h->device));
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }

@@ -1349,6 +1349,109 @@ __device__ __forceinline__ void block_excl_scan(i32 *v, int n, i32 *wtmp)
     __syncthreads();
 }
 
+// ---- pattern maps on the device (S1.photon_channels s1.py:138-159, S2.photon_channels s2.py:616-682; the maps are
+// straxen.InterpolatingMap objects built by load_resource.make_patternmap, method WeightedNearestNeighbors): the hit
+// pattern at a position is the inverse-distance weighted average of the 2 * dims nearest grid nodes (distance clipped at
+// 1e-6).  On the host that costs ~0.4 ms per instruction (10^4 S1: seconds); here one thread finds the neighbours of
+// an instruction and one workgroup turns them into the instruction's channel CDF row and its guide table.
+#define MAP_K 6                    // 2 * dims neighbours, dims <= 3
+struct MapArgs {
+    i32 dims, n[3], w[3];          // nodes per axis; half-width of the candidate block per axis
+    double lo[3], h[3];            // first node and spacing per axis
+    const float *values;           // [n0 * n1 * n2][n_map_ch]
+    i32 n_map_ch;                  // channels stored in the map; channels beyond get weight 1 (s2.py:648-650: top-only maps)
+    i64 n_rows;                    // instructions to evaluate
+    const i32 *row_ins;            // [n_rows] instruction of the row
+    const float *x, *y, *z;        // [n_ins] positions
+    const i64 *row_id;             // [n_rows] cdf row to write
+    i64 *nb_idx; double *nb_w;     // [n_rows][MAP_K]
+    double *cdf_table; unsigned short *cdf_guide;
+    const double *gains;           // [n_tpc] 0: turned-off PMT
+};
+
+__global__ void k_map_neighbours(MapArgs m)
+{
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m.n_rows) return;
+    const i32 ins = m.row_ins[r];
+    const double pos[3] = {(double)m.x[ins], (double)m.y[ins], m.dims > 2 ? (double)m.z[ins] : 0.0};
+    i32 c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+    for (int a = 0; a < m.dims; a++) {
+        i32 c = (i32)floor((pos[a] - m.lo[a]) / m.h[a]);
+        c = c < 0 ? 0 : (c > m.n[a] - 2 ? m.n[a] - 2 : c);
+        c0[a] = c - m.w[a] + 1 < 0 ? 0 : c - m.w[a] + 1;
+        c1[a] = c + m.w[a] > m.n[a] - 1 ? m.n[a] - 1 : c + m.w[a];
+    }
+    const int K = 2 * m.dims;
+    double bd[MAP_K]; i64 bi[MAP_K];
+    for (int k = 0; k < MAP_K; k++) { bd[k] = 1e300; bi[k] = -1; }
+    for (i32 i = c0[0]; i <= c1[0]; i++) {
+        const double dx = pos[0] - (m.lo[0] + i * m.h[0]);
+        for (i32 j = c0[1]; j <= c1[1]; j++) {
+            const double dy = m.dims > 1 ? pos[1] - (m.lo[1] + j * m.h[1]) : 0.0;
+            for (i32 l = c0[2]; l <= c1[2]; l++) {
+                const double dz = m.dims > 2 ? pos[2] - (m.lo[2] + l * m.h[2]) : 0.0;
+                const double d2 = dx * dx + dy * dy + dz * dz;
+                if (!(d2 < bd[K - 1])) continue;            // ties keep the node met first (lower linear index)
+                const i64 node = ((i64)i * (m.dims > 1 ? m.n[1] : 1) + j) * (m.dims > 2 ? m.n[2] : 1) + l;
+                int q = K - 1;
+                while (q > 0 && d2 < bd[q - 1]) { bd[q] = bd[q - 1]; bi[q] = bi[q - 1]; q--; }
+                bd[q] = d2; bi[q] = node;
+            }
+        }
+    }
+    for (int k = 0; k < MAP_K; k++) {
+        const double dist = sqrt(bd[k]);
+        m.nb_idx[r * MAP_K + k] = k < K ? bi[k] : -1;
+        m.nb_w[r * MAP_K + k] = (k < K && bi[k] >= 0) ? 1.0 / (dist < 1e-6 ? 1e-6 : dist) : 0.0;
+    }
+}
+
+// one workgroup per row: weighted average of the neighbours' patterns, turned-off PMTs removed, normalised, cumulative sum,
+// guide table (guide[c] = first channel whose cumulative probability exceeds c / CDF_G, as the host builds it)
+__global__ __launch_bounds__(256) void k_map_rows(MapArgs m, int nch)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *p = (double *)smem;                    // [nch]
+    __shared__ double s_part[4]; __shared__ double s_sum;
+    const i64 r = blockIdx.x; const int tid = threadIdx.x;
+    double w[MAP_K]; i64 idx[MAP_K]; double wsum = 0;
+    for (int k = 0; k < MAP_K; k++) { w[k] = m.nb_w[r * MAP_K + k]; idx[k] = m.nb_idx[r * MAP_K + k]; wsum += w[k]; }
+    double part = 0;
+    for (int c = tid; c < nch; c += 256) {
+        double v = 1.0;
+        if (c < m.n_map_ch) {
+            double acc = 0;
+            for (int k = 0; k < MAP_K; k++) if (idx[k] >= 0) acc += w[k] * (double)m.values[idx[k] * m.n_map_ch + c];
+            v = acc / wsum;
+        }
+        if (m.gains[c] == 0) v = 0;
+        p[c] = v; part += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        // np.random.choice: cdf = cumsum(p / sum); cdf /= cdf[-1]  (sequential, as numpy's cumsum)
+        double run = 0;
+        for (int c = 0; c < nch; c++) { run += tot > 0 ? p[c] / tot : 1.0 / nch; p[c] = run; }
+        s_sum = run;
+    }
+    __syncthreads();
+    const i64 rid = m.row_id[r];
+    double *row = m.cdf_table + rid * nch;
+    for (int c = tid; c < nch; c += 256) { p[c] = p[c] / s_sum; row[c] = p[c]; }
+    __syncthreads();
+    unsigned short *g = m.cdf_guide + rid * (CDF_G + 2);
+    for (int c = tid; c <= CDF_G + 1; c += 256) {
+        const double x = (double)c / CDF_G;
+        int lo = 0, hi = nch - 1;                   // first channel with p[ch] > x, at most nch - 1
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (p[mid] > x) hi = mid; else lo = mid + 1; }
+        g[c] = (unsigned short)lo;
+    }
+}
+
 // Between the passes: where in its tile every single-instruction block puts its photons.  Thread = (instruction,
 // channel): a running sum over the instruction's blocks in block order, starting behind whatever the generic path
 // already counted into the tile.  Consecutive blocks get consecutive ranges (no atomics, a reproducible layout).

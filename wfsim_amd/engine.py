@@ -41,7 +41,8 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_copy_records_dev', 'wfs_records_dev_ptr', 'wfs_copy_groups', 'wfs_copy_intervals',
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
            'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_instruction_photon_offsets', 'wfs_gather_photon_times', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
-           'wfs_kernel_times', 'wfs_set_profiling', 'wfs_set_delay_models', 'wfs_set_s1_propagation', 'wfs_set_instruction_models']
+           'wfs_kernel_times', 'wfs_set_profiling', 'wfs_set_delay_models', 'wfs_set_s1_propagation', 'wfs_set_instruction_models',
+           'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows']
 
 
 def load_library():
@@ -112,6 +113,25 @@ class Engine:
                     self._h, C.c_int32(e), C.c_int32(dc.shape[1]), C.c_int32(ac.shape[-1]), C.c_int32(ac.ndim == 2),
                     C.c_int32('Uniform' in name), C.c_double(d['delaytime_bin_size']), C.c_double(d['amplitude_bin_size']), _p(dc), _p(ac)))
 
+        # pattern maps on regular grids are evaluated on the device (one channel CDF row per instruction)
+        self.device_maps = set()
+        if config.get('device_pattern_maps', True):
+            from .itp_map import InterpolatingMap
+            for which, (kind, dims) in enumerate([('s1', 3), ('s2', 2)], start=1):
+                pm = getattr(resource, kind + '_pattern_map', None)
+                if not (isinstance(pm, InterpolatingMap) and pm.grid is not None and pm.dimensions == dims
+                        and pm.method == 'WeightedNearestNeighbors' and pm.map_names == ['map']):
+                    continue
+                grid, vals = pm.regular_grid()
+                if vals.ndim != dims + 1 or vals.shape[-1] > params['n_tpc']:
+                    continue
+                if kind == 's2' and vals.shape[-1] != params['n_tpc'] and (vals.shape[-1] - 1) in np.asarray(config['channels_bottom']):
+                    continue          # s2.py:648: such a map is not padded; leave the odd case to the host
+                v = np.ascontiguousarray(vals.reshape(-1, vals.shape[-1]), dtype=np.float32)
+                nn = np.asarray([len(g) for g in grid], dtype=np.int32)
+                lo, hi = np.asarray([g[0] for g in grid], dtype=np.float64), np.asarray([g[-1] for g in grid], dtype=np.float64)
+                self._check(self.lib.wfs_set_pattern_map(self._h, C.c_int32(which), C.c_int32(dims), _p(nn), _p(lo), _p(hi), _p(v), C.c_int32(v.shape[1])))
+                self.device_maps.add(kind)
         # model variants of the photon delays (S1 custom / optical propagation, S2 garfield / optical propagation)
         from .delay_models import DelayModels
         self.models = DelayModels(config, resource)
@@ -155,9 +175,20 @@ class Engine:
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
                                                    _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0),
                                                    _p(_arr(em_base, np.uint32) if em_base is not None else None)))
+        if np.any(a[10] < 0):           # rows from the device pattern maps
+            xyz = [_arr(ins[k], np.float32) for k in ('x', 'y', 'z')]
+            self._check(self.lib.wfs_eval_pattern_rows(self._h, C.c_int64(n), *[_p(q) for q in xyz]))
+        self._n_cdf_rows = a[11].shape[0] + int(np.sum(a[10] < 0))
         if self.models.active:
             tab, tabb, zi, zf = self.models.instruction_tables(ins, gid)
             self._check(self.lib.wfs_set_instruction_models(self._h, C.c_int64(n), _p(tab), _p(tabb), _p(zi), _p(zf)))
+
+    def cdf_rows(self):
+        """(cdf_row, cdf_table) of the loaded batch as the generator uses them, device-evaluated rows included"""
+        n, rows = self._n_loaded, self._n_cdf_rows
+        cdf_row, table = np.zeros(n, dtype=np.int32), np.zeros((rows, self.params['n_tpc']), dtype=np.float64)
+        self._check(self.lib.wfs_copy_cdf_rows(self._h, _p(cdf_row), _p(table), C.c_int64(rows)))
+        return cdf_row, table
 
     def load_optical(self, ins, gid, cluster, tmin, channels, timings, time_cutoff):
         """ins: optical instructions (with _first/_last) sorted by time; channels/timings: the flat photon arrays"""

@@ -137,9 +137,10 @@ def instruction_time(instructions, config):
     return instructions['time'] + (instructions['z'] / v * (instructions['type'] % 2 - 1)).astype(np.int64)
 
 
-def instruction_params(instructions, config, resource, gids=None):
+def instruction_params(instructions, config, resource, gids=None, device_maps=()):
     """Batch arrays for the device: hit/survival probability, drift parameters, secondary gain and the
-    cumulative channel table of every instruction (rows de-duplicated)."""
+    cumulative channel table of every instruction (rows de-duplicated).  ``device_maps``: kinds ('s1', 's2') whose pattern
+    map lives on the device (Engine.device_maps): their instructions get ``cdf_row = -1`` and no host row."""
     n = len(instructions)
     is_s1 = instructions['type'] == 1
     # types 4 (photo-ionisation electrons) and 6 (photo-electric electrons) are simulated by S2.__call__ (afterpulse.py:14, 94)
@@ -175,6 +176,11 @@ def instruction_params(instructions, config, resource, gids=None):
             sel_gids = None if gids is None else np.asarray(gids)[sel]
             probs = (lambda q: s2_channel_probabilities(np.array([q['x'], q['y']]).T, config, resource, sel_gids))
         idx = np.where(sel)[0]
+        if kind in device_maps and not (kind == 's2' and config.get('s2_aft_sigma', 0.0) != 0):
+            cdf_row[idx] = -1
+            if kind == 's2' and config.get('diffusion_constant_transverse', 0) > 0:         # s2.py:598, see s2_channel_probabilities
+                p_hit[idx[ins['x'].astype(np.float64) ** 2 + ins['y'].astype(np.float64) ** 2 > config['tpc_radius'] ** 2]] = 0.0
+            continue
         per_instruction = kind == 's2' and (config.get('s2_aft_sigma', 0.0) != 0 or (
             config.get('diffusion_constant_transverse', 0) > 0 and np.any(ins['x'].astype(np.float64) ** 2 + ins['y'].astype(np.float64) ** 2 > config['tpc_radius'] ** 2)))
         if isinstance(pmap, DummyMap) and not per_instruction:
@@ -190,6 +196,6 @@ def instruction_params(instructions, config, resource, gids=None):
             cdf = choice_cdf(p)
             cdf_row[idx] = len(rows) + np.arange(len(idx))
             rows.extend(list(cdf))
-    cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.zeros((1, n_ch))
+    cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.ones((1, n_ch))
     return dict(p_hit=p_hit, drift_mean=drift_mean, drift_spread=drift_spread, sc_gain=sc_gain,
                 cdf_row=cdf_row, cdf_table=cdf_table)

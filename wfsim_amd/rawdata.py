@@ -149,7 +149,7 @@ class RawData:
                         s_ins['amp'] * float(self.config.get('s2_secondary_sc_gain', 30)))     # types 2, 4, 6: electrons
 
     def _load_batch(self, ins, gid, cl, key):
-        ip = instruction_params(ins, self.config, self.resource, gids=gid)
+        ip = instruction_params(ins, self.config, self.resource, gids=gid, device_maps=self.engine.device_maps)
         # one pulse set per instruction, or -- save_full_truth off -- per group of nearby S1s / S2s (rawdata.py:106-127)
         # ...; electron-afterpulse instructions (types 4 / 6) of a cluster always share one call
         plain = self.config.get('save_full_truth', True) and bool(np.all(ins['type'] <= 2))
