@@ -84,3 +84,43 @@ def test_nveto_plugin():
     assert len(out['raw_records_nv']) >= 2 and len(rr) > 500
     assert rr['channel'].min() >= 2000 and rr['channel'].max() <= 2119
     assert len(truth) == len(ins) and np.all(np.diff(rr['time']) >= 0)
+
+
+def test_mc_chain_plugin_tpc_and_nveto():
+    """RawRecordsFromMcChain (strax_interface.py:753-1005) with supplied instructions: both detectors follow the same
+    event times; chunks of all six data types share the plugin's chunk boundaries"""
+    from wfsim_amd import ministrax
+    from wfsim_amd.dtypes import instruction_dtype
+    n_ev = 40
+    rng = np.random.default_rng(8)
+    tpc = np.zeros(2 * n_ev, dtype=instruction_dtype)
+    tpc['g4id'] = np.repeat(np.arange(n_ev), 2)
+    tpc['type'] = np.tile([1, 2], n_ev)
+    tpc['amp'] = np.tile([800, 40], n_ev)
+    tpc['z'], tpc['recoil'] = -rng.uniform(1, 90, 2 * n_ev), 7
+    tpc['time'] = np.tile([0, 200], n_ev)
+    tpc['event_number'] = tpc['g4id']
+    nv, channels, timings = optical_instructions(n_ev, 1000.0, 6)
+    nv['time'], nv['g4id'] = 0, np.arange(n_ev)
+    ncfg = nveto_config()
+    nveto_keys = {k: ncfg[k] for k in ('gains', 'n_tpc_pmts', 'n_top_pmts', 'channel_map', 'photon_area_distribution', 'right_raw_extension')}
+    cfg = xenonnt_test_config(seed=4, chunk_size=0.01, event_rate=1000.0, targets=('tpc', 'nveto'), instructions_epix=tpc,
+                              instructions_nveto=nv, nveto_channels=channels, nveto_timings=timings, fax_config_nveto=nveto_keys)
+    cfg['channel_map'] = dict(cfg['channel_map'], nveto=(2000, 2119))          # straxen's map holds all detectors
+    plugin = wfsim_amd.RawRecordsFromMcChain(cfg)
+    out = ministrax.run_plugin(plugin)
+    rr = np.concatenate([c.data for c in out['raw_records']])
+    rr_nv = np.concatenate([c.data for c in out['raw_records_nv']])
+    truth = np.concatenate([c.data for c in out['truth']])
+    truth_nv = np.concatenate([c.data for c in out['truth_nv']])
+    assert len(rr) > 100 and len(rr_nv) > 50 and len(truth) == 2 * n_ev and len(truth_nv) == n_ev
+    assert rr['channel'].max() < 494 and rr_nv['channel'].min() >= 2000 and rr_nv['channel'].max() <= 2119
+    assert np.all(np.diff(rr['time']) >= 0) and np.all(np.diff(rr_nv['time']) >= 0)
+    # both detectors saw event g at the same time (the nVeto photons arrive within ~100 ns, S1 photons within ~200 ns)
+    ev_t = plugin.event_times
+    for g in (0, 7, 39):
+        assert np.abs(rr['time'] - ev_t[g]).min() < 2000 and np.abs(rr_nv['time'] - ev_t[g]).min() < 2000
+    # TPC only
+    plugin = wfsim_amd.RawRecordsFromMcChain(dict(cfg, targets=('tpc',), entry_stop=None))
+    out2 = ministrax.run_plugin(plugin)
+    assert sum(len(c.data) for c in out2['raw_records_nv']) == 0 and sum(len(c.data) for c in out2['raw_records']) > 100

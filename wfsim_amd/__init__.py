@@ -12,6 +12,7 @@ from .config import load_fax_config, xenonnt_test_config, kernel_params  # noqa:
 from .rawdata import RawData, RawDataOptical, PULSE_TYPE_NAMES  # noqa: F401
 from .optical import optical_adjustment  # noqa: F401
 from .strax_interface import (ChunkRawRecords, SimulatorPlugin, RawRecordsFromFaxNT, RawRecordsFromFax1T,  # noqa: F401
-                              RawRecordsFromFaxOpticalNT, RawRecordsFromFaxnVeto, instruction_from_csv)
+                              RawRecordsFromFaxOpticalNT, RawRecordsFromFaxnVeto, RawRecordsFromMcChain,
+                              synchronise_timing, instruction_from_csv)
 
 __version__ = '0.1.0'

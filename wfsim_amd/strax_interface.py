@@ -392,3 +392,157 @@ class RawRecordsFromFaxnVeto(RawRecordsFromFaxOpticalNT):
         self._sort_check(rr)
         return {'raw_records_nv': self.chunk(start=self.sim.chunk_time_pre, end=self.sim.chunk_time, data=rr, data_type='raw_records_nv'),
                 'truth_nv': self.chunk(start=self.sim.chunk_time_pre, end=self.sim.chunk_time, data=result['truth'], data_type='truth_nv')}
+
+
+def synchronise_timing(config, instructions_tpc=None, instructions_nveto=None, rng=None):
+    """RawRecordsFromMcChain.set_timing, strax_interface.py:824-863: one random time per Geant4 event (``g4id``) at the
+    configured ``event_rate``, added to the TPC instructions (which keep their physical delays) and to the nVeto
+    instructions, so that both detectors see the same event at the same time; instructions that end up later than the
+    last event slot are dropped.  Returns (tpc, nveto, timings).  ``rng``: numpy Generator (default: seeded by the config)."""
+    c = config
+    g4 = [np.asarray(i['g4id']) for i in (instructions_tpc, instructions_nveto) if i is not None and len(i)]
+    g4id = np.unique(np.concatenate(g4)) if g4 else np.zeros(0, np.int64)
+    if c.get('entry_stop') is None:
+        c['entry_start'] = int(np.min(g4id))
+        c['entry_stop'] = int(np.max(g4id)) + 1
+    rate = c['event_rate'] / 1e9                      # Hz -> 1 / ns
+    rng = rng or np.random.default_rng(int(c.get('seed', 0) or 0))
+    n = c['entry_stop'] - c['entry_start']
+    timings = np.sort(rng.uniform((c['entry_start'] + 0.5) / rate, (c['entry_stop'] + 0.5) / rate, n)).astype(np.int64)
+    max_time = int((c['entry_stop'] + 0.5) / rate)
+    out = []
+    for ins in (instructions_tpc, instructions_nveto):
+        if ins is None:
+            out.append(None)
+            continue
+        ins = ins.copy()
+        ins['time'] += timings[np.searchsorted(np.arange(c['entry_start'], c['entry_stop']), ins['g4id'])]
+        out.append(ins[~(ins['time'] > max_time)])
+    return out[0], out[1], timings
+
+
+class RawRecordsFromMcChain(SimulatorPlugin):
+    """strax_interface.py:753-1005: TPC and neutron veto of the same Geant4 events in one plugin.  The readers in front
+    of it (epix for the TPC, read_optical for the nVeto: uproot) are out of scope; the instructions are supplied:
+    ``instructions_epix`` (instruction_dtype with g4id), ``instructions_nveto`` + ``nveto_channels`` + ``nveto_timings``
+    (optical), ``fax_config_nveto`` a dict of nVeto config values, ``to_pe_nveto`` or ``gains`` inside it."""
+    provides = ('raw_records', 'raw_records_he', 'raw_records_aqmon', 'raw_records_nv', 'truth', 'truth_nv')
+
+    def set_config(self):
+        self.config.setdefault('targets', ('tpc',))
+        self.config.setdefault('entry_start', 0)
+        self.config.setdefault('entry_stop', None)
+        super().set_config()
+        if 'nveto' in self.config['targets']:
+            from copy import deepcopy
+            skip = ('instructions_epix', 'instructions_nveto', 'nveto_channels', 'nveto_timings')
+            cn = {k: (v if k in skip else deepcopy(v)) for k, v in self.config.items()}
+            cn.update(self.config.get('fax_config_nveto') or {})
+            cn['detector'] = 'XENONnT_neutron_veto'
+            cn['channel_map'] = dict(cn['channel_map'])
+            if self.config.get('fax_config_override_nveto') is not None:
+                cn.update(self.config['fax_config_override_nveto'])
+            if 'to_pe_nveto' in cn:
+                to_pe = np.asarray(cn['to_pe_nveto'], dtype=np.float64)
+                cn['gains'] = np.divide((2e-9 * 2 / 2 ** 14) / (1.6e-19 * 1 * 50), to_pe, out=np.zeros_like(to_pe), where=to_pe != 0)
+            cn['channels_bottom'] = np.array([], np.int64)
+            self.config_nveto = cn
+
+    def get_instructions(self):
+        c = self.config
+        self.instructions_epix = self.instructions_nveto = None
+        if 'tpc' in c['targets']:
+            if c.get('instructions_epix') is None:
+                raise NotImplementedError('epix is not available (SURVEY.md 2.1 row 7): pass instructions_epix')
+            self.instructions_epix = np.asarray(c['instructions_epix'])
+        if 'nveto' in c['targets']:
+            if c.get('instructions_nveto') is None:
+                raise NotImplementedError('read_optical needs uproot (SURVEY.md 2.1 row 7): pass instructions_nveto, nveto_channels, nveto_timings')
+            ins = np.asarray(c['instructions_nveto'])
+            self.nveto_channels, self.nveto_timings = np.asarray(c['nveto_channels']), np.asarray(c['nveto_timings'])
+            if self.instructions_epix is not None:
+                ins = ins[(ins['_last'] - ins['_first']) >= 0]
+            self.instructions_nveto = ins
+        self.instructions_epix, self.instructions_nveto, self.event_times = synchronise_timing(c, self.instructions_epix, self.instructions_nveto)
+
+    def check_instructions(self):
+        c = self.config
+        if 'tpc' in c['targets']:
+            ins = self.instructions_epix
+            ins = ins[~((ins['z'] < - c['tpc_length']) & (ins['type'] == 2))]       # S1s below the cathode pass, S2s do not
+            self.instructions_epix = ins
+            r = np.sqrt(ins['x'] ** 2 + ins['y'] ** 2)
+            assert np.all((r < c['tpc_radius']) | np.isclose(r, c['tpc_radius'])), 'Interaction is outside the TPC (radius)'
+            assert np.all(ins['z'] < 0.25), 'Interaction is outside the TPC (in Z)'
+            assert np.all(ins['amp'] > 0), 'Interaction has zero size'
+            assert all(ins['g4id'] >= c['entry_start']) and all(ins['g4id'] < c['entry_stop'])
+        if 'nveto' in c['targets']:
+            ins = self.instructions_nveto
+            assert all(ins['g4id'] >= c['entry_start']) and all(ins['g4id'] < c['entry_stop'])
+            assert '_first' in ins.dtype.names, 'Require indexing info in optical instruction see optical extra dtype'
+            assert np.all(ins['type'] == 1), 'Only s1 type is supported for generating rawdata from optical input'
+
+    def _setup(self):
+        c = self.config
+        time_zero = int((c['entry_start'] + 0.5) / c['event_rate'] * 1e9)
+        if 'tpc' in c['targets']:
+            self.sim = ChunkRawRecords(c, device=self.device)
+            self.sim_iter = self.sim(self.instructions_epix, time_zero=time_zero)
+        if 'nveto' in c['targets']:
+            self.sim_nv = ChunkRawRecords(self.config_nveto, rawdata_generator=RawDataOptical, channels=self.nveto_channels,
+                                          timings=self.nveto_timings, device=self.device)
+            self.sim_nv.truth_buffer = np.zeros(10000, dtype=instruction_dtype + optical_extra_dtype + self._truth_dtype + [('fill', bool)])
+            self.sim_nv_iter = self.sim_nv(self.instructions_nveto, time_zero=time_zero)
+
+    def infer_dtype(self):
+        return {t: (instruction_dtype + self._truth_dtype) if 'truth' in t else raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH)
+                for t in self.provides}
+
+    def compute(self):
+        """strax_interface.py:916-996: one chunk of each detector; a depleted detector follows the other's chunk times"""
+        targets = self.config['targets']
+        dt = self.infer_dtype()
+        result, result_nv = None, None
+        if 'tpc' in targets:
+            try:
+                result = next(self.sim_iter)
+            except StopIteration:
+                if not self.sim.source_finished():
+                    raise RuntimeError("Bug in getting source finished")
+                result = {t: np.zeros(0, dt[t]) for t in self.provides if 'nv' not in t}
+                if 'nveto' in targets:
+                    self.sim.chunk_time, self.sim.chunk_time_pre = self.sim_nv.chunk_time, self.sim_nv.chunk_time_pre
+        if 'nveto' in targets:
+            try:
+                result_nv = next(self.sim_nv_iter)
+                result_nv = dict(result_nv, raw_records=result_nv['raw_records'].copy())
+                result_nv['raw_records']['channel'] += self.config['channel_map']['nveto'][0]
+            except StopIteration:
+                if not self.sim_nv.source_finished():
+                    raise RuntimeError("Bug in getting source finished")
+                result_nv = {t[:-3]: np.zeros(0, dt[t]) for t in self.provides if 'nv' in t}
+                if 'tpc' in targets:
+                    self.sim_nv.chunk_time, self.sim_nv.chunk_time_pre = self.sim.chunk_time, self.sim.chunk_time_pre
+        exist_tpc = result is not None and any(len(result[t]) > 0 for t in self.provides if 'nv' not in t)
+        exist_nv = result_nv is not None and any(len(result_nv[t[:-3]]) > 0 for t in self.provides if 'nv' in t)
+        chunk = {}
+        for t in self.provides:
+            mine, other = (exist_nv, exist_tpc) if 'nv' in t else (exist_tpc, exist_nv)
+            sim_mine, sim_other = (getattr(self, 'sim_nv', None), getattr(self, 'sim', None)) if 'nv' in t else (getattr(self, 'sim', None), getattr(self, 'sim_nv', None))
+            if mine:
+                data = result_nv[t[:-3]] if 'nv' in t else result[t]
+                chunk[t] = self.chunk(start=sim_mine.chunk_time_pre, end=sim_mine.chunk_time, data=data, data_type=t)
+            elif other:
+                chunk[t] = self.chunk(start=sim_other.chunk_time_pre, end=sim_other.chunk_time, data=np.zeros(0, dt[t]), data_type=t)
+            else:
+                chunk[t] = self.chunk(start=0, end=0, data=np.zeros(0, dt[t]), data_type=t)
+        self._sort_check([chunk[t].data for t in self.provides])
+        return chunk
+
+    def source_finished(self):
+        done = True
+        if 'tpc' in self.config['targets']:
+            done &= self.sim.source_finished()
+        if 'nveto' in self.config['targets']:
+            done &= self.sim_nv.source_finished()
+        return done
