@@ -1096,7 +1096,12 @@ int wfs_run(wfs_handle *h)
     TRY(ensure(h, h->records, (size_t)h->n_records * 244));
     za.rec_off = h->rec_off.as<i64>(); za.records = h->records.as<uint8_t>(); za.rec_capacity = h->n_records;
     if (h->n_active_rows > 0 && h->n_records > 0) { Timer t(h, "k_pack"); hipLaunchKernelGGL(k_pack, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
-    HIPCHK(hipStreamSynchronize(h->stream));
+    {   // totals of wfs_get_counts: afterpulse sets carry no truth (rawdata.py:322-323)
+        const i64 n_prim = (!h->injected && h->ap_active) ? h->n_psets : h->n_sets;
+        const i64 work = std::max<i64>(RS, n_prim);
+        hipLaunchKernelGGL(k_counts, dim3((unsigned)std::min<i64>(nblocks(work, 256), 2048)), dim3(256), 0, h->stream, h->itv_n.as<i32>(), RS, h->truth.as<double>(), n_prim, h->scal.as<i64>());
+    }
+    TRY(read_scal(h));
     HIPCHK(hipGetLastError());
     h->ran = true;
     return WFS_OK;
@@ -1110,16 +1115,7 @@ int wfs_get_counts(wfs_handle *h, wfs_counts *out)
     c.n_instructions = h->n_ins; c.n_pulse_sets = h->n_sets; c.n_emitters = h->n_emitters; c.n_photons = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0);
     c.n_tiles = h->n_active_tiles; c.n_groups = h->n_groups; c.n_rows = h->n_active_rows; c.n_raw_samples = h->s_raw;
     c.n_records = h->n_records;
-    // n_pe and n_intervals need device reductions: sum the per-set truth (cheap)
-    std::vector<double> tr((size_t)h->n_sets * 16);
-    HIPCHK(hipMemcpy(tr.data(), h->truth.p, tr.size() * 8, hipMemcpyDeviceToHost));
-    const i64 n_prim = (!h->injected && h->ap_active) ? h->n_psets : h->n_sets;       // afterpulse sets carry no truth (rawdata.py:322-323)
-    double npe = 0; for (i64 s = 0; s < n_prim; s++) npe += tr[s * 16 + 1];
-    c.n_pe = (i64)(npe + 0.5);
-    std::vector<i32> n((size_t)(h->n_clusters + 1) * h->dev.row_slots);
-    HIPCHK(hipMemcpy(n.data(), h->itv_n.p, n.size() * 4, hipMemcpyDeviceToHost));
-    i64 ni = 0; for (i32 v : n) ni += v;
-    c.n_intervals = ni;
+    c.n_intervals = h->h_scal[20]; c.n_pe = h->h_scal[21];          // reduced on the device at the end of wfs_run (k_counts)
     *out = c; h->counts = c;
     return WFS_OK;
 }

@@ -18,6 +18,17 @@
 __global__ void k_fill_i64(i64 *p, i64 n, i64 v) { i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_fill_i32(i32 *p, i64 n, i32 v) { i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
+// totals for wfs_get_counts, reduced on the device (copying itv_n back cost 300 MB per 10^5-cluster batch):
+// scal[20] = sum of itv_n (ZLE intervals), scal[21] = sum of the per-set n_pe (truth[s][1], integral doubles)
+__global__ void k_counts(const i32 *itv_n, i64 n_itv, const double *truth, i64 n_sets, i64 *scal)
+{
+    i64 a = 0, b = 0;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_itv; i += (i64)gridDim.x * blockDim.x) a += itv_n[i];
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n_sets; i += (i64)gridDim.x * blockDim.x) b += (i64)(truth[i * 16 + 1] + 0.5);
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); b += __shfl_down(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { if (a) atomicAdd((unsigned long long *)&scal[20], (unsigned long long)a); if (b) atomicAdd((unsigned long long *)&scal[21], (unsigned long long)b); }
+}
+
 // ------------------------------------------------------------------------------------------------ scan
 // exclusive scan i32[n] -> i64[n+1] in three launches (reduce / spine / down-sweep); 4096 items per block
 #define SCAN_TPB 256
