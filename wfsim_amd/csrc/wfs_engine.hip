@@ -50,7 +50,7 @@ struct wfs_handle {
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
     DevBuf truth, tminmax, tile_truth, tile_desc, gather_idx, gather_out, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
-    DevBuf scan_tmp, scal, noise_override; i64 n_noise_override = 0;
+    DevBuf row_desc, scan_tmp, scal, noise_override; i64 n_noise_override = 0;
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
@@ -340,7 +340,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -1089,6 +1089,8 @@ int wfs_run(wfs_handle *h)
         HIPCHK(hipStreamSynchronize(h->stream));
         za.row_dbg = h->row_dbg.as<i32>(); za.row_dbg_off = h->row_dbg_off.as<i64>();
     }
+    TRY(ensure(h, h->row_desc, (size_t)h->n_active_rows * sizeof(RowDesc))); za.desc = h->row_desc.as<RowDesc>();
+    if (h->n_active_rows > 0) { Timer t(h, "k_row_desc"); hipLaunchKernelGGL(k_row_desc, dim3(nblocks(h->n_active_rows, 256)), dim3(256), 0, h->stream, d, za); }
     if (h->n_active_rows > 0) { Timer t(h, "k_zle"); hipLaunchKernelGGL(k_zle, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
     TRY(scan(h, h->row_nrec.as<i32>(), RS, h->rec_off, 10));
     TRY(read_scal(h));

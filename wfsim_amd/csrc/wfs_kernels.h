@@ -944,7 +944,35 @@ struct ZleArgs {
     uint8_t *records; i64 rec_capacity;
     i32 *row_dbg; const i64 *row_dbg_off;   // debug: finished rows
     i32 spr;                     // samples per record
+    struct RowDesc *desc;        // [n_active_rows] everything a row's wave needs, prepared by k_row_desc
 };
+
+// One 64-byte descriptor per active row (thread per row: the divisions and the five dependent look-ups of a row are
+// done 64 rows at a time instead of once per wave; with 10^7 short S1 rows the per-row prologue was most of k_zle / k_pack)
+struct __attribute__((aligned(64))) RowDesc {
+    i64 acc_off;                 // first accumulated sample of the row in raw[]
+    i64 row_abs;                 // absolute sample index of the row's first sample
+    i64 ixr;                     // noise offset of the row's window
+    i64 itv_base;                // first interval slot of the row
+    i64 thr;                     // ZLE threshold of the channel
+    i64 idx;                     // row slot (group * row_slots + slot): index of itv_n / row_nrec / rec_off
+    i32 len, channel, he, pad;
+};
+
+__global__ void k_row_desc(WfsDev d, ZleArgs a)
+{
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_active_rows) return;
+    const i64 idx = a.active_rows[r];
+    const i64 g = idx / d.row_slots; const i32 slot = (i32)(idx - g * d.row_slots);
+    const bool he = slot >= d.n_tpc; const i32 acc_ch = he ? slot - d.n_tpc : slot, channel = he ? d.he_first + acc_ch : slot;
+    const i64 ridx = g * d.n_tpc + acc_ch;
+    RowDesc q;
+    q.acc_off = a.acc_off[ridx]; q.row_abs = a.row_lo[ridx] - d.tw; q.ixr = a.grp_ixrand[g]; q.itv_base = a.itv_off[idx];
+    q.thr = d.thr_zle[channel]; q.idx = idx; q.len = (i32)(a.row_hi[ridx] - a.row_lo[ridx] + 1 + 2 * (i64)d.tw);
+    q.channel = channel; q.he = he ? 1 : 0; q.pad = 0;
+    a.desc[r] = q;
+}
 
 // finished sample of a row: accumulated ADC + noise + baseline, clamped at 0
 // (rawdata.py:398-458 add_noise / add_baseline / digitizer_saturation, fused into the read)
@@ -974,17 +1002,15 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     const int lane = threadIdx.x & 63;
     i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.n_active_rows) return;
-    const i64 idx = a.active_rows[r];
-    i64 g; i32 channel, acc_ch; bool he;
-    row_of_slot(d, idx, g, channel, acc_ch, he);
-    const i64 ridx = g * d.n_tpc + acc_ch;
-    const i64 len = a.row_hi[ridx] - a.row_lo[ridx] + 1 + 2 * (i64)d.tw;
-    const i32 *acc = a.raw + a.acc_off[ridx];
-    const i64 thr = d.thr_zle[channel];
-    const i64 ixr = a.grp_ixrand[g];
+    const RowDesc q = a.desc[r];
+    const i64 idx = q.idx; const i32 channel = q.channel; const bool he = q.he != 0;
+    const i64 len = q.len;
+    const i32 *acc = a.raw + q.acc_off;
+    const i64 thr = q.thr;
+    const i64 ixr = q.ixr;
     i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
-    const i64 base = a.itv_off[idx];
-    const i64 row_abs = a.row_lo[ridx] - d.tw;
+    const i64 base = q.itv_base;
+    const i64 row_abs = q.row_abs;
     // close interval k = [rawl, rawr] (first / last hit): window, clip, even landing (rawdata.py:302-308),
     // absolute sample indices (rawdata.py:311); returns the number of records it needs
     auto close_interval = [&](i32 k, i64 rawl, i64 rawr) -> i32 {
@@ -992,8 +1018,8 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
         l = l < 0 ? 0 : (l > len - 1 ? len - 1 : l); rr = rr < 0 ? 0 : (rr > len - 1 ? len - 1 : rr);
         l = (l + 1) / 2 * 2; rr = rr / 2 * 2;                  // ceil(l/2)*2, floor(r/2)*2 for non-negative ints
         a.itv_left[base + k] = row_abs + l; a.itv_right[base + k] = row_abs + rr;
-        i64 plen = rr - l + 1;
-        return plen > 0 ? (i32)((plen + a.spr - 1) / a.spr) : 0;
+        const i32 plen = (i32)(rr - l + 1);                     // a row is shorter than 10^6 samples (k_group_final)
+        return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
     };
     i64 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;
     for (i64 c0 = 0; c0 < len; c0 += 64) {
@@ -1028,23 +1054,22 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const int lane = threadIdx.x & 63;
     i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= a.n_active_rows) return;
-    const i64 idx = a.active_rows[r];
+    const RowDesc q = a.desc[r];
+    const i64 idx = q.idx;
     const i32 count = a.itv_n[idx];
     if (count == 0) return;
-    i64 g; i32 channel, acc_ch; bool he;
-    row_of_slot(d, idx, g, channel, acc_ch, he);
-    const i64 ridx = g * d.n_tpc + acc_ch;
-    const i32 *acc = a.raw + a.acc_off[ridx];
-    const i64 row_abs = a.row_lo[ridx] - d.tw;
-    const i64 ixr = a.grp_ixrand[g];
-    const i64 base = a.itv_off[idx];
+    const i32 channel = q.channel; const bool he = q.he != 0;
+    const i32 *acc = a.raw + q.acc_off;
+    const i64 row_abs = q.row_abs;
+    const i64 ixr = q.ixr;
+    const i64 base = q.itv_base;
     const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
     i64 rec = a.rec_off[idx];
     for (i32 k = 0; k < count; k++) {
-        const i64 left = a.itv_left[base + k], plen = a.itv_right[base + k] - left + 1;
+        const i64 left = a.itv_left[base + k]; const i32 plen = (i32)(a.itv_right[base + k] - left + 1);
         if (plen <= 0) continue;
-        const i64 need = (plen + spr - 1) / spr;
-        for (i64 f = 0; f < need; f++, rec++) {
+        const i32 need = (plen + spr - 1) / spr;
+        for (i32 f = 0; f < need; f++, rec++) {
             if (rec >= a.rec_capacity) return;
             u32 *out = (u32 *)(a.records + rec * (24 + 2 * (i64)spr));
             const i64 time = (i64)d.dt * (left + spr * f);
