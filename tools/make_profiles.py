@@ -24,7 +24,8 @@ def timer_name(kernel):
 
 def per_launch(pattern, counter):
     agg, launches, seen = collections.defaultdict(float), collections.Counter(), set()
-    for f in glob.glob(os.path.join(src, pattern, '**', '*counter_collection.csv'), recursive=True):
+    files = glob.glob(os.path.join(src, pattern, '**', '*counter_collection.csv'), recursive=True)
+    for f in sorted(files, key=os.path.getmtime)[-1:]:          # gpurun merges into gpurun_out/: older runs may still lie there
         for row in csv.DictReader(open(f)):
             if row['Counter_Name'] != counter:
                 continue
@@ -39,7 +40,7 @@ line = [l for l in open(os.path.join(src, 'bench.json')) if l.startswith('{')][-
 json.dump(json.loads(line), open(os.path.join(dst, f'{tag}_bench.json'), 'w'), indent=1)
 stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, f'{tag}_kernel_stats.csv'))
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f'{tag}_kernel_stats.csv'))
 fetch, write = per_launch('fetch', 'FETCH_SIZE'), per_launch('write', 'WRITE_SIZE')
 out = dict(note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 0, per launch '
                 'averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half the bytes of coalesced '
