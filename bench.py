@@ -54,21 +54,40 @@ def algorithmic_bytes(counts):
     return 21 * counts['n_photons'] + 4 * counts['n_raw_samples'] + 244 * counts['n_records'] + 70 * counts['n_instructions']
 
 
-def cpu_baseline(cfg, n_sample):
-    """The C oracle (CPU restatement, one thread) on a bounded sample of the same workload."""
+def _cpu_worker(job):
+    """one process of the CPU baseline: `n` instructions of the bench batch through the C oracle"""
+    first, n, seed = job
     from tests.helpers import make_oracle
+    cfg = bench_config(seed)
     res = Resource(cfg)
-    ins = s2_batch(n_sample, 0)
+    ins = s2_batch(n, first)
     order, key, cluster = schedule(ins, cfg)
     ip = instruction_params(ins[order], cfg, res)
     orc = make_oracle(cfg)
     t0 = time.perf_counter()
-    orc.simulate(ins[order], order.astype(np.uint32), ip)
+    orc.simulate(ins[order], (first + order).astype(np.uint32), ip)
     rec = orc.pack_records()
-    dt = time.perf_counter() - t0
-    return dict(value=orc.n_pe / dt, unit='photoelectrons/s', cores=1, kind='port',
-                sample=f'{n_sample} S2 instructions of the bench batch (10^4 e-, ~10^6 PE each), {dt:.1f} s, '
-                       f'{len(rec) // 244} records, C oracle single thread'), dt
+    return orc.n_pe, len(rec) // 244, time.perf_counter() - t0
+
+
+def cpu_baseline(seed, n_sample, all_cores=True):
+    """The C oracle (CPU restatement) on a bounded sample of the same workload: one thread (the `value`), and one
+    process per host core of this GPU's share (`all_cores`).  Runs before anything touches the GPU (worker processes)."""
+    n_pe, n_rec, dt = _cpu_worker((0, n_sample, seed))
+    out = dict(value=n_pe / dt, unit='photoelectrons/s', cores=1, kind='port',
+               sample=f'{n_sample} S2 instructions of the bench batch (10^4 e-, ~10^6 PE each), {dt:.1f} s, '
+                      f'{n_rec} records, C oracle single thread')
+    if all_cores:
+        import multiprocessing as mp
+        cores = max(1, min(16, len(os.sched_getaffinity(0))))
+        per = max(2, n_sample // 4)
+        t0 = time.perf_counter()
+        with mp.get_context('fork').Pool(cores) as pool:
+            parts = pool.map(_cpu_worker, [(1000 + k * per, per, seed) for k in range(cores)])
+        wall = time.perf_counter() - t0
+        out['all_cores'] = dict(value=sum(p[0] for p in parts) / wall, unit='photoelectrons/s', cores=cores,
+                                sample=f'{cores} processes x {per} instructions, {wall:.1f} s wall incl. process start')
+    return out
 
 
 def main():
@@ -88,6 +107,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    cpu = None
+    if args.cpu_sample > 0 and world == 1:          # the CPU baseline is timed on rank 0 of the 1-GPU run only, before the GPU is touched
+        cpu = cpu_baseline(3, args.cpu_sample)
     import torch
     import torch.distributed as dist
     # WFS_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with ONE card (all ranks on device 0, the
@@ -181,6 +203,17 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
+    # measured ceiling next to the spec peak: a plain device-to-device copy of 1 GiB (bytes read + written per second)
+    src_buf = torch.empty(1 << 30, dtype=torch.uint8, device='cuda'); dst_buf = torch.empty_like(src_buf)
+    for _ in range(2):
+        dst_buf.copy_(src_buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        dst_buf.copy_(src_buf)
+    e1.record(); torch.cuda.synchronize()
+    copy_gbs = 2 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src_buf, dst_buf
     ms_per_step = 1e3 * elapsed / args.steps
     dom = max(ktimes, key=lambda k: ktimes[k][0])
     dom_ms, dom_launches = ktimes[dom]
@@ -205,10 +238,11 @@ def main():
         roofline=dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                       traffic=traffic, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,
                       pipeline_frac=b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      measured_copy_GBs=copy_gbs, frac_of_measured_copy=achieved / copy_gbs,
                       kernels_ms={k: round(v[0], 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}),
     )
-    if args.cpu_sample > 0 and world == 1:          # the CPU baseline is timed on rank 0 of the 1-GPU run only
-        out['cpu_baseline'], _ = cpu_baseline(cfg, args.cpu_sample)
+    if cpu is not None:
+        out['cpu_baseline'] = cpu
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
