@@ -154,6 +154,11 @@ int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_
 int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float *y, const float *z);
 int wfs_copy_cdf_rows(wfs_handle *h, int32_t *cdf_row, double *cdf_table, int64_t cap_rows);
 
+/* Order of the packed records of a batch: 0 (default) as the reference yields pulses (window, channel, interval,
+ * rawdata.py:282-311); 1 as strax.sort_by_time leaves them in ChunkRawRecords.final_results (strax_interface.py:453):
+ * by (time, channel) -- the windows of a batch do not overlap in time, so they stay contiguous.  Sorted on the device. */
+int wfs_set_record_order(wfs_handle *h, int32_t by_time);
+
 /* Parity entry: photons supplied instead of generated -- what RawDataOptical.sim_primary hands to Pulse
  * (rawdata.py:475-493) and what the golden vectors inject.  One "pulse set" = one Pulse.__call__ (pulse.py:39).
  *   set_cluster i32[n_sets], set_tmin i64[n_sets]   cluster id and scheduler key of the set's instruction
@@ -203,6 +208,8 @@ int wfs_copy_truth_per_pmt(wfs_handle *h, double *acc6, int64_t cap);
 /* raw_records, 244-byte packed strax layout, in the order the reference yields them (group, channel, interval,
  * fragment); dst may be a host or a device pointer (wfs_copy_records_dev). */
 int wfs_copy_records(wfs_handle *h, void *dst_host, int64_t capacity_records);
+/* the records [first, first + count) of the batch into a caller buffer (e.g. straight into the chunker's record buffer) */
+int wfs_copy_records_range(wfs_handle *h, void *dst, int64_t first, int64_t count);
 int wfs_copy_records_dev(wfs_handle *h, void *dst_dev, int64_t capacity_records);
 const void *wfs_records_dev_ptr(wfs_handle *h);
 /* digitise windows: rawdata.left / rawdata.right and the first record of each window (strax_interface.py:394-399) */

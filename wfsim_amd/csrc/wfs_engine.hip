@@ -1,5 +1,6 @@
 // wfs_engine.hip -- host side of libwfsim_amd.so: the C ABI of include/wfsim_amd.h, device memory arenas,
 // stage orchestration on one HIP stream.  gfx950 (MI355X) only.
+#include <hipcub/hipcub.hpp>
 #include "wfs_kernels.h"
 #include "../../include/wfsim_amd.h"
 
@@ -50,7 +51,8 @@ struct wfs_handle {
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
     DevBuf truth, tminmax, tile_truth, tile_desc, gather_idx, gather_out, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
-    DevBuf row_desc, scan_tmp, scal, noise_override; i64 n_noise_override = 0;
+    DevBuf row_desc, rec_key, rec_key2, rec_val, rec_val2, rec_dest, sort_tmp, scan_tmp, scal, noise_override;
+    bool sort_records = false; i64 n_noise_override = 0;
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
@@ -340,7 +342,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -1090,6 +1092,7 @@ int wfs_run(wfs_handle *h)
         za.row_dbg = h->row_dbg.as<i32>(); za.row_dbg_off = h->row_dbg_off.as<i64>();
     }
     TRY(ensure(h, h->row_desc, (size_t)h->n_active_rows * sizeof(RowDesc))); za.desc = h->row_desc.as<RowDesc>();
+    if (h->sort_records) { za.key_base = h->scal.as<i64>() + 22; hipLaunchKernelGGL(k_fill_i64, dim3(1), dim3(64), 0, h->stream, za.key_base, (i64)1, I64_MAX); }
     if (h->n_active_rows > 0) { Timer t(h, "k_row_desc"); hipLaunchKernelGGL(k_row_desc, dim3(nblocks(h->n_active_rows, 256)), dim3(256), 0, h->stream, d, za); }
     if (h->n_active_rows > 0) { Timer t(h, "k_zle"); hipLaunchKernelGGL(k_zle, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
     TRY(scan(h, h->row_nrec.as<i32>(), RS, h->rec_off, 10));
@@ -1097,6 +1100,21 @@ int wfs_run(wfs_handle *h)
     h->n_records = h->h_scal[10];
     TRY(ensure(h, h->records, (size_t)h->n_records * 244));
     za.rec_off = h->rec_off.as<i64>(); za.records = h->records.as<uint8_t>(); za.rec_capacity = h->n_records;
+    if (h->sort_records && h->n_records > 1 && h->n_active_rows > 0) {
+        // records by (time, channel): keys per record, one radix sort of the batch, k_pack writes to the sorted slots
+        const i64 NR = h->n_records;
+        if (NR > 0xffffffffLL) return h->fail(WFS_E_CAPACITY, "more than 2^32 records in one batch");
+        TRY(ensure(h, h->rec_key, (size_t)NR * 8)); TRY(ensure(h, h->rec_key2, (size_t)NR * 8));
+        TRY(ensure(h, h->rec_val, (size_t)NR * 4)); TRY(ensure(h, h->rec_val2, (size_t)NR * 4)); TRY(ensure(h, h->rec_dest, (size_t)NR * 4));
+        za.rec_key = h->rec_key.as<u64>(); za.rec_val = h->rec_val.as<u32>();
+        { Timer t(h, "k_rec_keys"); hipLaunchKernelGGL(k_rec_keys, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
+        size_t bytes = 0;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->rec_key.as<u64>(), h->rec_key2.as<u64>(), h->rec_val.as<u32>(), h->rec_val2.as<u32>(), (int)NR, 0, 64, h->stream));
+        TRY(ensure(h, h->sort_tmp, bytes));
+        { Timer t(h, "record_sort"); HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp.p, bytes, h->rec_key.as<u64>(), h->rec_key2.as<u64>(), h->rec_val.as<u32>(), h->rec_val2.as<u32>(), (int)NR, 0, 64, h->stream)); }
+        { Timer t(h, "k_invert_perm"); hipLaunchKernelGGL(k_invert_perm, dim3(nblocks(NR, 256)), dim3(256), 0, h->stream, h->rec_val2.as<u32>(), h->rec_dest.as<u32>(), NR); }
+        za.rec_dest = h->rec_dest.as<u32>();
+    }
     if (h->n_active_rows > 0 && h->n_records > 0) { Timer t(h, "k_pack"); hipLaunchKernelGGL(k_pack, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
     {   // totals of wfs_get_counts: afterpulse sets carry no truth (rawdata.py:322-323)
         const i64 n_prim = (!h->injected && h->ap_active) ? h->n_psets : h->n_sets;
@@ -1132,11 +1150,28 @@ int wfs_copy_records(wfs_handle *h, void *dst, int64_t cap)
     return WFS_OK;
 }
 
+int wfs_copy_records_range(wfs_handle *h, void *dst, int64_t first, int64_t count)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (first < 0 || count < 0 || first + count > h->n_records) return h->fail(WFS_E_INVALID, "record range outside the batch");
+    if (count) HIPCHK(hipMemcpy(dst, (const uint8_t *)h->records.p + (size_t)first * 244, (size_t)count * 244, hipMemcpyDeviceToHost));
+    return WFS_OK;
+}
+
 int wfs_copy_records_dev(wfs_handle *h, void *dst, int64_t cap)
 {
     if (!h || !h->ran) return WFS_E_STATE;
     if (cap < h->n_records) return h->fail(WFS_E_CAPACITY, "record buffer too small");
     if (h->n_records) { HIPCHK(hipMemcpyAsync(dst, h->records.p, (size_t)h->n_records * 244, hipMemcpyDeviceToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    return WFS_OK;
+}
+
+// records of a batch in the order strax.sort_by_time gives them ((time, channel); strax_interface.py:453) instead of the
+// order the reference yields pulses (window, channel, interval)
+int wfs_set_record_order(wfs_handle *h, int32_t by_time)
+{
+    if (!h) return WFS_E_INVALID;
+    h->sort_records = by_time != 0;
     return WFS_OK;
 }
 

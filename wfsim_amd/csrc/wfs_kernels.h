@@ -945,6 +945,8 @@ struct ZleArgs {
     i32 *row_dbg; const i64 *row_dbg_off;   // debug: finished rows
     i32 spr;                     // samples per record
     struct RowDesc *desc;        // [n_active_rows] everything a row's wave needs, prepared by k_row_desc
+    const u32 *rec_dest;         // record order by (time, channel): slot of record r in the output (nullptr: row order)
+    u64 *rec_key; u32 *rec_val; i64 *key_base;     // k_rec_keys: sort key (sample - *key_base) << 12 | channel, and the record index; *key_base = first sample of the batch (k_row_desc)
 };
 
 // One 64-byte descriptor per active row (thread per row: the divisions and the five dependent look-ups of a row are
@@ -972,6 +974,7 @@ __global__ void k_row_desc(WfsDev d, ZleArgs a)
     q.thr = d.thr_zle[channel]; q.idx = idx; q.len = (i32)(a.row_hi[ridx] - a.row_lo[ridx] + 1 + 2 * (i64)d.tw);
     q.channel = channel; q.he = he ? 1 : 0; q.pad = 0;
     a.desc[r] = q;
+    if (a.key_base) atomicMin(a.key_base, q.row_abs);
 }
 
 // finished sample of a row: accumulated ADC + noise + baseline, clamped at 0
@@ -1048,6 +1051,32 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     if (lane == 0) { a.itv_n[idx] = count; a.row_nrec[idx] = nrec; }
 }
 
+// Records ordered by (time, channel) as strax.sort_by_time leaves them (strax_interface.py:453): one key per record; the
+// windows of a batch do not overlap in time, so one sort of the whole batch keeps every window contiguous.
+__global__ __launch_bounds__(256) void k_rec_keys(WfsDev d, ZleArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= a.n_active_rows) return;
+    const RowDesc q = a.desc[r];
+    const i32 count = a.itv_n[q.idx];
+    if (count == 0) return;
+    i64 rec = a.rec_off[q.idx];
+    const i64 key_base = *a.key_base;
+    for (i32 k = 0; k < count; k++) {
+        const i64 left = a.itv_left[q.itv_base + k]; const i32 plen = (i32)(a.itv_right[q.itv_base + k] - left + 1);
+        if (plen <= 0) continue;
+        const i32 need = (plen + a.spr - 1) / a.spr;
+        for (i32 f = lane; f < need; f += 64) {
+            if (rec + f >= a.rec_capacity) break;
+            a.rec_key[rec + f] = ((u64)(left + (i64)a.spr * f - key_base) << 12) | (u64)(u32)q.channel;
+            a.rec_val[rec + f] = (u32)(rec + f);
+        }
+        rec += need;
+    }
+}
+__global__ void k_invert_perm(const u32 *val, u32 *dest, i64 n) { const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (p < n) dest[val[p]] = (u32)p; }
+
 // one wave per row: write its intervals as strax raw_records (strax_interface.py:425-435); a record is 61 dwords
 __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
 {
@@ -1071,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
         const i32 need = (plen + spr - 1) / spr;
         for (i32 f = 0; f < need; f++, rec++) {
             if (rec >= a.rec_capacity) return;
-            u32 *out = (u32 *)(a.records + rec * (24 + 2 * (i64)spr));
+            u32 *out = (u32 *)(a.records + (a.rec_dest ? (i64)a.rec_dest[rec] : rec) * (24 + 2 * (i64)spr));
             const i64 time = (i64)d.dt * (left + spr * f);
             const i32 length = (i32)((plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f);
             for (int q = lane; q < rec_dwords; q += 64) {

@@ -42,7 +42,7 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
            'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_instruction_photon_offsets', 'wfs_gather_photon_times', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
            'wfs_kernel_times', 'wfs_set_profiling', 'wfs_set_delay_models', 'wfs_set_s1_propagation', 'wfs_set_instruction_models',
-           'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows']
+           'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range']
 
 
 def load_library():
@@ -247,6 +247,17 @@ class Engine:
         out = np.zeros(n, dtype=raw_record_dtype())
         self._check(self.lib.wfs_copy_records(self._h, _p(out), C.c_int64(n)))
         return out
+
+    def records_into(self, out, count=None):
+        """device -> host copy of the first ``count`` packed records (default: all) straight into ``out`` (a contiguous
+        raw_record array, e.g. a slice of the chunker's record buffer)"""
+        n = self.counts['n_records'] if count is None else int(count)
+        assert out.flags['C_CONTIGUOUS'] and out.dtype.itemsize == np.dtype(raw_record_dtype()).itemsize and len(out) >= n
+        self._check(self.lib.wfs_copy_records_range(self._h, C.c_void_p(out.ctypes.data), C.c_int64(0), C.c_int64(n)))
+        return out[:n]
+
+    def set_record_order(self, by_time):
+        self._check(self.lib.wfs_set_record_order(self._h, C.c_int32(int(bool(by_time)))))
 
     def records_dev_ptr(self):
         return self.lib.wfs_records_dev_ptr(self._h)

@@ -69,6 +69,29 @@ class RawData:
         raw_records in the order the reference yields pulses (channel ascending, interval ascending)."""
         if truth_buffer is None:
             truth_buffer = []
+        self.engine.set_record_order(False)
+        for batch in self.iter_batches(instructions, want_truth=len(truth_buffer) > 0, **kwargs):
+            rows, before = batch['truth_rows'], batch['truth_before']
+            k = 0
+            n_win = len(batch['left'])
+            for w in range(n_win):
+                while k < len(rows) and before[k] <= w:         # the rows of this window's clusters (and of empty ones before it)
+                    self._write_truth(rows[k], truth_buffer)
+                    k += 1
+                self.left, self.right = int(batch['left'][w]), int(batch['right'][w])
+                if batch['finished'] and w == n_win - 1:
+                    self.source_finished = True
+                yield dict(left=self.left, right=self.right, records=batch['records'][batch['first'][w]:batch['first'][w + 1]])
+            while k < len(rows):
+                self._write_truth(rows[k], truth_buffer)
+                k += 1
+        self.source_finished = True
+
+    def iter_batches(self, instructions, want_truth=False, record_sink=None, **kwargs):
+        """The same stream batch by batch (what the chunker consumes): dict(left[], right[] of the batch's digitise windows
+        in time order, first[] record offsets (one more than windows), records, truth_rows + truth_before (row k belongs in
+        front of window truth_before[k]; == number of windows: after the last), finished).  ``record_sink(n)`` may hand out
+        the array the records are copied into (device -> host without a staging copy)."""
         self.source_finished = False
         if len(instructions) == 0:
             self.source_finished = True
@@ -93,6 +116,9 @@ class RawData:
         self.instruction_event_number = np.min(instructions['event_number'])
         # crude photon estimate per instruction: only used to bound a batch
         est_csum = np.cumsum(self._expected_quanta(s_ins))
+        # smallest key of every cluster (in feedback order the first instruction of a cluster need not carry it)
+        cl_start = np.concatenate([[0], np.where(np.diff(cluster) != 0)[0] + 1])
+        cl_min_key = np.minimum.reduceat(key, cl_start)
         a, scale = 0, 1
         has_pulse, runmax = False, 0         # RawData.last_pulse_end_time over everything emitted so far
         while a < n:
@@ -104,10 +130,9 @@ class RawData:
             self._batch_em_base = em_base[order[a:b]]
             self._batch_run_set = None if self._all_run_sets is None else self._all_run_sets[a:b] - self._all_run_sets[a]
             self._load_batch(ins, gid, cl, key[a:b])
-            self.engine.run()
+            counts = self.engine.run()
             groups = self.engine.groups()
-            records = self.engine.records()
-            first = np.append(groups['first_record'], len(records))
+            first = np.append(groups['first_record'], counts['n_records'])
             cl_group = self.engine.cluster_groups(int(cl[-1]) + 1)
             ins_group = cl_group[cl]
             n_groups = len(groups['left'])
@@ -118,29 +143,35 @@ class RawData:
                 # would the next cluster have been simulated before this batch's last window was digitised
                 # (rawdata.py:96-98)?  then that window is not complete: simulate it again with the next batch
                 run_all = max(int(ends.max()), runmax) if has_pulse else int(ends.max())
-                # (the key the rule looks at is the smallest of the next CLUSTER: in feedback order its first instruction
-                # need not carry it)
-                nxt = cluster == cluster[b]
-                if not (int(key[nxt].min()) - run_all > rext):
+                if not (int(cl_min_key[cluster[b] - cluster[0]]) - run_all > rext):
                     g_last = int(np.where(nonempty)[0][-1])
                     restart = a + int(np.argmax(ins_group >= g_last))
                     if restart == a:            # the whole batch is one open window: take a bigger batch
                         scale *= 2
                         continue
                     n_emit, b = g_last, restart
-            truth_rows = self._truth_rows(ins, cl) if len(truth_buffer) else None      # one per run set, in processing order
-            for g in range(n_emit):
-                if truth_rows is not None:
-                    for r in truth_rows:
-                        if ins_group[r['first']] == g:
-                            self._write_truth(r, truth_buffer)
-                if not nonempty[g]:
-                    continue
-                has_pulse, runmax = True, (max(runmax, int(ends[g])) if has_pulse else int(ends[g]))
-                self.left, self.right = int(groups['left'][g]), int(groups['right'][g])
-                if b >= n and g == n_groups - 1:
-                    self.source_finished = True
-                yield dict(left=self.left, right=self.right, records=records[first[g]:first[g + 1]])
+            n_rec = int(first[n_emit])
+            out = record_sink(n_rec) if record_sink is not None else None
+            if out is None:
+                out = np.empty(n_rec, dtype=raw_record_dtype())
+            records = self.engine.records_into(out, n_rec)
+            keep = np.where(nonempty[:n_emit])[0]
+            # window position of every emitted group: rows of a group go in front of its window, rows of a group without
+            # pulses in front of the next window that has some
+            pos_of_group = np.searchsorted(keep, np.arange(n_emit), side='left')
+            truth_rows, truth_before = [], np.zeros(0, dtype=np.int64)
+            if want_truth:
+                rows = self._truth_rows(ins, cl)           # one per run set, in processing order
+                grp = np.array([ins_group[r['first']] for r in rows], dtype=np.int64)
+                sel = grp < n_emit
+                truth_rows = [r for r, k in zip(rows, sel) if k]
+                truth_before = pos_of_group[grp[sel]]
+            if len(keep):
+                e = ends[keep]
+                runmax = max(int(e.max()), runmax) if has_pulse else int(e.max())
+                has_pulse = True
+            yield dict(left=groups['left'][keep], right=groups['right'][keep], first=np.append(first[keep], first[n_emit]) if len(keep) else np.array([first[n_emit]]),
+                       records=records, truth_rows=truth_rows, truth_before=truth_before, finished=b >= n)
             a, scale = b, 1
         self.source_finished = True
 

@@ -7,6 +7,8 @@ attributes, same record layout and chunk boundaries.  The instruction readers th
 """
 import logging
 
+import os
+
 import numpy as np
 
 from .dtypes import (instruction_dtype, optical_extra_dtype, truth_extra_dtype, extra_truth_dtype_per_pmt,
@@ -66,7 +68,10 @@ class ChunkRawRecords(object):
         self.chunk_time_pre = time_zero - self._rext if time_zero else np.min(instructions['time']) - self._rext
         self.chunk_time = self.chunk_time_pre + self._cksz
         self.current_digitized_right = self.last_digitized_right = 0
-        if hasattr(self.rawdata, 'iter_windows'):
+        self._sorted_stream = False
+        if hasattr(self.rawdata, 'iter_batches') and not os.environ.get('WFSIM_AMD_SCALAR_CHUNKER'):
+            yield from self._run_batches(instructions, **kwargs)
+        elif hasattr(self.rawdata, 'iter_windows'):
             yield from self._run_windows(instructions, **kwargs)
         else:
             yield from self._run_pulses(instructions, **kwargs)
@@ -100,6 +105,74 @@ class ChunkRawRecords(object):
         if self.rawdata.right != self.current_digitized_right:        # strax_interface.py:394-396
             self.last_digitized_right = self.current_digitized_right
             self.current_digitized_right = self.rawdata.right
+
+    # ---- batch granularity: the GPU hands over whole batches of windows, records already ordered by (time, channel) ----
+    def _run_batches(self, instructions, **kwargs):
+        """Same decisions as the per-pulse loop of the reference (strax_interface.py:388-436), taken once per stretch of
+        windows that cannot close a chunk: windows start in time order, so the first one beyond ``chunk_time + rext`` is
+        found by bisection and everything in front of it is committed in one go.  The records of a batch are copied
+        from the device straight into the record buffer (behind what is committed), ordered as strax.sort_by_time
+        would order them -- final_results then only cuts the buffer at ``chunk_time``."""
+        rd, buf, dt = self.rawdata, self.record_buffer, self._dt
+        L = len(buf)
+        rd.engine.set_record_order(True)
+        self._sorted_stream = True
+
+        def sink(n):
+            return buf[self.blevel:self.blevel + n] if self.blevel + n <= L else None
+
+        for batch in rd.iter_batches(instructions, want_truth=True, record_sink=sink, **kwargs):
+            rec, first, left, right = batch['records'], batch['first'], batch['left'], batch['right']
+            rows, before = batch['truth_rows'], batch['truth_before']
+            left_ns = left * dt
+            n_win, w, k = len(left), 0, 0
+            while w < n_win:
+                stop = w + int(np.searchsorted(left_ns[w:], self.chunk_time + self._rext, side='right'))
+                n_new = int(first[min(stop, n_win)] - first[w])
+                if stop > w and self.blevel + n_new <= L:
+                    # none of these windows starts beyond the open chunk: commit them together
+                    while k < len(rows) and before[k] < stop:
+                        rd._write_truth(rows[k], self.truth_buffer)
+                        k += 1
+                    for r in right[w:stop].tolist():
+                        if r != self.current_digitized_right:
+                            self.last_digitized_right, self.current_digitized_right = self.current_digitized_right, r
+                    rd.left, rd.right = int(left[stop - 1]), int(right[stop - 1])
+                    src = rec[first[w]:first[stop]]
+                    dst = buf[self.blevel:self.blevel + n_new]
+                    if n_new and src.ctypes.data != dst.ctypes.data:
+                        dst[:] = src
+                    self.blevel += n_new
+                    w = stop
+                    continue
+                # one window the reference's way: each of its pulses re-tests the chunk condition and can close one chunk
+                while k < len(rows) and before[k] <= w:
+                    rd._write_truth(rows[k], self.truth_buffer)
+                    k += 1
+                rd.left, rd.right = int(left[w]), int(right[w])
+                self._track_window()
+                wrec = rec[first[w]:first[w + 1]]
+                n_pulses = int(np.count_nonzero(wrec['record_i'] == 0))
+                closed = 0
+                while closed < n_pulses and rd.left * dt > self.chunk_time + self._rext:
+                    yield from self._maybe_close_chunk()
+                    closed += 1
+                if self.blevel + len(wrec) > L:
+                    yield from self._buffer_full_flush()
+                if self.blevel + len(wrec) > L:
+                    log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
+                    # the reference skips pulse by pulse in the order it yields them; here whole records in time order
+                    wrec = wrec[:max(L - self.blevel, 0)]
+                dst = buf[self.blevel:self.blevel + len(wrec)]
+                if len(wrec) and wrec.ctypes.data != dst.ctypes.data:
+                    dst[:] = wrec
+                self.blevel += len(wrec)
+                w += 1
+            while k < len(rows):
+                rd._write_truth(rows[k], self.truth_buffer)
+                k += 1
+            if batch['finished']:
+                rd.source_finished = True
 
     # ---- window granularity: records arrive packed from the GPU ------------------------------------
     def _run_windows(self, instructions, **kwargs):
@@ -159,9 +232,25 @@ class ChunkRawRecords(object):
     def final_results(self):
         """strax_interface.py:442-497"""
         records = self.record_buffer[:self.blevel]
-        maska = records['time'] <= self.chunk_time
-        records = records[maska]
-        records = sort_by_time(records)
+        if getattr(self, '_sorted_stream', False):
+            # the buffer is already in sort_by_time order (device sort inside a batch, windows in time order): cut it
+            t = records['time']
+            lo, hi = 0, self.blevel
+            while lo < hi:                      # first record later than chunk_time (a bisection on the strided field)
+                mid = (lo + hi) // 2
+                if t[mid] <= self.chunk_time:
+                    lo = mid + 1
+                else:
+                    hi = mid
+            n_out = lo
+            if os.environ.get('WFSIM_AMD_CHECK_SORTED'):
+                assert np.array_equal(records[:n_out], sort_by_time(records[records['time'] <= self.chunk_time]))
+            maska = None
+            records = records[:n_out]
+        else:
+            maska = records['time'] <= self.chunk_time
+            records = records[maska]
+            records = sort_by_time(records)
 
         tb = self.truth_buffer
         maskb = (tb['fill'] & ((tb['t_first_photon'] <= self.chunk_time)
@@ -178,15 +267,19 @@ class ChunkRawRecords(object):
 
         det = self.config['detector']
         if det == 'XENON1T' or det == 'XENONnT_neutron_veto':
-            yield dict(raw_records=records, truth=_truth)
+            yield dict(raw_records=records.copy() if maska is None else records, truth=_truth)
         elif det == 'XENONnT':
             he = self.config['channel_map']['he']
             yield dict(raw_records=records[records['channel'] < he[0]],
                        raw_records_he=records[(records['channel'] >= he[0]) & (records['channel'] <= he[-1])],
                        raw_records_aqmon=records[records['channel'] == 800],
                        truth=_truth)
-        n_left = int(np.sum(~maska))
-        self.record_buffer[:n_left] = self.record_buffer[:self.blevel][~maska]
+        if maska is None:
+            n_left = self.blevel - n_out
+            self.record_buffer[:n_left] = self.record_buffer[n_out:self.blevel]
+        else:
+            n_left = int(np.sum(~maska))
+            self.record_buffer[:n_left] = self.record_buffer[:self.blevel][~maska]
         self.blevel = n_left
 
     def _truth_out_dtype(self):
