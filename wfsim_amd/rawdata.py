@@ -71,25 +71,25 @@ class RawData:
             truth_buffer = []
         self.engine.set_record_order(False)
         for batch in self.iter_batches(instructions, want_truth=len(truth_buffer) > 0, **kwargs):
-            rows, before = batch['truth_rows'], batch['truth_before']
+            table, rows, before = batch['truth_table'], batch['truth_rows'], batch['truth_before']
             k = 0
             n_win = len(batch['left'])
             for w in range(n_win):
-                while k < len(rows) and before[k] <= w:         # the rows of this window's clusters (and of empty ones before it)
-                    self._write_truth(rows[k], truth_buffer)
-                    k += 1
+                k1 = int(np.searchsorted(before, w, side='right'))      # the rows of this window's clusters (and of empty ones before it)
+                if k1 > k:
+                    self._write_truth(table, rows[k:k1], truth_buffer)
+                    k = k1
                 self.left, self.right = int(batch['left'][w]), int(batch['right'][w])
                 if batch['finished'] and w == n_win - 1:
                     self.source_finished = True
                 yield dict(left=self.left, right=self.right, records=batch['records'][batch['first'][w]:batch['first'][w + 1]])
-            while k < len(rows):
-                self._write_truth(rows[k], truth_buffer)
-                k += 1
+            if k < len(rows):
+                self._write_truth(table, rows[k:], truth_buffer)
         self.source_finished = True
 
     def iter_batches(self, instructions, want_truth=False, record_sink=None, **kwargs):
         """The same stream batch by batch (what the chunker consumes): dict(left[], right[] of the batch's digitise windows
-        in time order, first[] record offsets (one more than windows), records, truth_rows + truth_before (row k belongs in
+        in time order, first[] record offsets (one more than windows), records, truth_table + truth_rows + truth_before (row truth_rows[k] of the table belongs in
         front of window truth_before[k]; == number of windows: after the last), finished).  ``record_sink(n)`` may hand out
         the array the records are copied into (device -> host without a staging copy)."""
         self.source_finished = False
@@ -159,19 +159,18 @@ class RawData:
             # window position of every emitted group: rows of a group go in front of its window, rows of a group without
             # pulses in front of the next window that has some
             pos_of_group = np.searchsorted(keep, np.arange(n_emit), side='left')
-            truth_rows, truth_before = [], np.zeros(0, dtype=np.int64)
+            truth_table, truth_rows, truth_before = None, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
             if want_truth:
-                rows = self._truth_rows(ins, cl)           # one per run set, in processing order
-                grp = np.array([ins_group[r['first']] for r in rows], dtype=np.int64)
-                sel = grp < n_emit
-                truth_rows = [r for r, k in zip(rows, sel) if k]
-                truth_before = pos_of_group[grp[sel]]
+                truth_table = self._truth_rows(ins, cl)           # one row per run set, in processing order
+                grp = ins_group[truth_table['first']].astype(np.int64)
+                truth_rows = np.flatnonzero(grp < n_emit)
+                truth_before = pos_of_group[grp[truth_rows]] if n_emit else np.zeros(0, dtype=np.int64)
             if len(keep):
                 e = ends[keep]
                 runmax = max(int(e.max()), runmax) if has_pulse else int(e.max())
                 has_pulse = True
             yield dict(left=groups['left'][keep], right=groups['right'][keep], first=np.append(first[keep], first[n_emit]) if len(keep) else np.array([first[n_emit]]),
-                       records=records, truth_rows=truth_rows, truth_before=truth_before, finished=b >= n)
+                       records=records, truth_table=truth_table, truth_rows=truth_rows, truth_before=truth_before, finished=b >= n)
             a, scale = b, 1
         self.source_finished = True
 
@@ -247,6 +246,8 @@ class RawData:
 
     # ---- truth (rawdata.py:313-375) ----------------------------------------------------------------
     def _truth_rows(self, ins, cl):
+        """Truth of the batch, one row per pulse set in processing order, as columns (RawData.get_truth, rawdata.py:313-375):
+        dict(first = index of the set's first instruction in the batch, n = rows, cols = {truth field: array})."""
         acc, ts = self.engine.truth()
         es = self.engine.electron_stats()
         per_pmt = self.engine.truth_per_pmt() if self.config.get('per_pmt_truth', False) else None      # pulse.py:62-66
@@ -254,66 +255,76 @@ class RawData:
         run_set = getattr(self, '_run_set', None)
         if run_set is None:
             # every instruction is its own pulse set (set index = position in the sorted batch); rows in processing order
-            members = [[int(i)] for i in processing_order(ins, np.arange(len(ins)), cl)]
-            set_ids = [m[0] for m in members]
+            first = np.asarray(processing_order(ins, np.arange(len(ins)), cl), dtype=np.int64)
+            set_ids, row = first, ins[first].copy()
         else:
             order = np.argsort(run_set, kind='stable')
-            cuts = np.where(np.diff(run_set[order]) != 0)[0] + 1
-            members = [m.tolist() for m in np.split(order, cuts)] if len(order) else []
-            set_ids = [int(run_set[m[0]]) for m in members]
-        rows = []
-        for q, m in zip(set_ids, members):
-            r = {'first': m[0]}
-            r['n_photon_t'] = (ts[q, 0], ts[q, 1], ts[q, 2], ts[q, 3], ts[q, 4])
-            r['electron'] = tuple(es[q]) if ins['type'][m[0]] % 2 == 0 else (0, np.nan, np.nan, np.nan, np.nan)
-            for j, f in enumerate(names):
-                r[f] = acc[q, j]
-                r[f + '_bottom'] = acc[q, 6 + j]
-                if per_pmt is not None:
-                    r[f + '_per_pmt'] = per_pmt[q, :, j]
-            # rawdata.py:364-372: the run set in one row -- mean position, summed amp, everything else from its first instruction
-            row = ins[m[0]].copy()
-            if len(m) > 1:
+            starts = np.concatenate([[0], np.where(np.diff(run_set[order]) != 0)[0] + 1]) if len(order) else np.zeros(0, np.int64)
+            first = order[starts]
+            set_ids = run_set[first].astype(np.int64)
+            row = ins[first].copy()
+            counts = np.diff(np.append(starts, len(order)))
+            multi = np.where(counts > 1)[0]
+            for k in multi:         # rawdata.py:364-372: mean position, summed amp, everything else from the set's first instruction
+                m = order[starts[k]:starts[k] + counts[k]]
                 for f in ('x', 'y', 'z'):
-                    row[f] = np.mean(ins[f][m])
-                row['amp'] = np.sum(ins['amp'][m])
-            r['instruction'] = row
-            rows.append(r)
-        return rows
-
-    def _write_truth(self, r, truth_buffer):
-        ix = np.argmin(truth_buffer['fill'])
-        tb = truth_buffer[ix]
-        n, mean, tmin, tmax, std = r['n_photon_t']
-        if n > 0:
-            tb['n_photon'], tb['t_mean_photon'], tb['t_first_photon'] = n, mean, tmin
-            tb['t_last_photon'], tb['t_sigma_photon'] = tmax, std
-        else:
-            tb['n_photon'] = 0
-            tb['t_mean_photon'] = tb['t_first_photon'] = tb['t_last_photon'] = tb['t_sigma_photon'] = np.nan
-        n, mean, tmin, tmax, std = r['electron']
-        if n > 0:
-            tb['n_electron'], tb['t_mean_electron'], tb['t_first_electron'] = n, mean, tmin
-            tb['t_last_electron'], tb['t_sigma_electron'] = tmax, std
-        else:
-            tb['n_electron'] = 0
-            tb['t_mean_electron'] = tb['t_first_electron'] = tb['t_last_electron'] = tb['t_sigma_electron'] = np.nan
-        tb['x_mean_electron'] = tb['y_mean_electron'] = np.nan          # field distortion models are off the path
-        ins = r['instruction']
+                    row[f][k] = np.mean(ins[f][m])
+                row['amp'][k] = np.sum(ins['amp'][m])
+        q = set_ids
+        cols = {}
+        n_ph = ts[q, 0]
+        has = n_ph > 0
+        cols['n_photon_t'] = np.where(has, n_ph, 0)
+        for j, f in enumerate(['t_mean_photon', 't_first_photon', 't_last_photon', 't_sigma_photon'], start=1):
+            cols[f] = np.where(has, ts[q, j], np.nan)
+        is_s2 = row['type'] % 2 == 0
+        n_el = np.where(is_s2, es[q, 0], 0)
+        he = n_el > 0
+        cols['n_electron'] = np.where(he, n_el, 0)
+        for j, f in enumerate(['t_mean_electron', 't_first_electron', 't_last_electron', 't_sigma_electron'], start=1):
+            cols[f] = np.where(he, es[q, j], np.nan)
         cfg = self.config
-        if np.isnan(tb['t_last_photon']):
-            tb['endtime'] = ins['time']
-        else:
-            tb['endtime'] = tb['t_last_photon'] + (cfg['samples_before_pulse_center'] + cfg['samples_after_pulse_center']
-                                                   + 1) * cfg['sample_duration']
+        tail = (cfg['samples_before_pulse_center'] + cfg['samples_after_pulse_center'] + 1) * cfg['sample_duration']
+        cols['endtime'] = np.where(has, cols['t_last_photon'] + tail, row['time']).astype(np.float64)
+        for j, f in enumerate(names):
+            cols[f] = acc[q, j]
+            cols[f + '_bottom'] = acc[q, 6 + j]
+            if per_pmt is not None:
+                cols[f + '_per_pmt'] = per_pmt[q, :, j]
+        # zero-photon electron afterpulses leave no truth row (rawdata.py:336-338)
+        keep = ~((~has) & ~np.isin(row['type'], (1, 2)))
+        return dict(first=first, n=len(first), cols=cols, instruction=row, keep=keep)
+
+    def _write_truth(self, table, rows, truth_buffer):
+        """rows of ``table`` (indices, in order) into the first free rows of the truth buffer (rawdata.py:320: np.argmin(fill)
+        per row = the free slots in ascending order)"""
+        rows = np.asarray(rows, dtype=np.int64)
+        rows = rows[table['keep'][rows]]
+        if len(rows) == 0:
+            return
+        free = np.flatnonzero(~truth_buffer['fill'])
+        if len(free) < len(rows):
+            # the reference keeps writing into row 0 once the buffer is full (argmin of an all-True array); so do we
+            free = np.concatenate([free, np.zeros(len(rows) - len(free), dtype=np.int64)])
+        slots = free[:len(rows)]
+        cols, ins = table['cols'], table['instruction'][rows]
+        names = truth_buffer.dtype.names
+        tb = truth_buffer
+        tb['n_photon'][slots] = cols['n_photon_t'][rows]
+        for f in ['t_mean_photon', 't_first_photon', 't_last_photon', 't_sigma_photon', 'n_electron', 't_mean_electron',
+                  't_first_electron', 't_last_electron', 't_sigma_electron']:
+            tb[f][slots] = cols[f][rows]
+        tb['x_mean_electron'][slots] = np.nan          # field distortion models are off the path
+        tb['y_mean_electron'][slots] = np.nan
+        tb['endtime'][slots] = cols['endtime'][rows]
         for f in ['n_pe', 'n_pe_trigger', 'n_photon', 'n_photon_trigger', 'raw_area', 'raw_area_trigger']:
             for suffix in ['', '_bottom', '_per_pmt']:          # rawdata.py:355-362: total + (bottom | per PMT)
-                if f + suffix in truth_buffer.dtype.names and f + suffix in r:
-                    tb[f + suffix] = r[f + suffix]
+                if f + suffix in names and f + suffix in cols:
+                    tb[f + suffix][slots] = cols[f + suffix][rows]
         for f in ins.dtype.names:
-            if f in truth_buffer.dtype.names:
-                tb[f] = ins[f]
-        tb['fill'] = True
+            if f in names:
+                tb[f][slots] = ins[f]
+        tb['fill'][slots] = True
 
     # ---- reference protocol ------------------------------------------------------------------------
     def __call__(self, instructions, truth_buffer=None, progress_bar=True, **kwargs):

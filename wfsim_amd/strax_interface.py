@@ -123,7 +123,7 @@ class ChunkRawRecords(object):
 
         for batch in rd.iter_batches(instructions, want_truth=True, record_sink=sink, **kwargs):
             rec, first, left, right = batch['records'], batch['first'], batch['left'], batch['right']
-            rows, before = batch['truth_rows'], batch['truth_before']
+            table, rows, before = batch['truth_table'], batch['truth_rows'], batch['truth_before']
             left_ns = left * dt
             n_win, w, k = len(left), 0, 0
             while w < n_win:
@@ -131,9 +131,10 @@ class ChunkRawRecords(object):
                 n_new = int(first[min(stop, n_win)] - first[w])
                 if stop > w and self.blevel + n_new <= L:
                     # none of these windows starts beyond the open chunk: commit them together
-                    while k < len(rows) and before[k] < stop:
-                        rd._write_truth(rows[k], self.truth_buffer)
-                        k += 1
+                    k1 = int(np.searchsorted(before, stop, side='left'))
+                    if k1 > k:
+                        rd._write_truth(table, rows[k:k1], self.truth_buffer)
+                        k = k1
                     for r in right[w:stop].tolist():
                         if r != self.current_digitized_right:
                             self.last_digitized_right, self.current_digitized_right = self.current_digitized_right, r
@@ -146,9 +147,10 @@ class ChunkRawRecords(object):
                     w = stop
                     continue
                 # one window the reference's way: each of its pulses re-tests the chunk condition and can close one chunk
-                while k < len(rows) and before[k] <= w:
-                    rd._write_truth(rows[k], self.truth_buffer)
-                    k += 1
+                k1 = int(np.searchsorted(before, w, side='right'))
+                if k1 > k:
+                    rd._write_truth(table, rows[k:k1], self.truth_buffer)
+                    k = k1
                 rd.left, rd.right = int(left[w]), int(right[w])
                 self._track_window()
                 wrec = rec[first[w]:first[w + 1]]
@@ -168,9 +170,8 @@ class ChunkRawRecords(object):
                     dst[:] = wrec
                 self.blevel += len(wrec)
                 w += 1
-            while k < len(rows):
-                rd._write_truth(rows[k], self.truth_buffer)
-                k += 1
+            if k < len(rows):
+                rd._write_truth(table, rows[k:], self.truth_buffer)
             if batch['finished']:
                 rd.source_finished = True
 
