@@ -14,6 +14,15 @@ if which == 'headline':
     ins = np.zeros(n, dtype=instruction_dtype)
     ins['type'], ins['z'], ins['amp'], ins['recoil'] = 2, -10.0, 10_000, 7
     ins['time'] = 1_000_000 * (1 + np.arange(n))
+elif which == 's1':
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
+    cfg = xenonnt_test_config(seed=2, chunk_size=5.0)
+    rng = np.random.default_rng(2)
+    ins = np.zeros(n, dtype=instruction_dtype)
+    ins['type'], ins['amp'], ins['recoil'] = 1, 1667, 7
+    ins['time'] = 1_000_000 * (1 + np.arange(n))
+    r, phi = 50 * np.sqrt(rng.random(n)), rng.uniform(0, 2 * np.pi, n)
+    ins['x'], ins['y'], ins['z'] = r * np.cos(phi), r * np.sin(phi), rng.uniform(-97, 0, n)
 else:
     n_ev = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -27,12 +27,8 @@ def processing_order(instructions, order, cluster):
     """Order in which the reference simulates the sorted instructions: cluster by cluster, S1s first, then S2s
     (rawdata.py:102-105); returns indices into the *sorted* array."""
     typ = instructions['type'][order]
-    out = []
-    for c in np.unique(cluster):
-        idx = np.where(cluster == c)[0]
-        for ptype in (1, 2, 4, 6):
-            out.extend(idx[typ[idx] == ptype].tolist())
-    return np.asarray(out, dtype=np.int64)
+    rank = np.searchsorted(np.array([1, 2, 4, 6]), typ)
+    return np.lexsort((np.arange(len(typ)), rank, cluster)).astype(np.int64)
 
 
 def run_sets(s_ins, key, cluster, config):
@@ -41,24 +37,19 @@ def run_sets(s_ins, key, cluster, config):
     whose keys are at most 100 ns apart and S2s at most ``int(0.2 / v)`` ns apart (2 mm of drift) share a set.
     Sets are numbered in processing order (cluster, S1 sets, then S2 sets).  Returns (run_set int32[n], n_sets)."""
     n = len(s_ins)
-    out = np.zeros(n, dtype=np.int32)
+    if n == 0:
+        return np.zeros(0, dtype=np.int32), 0
     full = config.get('save_full_truth', True)
-    gaps = {1: 100, 2: int(0.2 / config['drift_velocity_liquid'])}
-    typ = s_ins['type']
-    k = 0
-    bounds = np.concatenate([[0], np.where(np.diff(cluster) != 0)[0] + 1, [n]]) if n else np.zeros(1, dtype=np.int64)
-    for a, b in zip(bounds[:-1], bounds[1:]):
-        for ptype in (1, 2, 4, 6):
-            idx = np.arange(a, b)[typ[a:b] == ptype]
-            if len(idx) == 0:
-                continue
-            if full or ptype not in gaps:
-                new = np.ones(len(idx), dtype=bool) if ptype in gaps else np.concatenate([[True], np.zeros(len(idx) - 1, dtype=bool)])
-            else:
-                new = np.concatenate([[True], np.diff(key[idx]) > gaps[ptype]])
-            out[idx] = k + np.cumsum(new) - 1
-            k += int(new.sum())
-    return out, k
+    gap = np.array([100, int(0.2 / config['drift_velocity_liquid']), 0, 0], dtype=np.int64)      # S1, S2; types 4 / 6: one set per cluster
+    po = processing_order(s_ins, np.arange(n), cluster)               # cluster by cluster, S1s, S2s, type 4, type 6, key order inside
+    rank = np.searchsorted(np.array([1, 2, 4, 6]), s_ins['type'][po])
+    cl, k = np.asarray(cluster)[po], np.asarray(key)[po]
+    new_group = np.concatenate([[True], (np.diff(cl) != 0) | (np.diff(rank) != 0)])
+    dk = np.concatenate([[0], np.diff(k)])
+    new_set = new_group | ((rank < 2) & (full | (dk > gap[rank])))
+    out = np.zeros(n, dtype=np.int32)
+    out[po] = (np.cumsum(new_set) - 1).astype(np.int32)
+    return out, int(new_set.sum())
 
 
 FORCED_BREAK_KEY = np.int64(2 ** 62)
