@@ -64,10 +64,14 @@ def _assert_same(a, b):
     (0.003, 40_000, {}),
     (0.05, 2_000_000_000, dict(enable_pmt_afterpulses=True, enable_noise=True)),
     (0.004, 150_000, dict(save_full_truth=False, per_pmt_truth=True)),
+    (0.006, 100_000, dict(enable_electron_afterpulses=True, s2_secondary_sc_gain=60.0)),
 ])
 def test_tpc_chunks_identical_to_the_per_window_replay(chunk_size, quanta, kw):
     if kw.get('enable_pmt_afterpulses'):
         kw = dict(kw, uniform_to_pmt_ap=ap_tables_from_golden(), noise_data=golden('noise.npz')['noise'])
+    if kw.get('enable_electron_afterpulses'):
+        hist = np.exp(-np.arange(140) / 30.0)
+        kw = dict(kw, uniform_to_ele_ap=(hist * 3e-3 / hist.sum(), np.linspace(0, 150e3, 141)))
     cfg = xenonnt_test_config(seed=17, chunk_size=chunk_size, **kw)
     ins = _mixed(120, 3)
 
