@@ -113,6 +113,10 @@ class Engine:
                     self._h, C.c_int32(e), C.c_int32(dc.shape[1]), C.c_int32(ac.shape[-1]), C.c_int32(ac.ndim == 2),
                     C.c_int32('Uniform' in name), C.c_double(d['delaytime_bin_size']), C.c_double(d['amplitude_bin_size']), _p(dc), _p(ac)))
 
+        # HE records exist only when the HE rows can differ from a flat baseline (wfs_engine.hip refresh_dev): a non-zero
+        # int(high_energy_deamplification_factor) (rawdata.py:242) or noise columns for the HE channels
+        he_noise = bool(params['enable_noise']) and nc > params['he_first']
+        self.emits_he_records = bool(params['detector_nt'] and params['n_top'] > 0 and (params['he_factor'] != 0 or he_noise))
         # pattern maps on regular grids are evaluated on the device (one channel CDF row per instruction)
         self.device_maps = set()
         if config.get('device_pattern_maps', True):

@@ -271,10 +271,16 @@ class ChunkRawRecords(object):
             yield dict(raw_records=records.copy() if maska is None else records, truth=_truth)
         elif det == 'XENONnT':
             he = self.config['channel_map']['he']
-            yield dict(raw_records=records[records['channel'] < he[0]],
-                       raw_records_he=records[(records['channel'] >= he[0]) & (records['channel'] <= he[-1])],
-                       raw_records_aqmon=records[records['channel'] == 800],
-                       truth=_truth)
+            engine = getattr(self.rawdata, 'engine', None)
+            if maska is None and engine is not None and not engine.emits_he_records:
+                # every record is a TPC record (no HE rows are digitised, row 800 is never emitted): one plain copy
+                empty = records[:0].copy()
+                yield dict(raw_records=records.copy(), raw_records_he=empty, raw_records_aqmon=empty.copy(), truth=_truth)
+            else:
+                yield dict(raw_records=records[records['channel'] < he[0]],
+                           raw_records_he=records[(records['channel'] >= he[0]) & (records['channel'] <= he[-1])],
+                           raw_records_aqmon=records[records['channel'] == 800],
+                           truth=_truth)
         if maska is None:
             n_left = self.blevel - n_out
             self.record_buffer[:n_left] = self.record_buffer[n_out:self.blevel]
