@@ -93,3 +93,19 @@ def test_interpolated_pattern_maps_feed_the_channel_tables():
     p = np.diff(cdf, axis=1, prepend=0.0)
     assert np.all(p[:, [5, 300]] == 0)                       # turned-off PMTs never fire
     assert len(np.unique(ip['cdf_row'])) == 7
+
+
+def test_error_behaviour_of_bad_configs():
+    """the reference's exceptions for this path: ValueError for an unknown detector (load_resource.py:115),
+    KeyError for unknown S2 model names (s2.py:536, 552), AssertionError for unknown S1 model names (s1.py:52-58)"""
+    from wfsim_amd.config import kernel_params
+    with pytest.raises(ValueError):
+        Resource(xenonnt_test_config(detector='LZ'))
+    with pytest.raises(KeyError):
+        kernel_params(xenonnt_test_config(s2_luminescence_model='fancy'))
+    with pytest.raises(KeyError):
+        kernel_params(xenonnt_test_config(s2_time_model='whenever'))
+    with pytest.raises(AssertionError):
+        kernel_params(xenonnt_test_config(s1_model_type='simple+magic'))
+    with pytest.raises(NotImplementedError):
+        kernel_params(xenonnt_test_config(s1_model_type='nest'))

@@ -86,6 +86,8 @@ class Resource:
 
     def __init__(self, config):
         c = config
+        if c.get('detector', 'XENONnT') not in ('XENON1T', 'XENONnT', 'XENONnT_neutron_veto'):
+            raise ValueError(f"Unsupported detector {c['detector']}")          # load_resource.py:115
         pmt_mask = np.asarray(c['gains']) > 0
         self.s1_pattern_map = make_patternmap(c['s1_pattern_map'], pmt_mask=pmt_mask)
         self.s2_pattern_map = make_patternmap(c['s2_pattern_map'], pmt_mask=pmt_mask)
