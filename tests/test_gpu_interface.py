@@ -256,3 +256,35 @@ def test_electron_afterpulses_against_oracle():
     assert len(t) == n_sets - lost.sum() and (t['type'] == 4).sum() == ((o['call_kind'] == 4) & ~lost).sum() >= 3
     assert np.all(t['n_photon'][np.isin(t['type'], (4, 6))] > 0)
     assert np.all(t['n_electron'][t['type'] == 2] > 0) and t['n_electron'][t['type'] == 4].sum() > 10      # a lone secondary electron may be lost on the way
+
+
+def test_xenon1t_detector_through_the_1t_plugin():
+    """detector XENON1T (248 PMTs, no HE / aqmon streams, RawRecordsFromFax1T, strax_interface.py:716-719): records equal the
+    oracle's, the plugin provides raw_records + truth only"""
+    n_pmt, n_top = 248, 127
+    cfg = xenonnt_test_config(detector='XENON1T', seed=12, chunk_size=0.02, n_tpc_pmts=n_pmt, n_top_pmts=n_top)
+    cfg['gains'] = np.full(n_pmt, 2e6)
+    cfg['gains'][[1, 130]] = 0
+    cfg['channels_bottom'] = np.arange(n_top, n_pmt)
+    cfg['channel_map'] = dict(tpc=(0, n_pmt - 1), sum_signal=254)
+    cfg['photon_area_distribution'] = dict(cfg['photon_area_distribution'], n_channels=n_pmt)
+    cfg['s1_pattern_map'] = ['constant dummy', 1, [n_pmt]]
+    cfg['s2_pattern_map'] = ['constant dummy', 1, [n_pmt]]
+    ins = _s1_instructions()[:40]
+    ins['type'][1::2] = 2
+    ins['amp'][1::2] = 60
+    res = Resource(cfg)
+    order, key, cluster = schedule(ins, cfg)
+    ip = instruction_params(ins[order], cfg, res)
+    orc = make_oracle(cfg)
+    orc.simulate(ins[order], order.astype(np.uint32), ip)
+    rd = wfsim_amd.RawData(cfg)
+    rec = np.concatenate([w['records'] for w in rd.iter_windows(ins)])
+    assert rec.tobytes() == orc.pack_records().tobytes()
+    assert rec['channel'].max() < n_pmt and not np.isin(rec['channel'], [1, 130]).any()
+    plugin = wfsim_amd.RawRecordsFromFax1T(dict(cfg, instructions=ins))
+    out = ministrax.run_plugin(plugin)
+    assert set(out) == {'raw_records', 'truth'}
+    rr = np.concatenate([c.data for c in out['raw_records']])
+    assert len(rr) == len(rec) and np.all(np.diff(rr['time']) >= 0)
+    assert len(np.concatenate([c.data for c in out['truth']])) == len(ins)
