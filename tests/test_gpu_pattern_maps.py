@@ -142,3 +142,34 @@ def test_map_evaluation_speed():
     t_host = 10 * (time.perf_counter() - t0)
     print(f'load + device map evaluation of 10^4 S1: {1e3 * t_dev:.1f} ms; host evaluation: {1e3 * t_host:.0f} ms')
     assert t_dev < t_host
+
+
+def test_field_distortion_positions_reach_the_device_map():
+    """comsol field distortion (s2.py:51-71): the S2 pattern is looked up at the OBSERVED position, also on the device;
+    truth carries the mean observed position (rawdata.py:377-390)"""
+    import wfsim_amd
+    from wfsim_amd.dtypes import truth_extra_dtype
+    rg = np.linspace(0, 70, 36)
+    comsol = dict(coordinate_system=[['r', [0, 70, 36]], ['z', [-160, 10, 18]]], r_distortion_map=(0.8 * rg[:, None] * np.ones(18)[None, :]).tolist())
+    cfg = map_config(7, seed=13, field_distortion_model='comsol', field_distortion_comsol_map=comsol)
+    res = Resource(cfg)
+    eng = make_engine(cfg, resource=res)
+    ins = instructions(80, 21)
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    ip_dev = instruction_params(s_ins, cfg, res, device_maps=eng.device_maps)
+    eng.load_instructions(s_ins, order.astype(np.uint32), cluster, key, ip_dev)
+    row, table = eng.cdf_rows()
+    ip_host = instruction_params(s_ins, cfg, res)
+    p_host = np.diff(ip_host['cdf_table'][ip_host['cdf_row']], axis=1, prepend=0.0)
+    p_dev = np.diff(table[row], axis=1, prepend=0.0)
+    assert np.allclose(p_dev, p_host, rtol=1e-6, atol=1e-12)
+    undistorted = instruction_params(s_ins, dict(cfg, field_distortion_model='none'), res)
+    s2 = s_ins['type'] == 2
+    assert not np.allclose(np.diff(undistorted['cdf_table'][undistorted['cdf_row']], axis=1, prepend=0.0)[s2], p_host[s2], rtol=1e-3)
+    truth = np.zeros(400, dtype=instruction_dtype + truth_extra_dtype + [('fill', bool)])
+    list(wfsim_amd.RawData(cfg).iter_windows(ins, truth_buffer=truth))
+    t = truth[truth['fill']]
+    t2 = t[t['type'] == 2]
+    assert len(t2) > 5 and np.allclose(np.hypot(t2['x_mean_electron'], t2['y_mean_electron']), 0.8 * np.hypot(t2['x'], t2['y']), rtol=1e-4)
+    assert np.all(np.isnan(t[t['type'] == 1]['x_mean_electron']))

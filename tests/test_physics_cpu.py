@@ -109,3 +109,28 @@ def test_error_behaviour_of_bad_configs():
         kernel_params(xenonnt_test_config(s1_model_type='simple+magic'))
     with pytest.raises(NotImplementedError):
         kernel_params(xenonnt_test_config(s1_model_type='nest'))
+
+
+def test_field_distortion_models_move_the_observed_position():
+    """S2.__call__ (s2.py:81-103): survival / drift at the true position, S2 maps at the observed one; comsol: radial
+    map; inverse_fdc: fixed point of r_obs = r - dr(r_obs...) after six damped iterations"""
+    from wfsim_amd.physics import s2_observed_positions
+    ins = _s2(6, seed=3)
+    # comsol: r_obs = 0.9 * r on a regular (r, z) grid
+    rg, zg = np.linspace(0, 70, 36), np.linspace(-160, 10, 18)
+    comsol = dict(coordinate_system=[['r', [0, 70, 36]], ['z', [-160, 10, 18]]], r_distortion_map=(0.9 * rg[:, None] * np.ones(18)[None, :]).tolist())
+    cfg = xenonnt_test_config(field_distortion_model='comsol', field_distortion_comsol_map=comsol)
+    res = Resource(cfg)
+    z_obs, xy = s2_observed_positions(ins, cfg, res)
+    r = np.hypot(ins['x'], ins['y']).astype(np.float64)
+    assert np.allclose(np.hypot(xy[:, 0], xy[:, 1]), 0.9 * r, rtol=1e-6) and np.allclose(np.arctan2(xy[:, 1], xy[:, 0]), np.arctan2(ins['y'], ins['x']))
+    ip = instruction_params(ins, cfg, res)
+    assert np.allclose(ip['pattern_xy'], xy)
+    base = instruction_params(ins, xenonnt_test_config(), Resource(xenonnt_test_config()))
+    assert np.array_equal(ip['drift_mean'], base['drift_mean'])               # drift from the true position
+    # inverse_fdc with a constant correction dr = 1.5 cm: r_obs = r - 1.5, z_obs = -sqrt(z^2 + dr^2)
+    fdc = dict(coordinate_system=[['x', [-70, 70, 8]], ['y', [-70, 70, 8]], ['z', [-160 / 1.335e-4 * -1, 0, 5]]], map=np.full((8, 8, 5), 1.5).tolist())
+    cfg = xenonnt_test_config(field_distortion_model='inverse_fdc', fdc_3d=fdc)
+    z_obs, xy = s2_observed_positions(ins, cfg, Resource(cfg))
+    assert np.allclose(np.hypot(xy[:, 0], xy[:, 1]), r - 1.5, rtol=1e-6)
+    assert np.allclose(z_obs, -np.sqrt(ins['z'].astype(np.float64) ** 2 + 1.5 ** 2))

@@ -180,7 +180,8 @@ class Engine:
                                                    _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0),
                                                    _p(_arr(em_base, np.uint32) if em_base is not None else None)))
         if np.any(a[10] < 0):           # rows from the device pattern maps
-            xyz = [_arr(ins[k], np.float32) for k in ('x', 'y', 'z')]
+            pxy = ip.get('pattern_xy')          # S2: the observed position under a field distortion model
+            xyz = [_arr(ins['x'] if pxy is None else pxy[:, 0], np.float32), _arr(ins['y'] if pxy is None else pxy[:, 1], np.float32), _arr(ins['z'], np.float32)]
             self._check(self.lib.wfs_eval_pattern_rows(self._h, C.c_int64(n), *[_p(q) for q in xyz]))
         self._n_cdf_rows = a[11].shape[0] + int(np.sum(a[10] < 0))
         if self.models.active:

@@ -131,6 +131,32 @@ def s2_channel_probabilities(positions, config, resource, gids=None):
     return pattern
 
 
+def s2_observed_positions(instructions, config, resource):
+    """(z_obs, xy_obs) of S2-like instructions under the field distortion models of S2.__call__
+    (/root/reference/wfsim/core/s2.py:29-71, 81-88): ``inverse_fdc`` (XENON1T: the data-driven correction map applied
+    backwards, six damped iterations), ``comsol`` (radial distortion map), anything else: the true positions."""
+    x, y, z = (instructions[f].astype(np.float64) for f in ('x', 'y', 'z'))
+    model = config.get('field_distortion_model', 'none')
+    if model == 'inverse_fdc':
+        positions = np.array([x, y, z]).T
+        for i_iter in range(6):
+            dr = resource.fdc_3d(positions)
+            if i_iter > 0:
+                dr = 0.5 * dr + 0.5 * dr_pre
+            dr_pre = dr
+            r_obs = np.sqrt(x ** 2 + y ** 2) - dr
+            x_obs = x * r_obs / (r_obs + dr)
+            y_obs = y * r_obs / (r_obs + dr)
+            z_obs = - np.sqrt(z ** 2 + dr ** 2)
+            positions = np.array([x_obs, y_obs, z_obs]).T
+        return z_obs, np.array([x_obs, y_obs]).T
+    if model == 'comsol':
+        theta = np.arctan2(y, x)
+        r_obs = resource.fd_comsol(np.array([np.sqrt(x ** 2 + y ** 2), z]).T, map_name='r_distortion_map')
+        return z, np.array([r_obs * np.cos(theta), r_obs * np.sin(theta)]).T
+    return z, np.array([x, y]).T
+
+
 def instruction_time(instructions, config):
     """Ordering key of the scheduler, /root/reference/wfsim/core/rawdata.py:61 (float32 arithmetic, as numpy does)."""
     v = config['drift_velocity_liquid']
@@ -155,6 +181,7 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
     const_rows = {}
     rows = []
     cdf_row = np.zeros(n, dtype=np.int32)
+    pattern_xy = np.array([instructions['x'], instructions['y']], dtype=np.float64).T      # where the pattern map is evaluated
     for sel, kind in ((is_s1, 's1'), (is_s2, 's2')):
         if not sel.any():
             continue
@@ -166,23 +193,27 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
         else:
             x, y, z = ins['x'], ins['y'], ins['z']
             xy = np.array([x, y]).T
-            if config.get('field_distortion_model', 'none') != 'none':
-                raise NotImplementedError('field distortion models need private maps (SURVEY.md 2.1 row 3)')
-            p_hit[sel] = s2_electron_survival(z, xy, xy, config, resource)
+            # survival and drift use the true position, the S2 maps (correction, gain, pattern) the observed one (s2.py:81-103)
+            _, xy_obs = s2_observed_positions(ins, config, resource)
+            distorted = config.get('field_distortion_model', 'none') in ('inverse_fdc', 'comsol')
+            if not distorted:
+                xy_obs = xy
+            pattern_xy[sel] = xy_obs
+            p_hit[sel] = s2_electron_survival(z, xy, xy_obs, config, resource)
             m, s = s2_drift_time_params(z, xy, config, resource)
             drift_mean[sel], drift_spread[sel] = m, s
-            sc_gain[sel] = s2_secondary_gain(xy, config, resource)
+            sc_gain[sel] = s2_secondary_gain(xy_obs, config, resource)
             pmap = resource.s2_pattern_map
             sel_gids = None if gids is None else np.asarray(gids)[sel]
-            probs = (lambda q: s2_channel_probabilities(np.array([q['x'], q['y']]).T, config, resource, sel_gids))
+            probs = (lambda q, xy_obs=xy_obs: s2_channel_probabilities(xy_obs[:len(q)], config, resource, sel_gids))
         idx = np.where(sel)[0]
         if kind in device_maps and not (kind == 's2' and config.get('s2_aft_sigma', 0.0) != 0):
             cdf_row[idx] = -1
             if kind == 's2' and config.get('diffusion_constant_transverse', 0) > 0:         # s2.py:598, see s2_channel_probabilities
-                p_hit[idx[ins['x'].astype(np.float64) ** 2 + ins['y'].astype(np.float64) ** 2 > config['tpc_radius'] ** 2]] = 0.0
+                p_hit[idx[np.sum(pattern_xy[idx] ** 2, axis=1) > config['tpc_radius'] ** 2]] = 0.0
             continue
         per_instruction = kind == 's2' and (config.get('s2_aft_sigma', 0.0) != 0 or (
-            config.get('diffusion_constant_transverse', 0) > 0 and np.any(ins['x'].astype(np.float64) ** 2 + ins['y'].astype(np.float64) ** 2 > config['tpc_radius'] ** 2)))
+            config.get('diffusion_constant_transverse', 0) > 0 and np.any(np.sum(pattern_xy[idx] ** 2, axis=1) > config['tpc_radius'] ** 2)))
         if isinstance(pmap, DummyMap) and not per_instruction:
             const_rows[kind] = len(rows)
             rows.append(choice_cdf(probs(ins[:1]))[0])
@@ -198,4 +229,4 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
             rows.extend(list(cdf))
     cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.ones((1, n_ch))
     return dict(p_hit=p_hit, drift_mean=drift_mean, drift_spread=drift_spread, sc_gain=sc_gain,
-                cdf_row=cdf_row, cdf_table=cdf_table)
+                cdf_row=cdf_row, cdf_table=cdf_table, pattern_xy=pattern_xy)

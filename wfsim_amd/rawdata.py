@@ -291,6 +291,20 @@ class RawData:
             cols[f + '_bottom'] = acc[q, 6 + j]
             if per_pmt is not None:
                 cols[f + '_per_pmt'] = per_pmt[q, :, j]
+        # mean observed position of the electrons under a field distortion model (get_mean_xy_electron, rawdata.py:377-390)
+        cols['x_mean_electron'] = np.full(len(first), np.nan)
+        cols['y_mean_electron'] = np.full(len(first), np.nan)
+        if cfg.get('field_distortion_model', 'none') in ('comsol', 'inverse_fdc'):
+            from .physics import s2_observed_positions
+            s2rows = np.where(row['type'] == 2)[0]
+            if len(s2rows):
+                if run_set is None:
+                    _, xy = s2_observed_positions(ins[first[s2rows]], cfg, self.resource)
+                    cols['x_mean_electron'][s2rows], cols['y_mean_electron'][s2rows] = xy[:, 0], xy[:, 1]
+                else:
+                    for k in s2rows:
+                        _, xy = s2_observed_positions(ins[order[starts[k]:starts[k] + counts[k]]], cfg, self.resource)
+                        cols['x_mean_electron'][k], cols['y_mean_electron'][k] = np.mean(xy[:, 0]), np.mean(xy[:, 1])
         # zero-photon electron afterpulses leave no truth row (rawdata.py:336-338)
         keep = ~((~has) & ~np.isin(row['type'], (1, 2)))
         return dict(first=first, n=len(first), cols=cols, instruction=row, keep=keep)
@@ -314,8 +328,8 @@ class RawData:
         for f in ['t_mean_photon', 't_first_photon', 't_last_photon', 't_sigma_photon', 'n_electron', 't_mean_electron',
                   't_first_electron', 't_last_electron', 't_sigma_electron']:
             tb[f][slots] = cols[f][rows]
-        tb['x_mean_electron'][slots] = np.nan          # field distortion models are off the path
-        tb['y_mean_electron'][slots] = np.nan
+        tb['x_mean_electron'][slots] = cols['x_mean_electron'][rows]
+        tb['y_mean_electron'][slots] = cols['y_mean_electron'][rows]
         tb['endtime'][slots] = cols['endtime'][rows]
         for f in ['n_pe', 'n_pe_trigger', 'n_photon', 'n_photon_trigger', 'raw_area', 'raw_area_trigger']:
             for suffix in ['', '_bottom', '_per_pmt']:          # rawdata.py:355-362: total + (bottom | per PMT)

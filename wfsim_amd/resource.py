@@ -103,6 +103,13 @@ class Resource:
                 r = np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
                 return fmap(np.array([r, z]).T, **kwargs)
             self.field_dependencies_map = rz_map
+        # field distortion models of S2.__call__ (load_resource.py:310-315)
+        if c.get('field_distortion_model', 'none') == 'inverse_fdc':
+            self.fdc_3d = make_map(c['fdc_3d'])
+            if hasattr(self.fdc_3d, 'scale_coordinates'):
+                self.fdc_3d.scale_coordinates([1., 1., - c['drift_velocity_liquid']])
+        if c.get('field_distortion_model', 'none') == 'comsol':
+            self.fd_comsol = make_map(c['field_distortion_comsol_map'], method='RectBivariateSpline')
         # photon propagation splines (load_resource.py:354-365) and the garfield luminescence table (load_resource.py:293-309)
         if c.get('s1_time_spline', False):
             self.s1_optical_propagation_spline = make_map(c['s1_time_spline'], method='RegularGridInterpolator')
