@@ -134,3 +134,28 @@ def test_field_distortion_models_move_the_observed_position():
     z_obs, xy = s2_observed_positions(ins, cfg, Resource(cfg))
     assert np.allclose(np.hypot(xy[:, 0], xy[:, 1]), r - 1.5, rtol=1e-6)
     assert np.allclose(z_obs, -np.sqrt(ins['z'].astype(np.float64) ** 2 + 1.5 ** 2))
+
+
+def test_field_dependency_maps():
+    """enable_field_dependencies (load_resource.py:318-347, s2.py:158-179, 241-252): drift speed map with normalisation,
+    survival probability map, data-driven longitudinal diffusion -- all host maps over (r, z)"""
+    from wfsim_amd.physics import s2_drift_time_params, s2_electron_survival
+    rg, zg = np.linspace(0, 70, 15), np.linspace(-150, 0, 16)
+    speed = (1.2 + 0.002 * rg[:, None] + 0.0 * zg[None, :])                         # mm / us
+    surv = np.clip(0.9 - 0.002 * rg[:, None] + 0.0 * zg[None, :], 0, 1)
+    fmap = dict(coordinate_system=[['r', [0, 70, 15]], ['z', [-150, 0, 16]]], drift_speed_map=speed.tolist(), survival_probability_map=surv.tolist())
+    dmap = dict(coordinate_system=[['r', [0, 70, 15]], ['z', [-150, 0, 16]]], map=np.full((15, 16), 3.1e-8).tolist())
+    efd = dict(drift_speed_map=True, survival_probability_map=True, diffusion_longitudinal_map=True, norm_drift_velocity=True)
+    cfg = xenonnt_test_config(enable_field_dependencies=efd, field_dependencies_map=fmap, diffusion_longitudinal_map=dmap)
+    res = Resource(cfg)
+    assert np.isclose(res.drift_velocity_scaling, cfg['drift_velocity_liquid'] / 1.2e-4)
+    ins = _s2(5, seed=8)
+    xy = np.array([ins['x'], ins['y']], dtype=np.float64).T
+    z = ins['z'].astype(np.float64)
+    r = np.hypot(xy[:, 0], xy[:, 1])
+    mean, spread = s2_drift_time_params(z, xy, cfg, res)
+    v = (1.2 + 0.002 * r) * 1e-4 * res.drift_velocity_scaling
+    assert np.allclose(mean, -z / v + cfg['drift_time_gate'], rtol=1e-6)
+    assert np.allclose(spread, np.sqrt(2 * 3.1e-8 * mean) / v, rtol=1e-6)
+    cy = s2_electron_survival(z, xy, xy, cfg, res)
+    assert np.allclose(cy, cfg['electron_extraction_yield'] * np.exp(-mean / cfg['electron_lifetime_liquid']) * (0.9 - 0.002 * r), rtol=1e-5)

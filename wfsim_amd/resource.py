@@ -96,13 +96,25 @@ class Resource:
         self.se_gain_map = make_map(c.get('se_gain_map', ['constant dummy', 1, []]))
         efd = c.get('enable_field_dependencies', {})
         if any(efd.values()):
-            fmap = make_map(c.get('field_dependencies_map', ['constant dummy', 1, []]))
+            fmap = make_map(c.get('field_dependencies_map', ['constant dummy', 1, []]), method='RectBivariateSpline')
             self.drift_velocity_scaling = 1.0
+            # scale the drift speed map so that the drift time from the cathode at r = 0 matches the configured velocity
+            # (load_resource.py:325-333)
+            if efd.get('norm_drift_velocity', False):
+                norm_dvel = fmap(np.array([[0], [- c['tpc_length']]]).T, map_name='drift_speed_map')[0] * 1e-4
+                self.drift_velocity_scaling = c['drift_velocity_liquid'] / norm_dvel
 
             def rz_map(z, xy, **kwargs):           # load_resource.py:335-338
                 r = np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
                 return fmap(np.array([r, z]).T, **kwargs)
             self.field_dependencies_map = rz_map
+            if efd.get('diffusion_longitudinal_map', False):       # data-driven longitudinal diffusion (load_resource.py:340-347)
+                dmap = make_map(c['diffusion_longitudinal_map'])
+
+                def _rz_map(z, xy, **kwargs):
+                    r = np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
+                    return dmap(np.array([r, z]).T, **kwargs)
+                self.diffusion_longitudinal_map = _rz_map
         # field distortion models of S2.__call__ (load_resource.py:310-315)
         if c.get('field_distortion_model', 'none') == 'inverse_fdc':
             self.fdc_3d = make_map(c['fdc_3d'])
