@@ -159,3 +159,40 @@ def test_field_dependency_maps():
     assert np.allclose(spread, np.sqrt(2 * 3.1e-8 * mean) / v, rtol=1e-6)
     cy = s2_electron_survival(z, xy, xy, cfg, res)
     assert np.allclose(cy, cfg['electron_extraction_yield'] * np.exp(-mean / cfg['electron_lifetime_liquid']) * (0.9 - 0.002 * r), rtol=1e-5)
+
+
+def test_s2_mean_area_fraction_top_rescales_the_pattern_map():
+    """load_resource.py:255-272: the S2 pattern map is rescaled to the configured mean AFT, total efficiency preserved"""
+    rng = np.random.default_rng(12)
+    m = rng.random((9, 9, 494)) + 0.1
+    s2map = dict(coordinate_system=[['x', [-60, 60, 9]], ['y', [-60, 60, 9]]], map=m)
+    plain = Resource(xenonnt_test_config(s2_pattern_map=s2map, s2_mean_area_fraction_top=-1))
+    scaled = Resource(xenonnt_test_config(s2_pattern_map=s2map, s2_mean_area_fraction_top=0.7))
+    a, b = np.array(plain.s2_pattern_map.data['map']), np.array(scaled.s2_pattern_map.data['map'])
+    aft = (b[..., :253].sum(-1) / b.sum(-1)).mean()
+    assert abs(aft - 0.7) < 0.01 and not np.allclose(a, b)
+    orig = (a[..., :253].sum(-1) / a.sum(-1)).mean()
+    assert np.allclose(b[..., :253], a[..., :253] * 0.7 / orig) and np.allclose(b[..., 253:], a[..., 253:] * 0.3 / (1 - orig))
+    pos = np.array([[3.0, -7.0]])
+    assert scaled.s2_pattern_map(pos).shape == (1, 494)
+
+
+def test_correction_maps_derived_from_the_pattern_maps():
+    """load_resource.py:242-284: without explicit maps the S1 light-yield map is the pattern summed over the live PMTs, the
+    S2 correction map the summed pattern divided by its median"""
+    rng = np.random.default_rng(13)
+    s2map = dict(coordinate_system=[['x', [-60, 60, 7]], ['y', [-60, 60, 7]]], map=rng.random((7, 7, 494)) + 0.1)
+    s1map = dict(coordinate_system=[['x', [-60, 60, 4]], ['y', [-60, 60, 4]], ['z', [-100, 0, 5]]], map=0.001 * (rng.random((4, 4, 5, 494)) + 0.1))
+    cfg = xenonnt_test_config(s1_pattern_map=s1map, s2_pattern_map=s2map, s1_lce_correction_map=None, s2_correction_map=None,
+                              s2_mean_area_fraction_top=-1)
+    cfg['gains'] = np.array(cfg['gains'], dtype=np.float64); cfg['gains'][10] = 0
+    res = Resource(cfg)
+    live = np.arange(494) != 10
+    node = np.array([[-60.0, -60.0, -100.0]])
+    assert np.allclose(res.s1_lce_correction_map(node), s1map['map'][0, 0, 0, live].sum(), rtol=1e-4)
+    tot = s2map['map'][..., live].sum(-1)
+    assert np.allclose(res.s2_correction_map(np.array([[-60.0, -60.0]])), tot[0, 0] / np.median(tot), rtol=1e-4)
+    ins = _s2(4, seed=2)
+    ins['type'][:2] = 1
+    ip = instruction_params(ins, cfg, res)
+    assert np.all(ip['p_hit'] > 0) and np.all(ip['sc_gain'][2:] > 0)

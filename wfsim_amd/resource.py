@@ -91,8 +91,42 @@ class Resource:
         pmt_mask = np.asarray(c['gains']) > 0
         self.s1_pattern_map = make_patternmap(c['s1_pattern_map'], pmt_mask=pmt_mask)
         self.s2_pattern_map = make_patternmap(c['s2_pattern_map'], pmt_mask=pmt_mask)
-        self.s1_lce_correction_map = make_map(c.get('s1_lce_correction_map', ['constant dummy', 1, []]))
-        self.s2_correction_map = make_map(c.get('s2_correction_map', ['constant dummy', 1, []]))
+        # target mean area fraction top of the S2 pattern (load_resource.py:255-272): top and bottom arrays are rescaled
+        # separately so that the total efficiency is preserved; a dummy map is left alone
+        aft = c.get('s2_mean_area_fraction_top', -1)
+        if aft is not None and aft >= 0.0 and hasattr(self.s2_pattern_map, 'data'):
+            from .itp_map import InterpolatingMap
+            data = dict(self.s2_pattern_map.data)
+            m = np.array(data['map'], dtype=np.float64)
+            n_top = c['n_top_pmts']
+            top, tot = m[..., 0:n_top].sum(axis=-1), m.sum(axis=-1)
+            orig_aft = np.mean((top / np.where(tot > 0, tot, 1))[tot > 0.0])
+            m[..., 0:n_top] *= aft / orig_aft
+            m[..., n_top:c['n_tpc_pmts']] *= (1 - aft) / (1 - orig_aft)
+            data['map'] = m
+            self.s2_pattern_map = InterpolatingMap(data, method=self.s2_pattern_map.method)
+        # light-yield / S2 correction maps: the given ones, else derived from the pattern maps (load_resource.py:242-284)
+        from .itp_map import InterpolatingMap
+
+        def summed(pm, normalise):
+            data = dict(pm.data)
+            m = np.sum(np.array(data['map'], dtype=np.float64), axis=-1, keepdims=True, where=pmt_mask)
+            if normalise:
+                m = m / np.median(m[m > 0])
+            data['map'] = m
+            return InterpolatingMap(data, method=pm.method)
+        if c.get('s1_lce_correction_map'):
+            self.s1_lce_correction_map = make_map(c['s1_lce_correction_map'])
+        elif hasattr(self.s1_pattern_map, 'data'):
+            self.s1_lce_correction_map = summed(self.s1_pattern_map, False)
+        else:
+            self.s1_lce_correction_map = make_map(['constant dummy', 1, []])
+        if c.get('s2_correction_map'):
+            self.s2_correction_map = make_map(c['s2_correction_map'])
+        elif hasattr(self.s2_pattern_map, 'data'):
+            self.s2_correction_map = summed(self.s2_pattern_map, True)
+        else:
+            self.s2_correction_map = make_map(['constant dummy', 1, []])
         self.se_gain_map = make_map(c.get('se_gain_map', ['constant dummy', 1, []]))
         efd = c.get('enable_field_dependencies', {})
         if any(efd.values()):
