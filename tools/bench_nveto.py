@@ -1,7 +1,6 @@
 """Side benchmark: BASELINE config[4] shape -- nVeto optical instructions at ~1 MHz, ~10 photons each, 120 channels.
 Reports sustained instructions/s through RawDataOptical.iter_windows (host scheduling + GPU) -- not the headline metric."""
 import os, sys, time
-import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wfsim_amd
 from tests.test_gpu_optical import nveto_config, optical_instructions

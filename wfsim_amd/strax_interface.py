@@ -6,12 +6,11 @@ attributes, same record layout and chunk boundaries.  The instruction readers th
 (rand_instructions, epix, read_optical) are out of scope; CSV input is kept.
 """
 import logging
-
 import os
 
 import numpy as np
 
-from .dtypes import (instruction_dtype, optical_extra_dtype, truth_extra_dtype, extra_truth_dtype_per_pmt,
+from .dtypes import (instruction_dtype, optical_extra_dtype, extra_truth_dtype_per_pmt,
                      raw_record_dtype, DEFAULT_RECORD_LENGTH)
 from .rawdata import RawData, RawDataOptical
 
