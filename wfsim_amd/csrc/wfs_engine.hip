@@ -1182,11 +1182,8 @@ int wfs_copy_groups(wfs_handle *h, int64_t *left, int64_t *right, int64_t *first
     if (left) HIPCHK(hipMemcpy(left, h->grp_left.p, (size_t)G * 8, hipMemcpyDeviceToHost));
     if (right) HIPCHK(hipMemcpy(right, h->grp_right.p, (size_t)G * 8, hipMemcpyDeviceToHost));
     if (ix_rand) HIPCHK(hipMemcpy(ix_rand, h->grp_ixrand.p, (size_t)G * 8, hipMemcpyDeviceToHost));
-    if (first_record) {
-        std::vector<i64> ro((size_t)(h->n_clusters + 1) * h->dev.row_slots + 1);
-        HIPCHK(hipMemcpy(ro.data(), h->rec_off.p, ro.size() * 8, hipMemcpyDeviceToHost));
-        for (i64 g = 0; g < G; g++) first_record[g] = ro[(size_t)g * h->dev.row_slots];
-    }
+    if (first_record && G > 0)      // rec_off[g * row_slots]: a strided copy of one value per window (the whole array is 6 KB per cluster)
+        HIPCHK(hipMemcpy2D(first_record, 8, h->rec_off.p, (size_t)h->dev.row_slots * 8, 8, (size_t)G, hipMemcpyDeviceToHost));
     return WFS_OK;
 }
 
