@@ -163,3 +163,32 @@ def test_synchronise_timing_of_tpc_and_nveto():
     assert np.array_equal(b['time'], [slot[g] for g in nv['g4id']])
     a2, b2, t2 = synchronise_timing(dict(cfg, entry_stop=None), tpc, nv)
     assert np.array_equal(t, t2)                                     # seeded by the config
+
+
+def test_read_optical_events_thins_by_quantum_efficiency():
+    """read_optical behind the ROOT reader (strax_interface.py:235-333): entry selection, nVeto QE thinning per photon,
+    0-based channels, _first / _last ranges, times moved to the first photon"""
+    from wfsim_amd.optical import read_optical_events
+    rng = np.random.default_rng(5)
+    n_ev = 300
+    nph = rng.poisson(40, n_ev)
+    events = dict(eventid=np.arange(100, 100 + n_ev),
+                  pmthitID=[rng.integers(1995, 2125, k) for k in nph],             # a few outside the nVeto range
+                  pmthitTime=[np.sort(rng.exponential(80e-9, k)) + 1e-6 for k in nph],
+                  pmthitEnergy=[np.full(k, 1239.841984 / 400.0) for k in nph],      # 400 nm
+                  xp_pri=rng.uniform(-500, 500, n_ev), yp_pri=rng.uniform(-500, 500, n_ev), zp_pri=rng.uniform(-900, 0, n_ev))
+    qe = dict(nv_pmt_qe_wavelength=[300.0, 400.0, 500.0], nv_pmt_qe={str(c): [10.0, 30.0, 10.0] for c in range(2000, 2120)})
+    cfg = dict(detector='XENONnT_neutron_veto', channel_map=dict(nveto=(2000, 2119)), entry_start=150, entry_stop=None, seed=3, nv_pmt_ce_factor=0.5)
+    ins, channels, timings = read_optical_events(cfg, events, qe_data=qe)
+    assert cfg['entry_stop'] == 400 and len(ins) >= 250 and np.all(ins['g4id'] >= 150)
+    assert channels.min() >= 0 and channels.max() <= 119 and len(channels) == len(timings)
+    kept = len(channels) / sum(len(h[(h >= 2000) & (h <= 2119)]) for h in events['pmthitID'][50:])
+    assert abs(kept - 0.15) < 0.01                                     # QE 30 % x CE 0.5
+    first = ins[ins['_last'] > ins['_first']]
+    assert np.all(timings[first['_first'][:250]] >= 0) and np.all(first['time'][:250] >= 1000)      # time = first photon (>= 1 us)
+    assert np.all(np.diff(ins['_first'][:250]) >= 0) and ins['_last'][249] <= len(channels)
+    # TPC flavour: no thinning
+    tcfg = dict(detector='XENONnT', entry_start=0, entry_stop=None)
+    ev2 = dict(events, pmthitID=[rng.integers(0, 494, k) for k in nph])
+    ins2, ch2, t2 = read_optical_events(tcfg, ev2)
+    assert len(ch2) == nph.sum() and np.array_equal((ins2['_last'] - ins2['_first'])[:n_ev], nph)

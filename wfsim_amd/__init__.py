@@ -10,7 +10,7 @@ from .dtypes import (instruction_dtype, optical_extra_dtype, truth_extra_dtype, 
 from .resource import DummyMap, make_map, Resource  # noqa: F401
 from .config import load_fax_config, xenonnt_test_config, kernel_params  # noqa: F401
 from .rawdata import RawData, RawDataOptical, PULSE_TYPE_NAMES  # noqa: F401
-from .optical import optical_adjustment  # noqa: F401
+from .optical import optical_adjustment, read_optical, read_optical_events  # noqa: F401
 from .strax_interface import (ChunkRawRecords, SimulatorPlugin, RawRecordsFromFaxNT, RawRecordsFromFax1T,  # noqa: F401
                               RawRecordsFromFaxOpticalNT, RawRecordsFromFaxnVeto, RawRecordsFromMcChain,
                               synchronise_timing, instruction_from_csv)

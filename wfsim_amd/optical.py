@@ -51,3 +51,76 @@ def optical_adjustment(instructions, timings, channels):
     if extra:
         instructions = np.append(instructions, np.array(extra, dtype=instructions.dtype))
     return instructions
+
+
+def nveto_qe_table(qe_data, nveto_channels):
+    """(channel, wavelength in nm) -> quantum efficiency in percent, interpolated to every nm below 1000
+    (strax_interface.py:251-266); ``qe_data``: dict(nv_pmt_qe_wavelength=[...], nv_pmt_qe={str(channel): [...]}) or None
+    (all 100 %)"""
+    if qe_data is None:
+        return np.ones([len(nveto_channels), 1000]) * 100
+    from scipy.interpolate import interp1d
+    out = np.zeros([len(nveto_channels), 1000])
+    for ich, channel in enumerate(nveto_channels):
+        out[ich] = interp1d(qe_data['nv_pmt_qe_wavelength'], qe_data['nv_pmt_qe'][str(channel)], bounds_error=False,
+                            kind='linear', fill_value=(0, 0))(np.arange(1000))
+    return out
+
+
+def read_optical_events(config, events, qe_data=None, rng=None):
+    """``read_optical`` (strax_interface.py:282-333, 235-279) behind the ROOT reader: ``events`` holds what the reference
+    takes from the Geant4 tree -- ``eventid`` [n], per-event arrays ``pmthitID``, ``pmthitTime`` (s), ``pmthitEnergy``
+    (eV, nVeto only), and ``xp_pri`` / ``yp_pri`` / ``zp_pri`` (mm).  Selects the entries, applies the nVeto quantum /
+    collection efficiency thinning (a uniform draw per photon, here from ``rng``), builds the optical instructions and
+    runs ``optical_adjustment``.  Returns (instructions, channels, timings)."""
+    from .dtypes import instruction_dtype, optical_extra_dtype
+    g4id = np.asarray(events['eventid'])
+    if config.get('entry_stop', None) is None:
+        config['entry_stop'] = int(np.max(g4id)) + 1
+    mask = (g4id < config.get('entry_stop', int(2 ** 63 - 1))) & (g4id >= config.get('entry_start', 0))
+    sel = np.where(mask)[0]
+    n_events = len(sel)
+    hit_id = [np.asarray(events['pmthitID'][i]) for i in sel]
+    channels = np.hstack(hit_id).astype(np.int64) if n_events else np.zeros(0, np.int64)
+    timings = np.hstack([np.asarray(events['pmthitTime'][i]) * 1e9 for i in sel]).astype(np.int64) if n_events else np.zeros(0, np.int64)
+    lengths = np.array([len(h) for h in hit_id], dtype=np.int64)
+    if config['detector'] == 'XENONnT_neutron_veto':
+        lo, hi = config['channel_map']['nveto']
+        nveto_channels = np.arange(lo, hi + 1)
+        wavelengths = np.hstack([1239.841984 / np.asarray(events['pmthitEnergy'][i], dtype=np.float64) for i in sel])   # h * c / E, nm
+        qe = nveto_qe_table(qe_data, nveto_channels)
+        hit_mask = (channels >= nveto_channels[0]) & (channels <= nveto_channels[-1])
+        channels[~hit_mask] = nveto_channels[0]
+        wavelengths[(wavelengths < 0) | (wavelengths >= 999)] = 0
+        qes = qe[channels - nveto_channels[0], np.around(wavelengths).astype(np.int64)]
+        rng = rng or np.random.default_rng(int(config.get('seed', 0) or 0))
+        hit_mask &= rng.random(len(qes)) <= qes * config.get('nv_pmt_ce_factor', 1.0) / 100
+        ends = np.cumsum(lengths)
+        csum = np.concatenate([[0], np.cumsum(hit_mask)])
+        amplitudes = csum[ends] - csum[ends - lengths]
+        channels, timings = channels[hit_mask] - lo, timings[hit_mask]         # shifted to 0-based for the simulation
+    else:
+        amplitudes = lengths
+    ins = np.zeros(n_events, dtype=instruction_dtype + optical_extra_dtype)
+    for f, k in (('x', 'xp_pri'), ('y', 'yp_pri'), ('z', 'zp_pri')):
+        ins[f] = np.asarray(events[k]).flatten()[mask] / 10.
+    ins['event_number'] = np.arange(n_events)
+    ins['g4id'] = g4id[mask]
+    ins['type'] = 1
+    ins['recoil'] = 1
+    ins['_first'] = np.cumsum(amplitudes) - amplitudes
+    ins['_last'] = np.cumsum(amplitudes)
+    ins = optical_adjustment(ins, timings, channels)
+    return ins, channels, timings
+
+
+def read_optical(config):
+    """strax_interface.py:282-333: the Geant4 optical file named by ``config['fax_file']`` -> (instructions, channels,
+    timings).  Needs ``uproot`` for the ROOT file; everything behind the reader is ``read_optical_events``."""
+    try:
+        import uproot
+    except ImportError as e:
+        raise NotImplementedError('read_optical needs uproot to open the Geant4 file; pass the event arrays to read_optical_events') from e
+    events = uproot.open(config['fax_file']).get('events')
+    keys = ['eventid', 'pmthitID', 'pmthitTime', 'xp_pri', 'yp_pri', 'zp_pri'] + (['pmthitEnergy'] if config['detector'] == 'XENONnT_neutron_veto' else [])
+    return read_optical_events(config, {k: events[k].array(library='np') for k in keys}, qe_data=config.get('nv_pmt_qe_data'))

@@ -449,7 +449,9 @@ class RawRecordsFromFaxOpticalNT(RawRecordsFromFaxNT):
     def get_instructions(self):
         c = self.config
         if c.get('instructions') is None or c.get('channels') is None or c.get('timings') is None:
-            raise NotImplementedError('read_optical needs uproot (SURVEY.md 2.1 row 7): pass instructions, channels, timings')
+            from .optical import read_optical            # strax_interface.py:728: needs uproot for the Geant4 file
+            self.instructions, self.channels, self.timings = read_optical(c)
+            return
         self.instructions = np.asarray(c['instructions'])
         self.channels, self.timings = np.asarray(c['channels']), np.asarray(c['timings'])
 
