@@ -179,8 +179,13 @@ def test_simulate_sharded_single_rank_equals_rawdata():
     import torch.distributed as dist
     import wfsim_amd
     from wfsim_amd.distributed import simulate_sharded
+    import socket
     cfg, ins, ap = _random_case(1234)
-    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:29541', rank=0, world_size=1)
+    sock = socket.socket()
+    sock.bind(('127.0.0.1', 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
     try:
         rec = simulate_sharded(cfg, ins, device=0)
     finally:
