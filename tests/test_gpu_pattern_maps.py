@@ -173,3 +173,26 @@ def test_field_distortion_positions_reach_the_device_map():
     t2 = t[t['type'] == 2]
     assert len(t2) > 5 and np.allclose(np.hypot(t2['x_mean_electron'], t2['y_mean_electron']), 0.8 * np.hypot(t2['x'], t2['y']), rtol=1e-4)
     assert np.all(np.isnan(t[t['type'] == 1]['x_mean_electron']))
+
+
+def test_foreign_interpolating_map_objects_are_recognised():
+    """an object that merely looks like straxen.InterpolatingMap (callable with a .data dict on a regular grid) also goes to
+    the device"""
+    cfg = map_config(8, seed=3)
+    res = Resource(cfg)
+
+    class Foreign:                       # what wfsim.load_config(...).s2_pattern_map is: data + __call__
+        def __init__(self, m):
+            self.data, self._m = m.data, m
+
+        def __call__(self, *a, **k):
+            return self._m(*a, **k)
+    res.s1_pattern_map, res.s2_pattern_map = Foreign(res.s1_pattern_map), Foreign(res.s2_pattern_map)
+    eng = make_engine(cfg, resource=res)
+    assert eng.device_maps == {'s1', 's2'}
+    ins = instructions(50, 3)
+    order, key, cluster = schedule(ins, cfg)
+    eng.load_instructions(ins[order], order.astype(np.uint32), cluster, key, instruction_params(ins[order], cfg, res, device_maps=eng.device_maps))
+    row, table = eng.cdf_rows()
+    host = instruction_params(ins[order], cfg, res)
+    assert np.allclose(np.diff(table[row], axis=1, prepend=0.0), np.diff(host['cdf_table'][host['cdf_row']], axis=1, prepend=0.0), rtol=1e-6, atol=1e-12)

@@ -123,7 +123,14 @@ class Engine:
             from .itp_map import InterpolatingMap
             for which, (kind, dims) in enumerate([('s1', 3), ('s2', 2)], start=1):
                 pm = getattr(resource, kind + '_pattern_map', None)
-                if not (isinstance(pm, InterpolatingMap) and pm.grid is not None and pm.dimensions == dims
+                if not isinstance(pm, InterpolatingMap):
+                    # a straxen.InterpolatingMap handed over from the reference's own Resource: same data dict
+                    data = getattr(pm, 'data', None)
+                    csys = data.get('coordinate_system') if isinstance(data, dict) else None
+                    if not (csys and isinstance(csys[0], (list, tuple)) and isinstance(csys[0][0], str) and 'map' in data):
+                        continue
+                    pm = InterpolatingMap({k: data[k] for k in ('coordinate_system', 'map')}, method=getattr(pm, 'method', 'WeightedNearestNeighbors'))
+                if not (pm.grid is not None and pm.dimensions == dims
                         and pm.method == 'WeightedNearestNeighbors' and pm.map_names == ['map']):
                     continue
                 grid, vals = pm.regular_grid()
