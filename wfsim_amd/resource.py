@@ -104,7 +104,7 @@ class Resource:
             m[..., 0:n_top] *= aft / orig_aft
             m[..., n_top:c['n_tpc_pmts']] *= (1 - aft) / (1 - orig_aft)
             data['map'] = m
-            self.s2_pattern_map = InterpolatingMap(data, method=self.s2_pattern_map.method)
+            self.s2_pattern_map = InterpolatingMap(data, method=getattr(self.s2_pattern_map, 'method', 'WeightedNearestNeighbors'))
         # light-yield / S2 correction maps: the given ones, else derived from the pattern maps (load_resource.py:242-284)
         from .itp_map import InterpolatingMap
 
@@ -114,7 +114,7 @@ class Resource:
             if normalise:
                 m = m / np.median(m[m > 0])
             data['map'] = m
-            return InterpolatingMap(data, method=pm.method)
+            return InterpolatingMap(data, method=getattr(pm, 'method', 'WeightedNearestNeighbors'))
         if c.get('s1_lce_correction_map'):
             self.s1_lce_correction_map = make_map(c['s1_lce_correction_map'])
         elif hasattr(self.s1_pattern_map, 'data'):
