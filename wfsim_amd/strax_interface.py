@@ -26,6 +26,23 @@ except ImportError:                     # pragma: no cover - depends on the envi
 log = logging.getLogger('wfsim_amd.interface')
 
 
+def _copy_records(src, threads=4, min_records=200_000):
+    """a copy of a large record array made by a few threads (numpy releases the GIL while copying): the chunks the plugin
+    hands to strax are copies of the record buffer, 0.6 GB per headline batch"""
+    n = len(src)
+    if n < min_records:
+        return src.copy()
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty_like(src)
+    cuts = np.linspace(0, n, threads + 1).astype(np.int64)
+
+    def part(k):
+        out[cuts[k]:cuts[k + 1]] = src[cuts[k]:cuts[k + 1]]
+    with ThreadPoolExecutor(threads) as pool:
+        list(pool.map(part, range(threads)))
+    return out
+
+
 def instruction_from_csv(filename):
     """strax_interface.py:336-350"""
     import pandas as pd
@@ -267,14 +284,14 @@ class ChunkRawRecords(object):
 
         det = self.config['detector']
         if det == 'XENON1T' or det == 'XENONnT_neutron_veto':
-            yield dict(raw_records=records.copy() if maska is None else records, truth=_truth)
+            yield dict(raw_records=_copy_records(records) if maska is None else records, truth=_truth)
         elif det == 'XENONnT':
             he = self.config['channel_map']['he']
             engine = getattr(self.rawdata, 'engine', None)
             if maska is None and engine is not None and not engine.emits_he_records:
                 # every record is a TPC record (no HE rows are digitised, row 800 is never emitted): one plain copy
                 empty = records[:0].copy()
-                yield dict(raw_records=records.copy(), raw_records_he=empty, raw_records_aqmon=empty.copy(), truth=_truth)
+                yield dict(raw_records=_copy_records(records), raw_records_he=empty, raw_records_aqmon=empty.copy(), truth=_truth)
             else:
                 yield dict(raw_records=records[records['channel'] < he[0]],
                            raw_records_he=records[(records['channel'] >= he[0]) & (records['channel'] <= he[-1])],
