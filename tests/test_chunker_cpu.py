@@ -192,3 +192,17 @@ def test_read_optical_events_thins_by_quantum_efficiency():
     ev2 = dict(events, pmthitID=[rng.integers(0, 494, k) for k in nph])
     ins2, ch2, t2 = read_optical_events(tcfg, ev2)
     assert len(ch2) == nph.sum() and np.array_equal((ins2['_last'] - ins2['_first'])[:n_ev], nph)
+
+
+def test_instruction_from_csv_round_trip(tmp_path):
+    """strax_interface.py:336-350: columns named after instruction_dtype fields; missing columns stay zero"""
+    import pandas as pd
+    from wfsim_amd import instruction_from_csv
+    from wfsim_amd.dtypes import instruction_dtype
+    ins = np.zeros(6, dtype=instruction_dtype)
+    ins['type'], ins['time'], ins['amp'] = [1, 2] * 3, 1_000_000 * np.repeat([1, 2, 3], 2), [500, 40] * 3
+    ins['x'], ins['z'], ins['recoil'], ins['event_number'] = 1.5, -20.25, 7, np.repeat([0, 1, 2], 2)
+    path = str(tmp_path / 'ins.csv')
+    pd.DataFrame({k: ins[k] for k in ('event_number', 'type', 'time', 'x', 'z', 'amp', 'recoil')}).to_csv(path, index=False)
+    got = instruction_from_csv(path)
+    assert got.dtype == np.dtype(instruction_dtype) and np.array_equal(got, ins)

@@ -288,3 +288,25 @@ def test_xenon1t_detector_through_the_1t_plugin():
     rr = np.concatenate([c.data for c in out['raw_records']])
     assert len(rr) == len(rec) and np.all(np.diff(rr['time']) >= 0)
     assert len(np.concatenate([c.data for c in out['truth']])) == len(ins)
+
+
+def test_config3_shape_csv_instructions_afterpulses_noise(tmp_path):
+    """BASELINE configs[3] on one GPU: mixed S1+S2 instructions from a CSV file through RawRecordsFromFaxNT with PMT
+    afterpulses and noise on; the same records as RawData on the in-memory instructions"""
+    import pandas as pd
+    from tests.helpers import ap_tables_from_golden, golden
+    ins = _s1_instructions()[:60]
+    ins['type'][1::2] = 2
+    ins['amp'][1::2] = 80
+    path = str(tmp_path / 'instructions.csv')
+    pd.DataFrame({k: ins[k] for k in ins.dtype.names}).to_csv(path, index=False)
+    cfg = xenonnt_test_config(seed=21, chunk_size=0.02, enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap_tables_from_golden(),
+                              enable_noise=True, noise_data=golden('noise.npz')['noise'], fax_file=path)
+    out = ministrax.run_plugin(wfsim_amd.RawRecordsFromFaxNT(cfg))
+    rr = np.concatenate([c.data for c in out['raw_records']] + [c.data for c in out['raw_records_he']])
+    ref = np.concatenate([w['records'] for w in wfsim_amd.RawData(cfg).iter_windows(ins)])
+    assert len(rr) == len(ref) > 500
+    a = rr[np.lexsort((rr['channel'], rr['time']))]
+    b = ref[np.lexsort((ref['channel'], ref['time']))]
+    assert a.tobytes() == b.tobytes()
+    assert len(np.concatenate([c.data for c in out['truth']])) == len(ins)
