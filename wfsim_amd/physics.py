@@ -178,55 +178,52 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
     drift_spread = np.zeros(n)
     sc_gain = np.zeros(n)
     n_ch = config['n_tpc_pmts']
-    const_rows = {}
     rows = []
     cdf_row = np.zeros(n, dtype=np.int32)
     pattern_xy = np.array([instructions['x'], instructions['y']], dtype=np.float64).T      # where the pattern map is evaluated
+    outside = np.zeros(n, dtype=bool)         # S2 positions without a pattern (s2.py:598, see s2_channel_probabilities)
     for sel, kind in ((is_s1, 's1'), (is_s2, 's2')):
         if not sel.any():
             continue
         ins = instructions[sel]
+        idx = np.where(sel)[0]
         if kind == 's1':
             p_hit[sel] = s1_hit_probability(ins, config, resource)
             pmap = resource.s1_pattern_map
-            probs = (lambda q: s1_channel_probabilities(q, config, resource))
+
+            def probs(k):                      # channel probabilities of the first k instructions of this kind
+                return s1_channel_probabilities(ins[:k], config, resource)
+            per_instruction = False
         else:
-            x, y, z = ins['x'], ins['y'], ins['z']
-            xy = np.array([x, y]).T
+            xy = np.array([ins['x'], ins['y']]).T
             # survival and drift use the true position, the S2 maps (correction, gain, pattern) the observed one (s2.py:81-103)
-            _, xy_obs = s2_observed_positions(ins, config, resource)
-            distorted = config.get('field_distortion_model', 'none') in ('inverse_fdc', 'comsol')
-            if not distorted:
-                xy_obs = xy
+            xy_obs = s2_observed_positions(ins, config, resource)[1] if config.get('field_distortion_model', 'none') in ('inverse_fdc', 'comsol') else xy
             pattern_xy[sel] = xy_obs
-            p_hit[sel] = s2_electron_survival(z, xy, xy_obs, config, resource)
-            m, s = s2_drift_time_params(z, xy, config, resource)
-            drift_mean[sel], drift_spread[sel] = m, s
+            p_hit[sel] = s2_electron_survival(ins['z'], xy, xy_obs, config, resource)
+            drift_mean[sel], drift_spread[sel] = s2_drift_time_params(ins['z'], xy, config, resource)
             sc_gain[sel] = s2_secondary_gain(xy_obs, config, resource)
             pmap = resource.s2_pattern_map
             sel_gids = None if gids is None else np.asarray(gids)[sel]
-            probs = (lambda q, xy_obs=xy_obs: s2_channel_probabilities(xy_obs[:len(q)], config, resource, sel_gids))
-        idx = np.where(sel)[0]
+
+            def probs(k):
+                return s2_channel_probabilities(xy_obs[:k], config, resource, None if sel_gids is None else sel_gids[:k])
+            if config.get('diffusion_constant_transverse', 0) > 0:
+                outside[idx] = np.sum(np.asarray(xy_obs, dtype=np.float64) ** 2, axis=1) > config['tpc_radius'] ** 2
+            per_instruction = config.get('s2_aft_sigma', 0.0) != 0 or bool(outside[idx].any())
         if kind in device_maps and not (kind == 's2' and config.get('s2_aft_sigma', 0.0) != 0):
-            cdf_row[idx] = -1
-            if kind == 's2' and config.get('diffusion_constant_transverse', 0) > 0:         # s2.py:598, see s2_channel_probabilities
-                p_hit[idx[np.sum(pattern_xy[idx] ** 2, axis=1) > config['tpc_radius'] ** 2]] = 0.0
-            continue
-        per_instruction = kind == 's2' and (config.get('s2_aft_sigma', 0.0) != 0 or (
-            config.get('diffusion_constant_transverse', 0) > 0 and np.any(np.sum(pattern_xy[idx] ** 2, axis=1) > config['tpc_radius'] ** 2)))
-        if isinstance(pmap, DummyMap) and not per_instruction:
-            const_rows[kind] = len(rows)
-            rows.append(choice_cdf(probs(ins[:1]))[0])
-            cdf_row[idx] = const_rows[kind]
+            cdf_row[idx] = -1                  # the row comes from the device map; instructions without a pattern make no photons
+            p_hit[idx[outside[idx]]] = 0.0
+        elif isinstance(pmap, DummyMap) and not per_instruction:
+            cdf_row[idx] = len(rows)           # a constant map: one shared row
+            rows.append(choice_cdf(probs(1))[0])
         else:
-            p = probs(ins)
+            p = probs(len(ins))
             empty = p.sum(axis=1) == 0          # no pattern (all PMTs off / outside the TPC): the instruction makes no photons
             if empty.any():
                 p[empty] = 1.0
                 p_hit[idx[empty]] = 0.0
-            cdf = choice_cdf(p)
             cdf_row[idx] = len(rows) + np.arange(len(idx))
-            rows.extend(list(cdf))
+            rows.extend(list(choice_cdf(p)))
     cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.ones((1, n_ch))
     return dict(p_hit=p_hit, drift_mean=drift_mean, drift_spread=drift_spread, sc_gain=sc_gain,
                 cdf_row=cdf_row, cdf_table=cdf_table, pattern_xy=pattern_xy)
