@@ -176,6 +176,9 @@ class Oracle:
             lib().orc_set_instruction_models(self._s, C.c_int64(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0), C.c_void_p(0))
             return
         self._im = self._models.instruction_tables(instructions, gid)       # kept alive: the C side keeps the pointers
+        if getattr(self._models, 'per_batch', False):
+            base, off, pmf, vmin = self._models.table_arrays()
+            lib().orc_set_delay_models(self._s, C.c_int32(len(base)), _p(base), _p(off), _p(pmf), _p(vmin))
         lib().orc_set_instruction_models(self._s, C.c_int64(len(instructions)), *[_p(x) for x in self._im])
 
     def simulate(self, instructions, gid, ip, em_base=None):

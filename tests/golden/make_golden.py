@@ -641,6 +641,15 @@ def fixture_model_distributions(ref):
             np.random.seed(9300 + ch)
             t = s2.photon_timings(xy, np.array([n]), np.zeros(1, dtype=np.int64), np.array([n]), np.full(n, ch), 'gas', cfg, s2.resource)
             out[f's2_{tag}_{side}_v'], out[f's2_{tag}_{side}_c'] = hist(t + tts(cfg, n))
+    # S2 'simple' luminescence with gas gap warping (s2.py:360-378): the gas gap comes from a map of the position
+    cfg = base_config(enable_gas_gap_warping=True, s2_time_model='zero_delay')
+    ref.load_resource._cached_configs.clear()
+    s2 = ref.s2.S2(base_config())
+    s2.resource.gas_gap_length = lambda xy: 0.25 + 0.0004 * xy[:, 0]
+    for tag, x in [('narrow', -20.0), ('wide', 30.0)]:
+        np.random.seed(9400 + int(x))
+        t = s2.photon_timings(np.array([[x, 0.0]]), np.array([n]), np.zeros(1, dtype=np.int64), np.array([n]), np.full(n, 5), 'gas', cfg, s2.resource)
+        out[f's2_warp_{tag}_v'], out[f's2_warp_{tag}_c'] = hist(t + tts(cfg, n))
     np.savez_compressed(HERE + '/dists_models.npz', **out)
 
 

@@ -146,3 +146,19 @@ def test_interpolating_map_methods():
             json.dump(data, f)
         from wfsim_amd.resource import make_map
         assert np.allclose(make_map(path)(np.array([[0.1, 0.2]])), out[0])
+
+
+@pytest.mark.parametrize('tag,x', [('narrow', -20.0), ('wide', 30.0)])
+def test_gas_gap_warping_tables(tag, x):
+    """enable_gas_gap_warping (s2.py:360-378): one luminescence table per gas gap, i.e. per position"""
+    d = golden('dists_models.npz')
+    cfg = dict(xenonnt_test_config(enable_gas_gap_warping=True, gas_gap_map=(lambda xy: 0.25 + 0.0004 * xy[:, 0]), s2_time_model='zero_delay'), seed=80)
+    res = Resource(cfg)
+    orc = make_oracle(cfg, resource=res)
+    models = DelayModels(cfg, res)
+    assert models.per_batch
+    ins = np.concatenate([one_instruction(2, x=x), one_instruction(2, x=x), one_instruction(2, x=0.0), one_instruction(1)])
+    tab, tabb, zi, zf = models.instruction_tables(ins)
+    assert tab[0] == tab[1] != tab[2] and tab[3] == -1 and np.array_equal(tab, tabb)
+    orc.set_delay_models(models)                     # the tables of this batch
+    _check(d, 's2_warp_' + tag, orc.sample_delay(N, True, tab=int(tab[0])))

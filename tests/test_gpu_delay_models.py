@@ -30,6 +30,8 @@ def _case(seed):
               seed=int(rng.integers(1, 10 ** 6)), **model_resources(d))
     if kw['s1_model_type'] == 'simple' and (lum, tm) == ('simple', 's2_time_spread around zero'):
         kw['s1_model_type'] = 'custom'          # never the all-default combination
+    if lum == 'simple' and seed % 3 == 1:          # gas gap warping: a luminescence table per position (s2.py:360-378)
+        kw.update(enable_gas_gap_warping=True, gas_gap_map=(lambda xy: 0.255 + 0.0003 * xy[:, 0] - 0.0002 * xy[:, 1]))
     if rng.random() < 0.4:
         kw['save_full_truth'] = False
     ap = ap_tables_from_golden() if rng.random() < 0.4 else None

@@ -64,9 +64,6 @@ def kernel_params(config):
         if c.get('s2_luminescence_model') == 'garfield_gas_gap':
             raise NotImplementedError('s2_luminescence_model "garfield_gas_gap" is outside the MI355X hot path (delay_models.py)')
         raise KeyError(f"{c['s2_luminescence_model']} is not valid! Use 'simple' or 'garfield' or 'garfield_gas_gap'")
-    if c.get('enable_gas_gap_warping', False):
-        # s2.py:360-361: a luminescence table per instruction from the gas gap map -- not a fixed set of delay tables
-        raise NotImplementedError('enable_gas_gap_warping is outside the MI355X hot path (one luminescence table per position)')
     # same substring tests, in the same order, as s2.py:539-552; the propagation term itself is a delay table (delay_models.py)
     if 'optical_propagation' in c['s2_time_model'] or 'zero_delay' in c['s2_time_model']:
         s2_time_model = 0

@@ -561,7 +561,7 @@ int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, c
 {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
-    if (n_tables < 0 || n_tables > 4096 || (n_tables > 0 && (!base || !pmf_off || !pmf || !vmin))) return h->fail(WFS_E_INVALID, "wfs_set_delay_models: bad arguments");
+    if (n_tables < 0 || n_tables > 65536 || (n_tables > 0 && (!base || !pmf_off || !pmf || !vmin))) return h->fail(WFS_E_INVALID, "wfs_set_delay_models: bad arguments");
     HIPCHK(hipSetDevice(h->device));
     for (auto &b : h->x_cum) if (b.p) hipFree(b.p);
     for (auto &b : h->x_guide) if (b.p) hipFree(b.p);

@@ -114,6 +114,18 @@ def pmf_piecewise_linear(u, t):
     return Pmf(np.diff(cum, prepend=0.0), lo)
 
 
+def pmf_interp(x, t):
+    """trunc(np.interp(U, x, t)) for increasing x and t (the luminescence quantile table, s2.py:338): P(L <= y) is the inverse
+    of the piecewise linear map, evaluated at the integers; u below x[0] gives t[0] (np.interp clamps)"""
+    x, t = np.asarray(x, dtype=np.float64), np.asarray(t, dtype=np.float64)
+    lo, hi = int(np.floor(t[0])) - 1, int(np.ceil(t[-1])) + 1
+    ks = np.arange(lo, hi + 1)
+    y = np.where(ks >= 0, ks + 1, ks).astype(np.float64)          # trunc(L) <= k  <=>  L < k + 1 (k >= 0), L <= k (k < 0)
+    cum = np.where(y < t[0], 0.0, np.where(y >= t[-1], 1.0, np.interp(y, t, x)))
+    cum[-1] = 1.0
+    return Pmf(np.diff(cum, prepend=0.0), lo)
+
+
 def pmf_samples(values):
     """a value drawn uniformly from ``values`` (already integers)"""
     v = np.asarray(values, dtype=np.int64)
@@ -213,7 +225,18 @@ class DelayModels:
             raise NotImplementedError(f's2_luminescence_model "{lum_model}" is outside the MI355X hot path (delay_models.py)')
         elif s2_prop:
             self.s2_tables = [[self._add(2, s2_prop[0]), self._add(2, s2_prop[1])]]
-        self.active = bool(self.base) or self.s1_prop is not None
+        # gas gap warping (s2.py:360-378): the 'simple' luminescence depends on the gas gap under the instruction -> one table
+        # per S2 instruction, rebuilt for every batch (a functional path: ~1 ms of host work per instruction)
+        self.warp = bool(c.get('enable_gas_gap_warping', False)) and lum_model == 'simple'
+        self._s2_prop = s2_prop
+        self._gas_gap = getattr(resource, 'gas_gap_length', None)
+        if self.warp:
+            assert self._gas_gap is not None, 'enable_gas_gap_warping needs resource.gas_gap_length (config gas_gap_map)'
+            self.s2_tables = None               # the static top / bottom pair is replaced by per-instruction tables
+            self.base, self.pmfs = [b for b, q in zip(self.base, self.pmfs) if b != 2], [q for b, q in zip(self.base, self.pmfs) if b != 2]
+        self._n_static = len(self.base)
+        self.per_batch = self.warp
+        self.active = bool(self.base) or self.s1_prop is not None or self.warp
 
     def _add(self, base, pmf):
         self.base.append(base)
@@ -270,6 +293,20 @@ class DelayModels:
             i = np.clip(np.searchsorted(zg, z) - 1, 0, len(zg) - 2)          # scipy RegularGridInterpolator._find_indices
             zi[is_s1] = i
             zf[is_s1] = (z - zg[i]) / (zg[i + 1] - zg[i])
+        if self.warp and (~is_s1).any():
+            from .tables import luminescence_table
+            del self.base[self._n_static:], self.pmfs[self._n_static:]
+            s2 = np.where(~is_s1)[0]
+            xy = np.array([instructions['x'][s2], instructions['y'][s2]], dtype=np.float64).T
+            gaps = np.asarray(self._gas_gap(xy), dtype=np.float64).reshape(len(s2), -1)[:, 0]
+            if len(np.unique(gaps)) * (2 if self._s2_prop else 1) > 65536 - self._n_static:
+                raise ValueError('enable_gas_gap_warping: more than 65536 delay tables in one batch; lower RawData.max_batch_quanta')
+            made = {}
+            for i, g in zip(s2, gaps):
+                if g not in made:
+                    lum = pmf_interp(*luminescence_table(self.config, gas_gap=float(g)))
+                    made[g] = [self._add(3, lum.conv(p) if p is not None else lum) for p in (self._s2_prop or [None])]
+                tab[i], tabb[i] = made[g][0], made[g][-1]
         if self.s2_tables is not None and (~is_s1).any():
             s2 = np.where(~is_s1)[0]
             rows = self.garfield_rows(instructions[s2], None if gids is None else np.asarray(gids)[s2]) if self.s2_rows is not None else np.zeros(len(s2), dtype=np.int64)

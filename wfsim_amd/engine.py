@@ -193,6 +193,9 @@ class Engine:
         self._n_cdf_rows = a[11].shape[0] + int(np.sum(a[10] < 0))
         if self.models.active:
             tab, tabb, zi, zf = self.models.instruction_tables(ins, gid)
+            if self.models.per_batch:           # tables that depend on the batch (gas gap warping): upload them first
+                base, off, pmf, vmin = self.models.table_arrays()
+                self._check(self.lib.wfs_set_delay_models(self._h, C.c_int32(len(base)), _p(base), _p(off), _p(pmf), _p(vmin)))
             self._check(self.lib.wfs_set_instruction_models(self._h, C.c_int64(n), _p(tab), _p(tabb), _p(zi), _p(zf)))
 
     def cdf_rows(self):
