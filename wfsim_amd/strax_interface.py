@@ -3,7 +3,8 @@
 Drop-in for /root/reference/wfsim/strax_interface.py:353-504 (ChunkRawRecords) and :536-733, :1008-1011 (plugins):
 same constructor, same generator protocol, same ``chunk_time_pre`` / ``chunk_time`` / ``source_finished()``
 attributes, same record layout and chunk boundaries.  The instruction readers that need nestpy / epix / uproot
-(rand_instructions, epix, read_optical) are out of scope; CSV input is kept.
+(rand_instructions, epix, the ROOT reader of read_optical) are out of scope; CSV input is kept and
+read_optical is restated behind its reader (optical.read_optical_events).
 """
 import logging
 import os
@@ -454,7 +455,8 @@ class RawRecordsFromFax1T(RawRecordsFromFaxNT):
 
 class RawRecordsFromFaxOpticalNT(RawRecordsFromFaxNT):
     """strax_interface.py:722-737: photon channels / timings supplied with the instructions (optical Geant4 input).
-    The ROOT reader (read_optical, needs uproot) is out of scope: pass ``instructions``, ``channels``, ``timings``."""
+    Pass ``instructions``, ``channels``, ``timings`` (or a Geant4 file as ``fax_file`` where uproot is installed:
+    optical.read_optical)."""
 
     def _setup(self):
         self.sim = ChunkRawRecords(self.config, rawdata_generator=RawDataOptical, channels=self.channels,
