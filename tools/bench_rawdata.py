@@ -10,7 +10,7 @@ from wfsim_amd.dtypes import instruction_dtype
 which = sys.argv[1] if len(sys.argv) > 1 else 'headline'
 if which == 'headline':
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-    cfg = xenonnt_test_config(s2_secondary_sc_gain=100.0, seed=3, chunk_size=2.0)
+    cfg = xenonnt_test_config(s2_secondary_sc_gain=100.0, seed=3, chunk_size=1.0)
     ins = np.zeros(n, dtype=instruction_dtype)
     ins['type'], ins['z'], ins['amp'], ins['recoil'] = 2, -10.0, 10_000, 7
     ins['time'] = 1_000_000 * (1 + np.arange(n))
@@ -49,6 +49,8 @@ for rep in range(2):
     print(f'RawData.iter_windows: {len(ins)} instructions, {nwin} windows, {nrec} records, {dt * 1e3:.1f} ms')
 for rep in range(2):
     sim = wfsim_amd.ChunkRawRecords(cfg)
+    if os.environ.get('BATCH_QUANTA'):
+        sim.rawdata.max_batch_quanta = int(float(os.environ['BATCH_QUANTA']))
     t0 = time.perf_counter()
     nrec = ntruth = 0
     for chunk in sim(ins):

@@ -15,6 +15,8 @@ GPU (what the in-repo ``ChunkRawRecords`` uses).
 """
 import logging
 
+import os
+
 import numpy as np
 
 from .dtypes import raw_record_dtype
@@ -46,6 +48,8 @@ class RawData:
             self._pi_grid = ea.coarse_delay_grid(self._pi_hist, config)
         self.source_finished = False
         self.left = self.right = 0
+        #: run the kernels of the next batch while the consumer of iter_batches works on the current one
+        self.prefetch = os.environ.get('WFSIM_AMD_PREFETCH', '1') != '0'
         #: run-wide index of every instruction passed to __call__ (RNG stream ids); None: position in the input
         self.global_ids = None
 
@@ -119,15 +123,69 @@ class RawData:
         # smallest key of every cluster (in feedback order the first instruction of a cluster need not carry it)
         cl_start = np.concatenate([[0], np.where(np.diff(cluster) != 0)[0] + 1])
         cl_min_key = np.minimum.reduceat(key, cl_start)
-        a, scale = 0, 1
-        has_pulse, runmax = False, 0         # RawData.last_pulse_end_time over everything emitted so far
-        while a < n:
-            b = self._batch_end(a, est_csum, cluster, scale)
+        st = dict(s_ins=s_ins, gids=gids, order=order, key=key, cluster=cluster, em_base=em_base, est_csum=est_csum,
+                  cl_min_key=cl_min_key, n=n)
+        # the kernels of the next batch run (from a worker thread: the engine calls drop the GIL) while the consumer works on
+        # this one; the engine is only ever used by one thread at a time
+        pool = None
+        if self.prefetch and n > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(1)
+        launched, future = self._launch(st, 0, False, 0), None
+        try:
+            while True:
+                L = launched
+                ins, cl, n_emit, first, nonempty, ins_group, groups = L['ins'], L['cl'], L['n_emit'], L['first'], L['nonempty'], L['ins_group'], L['groups']
+                n_rec = int(first[n_emit])
+                out = record_sink(n_rec) if record_sink is not None else None
+                if out is None:
+                    out = np.empty(n_rec, dtype=raw_record_dtype())
+                records = self.engine.records_into(out, n_rec)
+                keep = np.where(nonempty[:n_emit])[0]
+                # window position of every emitted group: rows of a group go in front of its window, rows of a group without
+                # pulses in front of the next window that has some
+                pos_of_group = np.searchsorted(keep, np.arange(n_emit), side='left')
+                truth_table, truth_rows, truth_before = None, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+                if want_truth:
+                    truth_table = self._truth_rows(ins, cl, L['run_set'])           # one row per run set, in processing order
+                    grp = ins_group[truth_table['first']].astype(np.int64)
+                    truth_rows = np.flatnonzero(grp < n_emit)
+                    truth_before = pos_of_group[grp[truth_rows]] if n_emit else np.zeros(0, dtype=np.int64)
+                batch = dict(left=groups['left'][keep], right=groups['right'][keep],
+                             first=np.append(first[keep], first[n_emit]) if len(keep) else np.array([first[n_emit]]),
+                             records=records, truth_table=truth_table, truth_rows=truth_rows, truth_before=truth_before, finished=L['b'] >= n)
+                # everything of this batch is on the host now: the engine is free for the next one
+                if L['b'] < n:
+                    if pool is not None:
+                        future = pool.submit(self._launch, st, L['b'], L['has_pulse'], L['runmax'])
+                yield batch
+                if L['b'] >= n:
+                    break
+                launched = future.result() if future is not None else self._launch(st, L['b'], L['has_pulse'], L['runmax'])
+                future = None
+        finally:
+            if future is not None:          # the consumer stopped early: let the running batch finish before the engine is reused
+                try:
+                    future.result()
+                except Exception:
+                    pass
+            if pool is not None:
+                pool.shutdown(wait=True)
+        self.source_finished = True
+
+    def _launch(self, st, a, has_pulse, runmax):
+        """Loads and runs the batch that starts at sorted instruction ``a``; decides how much of it can be emitted."""
+        cfg = self.config
+        dt, tw, rext = cfg['sample_duration'], cfg['trigger_window'], cfg['right_raw_extension']
+        s_ins, gids, order, key, cluster, n = st['s_ins'], st['gids'], st['order'], st['key'], st['cluster'], st['n']
+        scale = 1
+        while True:
+            b = self._batch_end(a, st['est_csum'], cluster, scale)
             ins = s_ins[a:b]
             gid = gids[order[a:b]].astype(np.uint32)
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)
             self.engine.set_window_carry(has_pulse, runmax)
-            self._batch_em_base = em_base[order[a:b]]
+            self._batch_em_base = st['em_base'][order[a:b]]
             self._batch_run_set = None if self._all_run_sets is None else self._all_run_sets[a:b] - self._all_run_sets[a]
             self._load_batch(ins, gid, cl, key[a:b])
             counts = self.engine.run()
@@ -143,36 +201,20 @@ class RawData:
                 # would the next cluster have been simulated before this batch's last window was digitised
                 # (rawdata.py:96-98)?  then that window is not complete: simulate it again with the next batch
                 run_all = max(int(ends.max()), runmax) if has_pulse else int(ends.max())
-                if not (int(cl_min_key[cluster[b] - cluster[0]]) - run_all > rext):
+                if not (int(st['cl_min_key'][cluster[b] - cluster[0]]) - run_all > rext):
                     g_last = int(np.where(nonempty)[0][-1])
                     restart = a + int(np.argmax(ins_group >= g_last))
                     if restart == a:            # the whole batch is one open window: take a bigger batch
                         scale *= 2
                         continue
                     n_emit, b = g_last, restart
-            n_rec = int(first[n_emit])
-            out = record_sink(n_rec) if record_sink is not None else None
-            if out is None:
-                out = np.empty(n_rec, dtype=raw_record_dtype())
-            records = self.engine.records_into(out, n_rec)
             keep = np.where(nonempty[:n_emit])[0]
-            # window position of every emitted group: rows of a group go in front of its window, rows of a group without
-            # pulses in front of the next window that has some
-            pos_of_group = np.searchsorted(keep, np.arange(n_emit), side='left')
-            truth_table, truth_rows, truth_before = None, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
-            if want_truth:
-                truth_table = self._truth_rows(ins, cl)           # one row per run set, in processing order
-                grp = ins_group[truth_table['first']].astype(np.int64)
-                truth_rows = np.flatnonzero(grp < n_emit)
-                truth_before = pos_of_group[grp[truth_rows]] if n_emit else np.zeros(0, dtype=np.int64)
             if len(keep):
                 e = ends[keep]
                 runmax = max(int(e.max()), runmax) if has_pulse else int(e.max())
                 has_pulse = True
-            yield dict(left=groups['left'][keep], right=groups['right'][keep], first=np.append(first[keep], first[n_emit]) if len(keep) else np.array([first[n_emit]]),
-                       records=records, truth_table=truth_table, truth_rows=truth_rows, truth_before=truth_before, finished=b >= n)
-            a, scale = b, 1
-        self.source_finished = True
+            return dict(b=b, ins=ins, cl=cl, n_emit=n_emit, first=first, nonempty=nonempty, ins_group=ins_group, groups=groups,
+                        run_set=getattr(self, '_run_set', None), has_pulse=has_pulse, runmax=runmax)
 
     def _expected_quanta(self, s_ins):
         return np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15,
@@ -245,14 +287,13 @@ class RawData:
         return res if with_parent else res[:3]
 
     # ---- truth (rawdata.py:313-375) ----------------------------------------------------------------
-    def _truth_rows(self, ins, cl):
+    def _truth_rows(self, ins, cl, run_set=None):
         """Truth of the batch, one row per pulse set in processing order, as columns (RawData.get_truth, rawdata.py:313-375):
         dict(first = index of the set's first instruction in the batch, n = rows, cols = {truth field: array})."""
         acc, ts = self.engine.truth()
         es = self.engine.electron_stats()
         per_pmt = self.engine.truth_per_pmt() if self.config.get('per_pmt_truth', False) else None      # pulse.py:62-66
         names = ['n_photon', 'n_pe', 'n_photon_trigger', 'n_pe_trigger', 'raw_area', 'raw_area_trigger']
-        run_set = getattr(self, '_run_set', None)
         if run_set is None:
             # every instruction is its own pulse set (set index = position in the sorted batch); rows in processing order
             first = np.asarray(processing_order(ins, np.arange(len(ins)), cl), dtype=np.int64)
