@@ -196,3 +196,27 @@ def test_foreign_interpolating_map_objects_are_recognised():
     row, table = eng.cdf_rows()
     host = instruction_params(ins[order], cfg, res)
     assert np.allclose(np.diff(table[row], axis=1, prepend=0.0), np.diff(host['cdf_table'][host['cdf_row']], axis=1, prepend=0.0), rtol=1e-6, atol=1e-12)
+
+
+def test_top_only_s2_map_is_padded_with_ones_for_the_bottom_array():
+    """s2.py:648-650: a pattern map that stops before the bottom channels gets weight 1 for every bottom PMT -- on the device too"""
+    from wfsim_amd.itp_map import InterpolatingMap
+    cfg = map_config(9, seed=4)
+    cfg['s2_mean_area_fraction_top'] = -1
+    res = Resource(cfg)
+    # a map as the XENON1T loader builds it (load_resource.py:207: no PMT mask, top array only)
+    res.s2_pattern_map = InterpolatingMap(dict(coordinate_system=cfg['s2_pattern_map']['coordinate_system'],
+                                               map=np.asarray(cfg['s2_pattern_map']['map'])[..., :253] * 40))
+    eng = make_engine(cfg, resource=res)
+    assert 's2' in eng.device_maps
+    ins = instructions(60, 33)
+    ins['type'] = 2
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    eng.load_instructions(s_ins, order.astype(np.uint32), cluster, key, instruction_params(s_ins, cfg, res, device_maps=eng.device_maps))
+    row, table = eng.cdf_rows()
+    host = instruction_params(s_ins, cfg, res)
+    p_host, p_dev = np.diff(host['cdf_table'][host['cdf_row']], axis=1, prepend=0.0), np.diff(table[row], axis=1, prepend=0.0)
+    assert np.allclose(p_dev, p_host, rtol=1e-6, atol=1e-12)
+    live_bottom = np.setdiff1d(np.arange(253, 494), [260, 493])
+    assert np.allclose(p_dev[:, live_bottom], p_dev[:, live_bottom[:1]])          # equal weights on the bottom array

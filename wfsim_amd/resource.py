@@ -89,8 +89,13 @@ class Resource:
         if c.get('detector', 'XENONnT') not in ('XENON1T', 'XENONnT', 'XENONnT_neutron_veto'):
             raise ValueError(f"Unsupported detector {c['detector']}")          # load_resource.py:115
         pmt_mask = np.asarray(c['gains']) > 0
-        self.s1_pattern_map = make_patternmap(c['s1_pattern_map'], pmt_mask=pmt_mask)
-        self.s2_pattern_map = make_patternmap(c['s2_pattern_map'], pmt_mask=pmt_mask)
+        if c.get('detector', 'XENONnT') == 'XENON1T':
+            # load_resource.py:205-207: plain maps for 1T (its S2 map holds the top array only; S2.photon_channels pads the rest)
+            self.s1_pattern_map = make_map(c['s1_pattern_map'])
+            self.s2_pattern_map = make_map(c['s2_pattern_map'])
+        else:
+            self.s1_pattern_map = make_patternmap(c['s1_pattern_map'], pmt_mask=pmt_mask)
+            self.s2_pattern_map = make_patternmap(c['s2_pattern_map'], pmt_mask=pmt_mask)
         # target mean area fraction top of the S2 pattern (load_resource.py:255-272): top and bottom arrays are rescaled
         # separately so that the total efficiency is preserved; a dummy map is left alone
         aft = c.get('s2_mean_area_fraction_top', -1)
