@@ -204,7 +204,7 @@ def test_top_only_s2_map_is_padded_with_ones_for_the_bottom_array():
     cfg = map_config(9, seed=4)
     cfg['s2_mean_area_fraction_top'] = -1
     res = Resource(cfg)
-    # a map as the XENON1T loader builds it (load_resource.py:207: no PMT mask, top array only)
+    # a map as the XENON1T loader builds it (load_resource.py:220: no PMT mask, top array only)
     res.s2_pattern_map = InterpolatingMap(dict(coordinate_system=cfg['s2_pattern_map']['coordinate_system'],
                                                map=np.asarray(cfg['s2_pattern_map']['map'])[..., :253] * 40))
     eng = make_engine(cfg, resource=res)

@@ -90,7 +90,7 @@ class Resource:
             raise ValueError(f"Unsupported detector {c['detector']}")          # load_resource.py:115
         pmt_mask = np.asarray(c['gains']) > 0
         if c.get('detector', 'XENONnT') == 'XENON1T':
-            # load_resource.py:205-207: plain maps for 1T (its S2 map holds the top array only; S2.photon_channels pads the rest)
+            # load_resource.py:216-221: plain maps for 1T (its S2 map holds the top array only; S2.photon_channels pads the rest)
             self.s1_pattern_map = make_map(c['s1_pattern_map'])
             self.s2_pattern_map = make_map(c['s2_pattern_map'])
         else:
