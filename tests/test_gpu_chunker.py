@@ -120,3 +120,32 @@ def test_nveto_chunks_identical():
     fast, slow = _chunks(factory, ins, False), _chunks(factory, ins, True)
     _assert_same(fast, slow)
     assert len(fast) > 3
+
+
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_CHUNKER', 6)))))
+def test_random_chunker_runs_identical_to_the_per_window_replay(seed):
+    rng = np.random.default_rng(9000 + seed)
+    kw = dict(seed=int(rng.integers(1, 10 ** 6)), chunk_size=float(rng.choice([0.0007, 0.003, 0.02, 0.3])),
+              right_raw_extension=int(rng.choice([5_000, 100_000])))
+    if rng.random() < 0.3:
+        kw.update(enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap_tables_from_golden())
+    if rng.random() < 0.3:
+        kw.update(enable_noise=True, noise_data=golden('noise.npz')['noise'])
+    if rng.random() < 0.3:
+        kw['save_full_truth'] = False
+    cfg = xenonnt_test_config(**kw)
+    n_ev = int(rng.integers(5, 150))
+    ins = _mixed(n_ev, int(rng.integers(1, 1000)))
+    ins['time'] = np.repeat(np.cumsum(rng.choice([800, 30_000, 400_000, 5_000_000], n_ev)), 2).astype(np.int64) + 1_000_000
+    quanta = int(rng.choice([15_000, 200_000, 2_000_000_000]))
+    # (a buffer smaller than a single window is the one place where the two forms differ: which records of that window are
+    # dropped -- the reference skips pulses one at a time in channel order, the batch form keeps the earliest records)
+    buf = int(rng.choice([150_000, 5_000_000]))
+
+    def factory():
+        sim = wfsim_amd.ChunkRawRecords(cfg)
+        sim.rawdata.max_batch_quanta = quanta
+        if buf < 5_000_000:
+            sim.record_buffer = sim.record_buffer[:buf].copy()
+        return sim
+    _assert_same(_chunks(factory, ins, False), _chunks(factory, ins, True))
