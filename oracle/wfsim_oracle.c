@@ -10,7 +10,9 @@
  * Pulse-call structure of run sets and of the electron-afterpulse feedback loop (golden chains A-H).  The random
  * stages cannot be stream-compatible with numpy's legacy generator; they follow the reference's arithmetic
  * (same truncations, term by term) on a counter-based Philox4x32-10 stream (layout in DESIGN.md "RNG streams")
- * and are pinned statistically against histograms of the reference's own draws (tests/golden/dists.npz).
+ * and are pinned statistically against histograms of the reference's own draws (tests/golden/dists.npz, and
+ * dists_models.npz for the timing model variants).  Unpinned: the 244-byte raw_record layout of orc_pack_records (strax is
+ * not installed: restated from its published dtype).
  *
  * Each function names the reference lines it restates (paths relative to /root/reference/wfsim).
  */
