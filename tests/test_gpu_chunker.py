@@ -122,7 +122,7 @@ def test_nveto_chunks_identical():
     assert len(fast) > 3
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_CHUNKER', 6)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_CHUNKER', 12)))))
 def test_random_chunker_runs_identical_to_the_per_window_replay(seed):
     rng = np.random.default_rng(9000 + seed)
     kw = dict(seed=int(rng.integers(1, 10 ** 6)), chunk_size=float(rng.choice([0.0007, 0.003, 0.02, 0.3])),

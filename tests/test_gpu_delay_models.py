@@ -50,7 +50,7 @@ def _case(seed):
     return cfg, ins, ap
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS', 25)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS', 40)))))
 def test_model_variants_match_oracle(seed):
     cfg, ins, ap = _case(seed)
     res = Resource(cfg)
@@ -86,7 +86,7 @@ def test_models_change_the_result():
     assert out[0] != out[1]
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS_EAP', 6)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS_EAP', 10)))))
 def test_model_variants_with_electron_afterpulses(seed):
     """RawData end to end with electron afterpulses: the pre-pass recomputes photon times (k_photon_times) from the same
     tables, batches are cut at random"""

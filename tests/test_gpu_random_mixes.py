@@ -45,7 +45,7 @@ def _random_case(seed):
 import os
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES', 12)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES', 30)))))
 def test_random_mix_matches_oracle(seed):
     cfg, ins, ap = _random_case(1000 + seed)
     res = Resource(cfg)
@@ -68,7 +68,7 @@ def test_random_mix_matches_oracle(seed):
     assert counts['n_pe'] == orc.n_pe
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_EAP', 8)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_EAP', 15)))))
 def test_random_mix_with_electron_afterpulses(seed):
     """the same with electron afterpulses (and, half of the time, gate afterpulses / run sets): RawData end to end
     against the oracle fed with the same secondaries in the order of the feedback schedule"""
@@ -107,7 +107,7 @@ def test_random_mix_with_electron_afterpulses(seed):
     assert (rec.tobytes() if len(rec) else b'') == orc.pack_records().tobytes()
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_BATCH', 10)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_BATCH', 15)))))
 def test_random_mix_small_batches_equal_one_batch(seed):
     """RawData.iter_windows: windows and record bytes do not depend on how the run is cut into GPU batches
     (window carry across batches, re-run of an open window, truth rows) -- random mixes incl. afterpulses, noise, run sets"""
@@ -132,7 +132,7 @@ def test_random_mix_small_batches_equal_one_batch(seed):
     assert np.allclose(t1['raw_area'], t2['raw_area'], rtol=1e-12)        # float sum over the photons of a tile: order dependent
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_SHARD', 6)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_SHARD', 12)))))
 def test_random_mix_sharded_equals_single(seed):
     """what every rank of a multi-GPU run would compute (contiguous cluster ranges from shard_clusters, run-wide
     instruction ids), one after the other on this GPU: the concatenation equals the single-GPU run byte for byte"""
@@ -155,7 +155,7 @@ def test_random_mix_sharded_equals_single(seed):
     assert b''.join(parts) == single
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_OPT', 6)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MIXES_OPT', 12)))))
 def test_random_optical_matches_oracle(seed):
     """RawDataOptical at random rates / batch sizes against the oracle's optical scheduler"""
     import wfsim_amd
