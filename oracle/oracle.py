@@ -227,6 +227,18 @@ class Oracle:
                                C.c_double(pzf), _p(out))
         return out
 
+    def alias_pmf(self, slot=8, xtab=-1):
+        """(pmf the alias table of a delay table samples, pmf of its cumulative table, vmin); slot: 0 transit time, 7 / 8 the
+        summed delay of an S1 / S2 photon; xtab >= 0: a model-variant table"""
+        cap = 1 << 17
+        pa, pc = np.zeros(cap), np.zeros(cap)
+        n, vmin = C.c_int64(0), C.c_int64(0)
+        lib().orc_alias_pmf(self._s, C.c_int(slot), C.c_int32(xtab), _p(pa), _p(pc), C.c_int64(cap), C.byref(n), C.byref(vmin))
+        k = 2
+        while k < n.value:
+            k *= 2
+        return pa[:k], pc[:k], int(vmin.value)
+
     def sample_poisson(self, lam, n):
         out = np.zeros(n, dtype=np.int64)
         lib().orc_sample_poisson(self._s, C.c_double(lam), C.c_int64(n), _p(out))

@@ -64,6 +64,10 @@ typedef struct { uint8_t *p; i64 n, cap; } vec_u8;
 #define VEC_RESERVE(v, T, m) do { if ((v).n + (m) > (v).cap) { while ((v).n + (m) > (v).cap) (v).cap = (v).cap ? (v).cap * 2 : 1024; \
     (v).p = (T *)realloc((v).p, (size_t)(v).cap * sizeof(T)); } } while (0)
 
+/* a discrete delay distribution: cumulative probabilities (cum[i] = P(X <= vmin + i)) and -- for the tables photons are
+ * drawn from -- its Walker alias table (K = 2^lg cells of {threshold, alias}; see alias_build / alias_sample) */
+typedef struct { double *cum; i64 n; i64 vmin; u32 *thr, *alias; int lg; } orc_tab;
+
 typedef struct orc_session_s {
     orc_config c;
     const double *templates;     /* [10][tlen]                       pulse.py:146-187 */
@@ -94,9 +98,9 @@ typedef struct orc_session_s {
     const i64 *noise_override; i64 n_noise_override;
     u32 win_gid; int win_gid_set; /* noise stream of the open window: gid of the first instruction of its first cluster that made a pulse */
     int save_full_truth;         /* rawdata.py:42: 1 (default) = every instruction is its own Pulse call */
-    struct { double *cum; i64 n; i64 vmin; } tab[10];
+    orc_tab tab[10];
     /* model variants of the photon delays (orc_set_delay_models ...): extra tables, per-instruction choice, S1 propagation */
-    struct { double *cum; i64 n; i64 vmin; } *xtab; i32 n_xtab;
+    orc_tab *xtab; i32 n_xtab;
     const i32 *ins_tab, *ins_tabb, *ins_pzi; const double *ins_pzf; i64 n_ins_models;
     double *prop_top, *prop_bot; i32 prop_nz, prop_nu; double prop_u0, prop_du;
     i32 cur_tab, cur_tabb, cur_pzi; double cur_pzf;   /* trunc()-ed delay variates: the individual terms and their sums, see TAB_* */    /* tests: ix_rand per digitise call instead of the Philox draw */
@@ -118,8 +122,11 @@ static inline void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1,
 void orc_philox(const u32 *ctr, const u32 *key, u32 *out) { philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out); }
 
 /* draw sites (counter word 3); counter = (emitter, instruction gid, item, site) -- DESIGN.md "RNG streams" */
+/* RNG spec v5: SITE_PH, counter (emitter, gid, item): x, y -> summed delay (alias table), z -> double-PE flag and second SPE
+ * index, w -> first SPE index.  SITE_CH, counter (em_base, gid, P >> 2) with P the index of the photon among its
+ * instruction's photons: word P & 3 -> channel.  SITE_PH_X: S1 optical propagation coordinate. */
 enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
-       SITE_PH_A = 16, SITE_PH_B = 17, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
+       SITE_PH = 16, SITE_CH = 17, SITE_PH_X = 18, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
 
 static inline void draw(const orc_session *s, u32 emitter, u32 gid, u32 item, u32 site, u32 w[4])
 {
@@ -220,8 +227,8 @@ void orc_free(orc_session *s)
         (void **)&s->zl_right.p, (void **)&s->zl_data_off.p, (void **)&s->zl_ch.p, (void **)&s->zl_data.p,
         (void **)&s->truth.p };
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
-    for (int q = 0; q < TAB_N; q++) free(s->tab[q].cum);
-    for (i32 k = 0; k < s->n_xtab; k++) free(s->xtab[k].cum);
+    for (int q = 0; q < TAB_N; q++) { free(s->tab[q].cum); free(s->tab[q].thr); free(s->tab[q].alias); }
+    for (i32 k = 0; k < s->n_xtab; k++) { free(s->xtab[k].cum); free(s->xtab[k].thr); free(s->xtab[k].alias); }
     free(s->xtab); free(s->prop_top); free(s->prop_bot);
     free(s);
 }
@@ -570,6 +577,49 @@ static void tab_from_pmf(orc_session *s, int slot, pmf_t a)
     c[n - 1] = 1.0;
     s->tab[slot].cum = c; s->tab[slot].n = n; s->tab[slot].vmin = a.vmin + first;
 }
+/* Walker's alias method for the tables photons are drawn from (the summed delays): K = 2^lg >= max(n, 2) cells.  Vose's
+ * construction in a fixed order: q[i] = p[i] * K; cells with q < 1 ("small") and the others ("large") go on two stacks
+ * in ascending index order; the small cell on top gets {thr = floor(q * 2^32), alias = large cell on top}, the large
+ * cell keeps (q_l + q_s) - 1 and moves to the small stack when that is below 1; leftovers keep their own outcome.
+ * A draw takes cell c = x >> (32 - lg) and returns c if y < thr[c], else alias[c] (two independent 32-bit words). */
+static void alias_build(orc_tab *t)
+{
+    i64 K = 2; int lg = 1;
+    while (K < t->n) { K <<= 1; lg++; }
+    free(t->thr); free(t->alias);
+    t->lg = lg; t->thr = (u32 *)malloc((size_t)K * 4); t->alias = (u32 *)malloc((size_t)K * 4);
+    double *q = (double *)calloc((size_t)K, 8);
+    u32 *small = (u32 *)malloc((size_t)K * 4), *large = (u32 *)malloc((size_t)K * 4); i64 ns = 0, nl = 0;
+    for (i64 i = 0; i < t->n; i++) q[i] = (t->cum[i] - (i ? t->cum[i - 1] : 0.0)) * (double)K;
+    for (i64 i = 0; i < K; i++) { if (q[i] < 1.0) small[ns++] = (u32)i; else large[nl++] = (u32)i; t->thr[i] = 0xffffffffu; t->alias[i] = (u32)i; }
+    while (ns > 0 && nl > 0) {
+        const u32 si = small[--ns], l = large[nl - 1];
+        const double x = q[si] * 4294967296.0;
+        t->thr[si] = x >= 4294967295.0 ? 0xffffffffu : (u32)x; t->alias[si] = l;
+        q[l] = (q[l] + q[si]) - 1.0;
+        if (q[l] < 1.0) { nl--; small[ns++] = l; }
+    }
+    free(q); free(small); free(large);
+}
+static i64 alias_sample(const orc_tab *t, u32 x, u32 y)
+{
+    const u32 c = x >> (32 - t->lg);
+    return t->vmin + (i64)(y < t->thr[c] ? c : t->alias[c]);
+}
+/* the distribution an alias table samples, cell by cell (tests: it must equal the table's pmf to 2^-32 per outcome) */
+void orc_alias_pmf(const orc_session *s, int slot, i32 xtab, double *pmf_alias, double *pmf_cum, i64 cap, i64 *n_out, i64 *vmin_out)
+{
+    const orc_tab *t = xtab >= 0 ? &s->xtab[xtab] : &s->tab[slot];
+    const i64 K = 1ll << t->lg;
+    *n_out = t->n; *vmin_out = t->vmin;
+    if (cap < K) return;
+    for (i64 i = 0; i < K; i++) { pmf_alias[i] = 0.0; pmf_cum[i] = i < t->n ? t->cum[i] - (i ? t->cum[i - 1] : 0.0) : 0.0; }
+    for (i64 i = 0; i < K; i++) {
+        const double pa = t->alias[i] == (u32)i ? 1.0 : (double)t->thr[i] / 4294967296.0;
+        pmf_alias[i] += pa / (double)K; pmf_alias[t->alias[i]] += (1.0 - pa) / (double)K;
+    }
+}
+
 static void tab_totals(orc_session *s)
 {
     const orc_config *c = &s->c;
@@ -591,6 +641,7 @@ static void tab_totals(orc_session *s)
         tab_from_pmf(s, TAB_S2_NOLUM, nb); free(nb.p);
     }
     free(t1.p); free(t3.p); free(lum.p); free(st.p); free(b.p); free(tts.p);
+    alias_build(&s->tab[TAB_TTS]); alias_build(&s->tab[TAB_S1_TOTAL]); alias_build(&s->tab[TAB_S2_TOTAL]);
 }
 
 /* Model variants of S1.photon_timings (s1.py:162-238: 'custom' recoil models, optical propagation) and
@@ -601,7 +652,7 @@ static void tab_totals(orc_session *s)
 void orc_set_delay_models(orc_session *s, i32 n_tables, const i32 *base, const i64 *pmf_off, const double *pmf, const i32 *vmin)
 {
     static const int slot_of_base[4] = {TAB_TTS, TAB_S1_TOTAL, TAB_S2_TOTAL, TAB_S2_NOLUM};
-    for (i32 k = 0; k < s->n_xtab; k++) free(s->xtab[k].cum);
+    for (i32 k = 0; k < s->n_xtab; k++) { free(s->xtab[k].cum); free(s->xtab[k].thr); free(s->xtab[k].alias); }
     free(s->xtab); s->xtab = NULL; s->n_xtab = n_tables;
     if (n_tables <= 0) return;
     s->xtab = calloc((size_t)n_tables, sizeof *s->xtab);
@@ -615,6 +666,7 @@ void orc_set_delay_models(orc_session *s, i32 n_tables, const i32 *base, const i
         while (n > 1 && c[n - 2] >= 1.0) n--;
         c[n - 1] = 1.0;
         s->xtab[k].cum = c; s->xtab[k].n = n; s->xtab[k].vmin = r.vmin + first;
+        alias_build(&s->xtab[k]);
         free(b.p); free(r.p);
     }
 }
@@ -639,12 +691,6 @@ static void set_cur(orc_session *s, i64 i)
     const int on = i < s->n_ins_models;
     s->cur_tab = on && s->ins_tab ? s->ins_tab[i] : -1; s->cur_tabb = on && s->ins_tabb ? s->ins_tabb[i] : s->cur_tab;
     s->cur_pzi = on && s->ins_pzi ? s->ins_pzi[i] : -1; s->cur_pzf = on && s->ins_pzf ? s->ins_pzf[i] : 0.0;
-}
-static i64 sample_cum(const double *c, i64 n, i64 vmin, double u)
-{
-    i64 lo = 0, hi = n - 1;
-    while (lo < hi) { i64 mid = (lo + hi) >> 1; if (u < c[mid]) hi = mid; else lo = mid + 1; }
-    return vmin + lo;
 }
 /* multilinear interpolation as scipy's RegularGridInterpolator evaluates it: sum over the cell's corners of value * weights */
 static double s1_propagation(const orc_session *s, int bottom, i32 zi, double zf, double u)
@@ -694,22 +740,34 @@ static double interp_lum(const orc_session *s, double u)
 
 /* One photon: pulse.py:53-56 (TTS), :76-79 (DPE), :97-103 (SPE gain, idx = int(u*2000)+1), plus the timing terms of
  * s1.py:180-194 (simple) or s2.py:504-557 (luminescence simple + singlet/triplet + spread + electron time).
- * Every term is truncated to int64 on its own before it is added. */
-static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u32 item, i64 t0,
+ * Every term is truncated to int64 on its own before it is added: the sum is drawn from the table of the sum.
+ * RNG spec v5: the channel is word P & 3 of the call (em_base, gid, P >> 2, SITE_CH), P = index of the photon among the
+ * photons of its instruction; everything else comes from the photon's own call (emitter, gid, item, SITE_PH). */
+static inline u32 dpe_code(const orc_session *s, u32 z)
+{
+    const u64 thr = bern_threshold(s->c.p_dpe);
+    if (!((u64)z < thr)) return 0u;
+    /* given z < thr the word is uniform on [0, thr): int(z * 2000 / thr) + 1 is the uniform SPE table index */
+    u32 g2 = (u32)((double)z * (2000.0 / (double)thr)) + 1u;
+    return g2 > 2000u ? 2000u : g2;
+}
+static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u32 item, u32 em_base, u32 P, i64 t0,
                        const double *cdf, i64 *t_out, int *ch_out, int *dpe_out, double *gain_out)
 {
     const orc_config *c = &s->c;
-    u32 A[4], B[4];
-    draw(s, emitter, gid, item, SITE_PH_A, A);
-    draw(s, emitter, gid, item, SITE_PH_B, B);
-    int ch = channel_from_cdf(cdf, c->n_tpc, u53(A[0], A[1]));
-    int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
-    int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
+    u32 C[4], B[4];
+    draw(s, em_base, gid, P >> 2, SITE_CH, C);
+    draw(s, emitter, gid, item, SITE_PH, B);
+    int ch = channel_from_cdf(cdf, c->n_tpc, (double)C[P & 3u] * (1.0 / 4294967296.0));
+    int g1 = (int)(((u64)B[3] * 2000u) >> 32) + 1, g2 = (int)dpe_code(s, B[2]);
+    int is_dpe = g2 != 0;
     i64 t;                                                /* all delay terms from one table, see tab_totals / orc_set_delay_models */
-    if (s->cur_tab >= 0) { const i32 k = ch >= c->n_top ? s->cur_tabb : s->cur_tab; t = t0 + sample_cum(s->xtab[k].cum, s->xtab[k].n, s->xtab[k].vmin, u53(B[0], B[1])); }
-    else t = t0 + sample_tab(s, is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL, u53(B[0], B[1]));
-    if (!is_s2 && s->prop_top && s->cur_pzi >= 0)         /* s1.py:185-188; prop_time is an int64 array: the assignment truncates */
-        t += (i64)s1_propagation(s, ch >= c->n_top, s->cur_pzi, s->cur_pzf, ((double)B[3] + 0.5) * (1.0 / 4294967296.0));
+    if (s->cur_tab >= 0) t = t0 + alias_sample(&s->xtab[ch >= c->n_top ? s->cur_tabb : s->cur_tab], B[0], B[1]);
+    else t = t0 + alias_sample(&s->tab[is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL], B[0], B[1]);
+    if (!is_s2 && s->prop_top && s->cur_pzi >= 0) {       /* s1.py:185-188; prop_time is an int64 array: the assignment truncates */
+        u32 X[4]; draw(s, emitter, gid, item, SITE_PH_X, X);
+        t += (i64)s1_propagation(s, ch >= c->n_top, s->cur_pzi, s->cur_pzf, ((double)X[0] + 0.5) * (1.0 / 4294967296.0));
+    }
     int sc = c->n_spe_channels > ch ? ch : 0;
     const double *row = s->spe + (i64)sc * 2001;
     double G = s->gains[ch], gain = G * row[g1];
@@ -792,7 +850,7 @@ static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, doubl
     }
     for (i64 k = 0; k < n_hits; k++) {
         i64 t; int ch, dpe; double g;
-        one_photon(s, 0, 0, gid, (u32)k, time, cdf, &t, &ch, &dpe, &g);
+        one_photon(s, 0, 0, gid, (u32)k, 0, (u32)k, time, cdf, &t, &ch, &dpe, &g);
         ctx_push(x, t, ch, dpe, g, gid, 0, k);
     }
     return n_hits;
@@ -804,7 +862,7 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
                   double sc_gain, const double *cdf)
 {
     const orc_config *c = &s->c;
-    u64 T = bern_threshold(cy); u32 w[4]; i64 n0 = x->pb.t.n;
+    u64 T = bern_threshold(cy); u32 w[4]; i64 n0 = x->pb.t.n; u32 P = 0;       /* P: photons of this instruction so far */
     for (i64 j = 0; j < amp; j++) {
         if ((j & 3) == 0) draw(s, em_base, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);
         if (!((u64)w[j & 3] < T)) continue;
@@ -822,7 +880,7 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
         VEC_PUSH(s->e_t, i64, et);
         for (i64 m = 0; m < nph; m++) {
             i64 t; int ch, dpe; double g;
-            one_photon(s, 1, je, gid, (u32)m, et, cdf, &t, &ch, &dpe, &g);
+            one_photon(s, 1, je, gid, (u32)m, em_base, P++, et, cdf, &t, &ch, &dpe, &g);
             ctx_push(x, t, ch, dpe, g, gid, (i64)je, m);
         }
     }
@@ -852,12 +910,12 @@ i64 orc_optical(orc_session *s, u32 gid, int runset, i64 time, i64 n, const i64 
     photon_buf pb; memset(&pb, 0, sizeof pb);
     for (i64 k = 0; k < n; k++) {
         if (t_rel[k] < 0 || t_rel[k] >= cutoff) continue;
-        u32 A[4], B[4];
-        draw(s, 0, gid, (u32)k, SITE_PH_A, A); draw(s, 0, gid, (u32)k, SITE_PH_B, B);
-        int is_dpe = (u64)A[2] < bern_threshold(c->p_dpe);
-        int g1 = (int)(((u64)A[3] * 2000u) >> 32) + 1, g2 = (int)(((u64)B[2] * 2000u) >> 32) + 1;
+        u32 B[4];
+        draw(s, 0, gid, (u32)k, SITE_PH, B);
+        int g1 = (int)(((u64)B[3] * 2000u) >> 32) + 1, g2 = (int)dpe_code(s, B[2]);
+        int is_dpe = g2 != 0;
         i64 t = time + t_rel[k];
-        t += sample_tab(s, TAB_TTS, u53(B[0], B[1]));
+        t += alias_sample(&s->tab[TAB_TTS], B[0], B[1]);
         int ch = chan[k];
         int sc = c->n_spe_channels > ch ? ch : 0;
         const double *row = s->spe + (i64)sc * 2001;
@@ -1038,14 +1096,15 @@ void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 
     const orc_config *c = &s->c;
     for (i64 i = 0; i < n; i++) {
         u32 A[4], B[4]; u32 em = (u32)(i >> 20), item = (u32)(i & 0xfffff), gid = 777u;
-        draw(s, em, gid, item, SITE_PH_A, A); draw(s, em, gid, item, SITE_PH_B, B);
+        draw(s, em, gid, item, SITE_CH, A); draw(s, em, gid, item, SITE_PH, B);
         double z0, z1;
         if (kind == 0) out[i] = sample_tab(s, TAB_LUM, u53(B[0], B[1]));
         else if (kind == 1) out[i] = sample_tab(s, ((u64)B[3] < bern_threshold(c->sf_gas)) ? TAB_T1 : TAB_T3, u53(B[0], B[1]));
-        else if (kind == 2) out[i] = sample_tab(s, TAB_TTS, u53(B[0], B[1]));
+        else if (kind == 2) out[i] = alias_sample(&s->tab[TAB_TTS], B[0], B[1]);                /* as photons with given times draw it */
+        else if (kind == 10) out[i] = sample_tab(s, TAB_TTS, u53(B[0], B[1]));
         else if (kind == 3) out[i] = sample_tab(s, TAB_S1_EXP, u53(B[0], B[1])) + sample_tab(s, TAB_S1_SPREAD, u53(A[0], A[1]));
-        else if (kind == 5) out[i] = sample_tab(s, TAB_S1_TOTAL, u53(B[0], B[1]));
-        else if (kind == 6) out[i] = sample_tab(s, TAB_S2_TOTAL, u53(B[0], B[1]));
+        else if (kind == 5) out[i] = alias_sample(&s->tab[TAB_S1_TOTAL], B[0], B[1]);          /* as one_photon() draws them */
+        else if (kind == 6) out[i] = alias_sample(&s->tab[TAB_S2_TOTAL], B[0], B[1]);
         else if (kind == 7) out[i] = (i64)(-log(1.0 - u53(B[0], B[1])) * c->t3_gas);          /* the reference's expressions on the same uniform, */
         else if (kind == 8) out[i] = (i64)interp_lum(s, u53(B[0], B[1]));                      /* to check the tables sample by sample */
         else if (kind == 9) out[i] = sample_tab(s, TAB_T3, u53(B[0], B[1]));
@@ -1063,10 +1122,9 @@ void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 
 void orc_sample_delay(orc_session *s, i64 n, int is_s2, i32 tab, int bottom, i32 pzi, double pzf, i64 *out)
 {
     for (i64 i = 0; i < n; i++) {
-        u32 B[4]; draw(s, 0, 424242u, (u32)i, SITE_PH_B, B);
-        i64 t = tab >= 0 ? sample_cum(s->xtab[tab].cum, s->xtab[tab].n, s->xtab[tab].vmin, u53(B[0], B[1]))
-                         : sample_tab(s, is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL, u53(B[0], B[1]));
-        if (!is_s2 && s->prop_top && pzi >= 0) t += (i64)s1_propagation(s, bottom, pzi, pzf, ((double)B[3] + 0.5) * (1.0 / 4294967296.0));
+        u32 B[4], X[4]; draw(s, 0, 424242u, (u32)i, SITE_PH, B); draw(s, 0, 424242u, (u32)i, SITE_PH_X, X);
+        i64 t = tab >= 0 ? alias_sample(&s->xtab[tab], B[0], B[1]) : alias_sample(&s->tab[is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL], B[0], B[1]);
+        if (!is_s2 && s->prop_top && pzi >= 0) t += (i64)s1_propagation(s, bottom, pzi, pzf, ((double)X[0] + 0.5) * (1.0 / 4294967296.0));
         out[i] = t;
     }
 }

@@ -50,6 +50,21 @@ def test_timing_terms(orc, kind, key):
     assert abs(x.std() / s - 1) < 0.01
 
 
+@pytest.mark.parametrize('slot', [0, 7, 8])
+def test_alias_tables_sample_the_pmf_of_their_table(orc, slot):
+    """photon delays are drawn with Walker's alias method: the distribution the cells encode equals the pmf of the
+    cumulative table (which the tests below pin on the reference's draws) to the 2^-32 resolution of the thresholds"""
+    pa, pc, _ = orc.alias_pmf(slot)
+    assert abs(pa.sum() - 1) < 1e-12 and abs(pc.sum() - 1) < 1e-12
+    assert np.abs(pa - pc).max() < 2.0 ** -31
+
+
+def test_alias_draw_of_the_transit_time_matches_the_inverse_cdf_draw(orc):
+    a, b = orc.sample_term(2, N), orc.sample_term(10, N)      # alias vs inverse CDF of the same table
+    va, ca = np.unique(a, return_counts=True)
+    assert _ks(va, ca, b) < _ks_limit(N, N)
+
+
 def test_tables_reproduce_the_reference_expressions(orc):
     """trunc(Exp * tau) and trunc(np.interp(u, ...)) sampled from their tables == the reference's expressions on the
     same uniforms (pulse.py:341, s2.py:338)"""

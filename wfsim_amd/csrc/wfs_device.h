@@ -1,8 +1,9 @@
 // wfs_device.h -- device-side helpers of the MI355X WFSim hot path (gfx950 only).
 //
 // RNG: Philox4x32-10 (Salmon et al., SC'11), counter = (emitter, instruction gid, item, site), key = seed.
-// The stream layout is specified in DESIGN.md "RNG streams"; the CPU oracle implements the same layout
-// independently (oracle/wfsim_oracle.c) so that GPU and oracle results can be compared photon by photon.
+// The stream layout is specified in DESIGN.md "RNG streams" (spec v5: ONE call per photon for delay, double-PE flag and
+// both SPE indices; the channel words come from a stream of their own, four photons per call); the CPU oracle implements
+// the same layout independently (oracle/wfsim_oracle.c) so that GPU and oracle results can be compared photon by photon.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,7 +19,10 @@ typedef unsigned int u32;
 
 enum WfsSite : u32 {
     SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
-    SITE_PH_A = 16, SITE_PH_B = 17, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
+    SITE_PH = 16,        // per photon (emitter, gid, item): x, y -> delay (alias table), z -> double-PE flag + second SPE index, w -> first SPE index
+    SITE_CH = 17,        // per four photons (em_base, gid, P >> 2), P = index among the instruction's photons: word P & 3 -> channel
+    SITE_PH_X = 18,      // per photon, S1 optical propagation only: x -> spline coordinate
+    SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
 };
 
 struct u32x4 { u32 x, y, z, w; };
@@ -66,39 +70,31 @@ __device__ __forceinline__ void box_muller(u32x4 w, double &z0, double &z1)
     z0 = r * c; z1 = r * s;
 }
 
-// Integer-valued normal delays.  The reference draws a normal variate and truncates it to int64 before adding it
-// (pulse.py:54-56 transit time, s1.py:194 and s2.py:550 spreads).  trunc(Y) is a discrete variate; it is sampled here by
-// inverse CDF from one uniform: cum[i] = P(X <= vmin + i), result = vmin + (first i with u < cum[i]).  The tables are
-// built on the host (wfs_engine.hip, build_time_tables) from erfc; the CPU oracle builds its own the same way.
-// (Exponential delays use the closed form trunc(-log(1-u) * tau).)
-#ifndef DISC_G
-#define DISC_G 4096
-#endif
-struct DiscTab { const double *cum; const unsigned short *guide; i32 vmin, n; };
+// Integer-valued delays.  The reference draws float variates and truncates each to int64 before adding it (pulse.py:54-56
+// transit time, s1.py:193-194, s2.py:338, pulse.py:339-341, s2.py:550); only the SUM reaches the pulse, and the sum of
+// independent integer variates is one discrete variate whose probability mass function the host builds by convolution
+// (wfs_engine.hip, build_time_tables).  It is sampled with Walker's alias method: K = 2^k >= n cells, cell c holds
+// {thr, alias}; the draw picks cell c = x >> shift and returns c if y < thr, else alias.  One 8-byte gather per photon
+// (an inverse-CDF search needs a guide cell and three cumulative values: five gathers, and the texture addresser was the
+// fill pass's bottleneck).  The table is built by the same sequential algorithm on the host and in the CPU oracle.
+struct AliasTab { const uint2 *cell; i32 vmin, shift; };
 
-// Lookup in two steps so that several lookups of one photon can have their loads in flight together:
-// disc_begin issues the two guide loads, disc_finish the (usually 4-entry) window of cumulative probabilities.
-struct DiscReq { const double *cum; int lo, hi; double u; };
-
-__device__ __forceinline__ DiscReq disc_begin(const DiscTab &t, double u)
+__device__ __forceinline__ i64 alias_sample(const AliasTab &t, u32 x, u32 y)
 {
-    const int c = (int)(u * DISC_G);
-    DiscReq r; r.cum = t.cum; r.u = u; r.lo = t.guide[c]; r.hi = t.guide[c + 1];       // answer in [lo, hi]
-    return r;
+    const u32 c = x >> t.shift;
+    const uint2 e = t.cell[c];
+    return (i64)t.vmin + (i64)(y < e.x ? c : e.y);
 }
 
-__device__ __forceinline__ i64 disc_finish(const DiscTab &t, DiscReq r)
+// double-PE flag and second SPE index from ONE word (pulse.py:76-79, 101-103): z < thr is the Bernoulli trial, and given
+// z < thr the word is uniform on [0, thr), so int(z * 2000 / thr) + 1 is the uniform table index
+__device__ __forceinline__ u32 dpe_code(u32 z, u64 thr_dpe, double dpe_inv)
 {
-    int lo = r.lo, hi = r.hi;
-    while (hi - lo > 3) { const int mid = (lo + hi) >> 1; if (r.u < r.cum[mid]) hi = mid; else lo = mid + 1; }
-    // at most 4 candidates left: fetch them together (cum[n-1] == 1 > u, indices clamped to the table)
-    const int n1 = t.n - 1;
-    const double c0 = r.cum[lo], c1 = r.cum[lo + 1 < n1 ? lo + 1 : n1], c2 = r.cum[lo + 2 < n1 ? lo + 2 : n1];
-    const int k = r.u < c0 ? 0 : (r.u < c1 ? 1 : (r.u < c2 ? 2 : 3));
-    return (i64)t.vmin + lo + k;
+    if (!((u64)z < thr_dpe)) return 0u;
+    u32 g2 = (u32)((double)z * dpe_inv) + 1u;
+    return g2 > 2000u ? 2000u : g2;
 }
-
-__device__ __forceinline__ i64 sample_disc(const DiscTab &t, double u) { return disc_finish(t, disc_begin(t, u)); }
+__device__ __forceinline__ u32 spe_index(u32 w) { return (u32)(((u64)w * 2000u) >> 32) + 1u; }      // int(u * 2000) + 1, pulse.py:226
 
 // python-style floor division / modulo on int64 (numpy // and % on int64, pulse.py:305-306)
 __host__ __device__ __forceinline__ i64 floordiv(i64 a, i64 b) { i64 q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
@@ -114,8 +110,9 @@ struct WfsDev {
     double trap_time, gain_spread, pmt_ap_modifier, pmt_ap_t_modifier, rext;
     u32 k0, k1;
     u64 thr_dpe;                               // Bernoulli threshold on a 32-bit word: floor(p * 2^32)
+    double dpe_inv;                            // 2000 / thr_dpe
     double current_max[10];
-    DiscTab tab_tts, tab_s1, tab_s2;           // inverse-CDF tables of integer delays: transit time alone, all terms of an S1 / S2 photon
+    AliasTab tab_tts, tab_s1, tab_s2;          // alias tables of integer delays: transit time alone, all terms of an S1 / S2 photon
     // tables
     const double *templates, *spe, *gains, *thr_truth, *lum_x, *lum_t;
     const i64 *thr_zle;

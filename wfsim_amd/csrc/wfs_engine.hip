@@ -44,7 +44,7 @@ struct wfs_handle {
     i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_embase, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
-    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ph_slot;
+    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles;
     DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
@@ -63,12 +63,12 @@ struct wfs_handle {
     double h_templates[WFS_DT * 22] = {0};
     std::vector<double> h_gains;
     i64 zero64 = 0;
-    DevBuf tt_cum[6], tt_guide[6];
+    DevBuf tt_alias[6];
     std::vector<i64> h_rs_off; std::vector<i32> h_rs_list;        // run set -> instructions (host copy)
     std::vector<double> h_lum_x, h_lum_t;          // luminescence table (host copy, enters the S2 delay table)
     DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
     // model variants of the photon delays
-    std::vector<DevBuf> x_cum, x_guide; std::vector<DiscTab> h_tabs; DevBuf d_tabs; i32 n_user_tabs = 0;
+    std::vector<DevBuf> x_alias; std::vector<AliasTab> h_tabs; DevBuf d_tabs; i32 n_user_tabs = 0;
     std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
     DevBuf prop_top, prop_bot; i32 prop_nz = 0, prop_nu = 0; double prop_u0 = 0, prop_du = 1;
     DevBuf ins_tab, ins_tabb, ins_pzi, ins_pzf; bool ins_models = false;
@@ -178,20 +178,41 @@ static void normal_trunc_table(double mu, double sigma, std::vector<double> &cum
     cum.back() = 1.0;
 }
 
-static int upload_disc(wfs_handle *h, int slot, const std::vector<double> &cum, int vmin, DiscTab &out)
+// Walker alias table of a discrete distribution given by its cumulative probabilities (Vose's construction, sequential and
+// in a fixed order so that the CPU oracle -- which builds its own -- arrives at the same cells): K = 2^k >= max(n, 2) cells,
+// q[i] = p[i] * K; "small" (q < 1) and "large" cells on two stacks filled in ascending index order; pop a small s, pair it
+// with the large l on top: cell s = {thr = floor(q[s] * 2^32), alias = l}, q[l] = (q[l] + q[s]) - 1, l moves to the small
+// stack when it drops below 1; what is left over keeps its own outcome.  Sampling: wfs_device.h alias_sample.
+static void build_alias(const std::vector<double> &cum, std::vector<uint2> &cell, int &shift)
+{
+    const size_t n = cum.size();
+    size_t K = 2; int lg = 1;
+    while (K < n) { K <<= 1; lg++; }
+    shift = 32 - lg;
+    std::vector<double> q(K, 0.0);
+    for (size_t i = 0; i < n; i++) q[i] = (cum[i] - (i ? cum[i - 1] : 0.0)) * (double)K;
+    std::vector<u32> small, large; small.reserve(K); large.reserve(K);
+    for (size_t i = 0; i < K; i++) (q[i] < 1.0 ? small : large).push_back((u32)i);
+    cell.assign(K, uint2{0xffffffffu, 0u});
+    for (size_t i = 0; i < K; i++) cell[i].y = (u32)i;                       // default: own outcome with certainty
+    while (!small.empty() && !large.empty()) {
+        const u32 sidx = small.back(); small.pop_back();
+        const u32 l = large.back();
+        const double t = q[sidx] * 4294967296.0;
+        cell[sidx].x = t >= 4294967295.0 ? 0xffffffffu : (u32)t; cell[sidx].y = l;
+        q[l] = (q[l] + q[sidx]) - 1.0;
+        if (q[l] < 1.0) { large.pop_back(); small.push_back(l); }
+    }
+}
+
+static int upload_disc(wfs_handle *h, DevBuf &buf, const std::vector<double> &cum, int vmin, AliasTab &out)
 {
     if (cum.size() > 65000) return h->fail(WFS_E_CAPACITY, "delay table too long (time constant above ~1.5 us)");
-    std::vector<unsigned short> guide(DISC_G + 2);
-    size_t idx = 0;
-    for (int c = 0; c <= DISC_G + 1; c++) {                 // first index whose cumulative probability exceeds c / DISC_G
-        const double x = (double)c / DISC_G;
-        while (idx + 1 < cum.size() && cum[idx] <= x) idx++;
-        guide[c] = (unsigned short)idx;
-    }
-    TRY(upload(h, h->tt_cum[slot], cum.data(), cum.size() * 8));
-    TRY(upload(h, h->tt_guide[slot], guide.data(), guide.size() * 2));
+    std::vector<uint2> cell; int shift = 31;
+    build_alias(cum, cell, shift);
+    TRY(upload(h, buf, cell.data(), cell.size() * sizeof(uint2)));
     HIPCHK(hipStreamSynchronize(h->stream));
-    out.cum = h->tt_cum[slot].as<double>(); out.guide = h->tt_guide[slot].as<unsigned short>(); out.vmin = vmin; out.n = (i32)cum.size();
+    out.cell = buf.as<uint2>(); out.vmin = vmin; out.shift = shift;
     return WFS_OK;
 }
 
@@ -247,14 +268,21 @@ static Pmf pmf_conv(const Pmf &a, const Pmf &b)
     for (size_t i = 0; i < a.p.size(); i++) { const double ai = a.p[i]; if (ai == 0.0) continue; for (size_t j = 0; j < b.p.size(); j++) r.p[i + j] += ai * b.p[j]; }
     return r;
 }
-static int upload_pmf(wfs_handle *h, int slot, const Pmf &a, DiscTab &out)
+// cumulative table of a pmf: leading zeros dropped, cut where the running sum reaches 1 (the oracle does the same)
+static void cum_of_pmf(const Pmf &a, std::vector<double> &cum, long &vmin)
 {
     size_t first = 0; while (first + 1 < a.p.size() && a.p[first] == 0.0) first++;
-    std::vector<double> cum; double acc = 0;
+    cum.clear(); double acc = 0;
     for (size_t i = first; i < a.p.size(); i++) { acc += a.p[i]; cum.push_back(acc); if (acc >= 1.0) break; }
     while (cum.size() > 1 && cum[cum.size() - 2] >= 1.0) cum.pop_back();
     cum.back() = 1.0;
-    return upload_disc(h, slot, cum, (int)(a.vmin + (long)first), out);
+    vmin = a.vmin + (long)first;
+}
+static int upload_pmf(wfs_handle *h, int slot, const Pmf &a, AliasTab &out)
+{
+    std::vector<double> cum; long vmin;
+    cum_of_pmf(a, cum, vmin);
+    return upload_disc(h, h->tt_alias[slot], cum, (int)vmin, out);
 }
 
 // tab_tts: transit time alone (photons that arrive with their times: RawDataOptical); tab_s1 / tab_s2: every delay term of
@@ -289,7 +317,7 @@ void refresh_dev(wfs_handle *h)
     d.pmt_ap_modifier = c.pmt_ap_modifier; d.pmt_ap_t_modifier = c.pmt_ap_t_modifier; d.rext = c.rext;
     d.k0 = (u32)c.seed; d.k1 = (u32)(c.seed >> 32);
     auto thr = [](double p) -> u64 { if (!(p > 0)) return 0; if (p >= 1) return 4294967296ull; return (u64)(p * 4294967296.0); };
-    d.thr_dpe = thr(c.p_dpe);
+    d.thr_dpe = thr(c.p_dpe); d.dpe_inv = d.thr_dpe ? 2000.0 / (double)d.thr_dpe : 0.0;
     // HE rows are only materialised when they can differ from a flat baseline: a non-zero int(factor)
     // (rawdata.py:242) or noise columns for the HE channels
     d.enable_noise = (c.enable_noise && d.noise != nullptr) ? 1 : 0;
@@ -326,11 +354,10 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     hipFuncSetAttribute((const void *)k_pulse<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_photons<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_photons<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_photons<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_photons<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_photons<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photon_fill<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photon_fill<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photon_fill<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
@@ -342,7 +369,7 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ph_slot, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -351,9 +378,8 @@ int wfs_destroy(wfs_handle *h)
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
-    for (int q = 0; q < 6; q++) { if (h->tt_cum[q].p) hipFree(h->tt_cum[q].p); if (h->tt_guide[q].p) hipFree(h->tt_guide[q].p); }
-    for (auto &b : h->x_cum) if (b.p) hipFree(b.p);
-    for (auto &b : h->x_guide) if (b.p) hipFree(b.p);
+    for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
+    for (auto &b : h->x_alias) if (b.p) hipFree(b.p);
     for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); }
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (h->own_stream) hipStreamDestroy(h->stream);
@@ -563,30 +589,20 @@ int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, c
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
     if (n_tables < 0 || n_tables > 65536 || (n_tables > 0 && (!base || !pmf_off || !pmf || !vmin))) return h->fail(WFS_E_INVALID, "wfs_set_delay_models: bad arguments");
     HIPCHK(hipSetDevice(h->device));
-    for (auto &b : h->x_cum) if (b.p) hipFree(b.p);
-    for (auto &b : h->x_guide) if (b.p) hipFree(b.p);
-    h->x_cum.assign((size_t)n_tables, DevBuf{}); h->x_guide.assign((size_t)n_tables, DevBuf{});
-    h->h_tabs.assign((size_t)n_tables + 2, DiscTab{});
+    for (auto &b : h->x_alias) if (b.p) hipFree(b.p);
+    h->x_alias.assign((size_t)n_tables, DevBuf{});
+    h->h_tabs.assign((size_t)n_tables + 2, AliasTab{});
     h->n_user_tabs = n_tables; h->ins_models = false;
     for (int k = 0; k < n_tables; k++) {
         if (base[k] < 0 || base[k] > 3 || pmf_off[k + 1] <= pmf_off[k]) return h->fail(WFS_E_INVALID, "wfs_set_delay_models: bad base or empty pmf");
         Pmf e; e.vmin = vmin[k]; e.p.assign(pmf + pmf_off[k], pmf + pmf_off[k + 1]);
-        const Pmf a = pmf_conv(h->base_pmf[base[k]], e);
-        size_t first = 0; while (first + 1 < a.p.size() && a.p[first] == 0.0) first++;
-        std::vector<double> cum; double acc = 0;
-        for (size_t i = first; i < a.p.size(); i++) { acc += a.p[i]; cum.push_back(acc); if (acc >= 1.0) break; }
-        while (cum.size() > 1 && cum[cum.size() - 2] >= 1.0) cum.pop_back();
-        cum.back() = 1.0;
+        std::vector<double> cum; long v0;
+        cum_of_pmf(pmf_conv(h->base_pmf[base[k]], e), cum, v0);
         if (cum.size() > 65000) return h->fail(WFS_E_CAPACITY, "delay table too long");
-        std::vector<unsigned short> guide(DISC_G + 2);
-        size_t idx = 0;
-        for (int c = 0; c <= DISC_G + 1; c++) { const double x = (double)c / DISC_G; while (idx + 1 < cum.size() && cum[idx] <= x) idx++; guide[c] = (unsigned short)idx; }
-        TRY(upload(h, h->x_cum[k], cum.data(), cum.size() * 8)); TRY(upload(h, h->x_guide[k], guide.data(), guide.size() * 2));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        h->h_tabs[k] = DiscTab{h->x_cum[k].as<double>(), h->x_guide[k].as<unsigned short>(), (i32)(a.vmin + (long)first), (i32)cum.size()};
+        TRY(upload_disc(h, h->x_alias[k], cum, (int)v0, h->h_tabs[k]));
     }
     h->h_tabs[n_tables] = h->dev.tab_s1; h->h_tabs[n_tables + 1] = h->dev.tab_s2;       // "-1": the default table of the type
-    TRY(upload(h, h->d_tabs, h->h_tabs.data(), h->h_tabs.size() * sizeof(DiscTab)));
+    TRY(upload(h, h->d_tabs, h->h_tabs.data(), h->h_tabs.size() * sizeof(AliasTab)));
     HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
 }
@@ -823,7 +839,7 @@ static int run_generation(wfs_handle *h)
     g.el_stat = h->el_stat.as<double>(); g.el_minmax = h->el_minmax.as<i64>(); g.scal = h->scal.as<i64>();
     const bool ext = h->ins_models;
     if (ext) {
-        g.tabs = h->d_tabs.as<DiscTab>(); g.ins_tab = h->ins_tab.as<i32>(); g.ins_tabb = h->ins_tabb.as<i32>();
+        g.tabs = h->d_tabs.as<AliasTab>(); g.ins_tab = h->ins_tab.as<i32>(); g.ins_tabb = h->ins_tabb.as<i32>();
         g.ins_pzi = h->ins_pzi.as<i32>(); g.ins_pzf = h->ins_pzf.as<double>();
         if (h->prop_nz >= 2) { g.prop_top = h->prop_top.as<double>(); g.prop_bot = h->prop_bot.as<double>(); g.prop_nu = h->prop_nu; g.prop_u0 = h->prop_u0; g.prop_du = h->prop_du; }
     }
@@ -862,28 +878,27 @@ static int run_generation(wfs_handle *h)
         ap.cap = ap_cap; ap.ap_ins = h->ap_ins.as<i32>(); ap.ap_ch = h->ap_ch.as<i32>(); ap.ap_t = h->ap_t.as<i32>(); ap.ap_gain = h->ap_gain.as<double>();
         ap.count = h->scal.as<i64>() + 13;
     }
-    const size_t nch1 = (size_t)d.n_tpc + 1 + ((d.n_tpc + 1) & 1);
-    const size_t gen_lds_count = (size_t)GEN_WIN * 4 + (size_t)d.n_tpc * 8 + nch1 * 4 + (CDF_G + 8) * 2 + (size_t)GEN_BLOCK * 4 + 16;
-    const size_t gen_lds = (((size_t)GEN_WIN * 12 + (size_t)d.n_tpc * 16 + nch1 * 4 + (size_t)GEN_BLOCK * 2 + 7) & ~(size_t)7) + (ap_on ? (size_t)AP_STAGE * 20 : 0) + 16;
+    TRY(ensure(h, h->ins_ph0, (size_t)(N + 1) * 8)); g.ins_ph0 = h->ins_ph0.as<i64>();
+    { Timer t(h, "k_ins_ph0"); hipLaunchKernelGGL(k_ins_ph0, dim3(nblocks(N + 1, 256)), dim3(256), 0, h->stream, g); }
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         g.n_blocks = nb;
         TRY(ensure(h, h->blk_e, (size_t)nb * 16)); TRY(ensure(h, h->blk_base, (size_t)nb * d.n_tpc * 4)); TRY(ensure(h, h->blk_cnt, (size_t)nb * d.n_tpc * 2)); TRY(ensure(h, h->blk_ins, (size_t)nb * 4));
-        TRY(ensure(h, h->ph_slot, (size_t)P * 4));
-        g.blk_e = h->blk_e.as<i64>(); g.blk_base = h->blk_base.as<u32>(); g.blk_cnt = h->blk_cnt.as<unsigned short>(); g.blk_ins = h->blk_ins.as<i32>(); g.ph_slot = h->ph_slot.as<u32>();
+        g.blk_e = h->blk_e.as<i64>(); g.blk_base = h->blk_base.as<u32>(); g.blk_cnt = h->blk_cnt.as<unsigned short>(); g.blk_ins = h->blk_ins.as<i32>();
         { Timer t(h, "k_block_emitters"); hipLaunchKernelGGL(k_block_emitters, dim3(nblocks(nb, 256)), dim3(256), 0, h->stream, g); }
         // XCD x (workgroup id % 8) walks the photon blocks [x * chunk, (x + 1) * chunk) in order: the blocks that share
         // cache lines of a tile (consecutive ranges, k_block_ranges) run close together in time on the same L2
         g.xcd_chunk = (nb + 7) / 8;
         const unsigned nbx = (unsigned)(g.xcd_chunk * 8);
-        { Timer t(h, "k_photons_count"); hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<true, false>), dim3(nbx), dim3(GEN_TPB), gen_lds_count, h->stream, d, g, ap); }
+        { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(GEN_TPB), GEN_COUNT_LDS(d.n_tpc), h->stream, d, g); }
         { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
-        { Timer t(h, "k_photons_fill");
-          if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
-          else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
-          else if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photons<false, false>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap); }
+        const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, ap_on).total;
+        { Timer t(h, "k_photon_fill");
+          if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          else if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, false>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, false>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap); }
     } else {
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
     }

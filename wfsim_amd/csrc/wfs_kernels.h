@@ -1145,13 +1145,13 @@ struct GenArgs {
     i64 *blk_e;                   // [n_blocks][2] first / last emitter of every photon block
     u32 *blk_base;                // [n_blocks][n_tpc] start of the block's photons inside each tile (written by the count pass)
     unsigned short *blk_cnt;      // [n_blocks][n_tpc] the block's photons per channel (count pass, single-instruction blocks)
-    i32 *blk_ins;                 // [n_blocks] instruction of a single-instruction block, -1 otherwise
-    u32 *ph_slot;                 // [n_photons] slot inside its tile of every photon of a multi-instruction block (count pass)
+    i32 *blk_ins;                 // [n_blocks] instruction of a single-instruction block, -1 otherwise (k_block_emitters)
+    i64 *ins_ph0;                 // [n_ins + 1] first photon (generation order) of every instruction: em_ph_off[em_off[i]]
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
     i64 *scal;
     // model variants of the photon delays (wfs_set_delay_models / wfs_set_instruction_models); tabs == nullptr: the two default tables
-    const DiscTab *tabs;          // [n_tables + 2] user tables, then the default S1 and S2 tables
+    const AliasTab *tabs;         // [n_tables + 2] user tables, then the default S1 and S2 tables
     const i32 *ins_tab, *ins_tabb;        // [n_ins] table of the instruction's photons on top / bottom array channels
     const i32 *ins_pzi; const double *ins_pzf;    // [n_ins] S1 optical propagation: z cell of the spline grid and normalised distance in it (-1: none)
     const double *prop_top, *prop_bot; i32 prop_nu; double prop_u0, prop_du;      // spline node values [nz][nu], u grid
@@ -1300,7 +1300,7 @@ __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double
 #define GEN_TPB 256
 #define GEN_PPT 8
 #ifndef GEN_GRP
-#define GEN_GRP 2                  // photons a thread carries through the fill pass together (4: 6.5 ms, 8: 8.2 ms, registers)
+#define GEN_GRP 4                  // photons a thread carries through the fill pass together (their table gathers are in flight at once)
 #endif
 #define GEN_BLOCK (GEN_TPB * GEN_PPT)
 #define GEN_WIN 512                // emitter offsets staged in LDS per block
@@ -1331,6 +1331,16 @@ __global__ void k_block_emitters(GenArgs a)
         while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
         a.blk_e[2 * b + w] = lo;
     }
+    // the fast path of the generator needs all photons of the block in one instruction and the block's emitters in its LDS window
+    const i64 e_lo = a.blk_e[2 * b], e_hi = a.blk_e[2 * b + 1];
+    const i32 i0 = a.em_ins[e_lo];
+    a.blk_ins[b] = (e_hi - e_lo + 2 <= GEN_WIN && i0 == a.em_ins[e_hi]) ? i0 : -1;
+}
+
+__global__ void k_ins_ph0(GenArgs a)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= a.n_ins) a.ins_ph0[i] = a.em_ph_off[a.em_off[i]];
 }
 
 // PMT afterpulses of one photon (afterpulse.py:172-249): one uniform pair per element; generated photons are staged in
@@ -1375,24 +1385,22 @@ __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, c
     }
 }
 
-// Photon generator, two passes over the same photon index space (GEN_BLOCK consecutive photons per block).
-// Pass A (COUNT = true): Philox site A of every photon -> channel (s1.py:154-158 / s2.py:673-677), double-PE flag
-//   (pulse.py:76-79) and first SPE index (pulse.py:97-103); photons per tile.
-// Pass B (COUNT = false): Philox site B -> summed delay (s1.py:180-194 / s2.py:504-557, pulse.py:53-56) and the second
-//   SPE index; the finished photon is written straight into its tile's bucket.
-// Fast path ("single": all photons of the block belong to one instruction, the normal case for an S2): the emitter
-//   window, the instruction's channel CDF + a guide table, and the block's tile offsets live in LDS.  Pass A buckets the
-//   block's photons BY CHANNEL inside the block (LDS histogram -> ranks -> prefix sum) and leaves one packed word per
-//   photon in that order (photon index in the block | dpe << 11 | spe index << 12 | emitter slot << 23) plus the
-//   block's photons per channel; it reserves the block's range in every tile with ONE global atomic per non-empty tile.
-//   Pass B walks the words in bucket order: neighbouring lanes finish photons of the same tile and store them to
-//   consecutive addresses (a scattered 8-byte store per lane is bound by the L2 request rate), and it repeats neither
-//   Philox A nor the searches.
+// Photon generator, two passes over the same photon index space (GEN_BLOCK consecutive photons per block, generation
+// order = emitter by emitter).  RNG spec v5:
+//   channel (s1.py:154-158 / s2.py:673-677): word P & 3 of the call (em_base, gid, P >> 2, SITE_CH), P = index of the photon
+//     among its instruction's photons -- a quarter of a Philox call per photon;
+//   everything else: ONE call (emitter, gid, item, SITE_PH): x, y -> summed delay (alias table; s1.py:180-194 /
+//     s2.py:504-557, pulse.py:53-56), z -> double-PE flag and second SPE index, w -> first SPE index (pulse.py:76-103).
+// Count pass (k_photon_count): channel words only -> photons per (block, channel); no per-photon intermediate is left in
+//   HBM (the first version wrote a packed word per photon and read it back: 5.8 GB per 10^9-PE batch).
+// k_block_ranges: where in its tile every block puts its photons (consecutive blocks, consecutive ranges).
+// Fill pass (k_photon_fill): repeats the channel words (cheap), ranks the block's photons inside their channel with LDS
+//   counters and leaves the permutation generation order -> bucket order in LDS; then walks the BUCKET order:
+//   neighbouring lanes finish photons of the same tile and store them to consecutive addresses (a scattered 8-byte store
+//   per lane is bound by the L2 request rate).
+// Fast path ("single": all photons of the block belong to one instruction, the normal case for an S2): emitter window,
+//   channel CDF + guide table and tile offsets of the block live in LDS.
 // Generic path (a block spanning instructions: S1s, small S2s): per-photon global lookups and atomics.
-#define PW_PR(w) ((int)((w) & 2047u))
-#define PW_DPE(w) ((((w) >> 11) & 1u) != 0u)
-#define PW_G1(w) (((w) >> 12) & 2047u)
-#define PW_SLOT(w) ((int)((w) >> 23))
 
 // exclusive prefix sum over n <= 4 * GEN_TPB LDS integers, in place; v[n] receives the total.  All threads call it.
 __device__ __forceinline__ void block_excl_scan(i32 *v, int n, i32 *wtmp)
@@ -1529,7 +1537,7 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
     u32 run = (u32)a.tile_count[idx];
     for (i64 q = a.set_ins_off[set]; q < a.set_ins_off[set + 1]; q++) {      // the set's instructions, in order
         const i32 ins = a.set_ins_list[q];
-        const i64 pa = a.em_ph_off[a.em_off[ins]], pb = a.em_ph_off[a.em_off[ins + 1]];     // photons [pa, pb) of the instruction
+        const i64 pa = a.ins_ph0[ins], pb = a.ins_ph0[ins + 1];     // photons [pa, pb) of the instruction
         if (pb <= pa) continue;
         const i64 b1 = (pb - 1) / GEN_BLOCK;
         for (i64 b0 = pa / GEN_BLOCK; b0 <= b1; b0 += 8) {       // eight blocks at a time: their loads are in flight together
@@ -1547,205 +1555,256 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
     a.tile_count[idx] = (i32)run;
 }
 
-// EXT: delay tables per instruction and array (model variants), S1 optical propagation term
-template <bool COUNT, bool AP, bool EXT = false>
-__global__ __launch_bounds__(GEN_TPB) void k_photons(WfsDev d, GenArgs a, ApArgs ap)
+// channel of a photon from its 32-bit word: np.random.choice(p=...) = searchsorted(cdf, u, 'right') with u = w / 2^32,
+// started from a guide table (guide[c] = first channel whose cumulative probability exceeds c / CDF_G)
+__device__ __forceinline__ int channel_lookup(const double *cdf, const unsigned short *cguide, int nch, u32 w)
+{
+    const double u = (double)w * (1.0 / 4294967296.0);
+    int ch = cguide[w >> 23];                      // CDF_G = 512 cells
+    while (ch < nch - 1 && u >= cdf[ch]) ch++;
+    return ch;
+}
+__device__ __forceinline__ u32 word_of(const u32x4 &W, int k) { return k == 0 ? W.x : (k == 1 ? W.y : (k == 2 ? W.z : W.w)); }
+
+// photon p (generation order) -> emitter, instruction, Philox coordinates; generic path and k_photon_times
+struct PhotonId { i64 em; i32 ins; u32 gid, j, m, P; };
+__device__ __forceinline__ PhotonId photon_id(const GenArgs &a, i64 p)
+{
+    i64 lo = 0, hi = a.n_emitters;
+    while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
+    PhotonId r; r.em = lo; r.ins = a.em_ins[lo]; r.gid = a.ins_gid[r.ins];
+    r.j = (u32)(lo - a.em_off[r.ins]) + a.ins_embase[r.ins]; r.m = (u32)(p - a.em_ph_off[lo]); r.P = (u32)(p - a.ins_ph0[r.ins]);
+    return r;
+}
+__device__ __forceinline__ int photon_channel_global(const WfsDev &d, const GenArgs &a, const PhotonId &id)
+{
+    const u32x4 W = philox4x32_10(a.ins_embase[id.ins], id.gid, id.P >> 2, SITE_CH, d.k0, d.k1);
+    return channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[id.ins] * d.n_tpc, d.n_tpc, (double)word_of(W, (int)(id.P & 3u)) * (1.0 / 4294967296.0));
+}
+
+#define GEN_COUNT_LDS(nch) ((size_t)(nch) * 12 + (CDF_G + 8) * 2)
+
+__global__ __launch_bounds__(GEN_TPB) void k_photon_count(WfsDev d, GenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nch = d.n_tpc;
-    // LDS layout (plain integer offsets: a pointer that went through an integer cast loses its LDS address space)
-    //   count: win i32[GEN_WIN] | cdf f64[nch] | hist i32[nch + 1] | cguide u16[CDF_G + 8] | stage u32[GEN_BLOCK]
-    //   fill : win i32[GEN_WIN] | wtime i64[GEN_WIN] | hbase i64[nch] | hist i32[nch + 1] | hmin i32[nch] | hmax i32[nch] | chmap u16[GEN_BLOCK] | afterpulse staging
-    i32 *win = (i32 *)smem;                                  // first photon of the block's emitters, relative to the block's first photon
-    double *cdf = (double *)(smem + GEN_WIN * 4);
-    i64 *wtime = (i64 *)(smem + GEN_WIN * 4);                // emitter times
-    i64 *hbase = (i64 *)(smem + GEN_WIN * 12);               // fill: global slot of bucket position 0 of every channel
-    i32 *hist = (i32 *)(smem + (COUNT ? GEN_WIN * 4 + nch * 8 : GEN_WIN * 12 + nch * 8));      // counts, then their prefix sums
-    const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
-    unsigned short *cguide = (unsigned short *)(smem + GEN_WIN * 4 + nch * 8 + nch1 * 4);
-    u32 *stage = (u32 *)(smem + GEN_WIN * 4 + nch * 8 + nch1 * 4 + (CDF_G + 8) * 2);
-    i32 *hmin = (i32 *)(smem + GEN_WIN * 12 + nch * 8 + nch1 * 4), *hmax = hmin + nch;
-    unsigned short *chmap = (unsigned short *)(smem + GEN_WIN * 12 + nch * 16 + nch1 * 4);     // channel of every bucket position
-    const int o_ap = (GEN_WIN * 12 + nch * 16 + nch1 * 4 + GEN_BLOCK * 2 + 7) & ~7;
-    __shared__ i32 s_wtmp[GEN_TPB / 64];
-    ApStage aps;
-    aps.gain = (double *)(smem + o_ap); aps.ins = (i32 *)(smem + o_ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE;
-    __shared__ i32 s_apn; __shared__ i64 s_apbase;
-    aps.n = &s_apn;
-    const int tid = threadIdx.x;
-    if (AP && tid == 0) s_apn = 0;
+    const int nch = d.n_tpc, tid = threadIdx.x;
+    double *cdf = (double *)smem;                                   // [nch]
+    i32 *hist = (i32 *)(smem + (size_t)nch * 8);                    // [nch]
+    unsigned short *cguide = (unsigned short *)(smem + (size_t)nch * 12);
     // Workgroups are dealt to the 8 XCDs round robin: XCD x takes the photon blocks [x * chunk, (x + 1) * chunk) in
     // order, so that the blocks writing neighbouring ranges of a tile run close together in time behind the same L2.
     const i64 vb = (i64)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);
     if (vb >= a.n_blocks) return;                            // block-uniform (padding of the XCD order)
     const i64 p0 = vb * GEN_BLOCK;
     const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
-    const i64 e_lo = a.blk_e[2 * vb], e_hi = a.blk_e[2 * vb + 1];
-    const int nwin = (e_hi - e_lo + 2 <= GEN_WIN) ? (int)(e_hi - e_lo + 2) : 0;
-    const i32 ins_lo = a.em_ins[e_lo];
-    const bool single = nwin > 0 && ins_lo == a.em_ins[e_hi];      // all photons of the block in one pulse set
+    const i32 ins = a.blk_ins[vb];
+    if (ins >= 0) {
+        const size_t row = (size_t)a.ins_cdfrow[ins];
+        for (int c = tid; c < nch; c += GEN_TPB) { hist[c] = 0; cdf[c] = a.cdf_table[row * nch + c]; }
+        for (int c = tid; c <= CDF_G; c += GEN_TPB) cguide[c] = a.cdf_guide[row * (CDF_G + 2) + c];
+        __syncthreads();
+        const u32 gid = a.ins_gid[ins], eb = a.ins_embase[ins];
+        const i64 R0 = p0 - a.ins_ph0[ins];                   // index of the block's first photon among the instruction's photons
+        for (i64 q = (R0 >> 2) + tid; (q << 2) < R0 + np; q += GEN_TPB) {
+            const u32x4 W = philox4x32_10(eb, gid, (u32)q, SITE_CH, d.k0, d.k1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const i64 pr = (q << 2) + k - R0;
+                if (pr >= 0 && pr < np) atomicAdd(&hist[channel_lookup(cdf, cguide, nch, word_of(W, k))], 1);
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < nch; c += GEN_TPB) a.blk_cnt[vb * nch + c] = (unsigned short)hist[c];     // -> k_block_ranges
+    } else {
+        for (int q = 0; q < GEN_PPT; q++) {
+            const int pr = q * GEN_TPB + tid;
+            if (pr >= np) break;
+            const PhotonId id = photon_id(a, p0 + pr);
+            const int ch = photon_channel_global(d, a, id);
+            atomicAdd(&a.tile_count[(i64)a.ins_set[id.ins] * nch + ch], 1);
+        }
+    }
+}
 
-    if (single) {
-        const u32 gid = a.ins_gid[ins_lo]; const i64 emoff = a.em_off[ins_lo];
+// LDS layout of the fill pass (byte offsets; plain integer offsets: a pointer that went through an integer cast loses its
+// LDS address space)
+struct GenFillLds { int wtime, cdf, hist, hmin, hmax, chmap, perm, emap, cguide, ap, total; };
+__host__ __device__ inline GenFillLds gen_fill_lds(int nch, bool with_ap)
+{
+    const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
+    GenFillLds o;
+    o.wtime = GEN_WIN * 4;                                    // win i32[GEN_WIN] at 0: first photon of the block's emitters, relative to the block
+    o.cdf = o.wtime + GEN_WIN * 8;                            // wtime i64[GEN_WIN]: emitter times; cdf f64[nch], later hbase i64[nch]
+    o.hist = o.cdf + nch * 8;                                 // i32[nch1]: photons per channel, then their prefix sums
+    o.hmin = o.hist + nch1 * 4;                               // i32[nch]: rank counters of the channel phase, then earliest photon
+    o.hmax = o.hmin + nch * 4;                                // i32[nch]
+    o.chmap = (o.hmax + nch * 4 + 7) & ~7;                    // u16[GEN_BLOCK]: channel of every bucket position
+    o.perm = o.chmap + GEN_BLOCK * 2;                         // u16[GEN_BLOCK]: photon (generation order) of every bucket position
+    o.emap = o.perm + GEN_BLOCK * 2;                          // u16[GEN_BLOCK]: emitter slot of every photon (generation order)
+    o.cguide = o.emap + GEN_BLOCK * 2;                        // u16[CDF_G + 8]
+    o.ap = (o.cguide + (CDF_G + 8) * 2 + 7) & ~7;             // afterpulse staging
+    o.total = o.ap + (with_ap ? AP_STAGE * 20 : 0) + 16;
+    return o;
+}
+
+// EXT: delay tables per instruction and array (model variants), S1 optical propagation term
+template <bool AP, bool EXT>
+__global__ __launch_bounds__(GEN_TPB) void k_photon_fill(WfsDev d, GenArgs a, ApArgs ap)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nch = d.n_tpc, tid = threadIdx.x;
+    const GenFillLds o = gen_fill_lds(nch, AP);
+    i32 *win = (i32 *)smem;
+    i64 *wtime = (i64 *)(smem + o.wtime);
+    double *cdf = (double *)(smem + o.cdf);
+    i64 *hbase = (i64 *)(smem + o.cdf);                       // global slot of bucket position 0 of every channel (after the channel phase)
+    i32 *hist = (i32 *)(smem + o.hist);
+    i32 *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
+    i32 *cur = hmin;
+    unsigned short *chmap = (unsigned short *)(smem + o.chmap), *perm = (unsigned short *)(smem + o.perm), *emap = (unsigned short *)(smem + o.emap);
+    i32 *scr = (i32 *)(smem + o.chmap);                       // [GEN_BLOCK] scratch of the emitter map: chmap + perm, before they are written
+    unsigned short *cguide = (unsigned short *)(smem + o.cguide);
+    __shared__ i32 s_wtmp[GEN_TPB / 64];
+    ApStage aps;
+    aps.gain = (double *)(smem + o.ap); aps.ins = (i32 *)(smem + o.ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE;
+    __shared__ i32 s_apn; __shared__ i64 s_apbase;
+    aps.n = &s_apn;
+    if (AP && tid == 0) s_apn = 0;
+    const i64 vb = (i64)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);      // XCD order, see k_photon_count
+    if (vb >= a.n_blocks) return;
+    const i64 p0 = vb * GEN_BLOCK;
+    const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
+    const i32 ins_lo = a.blk_ins[vb];
+
+    if (ins_lo >= 0) {
+        const i64 e_lo = a.blk_e[2 * vb], e_hi = a.blk_e[2 * vb + 1];
+        const int nwin = (int)(e_hi - e_lo + 2);             // <= GEN_WIN (k_block_emitters)
+        const u32 gid = a.ins_gid[ins_lo], eb = a.ins_embase[ins_lo]; const i64 emoff = a.em_off[ins_lo];
         const i32 set_lo = a.ins_set[ins_lo]; const i64 itime = a.set_t0[set_lo];       // photon times are relative to the pulse set's origin
-        const DiscTab &tab = (a.ins_type[ins_lo] != 1) ? d.tab_s2 : d.tab_s1;
-        DiscTab tab_t = tab, tab_b = tab; i32 pzi = -1; double pzf = 0.0;
-        if (EXT && !COUNT) {
+        const AliasTab &tab = (a.ins_type[ins_lo] != 1) ? d.tab_s2 : d.tab_s1;
+        AliasTab tab_t = tab, tab_b = tab; i32 pzi = -1; double pzf = 0.0;
+        if (EXT) {
             tab_t = a.tabs[a.ins_tab[ins_lo]]; tab_b = a.tabs[a.ins_tabb[ins_lo]];
             if (a.prop_top && a.ins_type[ins_lo] == 1) { pzi = a.ins_pzi[ins_lo]; pzf = a.ins_pzf[ins_lo]; }
         }
 #define TAB_OF(k) (EXT ? (bot[k] ? tab_b : tab_t) : tab)
         const i64 tbase = (i64)set_lo * nch;
-        const u32 jbase = (u32)(e_lo - emoff) + a.ins_embase[ins_lo];
-        u32 pw[GEN_PPT];                                      // pass B: the packed words of this thread's bucket positions, loaded up front
-        if (!COUNT) {
-#pragma unroll
-            for (int q = 0; q < GEN_PPT; q++) { const int i = q * GEN_TPB + tid; pw[q] = i < np ? a.ph_slot[p0 + i] : 0u; }
-        }
-        for (int c = tid; c < nch; c += GEN_TPB) {
-            if (COUNT) { hist[c] = 0; cdf[c] = a.cdf_table[(size_t)a.ins_cdfrow[ins_lo] * nch + c]; }
-            else { hist[c] = (i32)a.blk_cnt[vb * nch + c]; hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000; }
-        }
+        const u32 jbase = (u32)(e_lo - emoff) + eb;
+        const i64 R0 = p0 - a.ins_ph0[ins_lo];
+        const size_t row = (size_t)a.ins_cdfrow[ins_lo];
+        for (int c = tid; c < nch; c += GEN_TPB) { hist[c] = (i32)a.blk_cnt[vb * nch + c]; cur[c] = 0; cdf[c] = a.cdf_table[row * nch + c]; }
+        for (int c = tid; c <= CDF_G; c += GEN_TPB) cguide[c] = a.cdf_guide[row * (CDF_G + 2) + c];
         for (int k = tid; k < nwin; k += GEN_TPB) {
             win[k] = (i32)(a.em_ph_off[e_lo + k] - p0);
-            if (!COUNT) wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] - itime : 0;
+            wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] - itime : 0;
+        }
+        for (int i = tid; i < GEN_BLOCK; i += GEN_TPB) scr[i] = 0;
+        __syncthreads();
+        // photon -> emitter slot (last k with win[k] <= pr) for the whole block at once: every emitter marks its first
+        // photon, a running maximum over the photon index fills the gaps
+        for (int k = tid; k < nwin; k += GEN_TPB) { const i32 w0 = win[k]; if (w0 > 0 && w0 < GEN_BLOCK) atomicMax(&scr[w0], k); }
+        block_excl_scan(hist, nch, s_wtmp);                  // (synchronises: the marks are complete behind it)
+        {
+            i32 v[GEN_PPT]; i32 mx = 0;
+#pragma unroll
+            for (int k = 0; k < GEN_PPT; k++) { const i32 x = scr[tid * GEN_PPT + k]; mx = x > mx ? x : mx; v[k] = mx; }
+            i32 inc = mx;                                    // inclusive running maximum over the threads of the wave
+            for (int s = 1; s < 64; s <<= 1) { const i32 y = __shfl_up(inc, s, 64); if ((tid & 63) >= s) inc = y > inc ? y : inc; }
+            if ((tid & 63) == 63) s_wtmp[tid >> 6] = inc;
+            i32 carry = __shfl_up(inc, 1, 64); if ((tid & 63) == 0) carry = 0;
+            __syncthreads();
+            for (int w = 0; w < (tid >> 6); w++) carry = s_wtmp[w] > carry ? s_wtmp[w] : carry;
+#pragma unroll
+            for (int k = 0; k < GEN_PPT; k++) emap[tid * GEN_PPT + k] = (unsigned short)(v[k] > carry ? v[k] : carry);
+        }
+        __syncthreads();                                     // scr is dead: perm may be written
+        // ---- channel phase: the channel words again, rank inside the channel -> bucket position of every photon
+        for (i64 q = (R0 >> 2) + tid; (q << 2) < R0 + np; q += GEN_TPB) {
+            const u32x4 W = philox4x32_10(eb, gid, (u32)q, SITE_CH, d.k0, d.k1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const i64 pr = (q << 2) + k - R0;
+                if (pr >= 0 && pr < np) {
+                    const int ch = channel_lookup(cdf, cguide, nch, word_of(W, k));
+                    perm[hist[ch] + atomicAdd(&cur[ch], 1)] = (unsigned short)pr;
+                }
+            }
         }
         __syncthreads();
-        if (COUNT) {
-            // guide[c] = first channel whose cumulative probability exceeds c / CDF_G (searchsorted side='right'), built on the host
-            for (int c = tid; c <= CDF_G; c += GEN_TPB) cguide[c] = a.cdf_guide[(size_t)a.ins_cdfrow[ins_lo] * (CDF_G + 2) + c];
-            // photon -> emitter slot (last k with win[k] <= pr) for the whole block at once: every emitter marks its first
-            // photon, a running maximum over the photon index fills the gaps (stage[] is free until the bucketing step)
-            i32 *emap = (i32 *)stage;
-            for (int i = tid; i < GEN_BLOCK; i += GEN_TPB) emap[i] = 0;
-            __syncthreads();
-            for (int k = tid; k < nwin; k += GEN_TPB) { const i32 w0 = win[k]; if (w0 > 0 && w0 < GEN_BLOCK) atomicMax(&emap[w0], k); }
-            __syncthreads();
-            {
-                i32 v[GEN_PPT]; i32 mx = 0;
-#pragma unroll
-                for (int k = 0; k < GEN_PPT; k++) { const i32 x = emap[tid * GEN_PPT + k]; mx = x > mx ? x : mx; v[k] = mx; }
-                i32 inc = mx;                                // inclusive running maximum over the threads of the wave
-                for (int o = 1; o < 64; o <<= 1) { const i32 y = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc = y > inc ? y : inc; }
-                if ((tid & 63) == 63) s_wtmp[tid >> 6] = inc;
-                i32 carry = __shfl_up(inc, 1, 64); if ((tid & 63) == 0) carry = 0;
-                __syncthreads();
-                for (int w = 0; w < (tid >> 6); w++) carry = s_wtmp[w] > carry ? s_wtmp[w] : carry;
-#pragma unroll
-                for (int k = 0; k < GEN_PPT; k++) emap[tid * GEN_PPT + k] = v[k] > carry ? v[k] : carry;
-            }
-            __syncthreads();
-            u32 word[GEN_PPT], cr[GEN_PPT];                  // packed word, channel << 16 | rank among the block's photons of that channel
-#pragma unroll 2
-            for (int q = 0; q < GEN_PPT; q++) {
-                const int pr = q * GEN_TPB + tid;
-                if (pr >= np) { cr[q] = 0xffffffffu; word[q] = 0; continue; }
-                const int lo = emap[pr];
-                const u32x4 A = philox4x32_10(jbase + (u32)lo, gid, (u32)(pr - win[lo]), SITE_PH_A, d.k0, d.k1);
-                const double uc = u53(A.x, A.y);
-                int ch = cguide[(int)(uc * CDF_G)];
-                while (ch < nch - 1 && uc >= cdf[ch]) ch++;
-                const u32 is_dpe = ((u64)A.z < d.thr_dpe) ? 1u : 0u, g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u;
-                cr[q] = ((u32)ch << 16) | (u32)atomicAdd(&hist[ch], 1);
-                word[q] = (u32)pr | (is_dpe << 11) | (g1 << 12) | ((u32)lo << 23);
-            }
-            __syncthreads();
-            for (int c = tid; c < nch; c += GEN_TPB) a.blk_cnt[vb * nch + c] = (unsigned short)hist[c];     // -> k_block_ranges
-            if (tid == 0) a.blk_ins[vb] = ins_lo;
-            __syncthreads();
-            block_excl_scan(hist, nch, s_wtmp);
-#pragma unroll
-            for (int q = 0; q < GEN_PPT; q++) if (cr[q] != 0xffffffffu) stage[hist[cr[q] >> 16] + (cr[q] & 0xffffu)] = word[q];
-            __syncthreads();
-            for (int i = tid; i < np; i += GEN_TPB) a.ph_slot[p0 + i] = stage[i];
-        } else {
-            block_excl_scan(hist, nch, s_wtmp);
-            for (int c = tid; c < nch; c += GEN_TPB) {
-                const i32 b0 = hist[c], b1 = hist[c + 1];
-                hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c] - b0;
-                for (i32 k = b0; k < b1; k++) chmap[k] = (unsigned short)c;
-            }
-            __syncthreads();
-            // Groups of GEN_GRP photons per thread move through the steps together, so that the table gathers of a group
-            // (guide cells, then cumulative probabilities) are in flight at the same time: the pass is bound by their latency.
-#pragma unroll
-            for (int q0 = 0; q0 < GEN_PPT; q0 += GEN_GRP) {
-                if (q0 * GEN_TPB >= np) break;               // block-uniform
-                int lo[GEN_GRP], hi[GEN_GRP], slot[GEN_GRP]; double u[GEN_GRP]; u32 g2[GEN_GRP], j[GEN_GRP], m[GEN_GRP], bw[GEN_GRP]; bool bot[GEN_GRP];
-#pragma unroll
-                for (int k = 0; k < GEN_GRP; k++) {
-                    const u32 w = pw[q0 + k];                // 0 past the end of the block: harmless values, nothing stored
-                    slot[k] = PW_SLOT(w);
-                    j[k] = jbase + (u32)slot[k]; m[k] = (u32)(PW_PR(w) - win[slot[k]]);
-                    const u32x4 B = philox4x32_10(j[k], gid, m[k], SITE_PH_B, d.k0, d.k1);
-                    g2[k] = (u32)(((u64)B.z * 2000u) >> 32) + 1u; bw[k] = B.w;
-                    u[k] = u53(B.x, B.y);
-                    const int c = (int)(u[k] * DISC_G);
-                    const int ib = (q0 + k) * GEN_TPB + tid;
-                    bot[k] = EXT && ib < np && chmap[ib] >= d.n_top;
-                    lo[k] = TAB_OF(k).guide[c]; hi[k] = TAB_OF(k).guide[c + 1];          // the answer is in [lo, hi]
-                }
-#pragma unroll
-                for (int k = 0; k < GEN_GRP; k++)            // rare: a guide cell with more than 4 table entries (the far tail)
-                    while (hi[k] - lo[k] > 3) { const int mid = (lo[k] + hi[k]) >> 1; if (u[k] < TAB_OF(k).cum[mid]) hi[k] = mid; else lo[k] = mid + 1; }
-                double c0[GEN_GRP], c1[GEN_GRP], c2[GEN_GRP];
-#pragma unroll
-                for (int k = 0; k < GEN_GRP; k++) {          // cum[n - 1] == 1 > u: clamped indices cannot change the outcome
-                    const int n1 = TAB_OF(k).n - 1;
-                    c0[k] = TAB_OF(k).cum[lo[k]]; c1[k] = TAB_OF(k).cum[lo[k] + 1 < n1 ? lo[k] + 1 : n1]; c2[k] = TAB_OF(k).cum[lo[k] + 2 < n1 ? lo[k] + 2 : n1];
-                }
-#pragma unroll
-                for (int k = 0; k < GEN_GRP; k++) {
-                    const int i = (q0 + k) * GEN_TPB + tid;  // bucket position
-                    if (i >= np) continue;
-                    const u32 w = pw[q0 + k];
-                    const int ch = chmap[i]; const bool is_dpe = PW_DPE(w);
-                    // every delay term of the photon in one draw from the table of their sum, relative to the instruction time
-                    i64 t = wtime[slot[k]] + (i64)TAB_OF(k).vmin + lo[k] + (u[k] < c0[k] ? 0 : (u[k] < c1[k] ? 1 : (u[k] < c2[k] ? 2 : 3)));
-                    if (EXT && pzi >= 0) t += (i64)s1_propagation(a, bot[k], pzi, pzf, bw[k]);     // s1.py:185-188: int64 array, the assignment truncates
-                    if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-                    if (AP) ap_generate(d, a, ap, aps, j[k], gid, m[k], set_lo, ch, is_dpe, itime, t);
-                    atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
-                    a.ph[hbase[ch] + i] = PhotonRec{(i32)t, PW_G1(w) | (is_dpe ? (g2[k] << 16) : 0u)};
-                }
-            }
-            __syncthreads();
-            for (int c = tid; c < nch; c += GEN_TPB)
-                if (hist[c + 1] > hist[c]) { atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]); }
+        for (int c = tid; c < nch; c += GEN_TPB) {
+            const i32 b0 = hist[c], b1 = hist[c + 1];
+            hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c] - b0;
+            for (i32 k = b0; k < b1; k++) chmap[k] = (unsigned short)c;
+            hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000;
         }
+        __syncthreads();
+        // ---- bucket order: groups of GEN_GRP photons per thread move through the steps together, so that the table gathers
+        // of a group are in flight at the same time
+#pragma unroll
+        for (int q0 = 0; q0 < GEN_PPT; q0 += GEN_GRP) {
+            if (q0 * GEN_TPB >= np) break;                   // block-uniform
+            int slot[GEN_GRP]; u32 j[GEN_GRP], m[GEN_GRP], code[GEN_GRP], yw[GEN_GRP], cell[GEN_GRP]; bool bot[GEN_GRP]; uint2 e[GEN_GRP];
+#pragma unroll
+            for (int k = 0; k < GEN_GRP; k++) {
+                const int i = (q0 + k) * GEN_TPB + tid;      // bucket position; past the end of the block: harmless values, nothing stored
+                const int pr = i < np ? (int)perm[i] : 0;
+                slot[k] = emap[pr];
+                j[k] = jbase + (u32)slot[k]; m[k] = (u32)(pr - win[slot[k]]);
+                const u32x4 B = philox4x32_10(j[k], gid, m[k], SITE_PH, d.k0, d.k1);
+                code[k] = spe_index(B.w) | (dpe_code(B.z, d.thr_dpe, d.dpe_inv) << 16);
+                bot[k] = EXT && i < np && chmap[i] >= d.n_top;
+                cell[k] = B.x >> TAB_OF(k).shift; yw[k] = B.y;
+                e[k] = TAB_OF(k).cell[cell[k]];
+            }
+#pragma unroll
+            for (int k = 0; k < GEN_GRP; k++) {
+                const int i = (q0 + k) * GEN_TPB + tid;
+                if (i >= np) continue;
+                const int ch = chmap[i];
+                // every delay term of the photon in one draw from the table of their sum, relative to the set's origin
+                i64 t = wtime[slot[k]] + (i64)TAB_OF(k).vmin + (i64)(yw[k] < e[k].x ? cell[k] : e[k].y);
+                if (EXT && pzi >= 0) {                       // s1.py:185-188: int64 array, the assignment truncates
+                    const u32x4 X = philox4x32_10(j[k], gid, m[k], SITE_PH_X, d.k0, d.k1);
+                    t += (i64)s1_propagation(a, bot[k], pzi, pzf, X.x);
+                }
+                if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
+                if (AP) ap_generate(d, a, ap, aps, j[k], gid, m[k], set_lo, ch, (code[k] >> 16) != 0, itime, t);
+                atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
+                a.ph[hbase[ch] + i] = PhotonRec{(i32)t, code[k]};
+            }
+        }
+        __syncthreads();
+        for (int c = tid; c < nch; c += GEN_TPB)
+            if (hist[c + 1] > hist[c]) { atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]); }
     } else {
-        if (COUNT && tid == 0) a.blk_ins[vb] = -1;
         if (AP) __syncthreads();                             // s_apn
         for (int q = 0; q < GEN_PPT; q++) {
             const int pr = q * GEN_TPB + tid;
             if (pr >= np) break;
-            const i64 p = p0 + pr;
-            i64 lo = 0, hi = a.n_emitters;                   // photon -> emitter, instruction, emitter index j, item m
-            while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
-            const u32 m = (u32)(p - a.em_ph_off[lo]);
-            const i32 ins = a.em_ins[lo];
-            const u32 gid = a.ins_gid[ins], j = (u32)(lo - a.em_off[ins]) + a.ins_embase[ins];
-            const u32x4 A = philox4x32_10(j, gid, m, SITE_PH_A, d.k0, d.k1);
-            const int ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * nch, nch, u53(A.x, A.y));
+            const PhotonId id = photon_id(a, p0 + pr);
+            const i32 ins = id.ins;
+            const int ch = photon_channel_global(d, a, id);
             const i32 set = a.ins_set[ins];
             const i64 tile = (i64)set * nch + ch;
-            if (COUNT) { a.ph_slot[p] = (u32)atomicAdd(&a.tile_count[tile], 1); continue; }      // the photon's slot in its tile
             const i64 itime = a.set_t0[set];
-            const u32x4 B = philox4x32_10(j, gid, m, SITE_PH_B, d.k0, d.k1);
-            const bool is_dpe = (u64)A.z < d.thr_dpe;
-            const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
-            i64 t = a.em_time[lo] - itime;
+            const u32x4 B = philox4x32_10(id.j, id.gid, id.m, SITE_PH, d.k0, d.k1);
+            const u32 code = spe_index(B.w) | (dpe_code(B.z, d.thr_dpe, d.dpe_inv) << 16);
+            i64 t = a.em_time[id.em] - itime;
             if (EXT) {
-                t += sample_disc(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], u53(B.x, B.y));
-                if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], B.w);
-            } else t += sample_disc(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
+                t += alias_sample(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], B.x, B.y);
+                if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) {
+                    const u32x4 X = philox4x32_10(id.j, id.gid, id.m, SITE_PH_X, d.k0, d.k1);
+                    t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], X.x);
+                }
+            } else t += alias_sample(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, B.x, B.y);
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-            if (AP) ap_generate(d, a, ap, aps, j, gid, m, set, ch, is_dpe, itime, t);
+            if (AP) ap_generate(d, a, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
-            a.ph[a.tile_off[tile] + a.ph_slot[p]] = PhotonRec{(i32)t, g1 | (is_dpe ? (g2 << 16) : 0u)};
+            // photons of multi-instruction blocks take the first slots of their tile (k_block_ranges starts behind them)
+            a.ph[a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1)] = PhotonRec{(i32)t, code};
         }
     }
-    if (AP && !COUNT) {
+    if (AP) {
         __syncthreads();
         const int nst = s_apn < AP_STAGE ? s_apn : AP_STAGE;
         if (tid == 0 && nst > 0) s_apbase = (i64)atomicAdd((u64 *)ap.count, (u64)nst);
@@ -1787,26 +1846,25 @@ __global__ void k_photon_times(WfsDev d, GenArgs a, i64 n, const i64 *index, i64
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const i64 p = index[i];
-    i64 lo = 0, hi = a.n_emitters;
-    while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
-    const i32 ins = a.em_ins[lo];
-    const u32 j = (u32)(lo - a.em_off[ins]) + a.ins_embase[ins], m = (u32)(p - a.em_ph_off[lo]);
-    const u32x4 B = philox4x32_10(j, a.ins_gid[ins], m, SITE_PH_B, d.k0, d.k1);
+    const PhotonId id = photon_id(a, index[i]);
+    const i32 ins = id.ins;
+    const u32x4 B = philox4x32_10(id.j, id.gid, id.m, SITE_PH, d.k0, d.k1);
     if (a.tabs) {                                            // model variants: the table depends on the photon's array
-        const u32x4 A = philox4x32_10(j, a.ins_gid[ins], m, SITE_PH_A, d.k0, d.k1);
-        const int ch = channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[ins] * d.n_tpc, d.n_tpc, u53(A.x, A.y));
-        i64 t = a.em_time[lo] + sample_disc(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], u53(B.x, B.y));
-        if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], B.w);
+        const int ch = photon_channel_global(d, a, id);
+        i64 t = a.em_time[id.em] + alias_sample(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], B.x, B.y);
+        if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) {
+            const u32x4 X = philox4x32_10(id.j, id.gid, id.m, SITE_PH_X, d.k0, d.k1);
+            t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], X.x);
+        }
         out[i] = t;
         return;
     }
-    out[i] = a.em_time[lo] + sample_disc(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, u53(B.x, B.y));
+    out[i] = a.em_time[id.em] + alias_sample(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, B.x, B.y);
 }
 
 // Optical input (RawDataOptical.sim_primary, rawdata.py:475-493): photons are supplied, already bucketed by the host
 // side of the ABI; what is left of Pulse.__call__ before add_current is drawn here per photon: transit time spread
-// (pulse.py:53-56), double-PE flag (pulse.py:76-79) and the SPE gain indices (pulse.py:97-103).  One thread per tile.
+// (pulse.py:53-56), double-PE flag (pulse.py:76-79) and the SPE gain indices (pulse.py:97-103): one Philox call.  One thread per tile.
 struct OpticalArgs { i64 n_tiles; const i32 *tile_count; const i64 *tile_off; i32 *tile_tmin, *tile_tmax; const u32 *set_gid;
                      const i32 *in_t; const u32 *in_item; PhotonRec *ph; i64 *scal; };
 
@@ -1821,14 +1879,11 @@ __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
     i32 tmin = 0x7fffffff, tmax = (i32)0x80000000;
     for (i32 p = 0; p < n; p++) {
         const u32 item = a.in_item[off + p];                 // index of the photon inside its instruction's range
-        const u32x4 A = philox4x32_10(0, gid, item, SITE_PH_A, d.k0, d.k1);
-        const u32x4 B = philox4x32_10(0, gid, item, SITE_PH_B, d.k0, d.k1);
-        const bool is_dpe = (u64)A.z < d.thr_dpe;
-        const u32 g1 = (u32)(((u64)A.w * 2000u) >> 32) + 1u, g2 = (u32)(((u64)B.z * 2000u) >> 32) + 1u;
+        const u32x4 B = philox4x32_10(0, gid, item, SITE_PH, d.k0, d.k1);
         i64 t = a.in_t[off + p];
-        t += sample_disc(d.tab_tts, u53(B.x, B.y));
+        t += alias_sample(d.tab_tts, B.x, B.y);
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-        a.ph[off + p] = PhotonRec{(i32)t, g1 | (is_dpe ? (g2 << 16) : 0u)};
+        a.ph[off + p] = PhotonRec{(i32)t, spe_index(B.w) | (dpe_code(B.z, d.thr_dpe, d.dpe_inv) << 16)};
         tmin = (i32)t < tmin ? (i32)t : tmin; tmax = (i32)t > tmax ? (i32)t : tmax;
     }
     a.tile_tmin[tile] = tmin; a.tile_tmax[tile] = tmax;
