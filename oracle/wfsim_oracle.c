@@ -122,11 +122,12 @@ static inline void philox4x32_10(u32 c0, u32 c1, u32 c2, u32 c3, u32 k0, u32 k1,
 void orc_philox(const u32 *ctr, const u32 *key, u32 *out) { philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], out); }
 
 /* draw sites (counter word 3); counter = (emitter, instruction gid, item, site) -- DESIGN.md "RNG streams" */
-/* RNG spec v5: SITE_PH, counter (emitter, gid, item): x, y -> summed delay (alias table), z -> double-PE flag and second SPE
- * index, w -> first SPE index.  SITE_CH, counter (em_base, gid, P >> 2) with P the index of the photon among its
- * instruction's photons: word P & 3 -> channel.  SITE_PH_X: S1 optical propagation coordinate. */
+/* RNG spec v6, photon streams: counter (em_base, gid, P >> 2, site) with P the index of the photon among its instruction's
+ * photons; photon P owns word P & 3 of SITE_DELAY -> summed delay (alias table), SITE_CH -> channel, SITE_GAIN -> first SPE
+ * index, double-PE flag, second SPE index.  SITE_PH, counter (0, gid, item): photons that arrive with time and channel
+ * (optical input): x -> transit time, y -> gains.  SITE_PH_X, counter (emitter, gid, item): S1 optical propagation. */
 enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
-       SITE_PH = 16, SITE_CH = 17, SITE_PH_X = 18, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
+       SITE_DELAY = 16, SITE_CH = 17, SITE_GAIN = 18, SITE_PH = 19, SITE_PH_X = 20, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
 
 static inline void draw(const orc_session *s, u32 emitter, u32 gid, u32 item, u32 site, u32 w[4])
 {
@@ -581,7 +582,8 @@ static void tab_from_pmf(orc_session *s, int slot, pmf_t a)
  * construction in a fixed order: q[i] = p[i] * K; cells with q < 1 ("small") and the others ("large") go on two stacks
  * in ascending index order; the small cell on top gets {thr = floor(q * 2^32), alias = large cell on top}, the large
  * cell keeps (q_l + q_s) - 1 and moves to the small stack when that is below 1; leftovers keep their own outcome.
- * A draw takes cell c = x >> (32 - lg) and returns c if y < thr[c], else alias[c] (two independent 32-bit words). */
+ * A draw uses ONE 32-bit word: its top lg bits pick the cell c, the remaining bits (left aligned) are compared with thr[c]:
+ * the outcome is c if they are below, else alias[c]. */
 static void alias_build(orc_tab *t)
 {
     i64 K = 2; int lg = 1;
@@ -601,10 +603,10 @@ static void alias_build(orc_tab *t)
     }
     free(q); free(small); free(large);
 }
-static i64 alias_sample(const orc_tab *t, u32 x, u32 y)
+static i64 alias_sample(const orc_tab *t, u32 w)
 {
-    const u32 c = x >> (32 - t->lg);
-    return t->vmin + (i64)(y < t->thr[c] ? c : t->alias[c]);
+    const u32 c = w >> (32 - t->lg);
+    return t->vmin + (i64)((u32)(w << t->lg) < t->thr[c] ? c : t->alias[c]);
 }
 /* the distribution an alias table samples, cell by cell (tests: it must equal the table's pmf to 2^-32 per outcome) */
 void orc_alias_pmf(const orc_session *s, int slot, i32 xtab, double *pmf_alias, double *pmf_cum, i64 cap, i64 *n_out, i64 *vmin_out)
@@ -738,40 +740,40 @@ static double interp_lum(const orc_session *s, double u)
     return slope * (u - xp[lo]) + fp[lo];
 }
 
+/* SPE indices and double-PE flag from one word (pulse.py:76-79, 97-103, 226): w * 2000 = g * 2^32 + frac; g + 1 =
+ * int(u * 2000) + 1 is the first index; frac < floor(p_dpe * 2^32) is the double-PE trial, and given that, frac is uniform
+ * below the threshold: int(frac * 2000 / thr) + 1 is the second index. */
+static inline void gain_code(const orc_session *s, u32 w, int *g1, int *g2)
+{
+    const u64 prod = (u64)w * 2000u, thr = bern_threshold(s->c.p_dpe);
+    const u32 frac = (u32)prod;
+    *g1 = (int)(prod >> 32) + 1; *g2 = 0;
+    if ((u64)frac < thr) { u32 v = (u32)((double)frac * (2000.0 / (double)thr)) + 1u; *g2 = (int)(v > 2000u ? 2000u : v); }
+}
 /* One photon: pulse.py:53-56 (TTS), :76-79 (DPE), :97-103 (SPE gain, idx = int(u*2000)+1), plus the timing terms of
  * s1.py:180-194 (simple) or s2.py:504-557 (luminescence simple + singlet/triplet + spread + electron time).
  * Every term is truncated to int64 on its own before it is added: the sum is drawn from the table of the sum.
- * RNG spec v5: the channel is word P & 3 of the call (em_base, gid, P >> 2, SITE_CH), P = index of the photon among the
- * photons of its instruction; everything else comes from the photon's own call (emitter, gid, item, SITE_PH). */
-static inline u32 dpe_code(const orc_session *s, u32 z)
-{
-    const u64 thr = bern_threshold(s->c.p_dpe);
-    if (!((u64)z < thr)) return 0u;
-    /* given z < thr the word is uniform on [0, thr): int(z * 2000 / thr) + 1 is the uniform SPE table index */
-    u32 g2 = (u32)((double)z * (2000.0 / (double)thr)) + 1u;
-    return g2 > 2000u ? 2000u : g2;
-}
+ * RNG spec v6: photon P of its instruction owns word P & 3 of the calls (em_base, gid, P >> 2, SITE_CH / _DELAY / _GAIN). */
 static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u32 item, u32 em_base, u32 P, i64 t0,
                        const double *cdf, i64 *t_out, int *ch_out, int *dpe_out, double *gain_out)
 {
     const orc_config *c = &s->c;
-    u32 C[4], B[4];
-    draw(s, em_base, gid, P >> 2, SITE_CH, C);
-    draw(s, emitter, gid, item, SITE_PH, B);
+    u32 C[4], D[4], G[4];
+    draw(s, em_base, gid, P >> 2, SITE_CH, C); draw(s, em_base, gid, P >> 2, SITE_DELAY, D); draw(s, em_base, gid, P >> 2, SITE_GAIN, G);
     int ch = channel_from_cdf(cdf, c->n_tpc, (double)C[P & 3u] * (1.0 / 4294967296.0));
-    int g1 = (int)(((u64)B[3] * 2000u) >> 32) + 1, g2 = (int)dpe_code(s, B[2]);
+    int g1, g2; gain_code(s, G[P & 3u], &g1, &g2);
     int is_dpe = g2 != 0;
     i64 t;                                                /* all delay terms from one table, see tab_totals / orc_set_delay_models */
-    if (s->cur_tab >= 0) t = t0 + alias_sample(&s->xtab[ch >= c->n_top ? s->cur_tabb : s->cur_tab], B[0], B[1]);
-    else t = t0 + alias_sample(&s->tab[is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL], B[0], B[1]);
+    if (s->cur_tab >= 0) t = t0 + alias_sample(&s->xtab[ch >= c->n_top ? s->cur_tabb : s->cur_tab], D[P & 3u]);
+    else t = t0 + alias_sample(&s->tab[is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL], D[P & 3u]);
     if (!is_s2 && s->prop_top && s->cur_pzi >= 0) {       /* s1.py:185-188; prop_time is an int64 array: the assignment truncates */
         u32 X[4]; draw(s, emitter, gid, item, SITE_PH_X, X);
         t += (i64)s1_propagation(s, ch >= c->n_top, s->cur_pzi, s->cur_pzf, ((double)X[0] + 0.5) * (1.0 / 4294967296.0));
     }
     int sc = c->n_spe_channels > ch ? ch : 0;
     const double *row = s->spe + (i64)sc * 2001;
-    double G = s->gains[ch], gain = G * row[g1];
-    if (is_dpe) gain += G * row[g2];
+    double G0 = s->gains[ch], gain = G0 * row[g1];
+    if (is_dpe) gain += G0 * row[g2];
     *t_out = t; *ch_out = ch; *dpe_out = is_dpe; *gain_out = gain;
 }
 
@@ -912,10 +914,10 @@ i64 orc_optical(orc_session *s, u32 gid, int runset, i64 time, i64 n, const i64 
         if (t_rel[k] < 0 || t_rel[k] >= cutoff) continue;
         u32 B[4];
         draw(s, 0, gid, (u32)k, SITE_PH, B);
-        int g1 = (int)(((u64)B[3] * 2000u) >> 32) + 1, g2 = (int)dpe_code(s, B[2]);
+        int g1, g2; gain_code(s, B[1], &g1, &g2);
         int is_dpe = g2 != 0;
         i64 t = time + t_rel[k];
-        t += alias_sample(&s->tab[TAB_TTS], B[0], B[1]);
+        t += alias_sample(&s->tab[TAB_TTS], B[0]);
         int ch = chan[k];
         int sc = c->n_spe_channels > ch ? ch : 0;
         const double *row = s->spe + (i64)sc * 2001;
@@ -1096,15 +1098,15 @@ void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 
     const orc_config *c = &s->c;
     for (i64 i = 0; i < n; i++) {
         u32 A[4], B[4]; u32 em = (u32)(i >> 20), item = (u32)(i & 0xfffff), gid = 777u;
-        draw(s, em, gid, item, SITE_CH, A); draw(s, em, gid, item, SITE_PH, B);
+        draw(s, em, gid, item, SITE_CH, A); draw(s, em, gid, item, SITE_DELAY, B);
         double z0, z1;
         if (kind == 0) out[i] = sample_tab(s, TAB_LUM, u53(B[0], B[1]));
         else if (kind == 1) out[i] = sample_tab(s, ((u64)B[3] < bern_threshold(c->sf_gas)) ? TAB_T1 : TAB_T3, u53(B[0], B[1]));
-        else if (kind == 2) out[i] = alias_sample(&s->tab[TAB_TTS], B[0], B[1]);                /* as photons with given times draw it */
+        else if (kind == 2) out[i] = alias_sample(&s->tab[TAB_TTS], B[0]);                /* as photons with given times draw it */
         else if (kind == 10) out[i] = sample_tab(s, TAB_TTS, u53(B[0], B[1]));
         else if (kind == 3) out[i] = sample_tab(s, TAB_S1_EXP, u53(B[0], B[1])) + sample_tab(s, TAB_S1_SPREAD, u53(A[0], A[1]));
-        else if (kind == 5) out[i] = alias_sample(&s->tab[TAB_S1_TOTAL], B[0], B[1]);          /* as one_photon() draws them */
-        else if (kind == 6) out[i] = alias_sample(&s->tab[TAB_S2_TOTAL], B[0], B[1]);
+        else if (kind == 5) out[i] = alias_sample(&s->tab[TAB_S1_TOTAL], B[0]);          /* as one_photon() draws them */
+        else if (kind == 6) out[i] = alias_sample(&s->tab[TAB_S2_TOTAL], B[0]);
         else if (kind == 7) out[i] = (i64)(-log(1.0 - u53(B[0], B[1])) * c->t3_gas);          /* the reference's expressions on the same uniform, */
         else if (kind == 8) out[i] = (i64)interp_lum(s, u53(B[0], B[1]));                      /* to check the tables sample by sample */
         else if (kind == 9) out[i] = sample_tab(s, TAB_T3, u53(B[0], B[1]));
@@ -1122,8 +1124,8 @@ void orc_sample_term(orc_session *s, int kind, i64 n, double p0, double p1, i64 
 void orc_sample_delay(orc_session *s, i64 n, int is_s2, i32 tab, int bottom, i32 pzi, double pzf, i64 *out)
 {
     for (i64 i = 0; i < n; i++) {
-        u32 B[4], X[4]; draw(s, 0, 424242u, (u32)i, SITE_PH, B); draw(s, 0, 424242u, (u32)i, SITE_PH_X, X);
-        i64 t = tab >= 0 ? alias_sample(&s->xtab[tab], B[0], B[1]) : alias_sample(&s->tab[is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL], B[0], B[1]);
+        u32 B[4], X[4]; draw(s, 0, 424242u, (u32)(i >> 2), SITE_DELAY, B); draw(s, 0, 424242u, (u32)i, SITE_PH_X, X);
+        i64 t = tab >= 0 ? alias_sample(&s->xtab[tab], B[i & 3]) : alias_sample(&s->tab[is_s2 ? TAB_S2_TOTAL : TAB_S1_TOTAL], B[i & 3]);
         if (!is_s2 && s->prop_top && pzi >= 0) t += (i64)s1_propagation(s, bottom, pzi, pzf, ((double)X[0] + 0.5) * (1.0 / 4294967296.0));
         out[i] = t;
     }

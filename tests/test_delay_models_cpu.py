@@ -33,7 +33,9 @@ def _check(d, key, x):
     assert _ks(v, c, x) < _ks_limit(c.sum(), len(x)), key
     m, s = _moments(v, c)
     assert abs(x.mean() - m) < 5 * s / np.sqrt(len(x)) + 5 * s / np.sqrt(c.sum()), key
-    assert abs(x.std() / s - 1) < 0.01, key
+    # the spread of a heavy-tailed delay (ER recombination: kurtosis ~ 280) fluctuates by sqrt((kurt - 1) / 4n): 5 sigma of that
+    kurt = ((v - m) ** 4 * c).sum() / c.sum() / s ** 4
+    assert abs(x.std() / s - 1) < max(0.01, 5 * np.sqrt((kurt - 1) / 4 * (1 / len(x) + 1 / c.sum()))), key
 
 
 @pytest.mark.parametrize('tag,model,recoil', [('er', 'custom', 7), ('nr', 'custom', 0), ('alpha', 'custom', 6), ('led', 'custom', 20),

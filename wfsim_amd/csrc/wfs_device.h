@@ -1,9 +1,10 @@
 // wfs_device.h -- device-side helpers of the MI355X WFSim hot path (gfx950 only).
 //
 // RNG: Philox4x32-10 (Salmon et al., SC'11), counter = (emitter, instruction gid, item, site), key = seed.
-// The stream layout is specified in DESIGN.md "RNG streams" (spec v5: ONE call per photon for delay, double-PE flag and
-// both SPE indices; the channel words come from a stream of their own, four photons per call); the CPU oracle implements
-// the same layout independently (oracle/wfsim_oracle.c) so that GPU and oracle results can be compared photon by photon.
+// The stream layout is specified in DESIGN.md "RNG streams" (spec v6: channel, delay and gain words of a photon come from
+// three streams indexed by the photon's position P among its instruction's photons, four photons per call -- 0.75 calls
+// per photon); the CPU oracle implements the same layout independently (oracle/wfsim_oracle.c) so that GPU and oracle
+// results can be compared photon by photon.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,9 +20,12 @@ typedef unsigned int u32;
 
 enum WfsSite : u32 {
     SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
-    SITE_PH = 16,        // per photon (emitter, gid, item): x, y -> delay (alias table), z -> double-PE flag + second SPE index, w -> first SPE index
-    SITE_CH = 17,        // per four photons (em_base, gid, P >> 2), P = index among the instruction's photons: word P & 3 -> channel
-    SITE_PH_X = 18,      // per photon, S1 optical propagation only: x -> spline coordinate
+    // photon streams, counter (em_base, gid, P >> 2, site), P = index of the photon among its instruction's photons; photon P owns word P & 3
+    SITE_DELAY = 16,     // -> summed delay (alias table)
+    SITE_CH = 17,        // -> channel
+    SITE_GAIN = 18,      // -> first SPE index, double-PE flag, second SPE index
+    SITE_PH = 19,        // photons that arrive with time and channel (optical input), counter (0, gid, item): x -> transit time, y -> gains
+    SITE_PH_X = 20,      // per photon (emitter, gid, item), S1 optical propagation only: x -> spline coordinate
     SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
 };
 
@@ -73,28 +77,41 @@ __device__ __forceinline__ void box_muller(u32x4 w, double &z0, double &z1)
 // Integer-valued delays.  The reference draws float variates and truncates each to int64 before adding it (pulse.py:54-56
 // transit time, s1.py:193-194, s2.py:338, pulse.py:339-341, s2.py:550); only the SUM reaches the pulse, and the sum of
 // independent integer variates is one discrete variate whose probability mass function the host builds by convolution
-// (wfs_engine.hip, build_time_tables).  It is sampled with Walker's alias method: K = 2^k >= n cells, cell c holds
-// {thr, alias}; the draw picks cell c = x >> shift and returns c if y < thr, else alias.  One 8-byte gather per photon
-// (an inverse-CDF search needs a guide cell and three cumulative values: five gathers, and the texture addresser was the
-// fill pass's bottleneck).  The table is built by the same sequential algorithm on the host and in the CPU oracle.
-struct AliasTab { const uint2 *cell; i32 vmin, shift; };
+// (wfs_engine.hip, build_time_tables).  It is sampled with Walker's alias method from ONE 32-bit word: K = 2^k >= n cells,
+// cell c holds {thr, alias}; the word's top k bits pick the cell, the remaining bits (left aligned) are compared with thr.
+// One 8-byte gather per photon (an inverse-CDF search needs a guide cell and three cumulative values: five gathers).
+// The table is built by the same sequential algorithm on the host and in the CPU oracle.
+struct AliasTab { const uint2 *cell; i32 vmin, shift; };      // shift = 32 - k
 
-__device__ __forceinline__ i64 alias_sample(const AliasTab &t, u32 x, u32 y)
+__device__ __forceinline__ u32 alias_cell(const AliasTab &t, u32 w) { return w >> t.shift; }
+__device__ __forceinline__ i32 alias_pick(const AliasTab &t, u32 w, u32 c, uint2 e) { return t.vmin + (i32)(((w << (32 - t.shift)) < e.x) ? c : e.y); }
+__device__ __forceinline__ i32 alias_sample(const AliasTab &t, u32 w) { const u32 c = alias_cell(t, w); return alias_pick(t, w, c, t.cell[c]); }
+
+// SPE indices and double-PE flag of a photon from ONE word (pulse.py:76-79, 97-103, 226): w * 2000 = g * 2^32 + frac;
+// g + 1 = int(u * 2000) + 1 is the first index; frac (the 32 low bits, equidistributed for every g) < thr is the double-PE
+// Bernoulli trial, and given frac < thr it is uniform on [0, thr): int(frac * 2000 / thr) + 1 is the second index.
+// Returns g1 | g2 << 16 with g2 = 0 when the photon makes a single PE.
+__device__ __forceinline__ u32 gain_code(u32 w, u64 thr_dpe, double dpe_inv)
 {
-    const u32 c = x >> t.shift;
-    const uint2 e = t.cell[c];
-    return (i64)t.vmin + (i64)(y < e.x ? c : e.y);
+    const u64 prod = (u64)w * 2000u;
+    const u32 g1 = (u32)(prod >> 32) + 1u, frac = (u32)prod;
+    if (!((u64)frac < thr_dpe)) return g1;
+    u32 g2 = (u32)((double)frac * dpe_inv) + 1u;
+    g2 = g2 > 2000u ? 2000u : g2;
+    return g1 | (g2 << 16);
 }
 
-// double-PE flag and second SPE index from ONE word (pulse.py:76-79, 101-103): z < thr is the Bernoulli trial, and given
-// z < thr the word is uniform on [0, thr), so int(z * 2000 / thr) + 1 is the uniform table index
-__device__ __forceinline__ u32 dpe_code(u32 z, u64 thr_dpe, double dpe_inv)
-{
-    if (!((u64)z < thr_dpe)) return 0u;
-    u32 g2 = (u32)((double)z * dpe_inv) + 1u;
-    return g2 > 2000u ? 2000u : g2;
-}
-__device__ __forceinline__ u32 spe_index(u32 w) { return (u32)(((u64)w * 2000u) >> 32) + 1u; }      // int(u * 2000) + 1, pulse.py:226
+// In-kernel phase stamps (diagnostic builds, -DWFS_STAMPS; MI355X_MICROARCH.md "In-kernel stamps"): thread 0 of every
+// workgroup adds the shader cycles since its previous stamp to slot i.  Production builds compile them away.
+#ifdef WFS_STAMPS
+#define STAMP_INIT unsigned long long st_last_ = __builtin_amdgcn_s_memtime()
+#define STAMP(d, i) do { if (threadIdx.x == 0 && (d).stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+    unsigned long long *row_ = (d).stamps + (size_t)(blockIdx.x & 4095u) * 64; \
+    atomicAdd(&row_[i], t_ - st_last_); atomicAdd(&row_[(i) + 32], 1ull); st_last_ = t_; } } while (0)
+#else
+#define STAMP_INIT
+#define STAMP(d, i)
+#endif
 
 // python-style floor division / modulo on int64 (numpy // and % on int64, pulse.py:305-306)
 __host__ __device__ __forceinline__ i64 floordiv(i64 a, i64 b) { i64 q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
@@ -109,6 +126,7 @@ struct WfsDev {
     double c2a, tts_mean, tts_sigma, p_dpe, s1_decay_time, s1_decay_spread, sf_gas, t1_gas, t3_gas, s2_time_spread;
     double trap_time, gain_spread, pmt_ap_modifier, pmt_ap_t_modifier, rext;
     u32 k0, k1;
+    unsigned long long *stamps;                // -DWFS_STAMPS builds only: per-phase cycle sums of the instrumented kernels (nullptr otherwise)
     u64 thr_dpe;                               // Bernoulli threshold on a 32-bit word: floor(p * 2^32)
     double dpe_inv;                            // 2000 / thr_dpe
     double current_max[10];

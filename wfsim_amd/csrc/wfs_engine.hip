@@ -27,7 +27,7 @@ struct KernelTime { std::string name; hipEvent_t a, b; };
 
 struct wfs_handle {
     wfs_config cfg;
-    int device = 0;
+    int device = 0, n_cus = 256;
     hipStream_t stream = nullptr; bool own_stream = false;
     std::string err;
     WfsDev dev;
@@ -44,13 +44,14 @@ struct wfs_handle {
     i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_embase, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
-    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0;
+    DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0, blk_desc;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles;
     DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
     DevBuf truth, tminmax, tile_truth, tile_desc, gather_idx, gather_out, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
+    DevBuf stamps;
     DevBuf row_desc, rec_key, rec_key2, rec_val, rec_val2, rec_dest, sort_tmp, scan_tmp, scal, noise_override;
     bool sort_records = false; i64 n_noise_override = 0;
     // host mirrors
@@ -342,11 +343,16 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     if (hipSetDevice(device) != hipSuccess) return WFS_E_HIP;
     wfs_handle *h = new wfs_handle();
     h->cfg = *cfg; h->device = device;
+    { hipDeviceProp_t prop; h->n_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
     memset(&h->dev, 0, sizeof(h->dev));
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return WFS_E_HIP; }
     h->own_stream = true;
     if (hipMalloc(&h->scal.p, 256) != hipSuccess) { delete h; return WFS_E_HIP; }
     h->scal.cap = 256;
+#ifdef WFS_STAMPS
+    if (hipMalloc(&h->stamps.p, 4096 * 64 * 8) != hipSuccess) { delete h; return WFS_E_HIP; }
+    h->stamps.cap = 4096 * 64 * 8; hipMemset(h->stamps.p, 0, 4096 * 64 * 8); h->dev.stamps = h->stamps.as<unsigned long long>();
+#endif
     refresh_dev(h);
     if (build_time_tables(h) != WFS_OK) { delete h; return WFS_E_HIP; }
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
@@ -369,7 +375,17 @@ int wfs_destroy(wfs_handle *h)
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+#ifdef WFS_STAMPS
+    {   // diagnostic build: average cycles per workgroup and phase
+        std::vector<unsigned long long> all((size_t)4096 * 64); unsigned long long v[64] = {0};
+        if (hipMemcpy(all.data(), h->stamps.p, all.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (size_t r = 0; r < 4096; r++) for (int i = 0; i < 64; i++) v[i] += all[r * 64 + i];
+            for (int i = 0; i < 32; i++) if (v[i + 32]) fprintf(stderr, "stamp %2d: %10.0f cycles/wg  (%llu wgs, %.3e cycles total)\n", i, (double)v[i] / (double)v[i + 32], v[i + 32], (double)v[i]);
+        }
+        hipFree(h->stamps.p);
+    }
+#endif
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -885,20 +901,21 @@ static int run_generation(wfs_handle *h)
         g.n_blocks = nb;
         TRY(ensure(h, h->blk_e, (size_t)nb * 16)); TRY(ensure(h, h->blk_base, (size_t)nb * d.n_tpc * 4)); TRY(ensure(h, h->blk_cnt, (size_t)nb * d.n_tpc * 2)); TRY(ensure(h, h->blk_ins, (size_t)nb * 4));
         g.blk_e = h->blk_e.as<i64>(); g.blk_base = h->blk_base.as<u32>(); g.blk_cnt = h->blk_cnt.as<unsigned short>(); g.blk_ins = h->blk_ins.as<i32>();
+        TRY(ensure(h, h->blk_desc, (size_t)nb * sizeof(BlockDesc))); g.blk_desc = h->blk_desc.as<BlockDesc>();
         { Timer t(h, "k_block_emitters"); hipLaunchKernelGGL(k_block_emitters, dim3(nblocks(nb, 256)), dim3(256), 0, h->stream, g); }
         // XCD x (workgroup id % 8) walks the photon blocks [x * chunk, (x + 1) * chunk) in order: the blocks that share
         // cache lines of a tile (consecutive ranges, k_block_ranges) run close together in time on the same L2
         g.xcd_chunk = (nb + 7) / 8;
         const unsigned nbx = (unsigned)(g.xcd_chunk * 8);
-        { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(GEN_TPB), GEN_COUNT_LDS(d.n_tpc), h->stream, d, g); }
+        { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(COUNT_TPB), GEN_COUNT_LDS(d.n_tpc), h->stream, d, g); }
         { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
         const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, ap_on).total;
         { Timer t(h, "k_photon_fill");
-          if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
-          else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, true>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
-          else if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, false>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap);
-          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, false>), dim3(nbx), dim3(GEN_TPB), gen_lds, h->stream, d, g, ap); }
+          if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);
+          else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);
+          else if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, false>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);
+          else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, false>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap); }
     } else {
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
     }
@@ -1060,6 +1077,7 @@ int wfs_run(wfs_handle *h)
         for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
         size_t lds = (size_t)(W + 2 * DENSE_PAD) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
         lds = (lds + 15) / 16 * 16;
+        pd.spe_lds = ((size_t)(W + 2 * DENSE_PAD) * d.dt >= 2001) ? 1 : 0;
         const unsigned grid = (unsigned)(h->n_dense_tiles * pd.n_win);
         Timer t(h, "k_pulse_dense");
         if (pd.n_win == 1) {

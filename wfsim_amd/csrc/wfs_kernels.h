@@ -345,6 +345,7 @@ struct PulseArgs {
     i32 W;                // start bins per LDS window (dense) / bins capacity (sparse)
     i32 NP;               // photon capacity of the sparse kernel's LDS list
     i32 n_win;            // dense kernel: workgroups (windows) per tile
+    i32 spe_lds;          // dense resident kernel: the H table has room for the channel's SPE row (2001 doubles), staged there before the gains are looked up
 };
 
 #define DENSE_PPT 8        // photons per thread per batch held in registers
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         for (int w = 0; w < TPB / 64; w++) n_dpe_tile += (i32)wsum[w];
     }
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2
+    STAMP_INIT;
 
     // A tile that fits one register batch and is worked on by a single workgroup (n_win == 1) is read ONCE: its photons
     // (ns, gain) stay in registers over all windows, and the truth sums are taken here.
@@ -443,6 +445,15 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         }
         if (mode == 0) {
             double s1[DENSE_PPT], s2[DENSE_PPT];
+            if (a.spe_lds) {
+                // The channel's SPE row (16 KB) goes through LDS (H is still free): two data-dependent 8-byte gathers per photon
+                // from global memory cost the texture addresser ~64 cycles per wave instruction, from LDS a few.
+                for (int i = tid; i < 2001; i += TPB) H[i] = spe_row[i];
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < DENSE_PPT; k++) { s1[k] = H[code[k] & 0xffffu]; s2[k] = H[code[k] >> 16]; }     // H[0] for "no second PE": unused
+                __syncthreads();                             // H is reused below
+            } else
 #pragma unroll
             for (int k = 0; k < DENSE_PPT; k++) {
                 s1[k] = spe_row[code[k] & 0xffffu];                    // index 0 for the unused slots: a valid address
@@ -456,6 +467,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 r_gain[k] = gk;
             }
         }
+        STAMP(d, 8);
         // truth sums of the tile (pulse.py:229-271).  The four counts need no vector reduction (tile_count, the DPE count
         // above, wave ballots); the four float sums go through LDS (H is still free) and one shuffle tree per quantity.
         u32 c_trig = 0, c_trig_dpe = 0;                   // wave-uniform
@@ -496,12 +508,14 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         }
     }
 
+    STAMP(d, 9);
     for (i64 w0 = (i64)win * (W - (tlen - 1)); w0 == 0 || w0 + (tlen - 1) < nb; w0 += (i64)a.n_win * (W - (tlen - 1))) {
         const int Wc = (int)((nb - w0 < W) ? nb - w0 : W);
         const bool first = (w0 == 0), last = (w0 + Wc >= nb);
         __syncthreads();
         for (int i = tid; i < (W + 2 * DENSE_PAD) * dt; i += TPB) H[i] = 0.0;
         __syncthreads();
+        STAMP(d, 10);
         if (RESIDENT) {
             const i32 ns_lo = (i32)w0 * dt, ns_hi = ns_lo + Wc * dt;       // the window in ns relative to the tile's first start bin
 #pragma unroll
@@ -565,6 +579,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             }
         }
         __syncthreads();
+        STAMP(d, 11);
         // ---- every sample gathers its tlen x dt possible contributions in ascending time (pulse.py:303-318)
         const i64 s_lo = first ? 0 : w0 + lead + (tlen - 1);
         const i64 s_hi = last ? L : w0 + Wc + lead;
@@ -611,6 +626,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 if (adc != 0) atomicAdd(&dst[s], (i32)adc);
             }
         }
+        STAMP(d, 12);
     }
 
     if (!RESIDENT && a.tile_truth && win == 0) {
@@ -1125,6 +1141,20 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------ generation
+// One 64-byte descriptor per photon block (k_block_emitters): a generator workgroup starts from ONE scalar load instead of a
+// chain of dependent look-ups (block -> emitters -> instruction -> pulse set ...), each a global round trip.
+struct __attribute__((aligned(64))) BlockDesc {
+    i64 e_lo;             // first emitter of the block
+    i64 itime;            // origin of the photon times of the instruction's pulse set
+    i64 R0;               // index of the block's first photon among its instruction's photons
+    i32 ins;              // instruction of a single-instruction block, -1: the block spans instructions (generic path)
+    i32 nwin;             // emitters of the block + 2 (<= GEN_WIN)
+    i32 set, row;         // pulse set, channel CDF row
+    u32 gid, eb, jbase;   // Philox coordinates: instruction id, emitter base, emitter id of e_lo
+    i32 is_s2;
+    i32 pad[2];
+};
+
 struct GenArgs {
     i64 n_ins, n_psets, n_emitters, n_photons;
     const u32 *ins_embase;        // [n_ins] offset of the instruction's emitter ids in the Philox counters (0 for primaries; the k-th
@@ -1146,6 +1176,7 @@ struct GenArgs {
     u32 *blk_base;                // [n_blocks][n_tpc] start of the block's photons inside each tile (written by the count pass)
     unsigned short *blk_cnt;      // [n_blocks][n_tpc] the block's photons per channel (count pass, single-instruction blocks)
     i32 *blk_ins;                 // [n_blocks] instruction of a single-instruction block, -1 otherwise (k_block_emitters)
+    struct BlockDesc *blk_desc;   // [n_blocks] everything a generator workgroup needs to know about its block
     i64 *ins_ph0;                 // [n_ins + 1] first photon (generation order) of every instruction: em_ph_off[em_off[i]]
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
@@ -1297,12 +1328,10 @@ __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double
     return lo < n ? lo : n - 1;
 }
 
-#define GEN_TPB 256
-#define GEN_PPT 8
-#ifndef GEN_GRP
-#define GEN_GRP 4                  // photons a thread carries through the fill pass together (their table gathers are in flight at once)
+#ifndef GEN_LOG
+#define GEN_LOG 11
 #endif
-#define GEN_BLOCK (GEN_TPB * GEN_PPT)
+#define GEN_BLOCK (1 << GEN_LOG)   // photons per block of the generator
 #define GEN_WIN 512                // emitter offsets staged in LDS per block
 #define CDF_G 512                  // guide cells of the per-block channel search
 
@@ -1334,7 +1363,16 @@ __global__ void k_block_emitters(GenArgs a)
     // the fast path of the generator needs all photons of the block in one instruction and the block's emitters in its LDS window
     const i64 e_lo = a.blk_e[2 * b], e_hi = a.blk_e[2 * b + 1];
     const i32 i0 = a.em_ins[e_lo];
-    a.blk_ins[b] = (e_hi - e_lo + 2 <= GEN_WIN && i0 == a.em_ins[e_hi]) ? i0 : -1;
+    const bool single = e_hi - e_lo + 2 <= GEN_WIN && i0 == a.em_ins[e_hi];
+    a.blk_ins[b] = single ? i0 : -1;
+    BlockDesc bd{};
+    bd.ins = -1;
+    if (single) {
+        bd.ins = i0; bd.e_lo = e_lo; bd.nwin = (i32)(e_hi - e_lo + 2); bd.set = a.ins_set[i0]; bd.itime = a.set_t0[bd.set];
+        bd.R0 = p0 - a.ins_ph0[i0]; bd.row = a.ins_cdfrow[i0]; bd.gid = a.ins_gid[i0]; bd.eb = a.ins_embase[i0];
+        bd.jbase = (u32)(e_lo - a.em_off[i0]) + bd.eb; bd.is_s2 = a.ins_type[i0] != 1;
+    }
+    a.blk_desc[b] = bd;
 }
 
 __global__ void k_ins_ph0(GenArgs a)
@@ -1386,27 +1424,27 @@ __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, c
 }
 
 // Photon generator, two passes over the same photon index space (GEN_BLOCK consecutive photons per block, generation
-// order = emitter by emitter).  RNG spec v5:
-//   channel (s1.py:154-158 / s2.py:673-677): word P & 3 of the call (em_base, gid, P >> 2, SITE_CH), P = index of the photon
-//     among its instruction's photons -- a quarter of a Philox call per photon;
-//   everything else: ONE call (emitter, gid, item, SITE_PH): x, y -> summed delay (alias table; s1.py:180-194 /
-//     s2.py:504-557, pulse.py:53-56), z -> double-PE flag and second SPE index, w -> first SPE index (pulse.py:76-103).
+// order = emitter by emitter).  RNG spec v6: photon P of an instruction (P = its index among the
+// instruction's photons) owns word P & 3 of three calls (em_base, gid, P >> 2, site): SITE_CH -> channel (s1.py:154-158 /
+// s2.py:673-677), SITE_DELAY -> summed delay (alias table; s1.py:180-194 / s2.py:504-557, pulse.py:53-56), SITE_GAIN ->
+// SPE indices and double-PE flag (pulse.py:76-103).  A thread that takes four consecutive photons spends 0.75 Philox
+// calls per photon (the generator is bound by VALU issue: 20 quarter-rate multiplies per call).
 // Count pass (k_photon_count): channel words only -> photons per (block, channel); no per-photon intermediate is left in
 //   HBM (the first version wrote a packed word per photon and read it back: 5.8 GB per 10^9-PE batch).
 // k_block_ranges: where in its tile every block puts its photons (consecutive blocks, consecutive ranges).
-// Fill pass (k_photon_fill): repeats the channel words (cheap), ranks the block's photons inside their channel with LDS
-//   counters and leaves the permutation generation order -> bucket order in LDS; then walks the BUCKET order:
-//   neighbouring lanes finish photons of the same tile and store them to consecutive addresses (a scattered 8-byte store
-//   per lane is bound by the L2 request rate).
+// Fill pass (k_photon_fill): all three calls per quad in generation order; every photon is ranked inside its channel with
+//   LDS counters and staged at its bucket position in LDS; the block then stores in BUCKET order: neighbouring lanes write
+//   photons of the same tile to consecutive addresses (a scattered 8-byte store per lane is bound by the L2 request rate).
 // Fast path ("single": all photons of the block belong to one instruction, the normal case for an S2): emitter window,
-//   channel CDF + guide table and tile offsets of the block live in LDS.
+//   channel thresholds + guide table and tile offsets of the block live in LDS.
 // Generic path (a block spanning instructions: S1s, small S2s): per-photon global lookups and atomics.
 
-// exclusive prefix sum over n <= 4 * GEN_TPB LDS integers, in place; v[n] receives the total.  All threads call it.
+// exclusive prefix sum over n <= 4 * TPB LDS integers, in place; v[n] receives the total.  All TPB threads call it.
+template <int TPB>
 __device__ __forceinline__ void block_excl_scan(i32 *v, int n, i32 *wtmp)
 {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int per = (n + GEN_TPB - 1) / GEN_TPB, b = tid * per;
+    const int per = (n + TPB - 1) / TPB, b = tid * per;
     i32 loc[4], s = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) { loc[k] = (k < per && b + k < n) ? v[b + k] : 0; s += loc[k]; }
@@ -1418,7 +1456,7 @@ __device__ __forceinline__ void block_excl_scan(i32 *v, int n, i32 *wtmp)
     for (int w = 0; w < wid; w++) run += wtmp[w];
 #pragma unroll
     for (int k = 0; k < 4; k++) if (k < per && b + k < n) { v[b + k] = run; run += loc[k]; }
-    if (tid == GEN_TPB - 1) v[n] = run;
+    if (tid == TPB - 1) v[n] = run;
     __syncthreads();
 }
 
@@ -1555,70 +1593,80 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
     a.tile_count[idx] = (i32)run;
 }
 
-// channel of a photon from its 32-bit word: np.random.choice(p=...) = searchsorted(cdf, u, 'right') with u = w / 2^32,
-// started from a guide table (guide[c] = first channel whose cumulative probability exceeds c / CDF_G)
-__device__ __forceinline__ int channel_lookup(const double *cdf, const unsigned short *cguide, int nch, u32 w)
+// channel thresholds of a CDF row for 32-bit words: channel = first c with w / 2^32 < cdf[c], i.e. w < cdf[c] * 2^32, i.e.
+// (w an integer) w <= ceil(cdf[c] * 2^32) - 1 =: T[c] -- exact, and the same decision as np.random.choice's
+// searchsorted(cdf, u, 'right') on u = w / 2^32.  Channels with cdf == 0 are never examined: the search starts at
+// guide[w >> 23], the first channel whose cumulative probability exceeds (w >> 23) / 512 >= 0.
+__device__ __forceinline__ u32 cdf_threshold(double c)
 {
-    const double u = (double)w * (1.0 / 4294967296.0);
+    const double x = ceil(c * 4294967296.0);
+    return x >= 4294967296.0 ? 0xffffffffu : (x >= 1.0 ? (u32)x - 1u : 0u);
+}
+__device__ __forceinline__ int channel_lookup(const u32 *T, const unsigned short *cguide, int nch, u32 w)
+{
     int ch = cguide[w >> 23];                      // CDF_G = 512 cells
-    while (ch < nch - 1 && u >= cdf[ch]) ch++;
+    while (ch < nch - 1 && w > T[ch]) ch++;
     return ch;
 }
 __device__ __forceinline__ u32 word_of(const u32x4 &W, int k) { return k == 0 ? W.x : (k == 1 ? W.y : (k == 2 ? W.z : W.w)); }
 
 // photon p (generation order) -> emitter, instruction, Philox coordinates; generic path and k_photon_times
-struct PhotonId { i64 em; i32 ins; u32 gid, j, m, P; };
+struct PhotonId { i64 em; i32 ins; u32 gid, eb, j, m, P; };
 __device__ __forceinline__ PhotonId photon_id(const GenArgs &a, i64 p)
 {
     i64 lo = 0, hi = a.n_emitters;
     while (hi - lo > 1) { i64 mid = (lo + hi) >> 1; if (a.em_ph_off[mid] <= p) lo = mid; else hi = mid; }
-    PhotonId r; r.em = lo; r.ins = a.em_ins[lo]; r.gid = a.ins_gid[r.ins];
-    r.j = (u32)(lo - a.em_off[r.ins]) + a.ins_embase[r.ins]; r.m = (u32)(p - a.em_ph_off[lo]); r.P = (u32)(p - a.ins_ph0[r.ins]);
+    PhotonId r; r.em = lo; r.ins = a.em_ins[lo]; r.gid = a.ins_gid[r.ins]; r.eb = a.ins_embase[r.ins];
+    r.j = (u32)(lo - a.em_off[r.ins]) + r.eb; r.m = (u32)(p - a.em_ph_off[lo]); r.P = (u32)(p - a.ins_ph0[r.ins]);
     return r;
+}
+__device__ __forceinline__ u32 photon_word(const WfsDev &d, const PhotonId &id, u32 site)
+{
+    return word_of(philox4x32_10(id.eb, id.gid, id.P >> 2, site, d.k0, d.k1), (int)(id.P & 3u));
 }
 __device__ __forceinline__ int photon_channel_global(const WfsDev &d, const GenArgs &a, const PhotonId &id)
 {
-    const u32x4 W = philox4x32_10(a.ins_embase[id.ins], id.gid, id.P >> 2, SITE_CH, d.k0, d.k1);
-    return channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[id.ins] * d.n_tpc, d.n_tpc, (double)word_of(W, (int)(id.P & 3u)) * (1.0 / 4294967296.0));
+    return channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[id.ins] * d.n_tpc, d.n_tpc, (double)photon_word(d, id, SITE_CH) * (1.0 / 4294967296.0));
 }
 
-#define GEN_COUNT_LDS(nch) ((size_t)(nch) * 12 + (CDF_G + 8) * 2)
+#define COUNT_TPB (GEN_BLOCK / 8)
+#define FILL_TPB (GEN_BLOCK / 4)   // one quad of photons per thread: many waves per workgroup keep enough table gathers in flight
 
-__global__ __launch_bounds__(GEN_TPB) void k_photon_count(WfsDev d, GenArgs a)
+// Workgroups are dealt to the 8 XCDs round robin: XCD x (= workgroup id % 8) takes the photon blocks [x * chunk, (x + 1) * chunk)
+// in order, so that the blocks writing neighbouring ranges of a tile run close together in time behind the same L2.
+__device__ __forceinline__ i64 block_of_workgroup(const GenArgs &a) { return (i64)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3); }
+
+#define GEN_COUNT_LDS(nch) ((size_t)(nch) * 8 + (CDF_G + 8) * 2)
+
+__global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nch = d.n_tpc, tid = threadIdx.x;
-    double *cdf = (double *)smem;                                   // [nch]
-    i32 *hist = (i32 *)(smem + (size_t)nch * 8);                    // [nch]
-    unsigned short *cguide = (unsigned short *)(smem + (size_t)nch * 12);
-    // Workgroups are dealt to the 8 XCDs round robin: XCD x takes the photon blocks [x * chunk, (x + 1) * chunk) in
-    // order, so that the blocks writing neighbouring ranges of a tile run close together in time behind the same L2.
-    const i64 vb = (i64)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);
+    u32 *T = (u32 *)smem;                                           // [nch]
+    i32 *hist = (i32 *)(smem + (size_t)nch * 4);                    // [nch]
+    unsigned short *cguide = (unsigned short *)(smem + (size_t)nch * 8);
+    const i64 vb = block_of_workgroup(a);
     if (vb >= a.n_blocks) return;                            // block-uniform (padding of the XCD order)
+    const BlockDesc bd = a.blk_desc[vb];                     // block-uniform: scalar loads
     const i64 p0 = vb * GEN_BLOCK;
     const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
-    const i32 ins = a.blk_ins[vb];
-    if (ins >= 0) {
-        const size_t row = (size_t)a.ins_cdfrow[ins];
-        for (int c = tid; c < nch; c += GEN_TPB) { hist[c] = 0; cdf[c] = a.cdf_table[row * nch + c]; }
-        for (int c = tid; c <= CDF_G; c += GEN_TPB) cguide[c] = a.cdf_guide[row * (CDF_G + 2) + c];
+    if (bd.ins >= 0) {
+        for (int c = tid; c < nch; c += COUNT_TPB) { hist[c] = 0; T[c] = cdf_threshold(a.cdf_table[(size_t)bd.row * nch + c]); }
+        for (int c = tid; c <= CDF_G; c += COUNT_TPB) cguide[c] = a.cdf_guide[(size_t)bd.row * (CDF_G + 2) + c];
         __syncthreads();
-        const u32 gid = a.ins_gid[ins], eb = a.ins_embase[ins];
-        const i64 R0 = p0 - a.ins_ph0[ins];                   // index of the block's first photon among the instruction's photons
-        for (i64 q = (R0 >> 2) + tid; (q << 2) < R0 + np; q += GEN_TPB) {
-            const u32x4 W = philox4x32_10(eb, gid, (u32)q, SITE_CH, d.k0, d.k1);
+        const u32 q0 = (u32)(bd.R0 >> 2); const int r = (int)(bd.R0 & 3);
+        for (int qi = tid; 4 * qi - r < np; qi += COUNT_TPB) {  // quad qi of the block: photons 4 * qi - r .. + 3 (block-relative)
+            const u32x4 W = philox4x32_10(bd.eb, bd.gid, q0 + (u32)qi, SITE_CH, d.k0, d.k1);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const i64 pr = (q << 2) + k - R0;
-                if (pr >= 0 && pr < np) atomicAdd(&hist[channel_lookup(cdf, cguide, nch, word_of(W, k))], 1);
+                const int pr = 4 * qi + k - r;
+                if (pr >= 0 && pr < np) atomicAdd(&hist[channel_lookup(T, cguide, nch, word_of(W, k))], 1);
             }
         }
         __syncthreads();
-        for (int c = tid; c < nch; c += GEN_TPB) a.blk_cnt[vb * nch + c] = (unsigned short)hist[c];     // -> k_block_ranges
+        for (int c = tid; c < nch; c += COUNT_TPB) a.blk_cnt[vb * nch + c] = (unsigned short)hist[c];     // -> k_block_ranges
     } else {
-        for (int q = 0; q < GEN_PPT; q++) {
-            const int pr = q * GEN_TPB + tid;
-            if (pr >= np) break;
+        for (int pr = tid; pr < np; pr += COUNT_TPB) {
             const PhotonId id = photon_id(a, p0 + pr);
             const int ch = photon_channel_global(d, a, id);
             atomicAdd(&a.tile_count[(i64)a.ins_set[id.ins] * nch + ch], 1);
@@ -1628,175 +1676,170 @@ __global__ __launch_bounds__(GEN_TPB) void k_photon_count(WfsDev d, GenArgs a)
 
 // LDS layout of the fill pass (byte offsets; plain integer offsets: a pointer that went through an integer cast loses its
 // LDS address space)
-struct GenFillLds { int wtime, cdf, hist, hmin, hmax, chmap, perm, emap, cguide, ap, total; };
+struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, cguide, stage, ap, total; };
 __host__ __device__ inline GenFillLds gen_fill_lds(int nch, bool with_ap)
 {
     const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
     GenFillLds o;
     o.wtime = GEN_WIN * 4;                                    // win i32[GEN_WIN] at 0: first photon of the block's emitters, relative to the block
-    o.cdf = o.wtime + GEN_WIN * 8;                            // wtime i64[GEN_WIN]: emitter times; cdf f64[nch], later hbase i64[nch]
-    o.hist = o.cdf + nch * 8;                                 // i32[nch1]: photons per channel, then their prefix sums
-    o.hmin = o.hist + nch1 * 4;                               // i32[nch]: rank counters of the channel phase, then earliest photon
-    o.hmax = o.hmin + nch * 4;                                // i32[nch]
-    o.chmap = (o.hmax + nch * 4 + 7) & ~7;                    // u16[GEN_BLOCK]: channel of every bucket position
-    o.perm = o.chmap + GEN_BLOCK * 2;                         // u16[GEN_BLOCK]: photon (generation order) of every bucket position
-    o.emap = o.perm + GEN_BLOCK * 2;                          // u16[GEN_BLOCK]: emitter slot of every photon (generation order)
-    o.cguide = o.emap + GEN_BLOCK * 2;                        // u16[CDF_G + 8]
-    o.ap = (o.cguide + (CDF_G + 8) * 2 + 7) & ~7;             // afterpulse staging
+    o.T = o.wtime + GEN_WIN * 4;                              // wtime i32[GEN_WIN]: emitter times relative to the set's origin
+    o.hist = o.T + nch * 4;                                   // T u32[nch]; hist i32[nch1]: photons per channel, then their prefix sums
+    o.cur = o.hist + nch1 * 4;                                // i32[nch]: rank counters
+    o.hmin = o.cur + nch * 4;                                 // i32[nch], i32[nch]: earliest / latest photon of the block per channel
+    o.hmax = o.hmin + nch * 4;
+    o.hoff = o.hmax + nch * 4;                                // i32[nch]: slot of bucket position 0 of every channel, relative to the set's first photon
+    o.chmap = o.hoff + nch * 4;                               // u16[GEN_BLOCK]: channel of every bucket position
+    o.cguide = o.chmap + GEN_BLOCK * 2;                       // u16[CDF_G + 8]
+    o.stage = (o.cguide + (CDF_G + 8) * 2 + 7) & ~7;          // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
+    o.ap = o.stage + GEN_BLOCK * 8;                           // afterpulse staging
     o.total = o.ap + (with_ap ? AP_STAGE * 20 : 0) + 16;
     return o;
 }
 
 // EXT: delay tables per instruction and array (model variants), S1 optical propagation term
 template <bool AP, bool EXT>
-__global__ __launch_bounds__(GEN_TPB) void k_photon_fill(WfsDev d, GenArgs a, ApArgs ap)
+__global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, ApArgs ap)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TPB = FILL_TPB, CPT = (WFS_MAX_CH + TPB - 1) / TPB;      // channels per thread
     const int nch = d.n_tpc, tid = threadIdx.x;
     const GenFillLds o = gen_fill_lds(nch, AP);
-    i32 *win = (i32 *)smem;
-    i64 *wtime = (i64 *)(smem + o.wtime);
-    double *cdf = (double *)(smem + o.cdf);
-    i64 *hbase = (i64 *)(smem + o.cdf);                       // global slot of bucket position 0 of every channel (after the channel phase)
-    i32 *hist = (i32 *)(smem + o.hist);
-    i32 *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
-    i32 *cur = hmin;
-    unsigned short *chmap = (unsigned short *)(smem + o.chmap), *perm = (unsigned short *)(smem + o.perm), *emap = (unsigned short *)(smem + o.emap);
-    i32 *scr = (i32 *)(smem + o.chmap);                       // [GEN_BLOCK] scratch of the emitter map: chmap + perm, before they are written
-    unsigned short *cguide = (unsigned short *)(smem + o.cguide);
-    __shared__ i32 s_wtmp[GEN_TPB / 64];
+    i32 *win = (i32 *)smem, *wtime = (i32 *)(smem + o.wtime);
+    u32 *T = (u32 *)(smem + o.T);
+    i32 *hist = (i32 *)(smem + o.hist), *cur = (i32 *)(smem + o.cur), *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
+    i32 *hoff = (i32 *)(smem + o.hoff);
+    unsigned short *chmap = (unsigned short *)(smem + o.chmap), *cguide = (unsigned short *)(smem + o.cguide);
+    PhotonRec *stage = (PhotonRec *)(smem + o.stage);
+    __shared__ i32 s_wtmp[TPB / 64];
     ApStage aps;
     aps.gain = (double *)(smem + o.ap); aps.ins = (i32 *)(smem + o.ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE;
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
     aps.n = &s_apn;
     if (AP && tid == 0) s_apn = 0;
-    const i64 vb = (i64)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3);      // XCD order, see k_photon_count
+    const i64 vb = block_of_workgroup(a);
     if (vb >= a.n_blocks) return;
+    STAMP_INIT;
+    const BlockDesc bd = a.blk_desc[vb];                     // block-uniform: scalar loads
     const i64 p0 = vb * GEN_BLOCK;
     const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
-    const i32 ins_lo = a.blk_ins[vb];
 
-    if (ins_lo >= 0) {
-        const i64 e_lo = a.blk_e[2 * vb], e_hi = a.blk_e[2 * vb + 1];
-        const int nwin = (int)(e_hi - e_lo + 2);             // <= GEN_WIN (k_block_emitters)
-        const u32 gid = a.ins_gid[ins_lo], eb = a.ins_embase[ins_lo]; const i64 emoff = a.em_off[ins_lo];
-        const i32 set_lo = a.ins_set[ins_lo]; const i64 itime = a.set_t0[set_lo];       // photon times are relative to the pulse set's origin
-        const AliasTab &tab = (a.ins_type[ins_lo] != 1) ? d.tab_s2 : d.tab_s1;
+    if (bd.ins >= 0) {
+        // ---- fast path: all photons of the block belong to one instruction.  Loads that depend on the block alone go first.
+        i32 cnt_r[CPT]; u32 base_r[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; q++) { const int c = tid + q * TPB; cnt_r[q] = c < nch ? (i32)a.blk_cnt[vb * nch + c] : 0; base_r[q] = c < nch ? a.blk_base[vb * nch + c] : 0u; }
+        const int nwin = bd.nwin;                            // <= GEN_WIN (k_block_emitters)
+        const u32 gid = bd.gid, eb = bd.eb; const i32 set_lo = bd.set; const i64 itime = bd.itime;     // photon times are relative to the pulse set's origin
+        const AliasTab &tab = bd.is_s2 ? d.tab_s2 : d.tab_s1;
         AliasTab tab_t = tab, tab_b = tab; i32 pzi = -1; double pzf = 0.0;
         if (EXT) {
-            tab_t = a.tabs[a.ins_tab[ins_lo]]; tab_b = a.tabs[a.ins_tabb[ins_lo]];
-            if (a.prop_top && a.ins_type[ins_lo] == 1) { pzi = a.ins_pzi[ins_lo]; pzf = a.ins_pzf[ins_lo]; }
+            tab_t = a.tabs[a.ins_tab[bd.ins]]; tab_b = a.tabs[a.ins_tabb[bd.ins]];
+            if (a.prop_top && !bd.is_s2) { pzi = a.ins_pzi[bd.ins]; pzf = a.ins_pzf[bd.ins]; }
         }
-#define TAB_OF(k) (EXT ? (bot[k] ? tab_b : tab_t) : tab)
+#define TAB_OF(c) (EXT ? ((c) >= d.n_top ? tab_b : tab_t) : tab)
         const i64 tbase = (i64)set_lo * nch;
-        const u32 jbase = (u32)(e_lo - emoff) + eb;
-        const i64 R0 = p0 - a.ins_ph0[ins_lo];
-        const size_t row = (size_t)a.ins_cdfrow[ins_lo];
-        for (int c = tid; c < nch; c += GEN_TPB) { hist[c] = (i32)a.blk_cnt[vb * nch + c]; cur[c] = 0; cdf[c] = a.cdf_table[row * nch + c]; }
-        for (int c = tid; c <= CDF_G; c += GEN_TPB) cguide[c] = a.cdf_guide[row * (CDF_G + 2) + c];
-        for (int k = tid; k < nwin; k += GEN_TPB) {
-            win[k] = (i32)(a.em_ph_off[e_lo + k] - p0);
-            wtime[k] = (e_lo + k < a.n_emitters) ? a.em_time[e_lo + k] - itime : 0;
-        }
-        for (int i = tid; i < GEN_BLOCK; i += GEN_TPB) scr[i] = 0;
-        __syncthreads();
-        // photon -> emitter slot (last k with win[k] <= pr) for the whole block at once: every emitter marks its first
-        // photon, a running maximum over the photon index fills the gaps
-        for (int k = tid; k < nwin; k += GEN_TPB) { const i32 w0 = win[k]; if (w0 > 0 && w0 < GEN_BLOCK) atomicMax(&scr[w0], k); }
-        block_excl_scan(hist, nch, s_wtmp);                  // (synchronises: the marks are complete behind it)
-        {
-            i32 v[GEN_PPT]; i32 mx = 0;
+        const i64 set_ph0 = a.tile_off[tbase];               // first photon slot of the set: per-channel offsets fit 32 bits
+        PhotonRec *out = a.ph + set_ph0;
+        const u32 q0 = (u32)(bd.R0 >> 2); const int r = (int)(bd.R0 & 3);
+        i32 toff_r[CPT];
 #pragma unroll
-            for (int k = 0; k < GEN_PPT; k++) { const i32 x = scr[tid * GEN_PPT + k]; mx = x > mx ? x : mx; v[k] = mx; }
-            i32 inc = mx;                                    // inclusive running maximum over the threads of the wave
-            for (int s = 1; s < 64; s <<= 1) { const i32 y = __shfl_up(inc, s, 64); if ((tid & 63) >= s) inc = y > inc ? y : inc; }
-            if ((tid & 63) == 63) s_wtmp[tid >> 6] = inc;
-            i32 carry = __shfl_up(inc, 1, 64); if ((tid & 63) == 0) carry = 0;
-            __syncthreads();
-            for (int w = 0; w < (tid >> 6); w++) carry = s_wtmp[w] > carry ? s_wtmp[w] : carry;
-#pragma unroll
-            for (int k = 0; k < GEN_PPT; k++) emap[tid * GEN_PPT + k] = (unsigned short)(v[k] > carry ? v[k] : carry);
+        for (int q = 0; q < CPT; q++) {
+            const int c = tid + q * TPB;
+            if (c < nch) {
+                T[c] = cdf_threshold(a.cdf_table[(size_t)bd.row * nch + c]); toff_r[q] = (i32)(a.tile_off[tbase + c] - set_ph0);
+                hist[c] = cnt_r[q]; cur[c] = 0; hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000;
+            }
         }
-        __syncthreads();                                     // scr is dead: perm may be written
-        // ---- channel phase: the channel words again, rank inside the channel -> bucket position of every photon
-        for (i64 q = (R0 >> 2) + tid; (q << 2) < R0 + np; q += GEN_TPB) {
-            const u32x4 W = philox4x32_10(eb, gid, (u32)q, SITE_CH, d.k0, d.k1);
+        for (int c = tid; c <= CDF_G; c += TPB) cguide[c] = a.cdf_guide[(size_t)bd.row * (CDF_G + 2) + c];
+        for (int k = tid; k < nwin; k += TPB) {
+            win[k] = (i32)(a.em_ph_off[bd.e_lo + k] - p0);
+            // the block's own emitters only (slot nwin - 1 is the sentinel behind them); I64_MIN: an electron that did not survive (no photons)
+            i64 wt = (k < nwin - 1) ? a.em_time[bd.e_lo + k] : I64_MIN;
+            wt = wt == I64_MIN ? 0 : wt - itime;
+            if (wt > 0x3fffffffLL || wt < -0x3fffffffLL) atomicMax(&a.scal[1], (i64)2);      // emitter further than 2^30 ns from its set's origin
+            wtime[k] = (i32)wt;
+        }
+        __syncthreads();                                     // hist is complete
+        STAMP(d, 0);
+        block_excl_scan<TPB>(hist, nch, s_wtmp);             // (ends with a barrier)
+#pragma unroll
+        for (int q = 0; q < CPT; q++) {
+            const int c = tid + q * TPB;
+            if (c < nch) {
+                const i32 b0 = hist[c], b1 = hist[c + 1];
+                hoff[c] = toff_r[q] + (i32)base_r[q] - b0;
+                for (i32 k = b0; k < b1; k++) chmap[k] = (unsigned short)c;
+            }
+        }
+        STAMP(d, 1);
+        // ---- generation order: a thread takes a quad of consecutive photons; their channel, delay and gain words come from
+        // three Philox calls.  The finished photon goes to its bucket position (rank inside its channel) in LDS.
+        for (int qi = tid; 4 * qi - r < np; qi += TPB) {
+            const u32x4 C = philox4x32_10(eb, gid, q0 + (u32)qi, SITE_CH, d.k0, d.k1);
+            const u32x4 D = philox4x32_10(eb, gid, q0 + (u32)qi, SITE_DELAY, d.k0, d.k1);
+            const int pr0 = 4 * qi - r;
+            int ch[4]; u32 cell[4]; uint2 e[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {                    // (photons outside the block: harmless values, nothing stored)
+                ch[k] = channel_lookup(T, cguide, nch, word_of(C, k));
+                cell[k] = alias_cell(TAB_OF(ch[k]), word_of(D, k));
+                e[k] = TAB_OF(ch[k]).cell[cell[k]];
+            }
+            const u32x4 G = philox4x32_10(eb, gid, q0 + (u32)qi, SITE_GAIN, d.k0, d.k1);      // (under the latency of the table gathers)
+            // emitter of the quad's first photon: last slot with win[slot] <= pr (emitters without photons are skipped);
+            // photons are spread evenly over the block's emitters, so an interpolated guess lands within a step or two
+            int slot;
+            {
+                const int prf = pr0 < 0 ? 0 : pr0;
+                slot = (int)(((u32)prf * (u32)(nwin - 1)) >> GEN_LOG);   // GEN_BLOCK >= np: slot <= nwin - 2
+                while (win[slot] > prf) slot--;                          // win[0] <= 0 <= prf
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const i64 pr = (q << 2) + k - R0;
-                if (pr >= 0 && pr < np) {
-                    const int ch = channel_lookup(cdf, cguide, nch, word_of(W, k));
-                    perm[hist[ch] + atomicAdd(&cur[ch], 1)] = (unsigned short)pr;
-                }
-            }
-        }
-        __syncthreads();
-        for (int c = tid; c < nch; c += GEN_TPB) {
-            const i32 b0 = hist[c], b1 = hist[c + 1];
-            hbase[c] = a.tile_off[tbase + c] + a.blk_base[vb * nch + c] - b0;
-            for (i32 k = b0; k < b1; k++) chmap[k] = (unsigned short)c;
-            hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000;
-        }
-        __syncthreads();
-        // ---- bucket order: groups of GEN_GRP photons per thread move through the steps together, so that the table gathers
-        // of a group are in flight at the same time
-#pragma unroll
-        for (int q0 = 0; q0 < GEN_PPT; q0 += GEN_GRP) {
-            if (q0 * GEN_TPB >= np) break;                   // block-uniform
-            int slot[GEN_GRP]; u32 j[GEN_GRP], m[GEN_GRP], code[GEN_GRP], yw[GEN_GRP], cell[GEN_GRP]; bool bot[GEN_GRP]; uint2 e[GEN_GRP];
-#pragma unroll
-            for (int k = 0; k < GEN_GRP; k++) {
-                const int i = (q0 + k) * GEN_TPB + tid;      // bucket position; past the end of the block: harmless values, nothing stored
-                const int pr = i < np ? (int)perm[i] : 0;
-                slot[k] = emap[pr];
-                j[k] = jbase + (u32)slot[k]; m[k] = (u32)(pr - win[slot[k]]);
-                const u32x4 B = philox4x32_10(j[k], gid, m[k], SITE_PH, d.k0, d.k1);
-                code[k] = spe_index(B.w) | (dpe_code(B.z, d.thr_dpe, d.dpe_inv) << 16);
-                bot[k] = EXT && i < np && chmap[i] >= d.n_top;
-                cell[k] = B.x >> TAB_OF(k).shift; yw[k] = B.y;
-                e[k] = TAB_OF(k).cell[cell[k]];
-            }
-#pragma unroll
-            for (int k = 0; k < GEN_GRP; k++) {
-                const int i = (q0 + k) * GEN_TPB + tid;
-                if (i >= np) continue;
-                const int ch = chmap[i];
-                // every delay term of the photon in one draw from the table of their sum, relative to the set's origin
-                i64 t = wtime[slot[k]] + (i64)TAB_OF(k).vmin + (i64)(yw[k] < e[k].x ? cell[k] : e[k].y);
+                const int pr = pr0 + k;
+                if (pr < 0 || pr >= np) continue;
+                while (win[slot + 1] <= pr) slot++;          // win[nwin - 1] = first photon behind the block's last emitter > pr
+                const int c = ch[k];
+                i32 t = wtime[slot] + alias_pick(TAB_OF(c), word_of(D, k), cell[k], e[k]);
+                const u32 code = gain_code(word_of(G, k), d.thr_dpe, d.dpe_inv);
+                const u32 j = bd.jbase + (u32)slot, m = (u32)(pr - win[slot]);
                 if (EXT && pzi >= 0) {                       // s1.py:185-188: int64 array, the assignment truncates
-                    const u32x4 X = philox4x32_10(j[k], gid, m[k], SITE_PH_X, d.k0, d.k1);
-                    t += (i64)s1_propagation(a, bot[k], pzi, pzf, X.x);
+                    const u32x4 X = philox4x32_10(j, gid, m, SITE_PH_X, d.k0, d.k1);
+                    t += (i32)(i64)s1_propagation(a, c >= d.n_top, pzi, pzf, X.x);
                 }
-                if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-                if (AP) ap_generate(d, a, ap, aps, j[k], gid, m[k], set_lo, ch, (code[k] >> 16) != 0, itime, t);
-                atomicMin(&hmin[ch], (i32)t); atomicMax(&hmax[ch], (i32)t);
-                a.ph[hbase[ch] + i] = PhotonRec{(i32)t, code[k]};
+                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t);
+                atomicMin(&hmin[c], t); atomicMax(&hmax[c], t);
+                stage[hist[c] + atomicAdd(&cur[c], 1)] = PhotonRec{t, code};
             }
         }
+        STAMP(d, 2);
         __syncthreads();
-        for (int c = tid; c < nch; c += GEN_TPB)
+        STAMP(d, 3);
+        // ---- bucket order: neighbouring lanes store photons of the same tile to consecutive addresses
+        for (int i = tid; i < np; i += TPB) out[hoff[chmap[i]] + i] = stage[i];
+        STAMP(d, 4);
+        for (int c = tid; c < nch; c += TPB)
             if (hist[c + 1] > hist[c]) { atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]); }
+        STAMP(d, 5);
+#undef TAB_OF
     } else {
+        // ---- generic path: per-photon global lookups and atomics
         if (AP) __syncthreads();                             // s_apn
-        for (int q = 0; q < GEN_PPT; q++) {
-            const int pr = q * GEN_TPB + tid;
-            if (pr >= np) break;
+        for (int pr = tid; pr < np; pr += TPB) {
             const PhotonId id = photon_id(a, p0 + pr);
             const i32 ins = id.ins;
             const int ch = photon_channel_global(d, a, id);
             const i32 set = a.ins_set[ins];
             const i64 tile = (i64)set * nch + ch;
             const i64 itime = a.set_t0[set];
-            const u32x4 B = philox4x32_10(id.j, id.gid, id.m, SITE_PH, d.k0, d.k1);
-            const u32 code = spe_index(B.w) | (dpe_code(B.z, d.thr_dpe, d.dpe_inv) << 16);
+            const u32 code = gain_code(photon_word(d, id, SITE_GAIN), d.thr_dpe, d.dpe_inv);
             i64 t = a.em_time[id.em] - itime;
-            if (EXT) {
-                t += alias_sample(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], B.x, B.y);
-                if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) {
-                    const u32x4 X = philox4x32_10(id.j, id.gid, id.m, SITE_PH_X, d.k0, d.k1);
-                    t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], X.x);
-                }
-            } else t += alias_sample(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, B.x, B.y);
+            const AliasTab &tb = EXT ? a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]] : (a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1);
+            t += alias_sample(tb, photon_word(d, id, SITE_DELAY));
+            if (EXT && a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) {
+                const u32x4 X = philox4x32_10(id.j, id.gid, id.m, SITE_PH_X, d.k0, d.k1);
+                t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], X.x);
+            }
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
             if (AP) ap_generate(d, a, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
@@ -1809,14 +1852,12 @@ __global__ __launch_bounds__(GEN_TPB) void k_photon_fill(WfsDev d, GenArgs a, Ap
         const int nst = s_apn < AP_STAGE ? s_apn : AP_STAGE;
         if (tid == 0 && nst > 0) s_apbase = (i64)atomicAdd((u64 *)ap.count, (u64)nst);
         __syncthreads();
-        for (int k = tid; k < nst; k += GEN_TPB) {
+        for (int k = tid; k < nst; k += TPB) {
             const i64 gk = s_apbase + k;
             if (gk < ap.cap) { ap.ap_ins[gk] = aps.ins[k]; ap.ap_ch[gk] = aps.ch[k]; ap.ap_t[gk] = aps.t[k]; ap.ap_gain[gk] = aps.gain[k]; }
         }
     }
 }
-
-#undef TAB_OF
 
 // afterpulse photons -> tiles of the afterpulse pulse set of their primary set (set n_psets + set): count, then place
 __global__ void k_ap_count(WfsDev d, GenArgs a, ApArgs ap)
@@ -1848,10 +1889,10 @@ __global__ void k_photon_times(WfsDev d, GenArgs a, i64 n, const i64 *index, i64
     if (i >= n) return;
     const PhotonId id = photon_id(a, index[i]);
     const i32 ins = id.ins;
-    const u32x4 B = philox4x32_10(id.j, id.gid, id.m, SITE_PH, d.k0, d.k1);
+    const u32 w = photon_word(d, id, SITE_DELAY);
     if (a.tabs) {                                            // model variants: the table depends on the photon's array
         const int ch = photon_channel_global(d, a, id);
-        i64 t = a.em_time[id.em] + alias_sample(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], B.x, B.y);
+        i64 t = a.em_time[id.em] + alias_sample(a.tabs[ch >= d.n_top ? a.ins_tabb[ins] : a.ins_tab[ins]], w);
         if (a.prop_top && a.ins_type[ins] == 1 && a.ins_pzi[ins] >= 0) {
             const u32x4 X = philox4x32_10(id.j, id.gid, id.m, SITE_PH_X, d.k0, d.k1);
             t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], X.x);
@@ -1859,7 +1900,7 @@ __global__ void k_photon_times(WfsDev d, GenArgs a, i64 n, const i64 *index, i64
         out[i] = t;
         return;
     }
-    out[i] = a.em_time[id.em] + alias_sample(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, B.x, B.y);
+    out[i] = a.em_time[id.em] + alias_sample(a.ins_type[ins] != 1 ? d.tab_s2 : d.tab_s1, w);
 }
 
 // Optical input (RawDataOptical.sim_primary, rawdata.py:475-493): photons are supplied, already bucketed by the host
@@ -1881,9 +1922,9 @@ __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
         const u32 item = a.in_item[off + p];                 // index of the photon inside its instruction's range
         const u32x4 B = philox4x32_10(0, gid, item, SITE_PH, d.k0, d.k1);
         i64 t = a.in_t[off + p];
-        t += alias_sample(d.tab_tts, B.x, B.y);
+        t += alias_sample(d.tab_tts, B.x);
         if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-        a.ph[off + p] = PhotonRec{(i32)t, spe_index(B.w) | (dpe_code(B.z, d.thr_dpe, d.dpe_inv) << 16)};
+        a.ph[off + p] = PhotonRec{(i32)t, gain_code(B.y, d.thr_dpe, d.dpe_inv)};
         tmin = (i32)t < tmin ? (i32)t : tmin; tmax = (i32)t > tmax ? (i32)t : tmax;
     }
     a.tile_tmin[tile] = tmin; a.tile_tmax[tile] = tmax;
