@@ -1061,23 +1061,20 @@ int wfs_run(wfs_handle *h)
         pd.active_tiles = h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles;
         pd.desc = h->tile_desc.as<TileDesc>() + h->n_tiny_tiles + h->n_sparse_tiles;
         if (pd.cur_off) pd.cur_off += h->n_tiny_tiles + h->n_sparse_tiles;
-        // windows of up to W_WIN start bins: LDS per workgroup stays below 160 KB / 7 and a
-        // 10^6-PE tile is spread over three workgroups; very long tiles loop over further windows inside the kernel
-        const int W_WIN = 240, NWIN_MAX = 8;      // 240 start bins + padding = 22.9 KB of LDS: 7 workgroups per CU (256: 6; measured 6.9 vs 7.25 ms)
-        int W = (int)std::min<i64>(std::max<i64>(h->max_nb_dense, d.tlen + 1), W_WIN);
-        W = (W + 7) / 8 * 8;
-        pd.W = W;
-        const i64 step = W - (d.tlen - 1);
-        const bool small = W <= 128;
+        // chunks of TPB live samples per pass (TPB + 21 start-bin rows of 80 bytes in LDS: 22 KB for 256 -> 7 workgroups per CU)
+        const i64 n_live_max = h->max_nb_dense + d.tlen - 1;
+        const bool small = n_live_max <= 128;
         const int tpb = small ? 128 : 256;
-        // tiles that fit one register batch: one workgroup per tile walks the windows with the photons resident in
-        // registers; longer tiles: one workgroup per window (each re-reads the tile's photons)
-        pd.n_win = (h->max_tile_dense <= (i64)tpb * DENSE_PPT) ? 1 : (int)std::min<i64>(NWIN_MAX, std::max<i64>(1, (h->max_nb_dense + step - 1) / step));
+        const int NWIN_MAX = 8;
+        // tiles that fit one register batch: one workgroup per tile walks the chunks with the photons resident in
+        // registers; longer tiles: several workgroups per tile (each re-reads the tile's photons for its chunks)
+        pd.n_win = (h->max_tile_dense <= (i64)tpb * DENSE_PPT) ? 1 : (int)std::min<i64>(NWIN_MAX, std::max<i64>(1, (n_live_max + tpb - 1) / tpb));
+        pd.W = tpb;
         TemplateArg tp;
         for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
-        size_t lds = (size_t)(W + 2 * DENSE_PAD) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
+        size_t lds = (size_t)(tpb + d.tlen - 1) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
         lds = (lds + 15) / 16 * 16;
-        pd.spe_lds = ((size_t)(W + 2 * DENSE_PAD) * d.dt >= 2001) ? 1 : 0;
+        pd.spe_lds = ((size_t)(tpb + d.tlen - 1) * d.dt >= 2001) ? 1 : 0;
         const unsigned grid = (unsigned)(h->n_dense_tiles * pd.n_win);
         Timer t(h, "k_pulse_dense");
         if (pd.n_win == 1) {

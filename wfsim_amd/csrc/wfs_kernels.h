@@ -342,15 +342,13 @@ struct PulseArgs {
     i32 *raw;
     double *tile_truth;   // [n_tiles][8] per-tile partial sums: n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2 -> k_truth_reduce
     double *currents; const i64 *cur_off;     // debug: f64 tile currents
-    i32 W;                // start bins per LDS window (dense) / bins capacity (sparse)
+    i32 W;                // bins capacity of the sparse kernel's LDS tables
     i32 NP;               // photon capacity of the sparse kernel's LDS list
-    i32 n_win;            // dense kernel: workgroups (windows) per tile
+    i32 n_win;            // dense kernel: workgroups per tile (each takes every n_win-th chunk of TPB samples)
     i32 spe_lds;          // dense resident kernel: the H table has room for the channel's SPE row (2001 doubles), staged there before the gains are looked up
 };
 
 #define DENSE_PPT 8        // photons per thread per batch held in registers
-#define DENSE_SPT 1        // samples per thread carried through the tap loop (more costs registers, i.e. occupancy)
-#define DENSE_PAD 21       // zero start bins on either side of the window: no bounds checks in the tap loop
 
 struct TemplateArg { double t[22 * WFS_DT]; };    // t[k * dt + r] = templates[r][k]; kernarg segment -> scalar loads, the taps live in SGPRs
 
@@ -379,17 +377,18 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int dt = WFS_DT, tlen = 22;
-    const int W = a.W;
-    double *H = (double *)smem;                           // [W + 2 * DENSE_PAD][dt]: merged gain per (start bin, ns remainder)
-    double *red = H + (size_t)(W + 2 * DENSE_PAD) * dt;   // [TPB / 64][8]
+    // The live samples of a tile (sample s' = s - lead sees the start bins s' - 21 .. s') are worked off in chunks of TPB
+    // consecutive samples, one per thread; a chunk needs the TPB + tlen - 1 start bins from 21 before its first sample on.
+    constexpr int HROWS = TPB + tlen - 1;
+    double *H = (double *)smem;                           // [HROWS][dt]: merged gain per (start bin, ns remainder)
+    double *red = H + (size_t)HROWS * dt;                 // [TPB / 64][8]
     u32 *wsum = (u32 *)(red + 8 * (TPB / 64));
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // pulse.py:32 current_max, indexed per photon: from LDS (indexing the kernarg copy per lane becomes a global load)
     __shared__ double s_cmax[WFS_DT];
     if (tid < WFS_DT) s_cmax[tid] = d.current_max[tid];
 
-    // grid = tiles x windows: every workgroup owns one window of W start bins of one tile (a.n_win windows per tile;
-    // consecutive windows overlap by tlen - 1 bins so that every sample sees all its taps inside one window)
+    // grid = tiles x a.n_win: workgroup `win` of a tile takes the chunks win, win + n_win, ... (n_win = 1: the resident form)
     const i64 tidx = blockIdx.x / a.n_win;
     const int win = (int)(blockIdx.x - tidx * a.n_win);
     const TileDesc td = a.desc[tidx];                     // block-uniform: scalar loads
@@ -403,8 +402,8 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     const double thr = td.thr;
     const i64 rel0 = td.rel0;                             // ns of the tile's first start bin relative to t0
 
-    // window w exists iff it is the first or the previous one did not already reach the last start bin (block-uniform)
-    if (win > 0 && (i64)win * (W - (tlen - 1)) + (tlen - 1) >= nb) return;
+    const i64 n_live = nb + (tlen - 1);                   // samples lead .. lead + n_live - 1 can be non-zero
+    if (win > 0 && (i64)win * TPB >= n_live) return;      // no chunk for this workgroup (block-uniform)
     // number of DPE photons of the tile (truth quirk pulse.py:255); truth is window 0's job.  A tile that fits one
     // register batch is counted from the registers inside the photon loop, longer ones with a scan of their own.
     i32 n_dpe_tile = 0;
@@ -425,6 +424,22 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     i32 r_ns[DENSE_PPT]; double r_gain[DENSE_PPT];
     if (RESIDENT) {
         u32 code[DENSE_PPT];
+        // The channel's SPE row (16 KB) goes through LDS (H is still free): two data-dependent 8-byte gathers per photon from
+        // global memory cost the texture addresser ~64 cycles per wave instruction, from LDS a few.  Its loads are issued
+        // together with the photon loads: one global round trip for both.
+        // They bypass the registers (global_load_lds: 16 bytes per lane, a wave fills 1 KB of LDS per instruction).
+        const bool spe_lds = mode == 0 && a.spe_lds;         // block-uniform
+        if (spe_lds) {
+            constexpr int NIT = (2001 * 8 + TPB * 16 - 1) / (TPB * 16);
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                // first double of this lane's 16 bytes; the lanes behind the row re-read its last entry (index 2000: its second
+                // half is the first entry of the next row or, behind the last row, the slack every device buffer has)
+                const int i = (it * TPB + tid) * 2;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(spe_row + (i < 2001 ? i : 2000)),
+                                                 (__attribute__((address_space(3))) void *)(H + (it * TPB + (tid & ~63)) * 2), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < DENSE_PPT; k++) {
             const i32 p = tid + k * TPB;
@@ -440,31 +455,41 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             for (int k = 0; k < DENSE_PPT; k++) c += (code[k] >> 16) != 0;
             for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
             if (lane == 0) wsum[wid] = (u32)c;
+            if (spe_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the SPE row has landed in LDS
             __syncthreads();
             for (int w = 0; w < TPB / 64; w++) n_dpe_tile += (i32)wsum[w];
         }
         if (mode == 0) {
-            double s1[DENSE_PPT], s2[DENSE_PPT];
-            if (a.spe_lds) {
-                // The channel's SPE row (16 KB) goes through LDS (H is still free): two data-dependent 8-byte gathers per photon
-                // from global memory cost the texture addresser ~64 cycles per wave instruction, from LDS a few.
-                for (int i = tid; i < 2001; i += TPB) H[i] = spe_row[i];
-                __syncthreads();
+            if (spe_lds) {
+                // (in two halves: sixteen 8-byte values in flight at once cost the registers of a seventh wave per SIMD)
 #pragma unroll
-                for (int k = 0; k < DENSE_PPT; k++) { s1[k] = H[code[k] & 0xffffu]; s2[k] = H[code[k] >> 16]; }     // H[0] for "no second PE": unused
+                for (int h0 = 0; h0 < DENSE_PPT; h0 += DENSE_PPT / 2) {
+                    double s1[DENSE_PPT / 2], s2[DENSE_PPT / 2];
+#pragma unroll
+                    for (int k = 0; k < DENSE_PPT / 2; k++) { s1[k] = H[code[h0 + k] & 0xffffu]; s2[k] = H[code[h0 + k] >> 16]; }     // H[0] for "no second PE": unused
+#pragma unroll
+                    for (int k = 0; k < DENSE_PPT / 2; k++) {
+                        double gk = G * s1[k];                          // pulse.py:97-98
+                        if (code[h0 + k] >> 16) gk += G * s2[k];        // pulse.py:101-103
+                        r_gain[h0 + k] = gk;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 __syncthreads();                             // H is reused below
-            } else
+            } else {
+                double s1[DENSE_PPT], s2[DENSE_PPT];
 #pragma unroll
-            for (int k = 0; k < DENSE_PPT; k++) {
-                s1[k] = spe_row[code[k] & 0xffffu];                    // index 0 for the unused slots: a valid address
-                s2[k] = 0;
-                if (code[k] >> 16) s2[k] = spe_row[code[k] >> 16];
-            }
+                for (int k = 0; k < DENSE_PPT; k++) {
+                    s1[k] = spe_row[code[k] & 0xffffu];                // index 0 for the unused slots: a valid address
+                    s2[k] = 0;
+                    if (code[k] >> 16) s2[k] = spe_row[code[k] >> 16];
+                }
 #pragma unroll
-            for (int k = 0; k < DENSE_PPT; k++) {
-                double gk = G * s1[k];                                  // pulse.py:97-98
-                if (code[k] >> 16) gk += G * s2[k];                     // pulse.py:101-103
-                r_gain[k] = gk;
+                for (int k = 0; k < DENSE_PPT; k++) {
+                    double gk = G * s1[k];                              // pulse.py:97-98
+                    if (code[k] >> 16) gk += G * s2[k];                 // pulse.py:101-103
+                    r_gain[k] = gk;
+                }
             }
         }
         STAMP(d, 8);
@@ -509,20 +534,22 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     }
 
     STAMP(d, 9);
-    for (i64 w0 = (i64)win * (W - (tlen - 1)); w0 == 0 || w0 + (tlen - 1) < nb; w0 += (i64)a.n_win * (W - (tlen - 1))) {
-        const int Wc = (int)((nb - w0 < W) ? nb - w0 : W);
-        const bool first = (w0 == 0), last = (w0 + Wc >= nb);
+    // samples before the first start bin can reach (lead of them) and behind the reach of the last one are exactly zero and the
+    // accumulators start from zero: nothing to do for them (the debug copy of the currents wants every sample)
+    if (a.currents && win == 0) for (i64 sz = tid; sz < L; sz += TPB) if (sz < lead || sz >= lead + n_live) a.currents[a.cur_off[tidx] + sz] = 0.0;
+    for (i64 c0 = (i64)win * TPB; c0 < n_live; c0 += (i64)a.n_win * TPB) {
+        const bool first = (c0 == 0);
+        const i64 b_lo = c0 - (tlen - 1);                  // start bin of H row 0 (may be negative: those rows stay empty)
         __syncthreads();
-        for (int i = tid; i < (W + 2 * DENSE_PAD) * dt; i += TPB) H[i] = 0.0;
+        for (int i = tid; i < HROWS * dt; i += TPB) H[i] = 0.0;
         __syncthreads();
         STAMP(d, 10);
         if (RESIDENT) {
-            const i32 ns_lo = (i32)w0 * dt, ns_hi = ns_lo + Wc * dt;       // the window in ns relative to the tile's first start bin
+            const i32 ns_lo = (i32)b_lo * dt, ns_hi = ns_lo + HROWS * dt;   // the chunk's start bins in ns relative to the tile's first start bin
 #pragma unroll
             for (int k = 0; k < DENSE_PPT; k++) {
-                if (r_ns[k] < ns_lo || r_ns[k] >= ns_hi) continue;
-                const int q = r_ns[k] - ns_lo;                             // (start bin - w0) * dt + r
-                atomicAdd(&H[DENSE_PAD * dt + q], r_gain[k]);
+                if (r_ns[k] < 0 || r_ns[k] < ns_lo || r_ns[k] >= ns_hi) continue;
+                atomicAdd(&H[r_ns[k] - ns_lo], r_gain[k]);                  // (start bin - b_lo) * dt + r
             }
         } else
         // ---- photons -> H, in register batches so that the global loads of a batch are all in flight together
@@ -535,8 +562,8 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 const PhotonRec rec = a.ph[off + (v ? p : 0)];        // branch-free: tiles on the work list have n >= 1
                 ns[k] = v ? (i32)(rec.t - rel0) : -1;
                 code[k] = v ? rec.code : 0u;
-                const i64 jw = (i64)(ns[k] / dt) - w0;
-                use[k] = v && (first || (jw >= 0 && jw < Wc));         // window 0 needs every photon (truth), the others only their own
+                const i64 jw = (i64)(ns[k] / dt) - b_lo;
+                use[k] = v && (first || (jw >= 0 && jw < HROWS));      // chunk 0 needs every photon (truth), the others only their own
                 gain[k] = (use[k] && mode != 0) ? a.ph_gain[off + p] : 0.0;
             }
             if (first && one_batch) {                // (one batch, several workgroups per tile)
@@ -566,8 +593,8 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             for (int k = 0; k < DENSE_PPT; k++) {
                 if (!use[k]) continue;
                 const int bin = ns[k] / dt, r = ns[k] - bin * dt;
-                const i64 jw = bin - w0;
-                if (jw >= 0 && jw < Wc) atomicAdd(&H[((int)jw + DENSE_PAD) * dt + r], gain[k]);
+                const i64 jw = bin - b_lo;
+                if (jw >= 0 && jw < HROWS) atomicAdd(&H[(int)jw * dt + r], gain[k]);
                 if (first) {
                     const bool above = gain[k] * s_cmax[r] * d.c2a > thr;
                     const bool is_dpe = (code[k] >> 16) != 0;
@@ -580,50 +607,31 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         }
         __syncthreads();
         STAMP(d, 11);
-        // ---- every sample gathers its tlen x dt possible contributions in ascending time (pulse.py:303-318)
-        const i64 s_lo = first ? 0 : w0 + lead + (tlen - 1);
-        const i64 s_hi = last ? L : w0 + Wc + lead;
-        // Tap loop outermost so that only the dt taps of one k are live in SGPRs; each thread carries DENSE_SPT samples
-        for (i64 sb = s_lo; sb < s_hi; sb += (i64)TPB * DENSE_SPT) {
-            double cur[DENSE_SPT]; const double *Hs[DENSE_SPT]; bool act[DENSE_SPT];
-            const int nq = (int)((s_hi - sb + TPB - 1) / TPB);      // block-uniform number of live sample slots
-#pragma unroll
-            for (int q = 0; q < DENSE_SPT; q++) {
-                const i64 s = sb + tid + (i64)q * TPB;
-                const i64 jhi = s - lead - w0;             // window-relative start bin of tap k = 0
-                act[q] = s < s_hi && jhi >= 0 && jhi - (tlen - 1) < Wc;
-                Hs[q] = H + ((act[q] ? (int)jhi : 0) + DENSE_PAD) * dt;
-                cur[q] = 0.0;
-            }
-            bool wact[DENSE_SPT];
-#pragma unroll
-            for (int q = 0; q < DENSE_SPT; q++) wact[q] = __any(act[q]);
-#pragma unroll 2
+        // ---- every sample gathers its tlen x dt possible contributions in ascending time (pulse.py:303-318): sample c0 + tid
+        // reads the rows tid (tap k = 21) .. tid + 21 (tap k = 0).  The tap loop is outermost so that only the dt taps of one
+        // k are live in SGPRs.
+        const bool act = c0 + tid < n_live;
+        if (__any(act)) {                                  // wave-uniform
+            const double *Hs = H + (tid + (tlen - 1)) * dt;
+            double c = 0.0;
+#pragma unroll 1
             for (int k = tlen - 1; k >= 0; k--) {
-                const double *Tk = tp.t + k * dt;            // the dt taps of one k are contiguous: two wide scalar loads
+                const double *Tk = tp.t + k * dt;          // the dt taps of one k are contiguous: two wide scalar loads
                 const double T0 = Tk[0], T1 = Tk[1], T2 = Tk[2], T3 = Tk[3], T4 = Tk[4], T5 = Tk[5], T6 = Tk[6], T7 = Tk[7], T8 = Tk[8], T9 = Tk[9];
-#pragma unroll
-                for (int q = 0; q < DENSE_SPT; q++) {
-                    if (q >= nq || !wact[q]) continue;       // wave-uniform
-                    const double2 *hp = (const double2 *)(Hs[q] - k * dt);
-                    const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
-                    double c = cur[q], prod;
-                    prod = T0 * h0.x; c = c + prod;  prod = T1 * h0.y; c = c + prod;
-                    prod = T2 * h1.x; c = c + prod;  prod = T3 * h1.y; c = c + prod;
-                    prod = T4 * h2.x; c = c + prod;  prod = T5 * h2.y; c = c + prod;
-                    prod = T6 * h3.x; c = c + prod;  prod = T7 * h3.y; c = c + prod;
-                    prod = T8 * h4.x; c = c + prod;  prod = T9 * h4.y; c = c + prod;
-                    cur[q] = c;
-                }
+                const double2 *hp = (const double2 *)(Hs - k * dt);
+                const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
+                double prod;
+                prod = T0 * h0.x; c = c + prod;  prod = T1 * h0.y; c = c + prod;
+                prod = T2 * h1.x; c = c + prod;  prod = T3 * h1.y; c = c + prod;
+                prod = T4 * h2.x; c = c + prod;  prod = T5 * h2.y; c = c + prod;
+                prod = T6 * h3.x; c = c + prod;  prod = T7 * h3.y; c = c + prod;
+                prod = T8 * h4.x; c = c + prod;  prod = T9 * h4.y; c = c + prod;
             }
-#pragma unroll
-            for (int q = 0; q < DENSE_SPT; q++) {
-                const i64 s = sb + tid + (i64)q * TPB;
-                if (s >= s_hi) continue;
-                const double c = act[q] ? cur[q] : 0.0;
-                if (a.currents) a.currents[a.cur_off[tidx] + s] = c;
-                const i64 adc = -(i64)rint(c * d.c2a);             // rawdata.py:236, np.around = round half to even
-                if (adc != 0) atomicAdd(&dst[s], (i32)adc);
+            if (act) {
+                const i64 sx = lead + c0 + tid;            // sample of the tile
+                if (a.currents) a.currents[a.cur_off[tidx] + sx] = c;
+                const i64 adc = -(i64)rint(c * d.c2a);     // rawdata.py:236, np.around = round half to even
+                if (adc != 0) atomicAdd(&dst[sx], (i32)adc);
             }
         }
         STAMP(d, 12);
