@@ -210,6 +210,14 @@ int wfs_copy_truth_per_pmt(wfs_handle *h, double *acc6, int64_t cap);
 int wfs_copy_records(wfs_handle *h, void *dst_host, int64_t capacity_records);
 /* the records [first, first + count) of the batch into a caller buffer (e.g. straight into the chunker's record buffer) */
 int wfs_copy_records_range(wfs_handle *h, void *dst, int64_t first, int64_t count);
+/* The same without waiting: the copy runs on the handle's copy stream and overlaps the kernels of the next wfs_run (the
+ * engine keeps the records of the last two batches); dst should be pinned (wfs_host_register: e.g. the chunker's record
+ * buffer, strax_interface.py:360-364, registered once) -- from pageable memory the driver stages the copy and nothing
+ * overlaps.  wfs_wait_records returns when every copy issued so far has landed. */
+int wfs_copy_records_range_async(wfs_handle *h, void *dst, int64_t first, int64_t count);
+int wfs_wait_records(wfs_handle *h);
+int wfs_host_register(void *ptr, int64_t bytes);
+int wfs_host_unregister(void *ptr);
 int wfs_copy_records_dev(wfs_handle *h, void *dst_dev, int64_t capacity_records);
 const void *wfs_records_dev_ptr(wfs_handle *h);
 /* digitise windows: rawdata.left / rawdata.right and the first record of each window (strax_interface.py:394-399) */

@@ -49,7 +49,11 @@ struct wfs_handle {
     DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
-    DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off, records;
+    DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off;
+    // packed records: two arenas used in turn, so that the device -> host copy of one batch (copy stream, pinned host memory)
+    // runs under the kernels of the next batch
+    DevBuf records_ab[2]; int rec_cur = 0; hipStream_t copy_stream = nullptr; hipEvent_t rec_copied[2] = {nullptr, nullptr}; bool rec_pending[2] = {false, false};
+    DevBuf &records_buf() { return records_ab[rec_cur]; }
     DevBuf truth, tminmax, tile_truth, tile_desc, gather_idx, gather_out, currents, cur_len, cur_off, row_dbg, row_dbg_len, row_dbg_off;
     DevBuf stamps;
     DevBuf row_desc, rec_key, rec_key2, rec_val, rec_val2, rec_dest, sort_tmp, scan_tmp, scal, noise_override;
@@ -347,6 +351,8 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     memset(&h->dev, 0, sizeof(h->dev));
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return WFS_E_HIP; }
     h->own_stream = true;
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->rec_copied[0], hipEventDisableTiming) != hipSuccess
+        || hipEventCreateWithFlags(&h->rec_copied[1], hipEventDisableTiming) != hipSuccess) { delete h; return WFS_E_HIP; }
     if (hipMalloc(&h->scal.p, 256) != hipSuccess) { delete h; return WFS_E_HIP; }
     h->scal.cap = 256;
 #ifdef WFS_STAMPS
@@ -391,7 +397,7 @@ int wfs_destroy(wfs_handle *h)
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
-        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records, &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
+        &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
@@ -399,6 +405,8 @@ int wfs_destroy(wfs_handle *h)
     for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); }
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (h->own_stream) hipStreamDestroy(h->stream);
+    if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
+    for (int q = 0; q < 2; q++) if (h->rec_copied[q]) hipEventDestroy(h->rec_copied[q]);
     delete h;
     return WFS_OK;
 }
@@ -1128,8 +1136,11 @@ int wfs_run(wfs_handle *h)
     TRY(scan(h, h->row_nrec.as<i32>(), RS, h->rec_off, 10));
     TRY(read_scal(h));
     h->n_records = h->h_scal[10];
-    TRY(ensure(h, h->records, (size_t)h->n_records * 244));
-    za.rec_off = h->rec_off.as<i64>(); za.records = h->records.as<uint8_t>(); za.rec_capacity = h->n_records;
+    // the other arena: the previous batch's records may still be on their way to the host
+    h->rec_cur ^= 1;
+    if (h->rec_pending[h->rec_cur]) { HIPCHK(hipEventSynchronize(h->rec_copied[h->rec_cur])); h->rec_pending[h->rec_cur] = false; }
+    TRY(ensure(h, h->records_buf(), (size_t)h->n_records * 244));
+    za.rec_off = h->rec_off.as<i64>(); za.records = h->records_buf().as<uint8_t>(); za.rec_capacity = h->n_records;
     if (h->sort_records && h->n_records > 1 && h->n_active_rows > 0) {
         // records by (time, channel): keys per record, one radix sort of the batch, k_pack writes to the sorted slots
         const i64 NR = h->n_records;
@@ -1170,13 +1181,13 @@ int wfs_get_counts(wfs_handle *h, wfs_counts *out)
     return WFS_OK;
 }
 
-const void *wfs_records_dev_ptr(wfs_handle *h) { return h ? h->records.p : nullptr; }
+const void *wfs_records_dev_ptr(wfs_handle *h) { return h ? h->records_buf().p : nullptr; }
 
 int wfs_copy_records(wfs_handle *h, void *dst, int64_t cap)
 {
     if (!h || !h->ran) return WFS_E_STATE;
     if (cap < h->n_records) return h->fail(WFS_E_CAPACITY, "record buffer too small");
-    if (h->n_records) HIPCHK(hipMemcpy(dst, h->records.p, (size_t)h->n_records * 244, hipMemcpyDeviceToHost));
+    if (h->n_records) HIPCHK(hipMemcpy(dst, h->records_buf().p, (size_t)h->n_records * 244, hipMemcpyDeviceToHost));
     return WFS_OK;
 }
 
@@ -1184,7 +1195,36 @@ int wfs_copy_records_range(wfs_handle *h, void *dst, int64_t first, int64_t coun
 {
     if (!h || !h->ran) return WFS_E_STATE;
     if (first < 0 || count < 0 || first + count > h->n_records) return h->fail(WFS_E_INVALID, "record range outside the batch");
-    if (count) HIPCHK(hipMemcpy(dst, (const uint8_t *)h->records.p + (size_t)first * 244, (size_t)count * 244, hipMemcpyDeviceToHost));
+    if (count) HIPCHK(hipMemcpy(dst, (const uint8_t *)h->records_buf().p + (size_t)first * 244, (size_t)count * 244, hipMemcpyDeviceToHost));
+    return WFS_OK;
+}
+
+// Pinned host memory + the copy stream: the records of a batch travel to the host while the next batch's kernels run
+// (strax_interface.py:360-364: the caller owns the record buffer; pinning it once removes the staging copy of pageable
+// transfers -- 15 GB/s -- and lets the transfer overlap).  wfs_run leaves the records of the last TWO batches intact.
+int wfs_host_register(void *ptr, int64_t bytes)
+{
+    if (!ptr || bytes <= 0) return WFS_E_INVALID;
+    return hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? WFS_OK : WFS_E_HIP;
+}
+int wfs_host_unregister(void *ptr) { return (ptr && hipHostUnregister(ptr) == hipSuccess) ? WFS_OK : WFS_E_HIP; }
+
+int wfs_copy_records_range_async(wfs_handle *h, void *dst, int64_t first, int64_t count)
+{
+    if (!h || !h->ran) return WFS_E_STATE;
+    if (first < 0 || count < 0 || first + count > h->n_records) return h->fail(WFS_E_INVALID, "record range outside the batch");
+    HIPCHK(hipSetDevice(h->device));
+    if (count) HIPCHK(hipMemcpyAsync(dst, (const uint8_t *)h->records_buf().p + (size_t)first * 244, (size_t)count * 244, hipMemcpyDeviceToHost, h->copy_stream));
+    HIPCHK(hipEventRecord(h->rec_copied[h->rec_cur], h->copy_stream));
+    h->rec_pending[h->rec_cur] = true;
+    return WFS_OK;
+}
+
+int wfs_wait_records(wfs_handle *h)
+{
+    if (!h) return WFS_E_INVALID;
+    HIPCHK(hipStreamSynchronize(h->copy_stream));
+    h->rec_pending[0] = h->rec_pending[1] = false;
     return WFS_OK;
 }
 
@@ -1192,7 +1232,7 @@ int wfs_copy_records_dev(wfs_handle *h, void *dst, int64_t cap)
 {
     if (!h || !h->ran) return WFS_E_STATE;
     if (cap < h->n_records) return h->fail(WFS_E_CAPACITY, "record buffer too small");
-    if (h->n_records) { HIPCHK(hipMemcpyAsync(dst, h->records.p, (size_t)h->n_records * 244, hipMemcpyDeviceToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+    if (h->n_records) { HIPCHK(hipMemcpyAsync(dst, h->records_buf().p, (size_t)h->n_records * 244, hipMemcpyDeviceToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
     return WFS_OK;
 }
 
@@ -1249,7 +1289,7 @@ int wfs_copy_interval_data(wfs_handle *h, int16_t *data, int64_t cap)
     // unpack the records: fragments of one interval are consecutive
     if (!h || !h->ran) return WFS_E_STATE;
     std::vector<uint8_t> rec((size_t)h->n_records * 244);
-    if (h->n_records) HIPCHK(hipMemcpy(rec.data(), h->records.p, rec.size(), hipMemcpyDeviceToHost));
+    if (h->n_records) HIPCHK(hipMemcpy(rec.data(), h->records_buf().p, rec.size(), hipMemcpyDeviceToHost));
     i64 k = 0;
     for (i64 r = 0; r < h->n_records; r++) {
         i32 len; memcpy(&len, &rec[(size_t)r * 244 + 8], 4);

@@ -22,6 +22,42 @@ _F64 = ['c2a', 'tts_mean', 'tts_sigma', 'p_dpe', 's1_decay_time', 's1_decay_spre
         's2_time_spread', 'trap_time', 'gain_spread', 'pmt_ap_modifier', 'pmt_ap_t_modifier', 'rext', 'drift_velocity']
 
 
+def pin_host(array):
+    """page-locks a host array (hipHostRegister): device -> host copies into it then run at PCIe speed and asynchronously.
+    Returns True on success; a failure is not an error (copies still work, staged by the driver)."""
+    a = np.asarray(array)
+    if a.nbytes == 0 or not a.flags['C_CONTIGUOUS']:
+        return False
+    return load_library().wfs_host_register(C.c_void_p(a.ctypes.data), C.c_int64(a.nbytes)) == 0
+
+
+def unpin_host(array):
+    load_library().wfs_host_unregister(C.c_void_p(np.asarray(array).ctypes.data))
+
+
+_RECORD_BUFFERS = []        # [array, in use]: page-locked record buffers, kept for the life of the process
+
+
+def acquire_record_buffer(length, dtype, pin=True):
+    """A record buffer for ChunkRawRecords (strax_interface.py:360-361: np.zeros(5000000, raw_record_dtype), 1.2 GB).
+    Page-locking that much memory takes a few hundred ms, so pinned buffers are recycled between instances."""
+    dtype = np.dtype(dtype)
+    for slot in _RECORD_BUFFERS:
+        if not slot[1] and len(slot[0]) == length and slot[0].dtype == dtype:
+            slot[1] = True
+            return slot[0]
+    buf = np.zeros(length, dtype=dtype)
+    if pin and pin_host(buf):
+        _RECORD_BUFFERS.append([buf, True])
+    return buf
+
+
+def release_record_buffer(buf):
+    for slot in _RECORD_BUFFERS:
+        if slot[0] is buf:
+            slot[1] = False
+
+
 class WfsConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in _I32] + [(n, C.c_double) for n in _F64] + [('seed', C.c_uint64)]
 
@@ -42,7 +78,8 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_copy_interval_data', 'wfs_copy_pulses', 'wfs_copy_currents', 'wfs_copy_rows', 'wfs_copy_row_data',
            'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_instruction_photon_offsets', 'wfs_gather_photon_times', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
            'wfs_kernel_times', 'wfs_set_profiling', 'wfs_set_delay_models', 'wfs_set_s1_propagation', 'wfs_set_instruction_models',
-           'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range']
+           'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range',
+           'wfs_copy_records_range_async', 'wfs_wait_records', 'wfs_host_register', 'wfs_host_unregister']
 
 
 def load_library():
@@ -90,6 +127,7 @@ class Engine:
         for n, _ in WfsConfig._fields_:
             setattr(cfg, n, params[n])
         self._h = C.c_void_p(0)
+        self._pinned = []
         rc = self.lib.wfs_create(C.byref(cfg), C.c_int(device), C.byref(self._h))
         if rc != 0:
             raise WfsError(f'wfs_create failed with code {rc}: no usable MI355X / HIP runtime (device {device})')
@@ -162,6 +200,8 @@ class Engine:
 
     def close(self):
         if self._h:
+            self.lib.wfs_wait_records(self._h)
+            self.unpin_all()
             self.lib.wfs_destroy(self._h)
             self._h = C.c_void_p(0)
 
@@ -270,6 +310,29 @@ class Engine:
         assert out.flags['C_CONTIGUOUS'] and out.dtype.itemsize == np.dtype(raw_record_dtype()).itemsize and len(out) >= n
         self._check(self.lib.wfs_copy_records_range(self._h, C.c_void_p(out.ctypes.data), C.c_int64(0), C.c_int64(n)))
         return out[:n]
+
+    def records_into_async(self, out, count=None):
+        """the same on the copy stream, without waiting: ``out`` must stay alive (and should be pinned, ``pin``) until
+        ``wait_records`` returns; the copy overlaps the next ``run``"""
+        n = self.counts['n_records'] if count is None else int(count)
+        assert out.flags['C_CONTIGUOUS'] and out.dtype.itemsize == np.dtype(raw_record_dtype()).itemsize and len(out) >= n
+        self._check(self.lib.wfs_copy_records_range_async(self._h, C.c_void_p(out.ctypes.data), C.c_int64(0), C.c_int64(n)))
+        return out[:n]
+
+    def wait_records(self):
+        self._check(self.lib.wfs_wait_records(self._h))
+
+    def pin(self, array):
+        """page-locks a host array for this engine's lifetime (see ``pin_host``)"""
+        if not pin_host(array):
+            return False
+        self._pinned.append(np.asarray(array))
+        return True
+
+    def unpin_all(self):
+        for a in self._pinned:
+            unpin_host(a)
+        self._pinned = []
 
     def set_record_order(self, by_time):
         self._check(self.lib.wfs_set_record_order(self._h, C.c_int32(int(bool(by_time)))))

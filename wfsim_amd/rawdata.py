@@ -34,6 +34,9 @@ PULSE_TYPE_NAMES = ('RESERVED', 's1', 's2', 'unknown', 'pi_el', 'pmt_ap', 'pe_el
 class RawData:
     #: upper bound on the expected photons of one GPU batch (sizes the HBM arenas; 288 GB HBM3E leaves room for ~10^10)
     max_batch_quanta = 2_000_000_000
+    #: upper bound on the expected records of one batch (None: unbounded).  ChunkRawRecords sets it to half its record buffer
+    #: so that a batch's records can be copied from the device straight into the buffer (strax_interface.py:360-364).
+    record_budget = None
 
     def __init__(self, config, device=0, resource=None, seed=None):
         self.config = config
@@ -58,11 +61,14 @@ class RawData:
         return PULSE_TYPE_NAMES[ptype]
 
     # ------------------------------------------------------------------------------------------
-    def _batch_end(self, start, est_csum, cluster, scale=1):
+    def _batch_end(self, start, est_csum, cluster, scale=1, rec_csum=None):
         """End of the batch starting at sorted index ``start``: whole clusters, bounded by expected quanta."""
         n = len(cluster)
         limit = (est_csum[start - 1] if start else 0) + self.max_batch_quanta * scale
         stop = int(np.searchsorted(est_csum, limit, side='right'))
+        if self.record_budget is not None and rec_csum is not None:
+            rlimit = (rec_csum[start - 1] if start else 0) + self.record_budget * scale / self._rec_scale
+            stop = min(stop, int(np.searchsorted(rec_csum, rlimit, side='right')))
         stop = max(stop, start + 1)
         while stop < n and cluster[stop] == cluster[stop - 1]:      # never cut a cluster
             stop += 1
@@ -120,10 +126,12 @@ class RawData:
         self.instruction_event_number = np.min(instructions['event_number'])
         # crude photon estimate per instruction: only used to bound a batch
         est_csum = np.cumsum(self._expected_quanta(s_ins))
+        rec_csum = np.cumsum(self._expected_records(s_ins))
+        self._rec_scale = 1.0
         # smallest key of every cluster (in feedback order the first instruction of a cluster need not carry it)
         cl_start = np.concatenate([[0], np.where(np.diff(cluster) != 0)[0] + 1])
         cl_min_key = np.minimum.reduceat(key, cl_start)
-        st = dict(s_ins=s_ins, gids=gids, order=order, key=key, cluster=cluster, em_base=em_base, est_csum=est_csum,
+        st = dict(s_ins=s_ins, gids=gids, order=order, key=key, cluster=cluster, em_base=em_base, est_csum=est_csum, rec_csum=rec_csum,
                   cl_min_key=cl_min_key, n=n)
         # the kernels of the next batch run (from a worker thread: the engine calls drop the GIL) while the consumer works on
         # this one; the engine is only ever used by one thread at a time
@@ -140,7 +148,6 @@ class RawData:
                 out = record_sink(n_rec) if record_sink is not None else None
                 if out is None:
                     out = np.empty(n_rec, dtype=raw_record_dtype())
-                records = self.engine.records_into(out, n_rec)
                 keep = np.where(nonempty[:n_emit])[0]
                 # window position of every emitted group: rows of a group go in front of its window, rows of a group without
                 # pulses in front of the next window that has some
@@ -151,13 +158,18 @@ class RawData:
                     grp = ins_group[truth_table['first']].astype(np.int64)
                     truth_rows = np.flatnonzero(grp < n_emit)
                     truth_before = pos_of_group[grp[truth_rows]] if n_emit else np.zeros(0, dtype=np.int64)
+                # the records travel on the engine's copy stream: the next batch's kernels are started first, then the copy is
+                # awaited (the small copies above come first: behind 0.6 GB of records they would wait for them)
+                records = self.engine.records_into_async(out, n_rec)
                 batch = dict(left=groups['left'][keep], right=groups['right'][keep],
                              first=np.append(first[keep], first[n_emit]) if len(keep) else np.array([first[n_emit]]),
                              records=records, truth_table=truth_table, truth_rows=truth_rows, truth_before=truth_before, finished=L['b'] >= n)
-                # everything of this batch is on the host now: the engine is free for the next one
+                # everything else of this batch is on the host now: the engine is free for the next one (it keeps the records of
+                # two batches: this batch's copy overlaps the next batch's kernels)
                 if L['b'] < n:
                     if pool is not None:
                         future = pool.submit(self._launch, st, L['b'], L['has_pulse'], L['runmax'])
+                self.engine.wait_records()
                 yield batch
                 if L['b'] >= n:
                     break
@@ -180,7 +192,7 @@ class RawData:
         s_ins, gids, order, key, cluster, n = st['s_ins'], st['gids'], st['order'], st['key'], st['cluster'], st['n']
         scale = 1
         while True:
-            b = self._batch_end(a, st['est_csum'], cluster, scale)
+            b = self._batch_end(a, st['est_csum'], cluster, scale, st.get('rec_csum'))
             ins = s_ins[a:b]
             gid = gids[order[a:b]].astype(np.uint32)
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)
@@ -191,6 +203,10 @@ class RawData:
             counts = self.engine.run()
             groups = self.engine.groups()
             first = np.append(groups['first_record'], counts['n_records'])
+            if st.get('rec_csum') is not None:           # records per expected record of this batch, with a margin: sizes the next one
+                est = st['rec_csum'][b - 1] - (st['rec_csum'][a - 1] if a else 0)
+                if est > 0:
+                    self._rec_scale = float(min(8.0, max(0.125, 1.3 * counts['n_records'] / est)))
             cl_group = self.engine.cluster_groups(int(cl[-1]) + 1)
             ins_group = cl_group[cl]
             n_groups = len(groups['left'])
@@ -219,6 +235,11 @@ class RawData:
     def _expected_quanta(self, s_ins):
         return np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15,
                         s_ins['amp'] * float(self.config.get('s2_secondary_sc_gain', 30)))     # types 2, 4, 6: electrons
+
+    def _expected_records(self, s_ins):
+        """crude: a record per quantum for small signals, up to ~5 records on every PMT plus one per 400 quanta for big ones"""
+        q = self._expected_quanta(s_ins)
+        return np.minimum(q, 5 * len(self.config.get('gains', np.zeros(494))) + q / 400)
 
     def _load_batch(self, ins, gid, cl, key):
         ip = instruction_params(ins, self.config, self.resource, gids=gid, device_maps=self.engine.device_maps)

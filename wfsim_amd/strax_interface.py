@@ -27,14 +27,15 @@ except ImportError:                     # pragma: no cover - depends on the envi
 log = logging.getLogger('wfsim_amd.interface')
 
 
-def _copy_records(src, threads=4, min_records=200_000):
+def _copy_records(src, threads=8, min_records=200_000):
     """a copy of a large record array made by a few threads (numpy releases the GIL while copying): the chunks the plugin
     hands to strax are copies of the record buffer, 0.6 GB per headline batch"""
     n = len(src)
     if n < min_records:
         return src.copy()
     from concurrent.futures import ThreadPoolExecutor
-    out = np.empty_like(src)
+    threads = max(1, min(threads, os.cpu_count() or 1))
+    out = np.empty_like(src)            # (fresh pages: most of the time goes to the first touch, which the threads share)
     cuts = np.linspace(0, n, threads + 1).astype(np.int64)
 
     def part(k):
@@ -60,12 +61,25 @@ class ChunkRawRecords(object):
     def __init__(self, config, rawdata_generator=RawData, **kwargs):
         self.config = config
         self.rawdata = rawdata_generator(self.config, **kwargs)
-        self.record_buffer = np.zeros(self.record_buffer_length,
-                                      dtype=raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH))
+        # strax_interface.py:360-361; page-locked when the HIP generator fills it (the records of a batch then arrive at PCIe
+        # speed while the next batch's kernels run) and recycled between instances: pinning 1.2 GB takes a few hundred ms
+        rdt = raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH)
+        if hasattr(self.rawdata, 'iter_batches') and config.get('pin_record_buffer', True):
+            from .engine import acquire_record_buffer
+            self.record_buffer = acquire_record_buffer(self.record_buffer_length, rdt)
+        else:
+            self.record_buffer = np.zeros(self.record_buffer_length, dtype=rdt)
         truth_per_n_pmts = self._n_channels if config.get('per_pmt_truth') else False
         self.truth_dtype = extra_truth_dtype_per_pmt(truth_per_n_pmts)
         self.truth_buffer = np.zeros(10000, dtype=instruction_dtype + self.truth_dtype + [('fill', bool)])
         self.blevel = 0
+
+    def __del__(self):
+        try:
+            from .engine import release_record_buffer
+            release_record_buffer(self.record_buffer)
+        except Exception:
+            pass
 
     @property
     def _n_channels(self):
@@ -133,6 +147,7 @@ class ChunkRawRecords(object):
         rd, buf, dt = self.rawdata, self.record_buffer, self._dt
         L = len(buf)
         rd.engine.set_record_order(True)
+        rd.record_budget = max(L // 2, 1)       # a batch's records go from the device straight into the buffer
         self._sorted_stream = True
 
         def sink(n):
