@@ -93,3 +93,52 @@ def import_reference():
                  'core.afterpulse', 'core.rawdata']:
         setattr(ns, name.split('.')[-1], importlib.import_module('wfsim.' + name))
     return ns
+
+
+def import_reference_interface():
+    """The reference's strax_interface module (ChunkRawRecords, strax_interface.py:354-504) on top of ``import_reference``.
+
+    strax / straxen are not installed: ``strax.raw_record_dtype`` / ``sort_by_time`` / ``DEFAULT_RECORD_LENGTH`` come from the
+    repo's RECALLED restatement (wfsim_amd/ministrax.py), the plugin machinery (``Plugin``, ``Option``, ``takes_config``,
+    ``straxen.URLConfig``) from empty shells.  The chunk DECISIONS this is used to pin (chunk bounds, which records and truth
+    rows go into which chunk) do not depend on the record layout; the fixtures store record fields, not record bytes."""
+    import numpy as np
+    ns = import_reference()
+    import importlib.util
+    import os
+    # (by file: importing the wfsim_amd package would pick up the strax shell registered above)
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location('_dtypes_for_stubs', os.path.join(here, '..', '..', 'wfsim_amd', 'dtypes.py'))
+    dtypes = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dtypes)
+
+    def sort_by_time(x):            # strax.sort_by_time: by time, ties by channel (as wfsim_amd/ministrax.py)
+        return x if len(x) == 0 else x[np.lexsort((x['channel'], x['time']))]
+
+    class immutabledict(dict):
+        pass
+    _module('immutabledict', immutabledict=immutabledict)
+    _module('uproot')
+    strax = sys.modules['strax']
+
+    class Plugin:
+        def __init__(self, *a, **k):
+            pass
+
+    class Option:
+        def __init__(self, *a, **k):
+            pass
+    strax.Plugin, strax.Option = Plugin, Option
+    strax.takes_config = lambda *opts: (lambda cls: cls)
+    strax.raw_record_dtype = dtypes.raw_record_dtype
+    strax.DEFAULT_RECORD_LENGTH = dtypes.DEFAULT_RECORD_LENGTH
+    strax.sort_by_time = sort_by_time
+    straxen = sys.modules['straxen']
+    straxen.tpc_r, straxen.tpc_z, straxen.n_tpc_pmts = 66.4, 148.6, 494
+    straxen.URLConfig = lambda *a, **k: None
+    pkg = sys.modules['wfsim']
+    pkg.RawData, pkg.RawDataOptical = ns.rawdata.RawData, ns.rawdata.RawDataOptical
+    pkg.load_config = ns.load_resource.load_config
+    pkg.optical_adjustment = ns.utils.optical_adjustment
+    ns.strax_interface = importlib.import_module('wfsim.strax_interface')
+    return ns

@@ -29,7 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
-from _ref_stubs import import_reference, REFERENCE_ROOT   # noqa: E402
+from _ref_stubs import import_reference, import_reference_interface, REFERENCE_ROOT   # noqa: E402
 from wfsim_amd.dtypes import instruction_dtype, truth_extra_dtype, optical_extra_dtype   # noqa: E402
 
 TMP = '/tmp/wfsim_golden_tmp'
@@ -501,6 +501,125 @@ def fixture_chain_electron_ap(ref):
                         **run_chain(ref, base_config(), make_instructions(rows), 808, pat, ele_ap=StubDelayHist(h, edges)))
 
 
+def run_chunker(ref, config, instructions, seed, pattern_maps=None, record_buffer_length=None, ele_ap=None):
+    """The reference's ChunkRawRecords (strax_interface.py:354-504) around the reference's RawData: records the stream the
+    generator hands to the chunker -- every yielded (channel, left, right, data) with rawdata.left / .right at that moment,
+    every truth row with the position in the stream where it was written -- and every chunk the chunker yields (bounds,
+    the records of each data type by FIELD, the truth rows)."""
+    config = dict(config)
+    ref.load_resource._cached_configs.clear()
+    ref.pulse._cached_pmt_current_templates.clear()
+    ref.pulse._cached_uniform_to_pe_arr.clear()
+    si = ref.strax_interface
+    log = dict(pulses=[], truth_at=[], truth_rows=[])
+
+    class RecordingRawData(ref.rawdata.RawData):
+        def __call__(self, instructions, truth_buffer=None, **kwargs):
+            for tup in super().__call__(instructions, truth_buffer=truth_buffer, progress_bar=False):
+                ch, left, right, data = tup
+                log['pulses'].append((int(ch), int(left), int(right), np.array(data, dtype=np.int64), int(self.left), int(self.right)))
+                yield tup
+
+        def get_truth(self, instruction, truth_buffer):
+            before = truth_buffer['fill'].copy()
+            super().get_truth(instruction, truth_buffer)
+            new = np.flatnonzero(truth_buffer['fill'] & ~before)
+            for ix in new:
+                log['truth_at'].append(len(log['pulses']))          # written before this pulse of the stream is yielded
+                log['truth_rows'].append(truth_buffer[ix].copy())
+
+    if ele_ap is not None:
+        config['enable_electron_afterpulses'] = True
+        config['ele_ap_pdfs'] = ''
+        orig_get = ref.load_resource.straxen.get_resource
+        ref.load_resource.straxen.get_resource = lambda path, fmt='text': (ele_ap if fmt in ('dill', 'pkl.gz') else orig_get(path, fmt=fmt))
+    try:
+        sim = si.ChunkRawRecords(config, rawdata_generator=RecordingRawData)
+    finally:
+        if ele_ap is not None:
+            ref.load_resource.straxen.get_resource = orig_get
+    if ele_ap is not None:
+        sim.rawdata.resource.uniform_to_ele_ap = ele_ap
+    if pattern_maps is not None:
+        sim.rawdata.resource.s1_pattern_map = pattern_maps['s1']
+        sim.rawdata.resource.s2_pattern_map = pattern_maps['s2']
+    if record_buffer_length is not None:
+        sim.record_buffer = np.zeros(record_buffer_length, dtype=sim.record_buffer.dtype)
+    np.random.seed(seed)
+    chunks = []
+    for res in sim(instructions):
+        chunks.append(dict(pre=int(sim.chunk_time_pre), end=int(sim.chunk_time),
+                           **{k: np.array(v) for k, v in res.items()}))
+    out = dict(instructions=instructions, seed=np.int64(seed), record_buffer_length=np.int64(len(sim.record_buffer)),
+               source_finished=np.bool_(sim.source_finished()))
+    P = log['pulses']
+    out['p_ch'] = np.array([q[0] for q in P], dtype=np.int16); out['p_left'] = np.array([q[1] for q in P], dtype=np.int64)
+    out['p_right'] = np.array([q[2] for q in P], dtype=np.int64)
+    out['p_data_off'] = np.concatenate([[0], np.cumsum([len(q[3]) for q in P])]).astype(np.int64)
+    out['p_data'] = np.concatenate([q[3] for q in P] + [np.zeros(0, np.int64)]).astype(np.int32)
+    out['p_gen_left'] = np.array([q[4] for q in P], dtype=np.int64); out['p_gen_right'] = np.array([q[5] for q in P], dtype=np.int64)
+    out['t_at'] = np.array(log['truth_at'], dtype=np.int64)
+    trows = np.array(log['truth_rows']) if log['truth_rows'] else np.zeros(0, dtype=sim.truth_buffer.dtype)
+    for name in trows.dtype.names:
+        if name != 'fill':
+            out['t_' + name] = trows[name]
+    out['c_pre'] = np.array([c['pre'] for c in chunks], dtype=np.int64); out['c_end'] = np.array([c['end'] for c in chunks], dtype=np.int64)
+    for kind in ('raw_records', 'raw_records_he', 'raw_records_aqmon'):
+        recs = [c[kind] for c in chunks if kind in c]
+        if not recs:
+            continue
+        out[f'c_{kind}_off'] = np.concatenate([[0], np.cumsum([len(r) for r in recs])]).astype(np.int64)
+        allr = np.concatenate(recs)
+        for f in ('time', 'length', 'dt', 'channel', 'pulse_length', 'record_i', 'baseline'):
+            out[f'c_{kind}_{f}'] = allr[f]
+        out[f'c_{kind}_data_sum'] = allr['data'].astype(np.int64).sum(axis=1) if len(allr) else np.zeros(0, np.int64)
+        out[f'c_{kind}_data_head'] = allr['data'][:, :8].astype(np.int32) if len(allr) else np.zeros((0, 8), np.int32)
+    tr = [c['truth'] for c in chunks]
+    out['c_truth_off'] = np.concatenate([[0], np.cumsum([len(t) for t in tr])]).astype(np.int64)
+    allt = np.concatenate(tr)
+    for name in allt.dtype.names:
+        out['c_truth_' + name] = allt[name]
+    return out
+
+
+def fixture_chunker(ref):
+    """golden chains for the chunker (reference ChunkRawRecords): several chunks; a chunk closing inside an event
+    (strax_interface.py:400-404); a record buffer smaller than the run (flush :409-418 and skipped pulses :420-422);
+    electron afterpulses (secondaries fed back while chunks close)."""
+    pat = dict(s1=SyntheticPatternMap(14e-5, 30.0, 18.0, 0.15), s2=SyntheticPatternMap(30e-5, 9.0, 25.0, 0.02))
+    MS = 1_000_000
+    rng = np.random.default_rng(77)
+    # A: 14 S1 + S2 pairs over 21 ms, 4 ms chunks
+    rows = []
+    for i in range(14):
+        t = int(MS * (1 + 1.5 * i) + rng.integers(0, 200_000))
+        x, y, z = rng.uniform(-25, 25), rng.uniform(-25, 25), -rng.uniform(2, 90)
+        rows += [dict(type=1, time=t, x=x, y=y, z=z, amp=int(rng.choice([300, 1200, 4000]))),
+                 dict(type=2, time=t, x=x, y=y, z=z, amp=int(rng.choice([20, 90, 300])))]
+    np.savez_compressed(HERE + '/chunker_multi.npz', **run_chunker(ref, base_config(chunk_size=0.004), make_instructions(rows), 901, pat))
+    # B: chunk boundaries inside events: S2s 0.45 ms apart chain the clusters' windows over several 1 ms chunks
+    rows = [dict(type=2, time=MS + 450_000 * i, x=3 * i - 10, y=5 - i, z=-70 - i, amp=150) for i in range(9)]
+    rows += [dict(type=1, time=9 * MS, x=0, y=0, z=-30, amp=2000), dict(type=2, time=9 * MS, x=0, y=0, z=-30, amp=60),
+             dict(type=1, time=12 * MS, x=4, y=4, z=-3, amp=700)]
+    np.savez_compressed(HERE + '/chunker_midevent.npz',
+                        **run_chunker(ref, base_config(chunk_size=0.001, right_raw_extension=500_000), make_instructions(rows), 902, pat))
+    # C: record buffer of 700 records: the S2s of ~500 records each force flushes, the big one is partly skipped
+    rows = [dict(type=2, time=MS * (1 + 2 * i), x=2 * i, y=-i, z=-20 - 5 * i, amp=int(a)) for i, a in enumerate([120, 200, 80, 2500, 150, 60])]
+    rows += [dict(type=1, time=MS * (2 + 2 * i), x=1, y=1, z=-10, amp=900) for i in range(5)]
+    np.savez_compressed(HERE + '/chunker_tinybuffer.npz',
+                        **run_chunker(ref, base_config(chunk_size=0.005), make_instructions(rows), 903, pat, record_buffer_length=700))
+    # D: electron afterpulses (delays up to 0.7 ms), 2 ms chunks
+    edges = np.linspace(0, 700e3, 141)
+    h = np.exp(-np.arange(140) / 30.0); h *= 4e-3 / h.sum()
+    rows = [dict(type=1, time=MS, x=0, y=0, z=-20, amp=2000), dict(type=2, time=MS, x=0, y=0, z=-20, amp=300),
+            dict(type=2, time=MS + 450_000, x=5, y=-3, z=-60, amp=400),
+            dict(type=1, time=4 * MS, x=5, y=-3, z=-61, amp=900), dict(type=2, time=4 * MS, x=5, y=-3, z=-61, amp=250),
+            dict(type=2, time=6 * MS, x=-9, y=4, z=-5, amp=150), dict(type=1, time=9 * MS, x=-9, y=4, z=-5, amp=400)]
+    np.savez_compressed(HERE + '/chunker_ele_ap.npz',
+                        **run_chunker(ref, base_config(chunk_size=0.002), make_instructions(rows), 904, pat, ele_ap=StubDelayHist(h, edges)))
+
+
+
 def fixture_optical_adjustment(ref):
     """utils.optical_adjustment (host preparation of optical input): random photon lists, a third of the entries longer
     than PULSE_MAX_DURATION, some empty"""
@@ -678,8 +797,8 @@ def fixture_chain_stats(ref):
 
 
 if __name__ == '__main__':
-    ref = import_reference()
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats']
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker']
+    ref = import_reference_interface() if 'chunker' in which else import_reference()
     p = fixture_tables(ref)
     if 'add_current' in which:
         fixture_add_current(ref, p)
@@ -699,6 +818,8 @@ if __name__ == '__main__':
         fixture_model_distributions(ref)
     if 'stats' in which:
         fixture_chain_stats(ref)
+    if 'chunker' in which:
+        fixture_chunker(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(('.npz', '.json')):
             print(f'{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:9.1f} KiB')

@@ -86,6 +86,44 @@ def test_tpc_chunks_identical_to_the_per_window_replay(chunk_size, quanta, kw):
         assert len(fast) > 5
 
 
+class _PulseProtocolOnly:
+    """the HIP generator behind nothing but the reference's RawData protocol (rawdata.py:38-157: iterate (channel, left,
+    right, data), read .left / .right / .source_finished): ChunkRawRecords then runs its per-pulse loop, the path that
+    tests/test_chunker_reference.py pins on the reference's own chunker"""
+
+    def __init__(self, config, **kwargs):
+        self._rd = wfsim_amd.RawData(config, **kwargs)
+
+    def __call__(self, instructions, truth_buffer=None, **kwargs):
+        return self._rd(instructions, truth_buffer=truth_buffer, **kwargs)
+
+    left = property(lambda self: self._rd.left)
+    right = property(lambda self: self._rd.right)
+    source_finished = property(lambda self: self._rd.source_finished, lambda self, v: setattr(self._rd, 'source_finished', v))
+
+
+@pytest.mark.parametrize('chunk_size,quanta,kw', [
+    (0.003, 40_000, {}),
+    (0.02, 2_000_000_000, dict(enable_pmt_afterpulses=True)),
+    (0.004, 150_000, dict(save_full_truth=False)),
+])
+def test_batch_chunker_identical_to_the_reference_pinned_per_pulse_loop(chunk_size, quanta, kw):
+    """closes the chain reference chunker == per-pulse loop (CPU, golden replay) == batch chunker (here, on the GPU's pulses)"""
+    if kw.get('enable_pmt_afterpulses'):
+        kw = dict(kw, uniform_to_pmt_ap=ap_tables_from_golden())
+    cfg = xenonnt_test_config(seed=23, chunk_size=chunk_size, **kw)
+    ins = _mixed(90, 4)
+
+    def batch():
+        sim = wfsim_amd.ChunkRawRecords(cfg)
+        sim.rawdata.max_batch_quanta = quanta
+        return sim
+    fast = _chunks(batch, ins, False)
+    slow = _chunks(lambda: wfsim_amd.ChunkRawRecords(cfg, rawdata_generator=_PulseProtocolOnly), ins, False)
+    _assert_same(fast, slow)
+    assert len(fast) > (5 if chunk_size < 0.01 else 1)
+
+
 def test_sorted_fast_path_equals_sort_by_time(monkeypatch):
     monkeypatch.setenv('WFSIM_AMD_CHECK_SORTED', '1')            # final_results asserts prefix == sort_by_time(mask)
     cfg = xenonnt_test_config(seed=5, chunk_size=0.01, s2_secondary_sc_gain=60.0)
