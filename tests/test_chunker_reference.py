@@ -100,3 +100,18 @@ def test_the_fixtures_cover_the_corners():
     d = golden('chunker_ele_ap.npz')
     assert np.any(d['t_type'] == 4)                                                           # secondaries got truth rows
     assert len(golden('chunker_multi.npz')['c_pre']) >= 4
+
+
+def test_truth_chunks_never_carry_the_optical_columns():
+    """the optical plugins give the truth buffer _first / _last columns (strax_interface.py:730); the chunks are still
+    instruction_dtype + truth fields (:478), which is what the plugins declare (:699, :911)"""
+    from wfsim_amd.dtypes import instruction_dtype, optical_extra_dtype
+    z = golden('chunker_multi.npz')
+    d = {k: z[k] for k in z.files}
+    d['t__first'] = np.arange(len(d['t_at']), dtype=np.int32); d['t__last'] = d['t__first'] + 7
+    cfg = xenonnt_test_config(chunk_size=0.004)
+    sim = wfsim_amd.ChunkRawRecords(cfg, rawdata_generator=ReplayRawData, fixture=d)
+    sim.truth_buffer = np.zeros(10000, dtype=instruction_dtype + optical_extra_dtype + sim.truth_dtype + [('fill', bool)])
+    truth = np.concatenate([c['truth'] for c in sim(d['instructions'])])
+    assert truth.dtype == np.dtype(instruction_dtype + sim.truth_dtype) and len(truth) == len(d['t_at'])
+    assert np.array_equal(np.sort(truth['n_photon']), np.sort(d['c_truth_n_photon']))

@@ -67,7 +67,8 @@ def test_nveto_chunker_output():
     assert len(chunks) >= 3 and set(chunks[0].keys()) == {'raw_records', 'truth'}
     rr = np.concatenate([c['raw_records'] for c in chunks])
     truth = np.concatenate([c['truth'] for c in chunks])
-    assert len(truth) == len(ins) and '_first' in truth.dtype.names
+    # the chunks are instruction_dtype + truth fields (strax_interface.py:478), without the buffer's _first / _last columns
+    assert len(truth) == len(ins) and truth.dtype == np.dtype(instruction_dtype + sim.truth_dtype)
     assert np.all(np.diff(rr['time']) >= 0) and rr['data'].sum() > 0
     ok = (timings >= 0) & (timings < 1e6) & (channels != 7)
     assert truth['n_photon'].sum() == ok.sum()

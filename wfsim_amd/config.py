@@ -50,6 +50,15 @@ def current_2_adc(config):
             / (config['digitizer_voltage_range'] / 2 ** (config['digitizer_bits'])))
 
 
+def afterpulse_switches(config):
+    """The three afterpulse switches with the defaults RawData.sim_data gives them (rawdata.py:176, 194, 198): PMT and
+    photo-ionisation afterpulses ON, gate afterpulses OFF when a key is missing.  One place for every user (RawData,
+    kernel_params, the shard planner), so that they cannot disagree."""
+    return dict(pmt=bool(config.get('enable_pmt_afterpulses', True)),
+                electron=bool(config.get('enable_electron_afterpulses', True)),
+                gate=bool(config.get('enable_gate_afterpulses', False)))
+
+
 def kernel_params(config):
     """Scalars of the hot path, named as the fields of ``wfs_config`` (include/wfsim_amd.h)."""
     c = config
@@ -93,7 +102,7 @@ def kernel_params(config):
         enable_noise=int(bool(c.get('enable_noise', True))),
         s1_simple=int('simple' in s1_model),
         s2_time_model=s2_time_model,
-        enable_pmt_ap=int(bool(c.get('enable_pmt_afterpulses', True))),
+        enable_pmt_ap=int(afterpulse_switches(c)['pmt']),
         c2a=float(current_2_adc(c)),
         tts_mean=float(c['pmt_transit_time_mean']),
         tts_sigma=float(c['pmt_transit_time_spread'] / 2.35482),          # pulse.py:52-56

@@ -1144,7 +1144,7 @@ int wfs_run(wfs_handle *h)
     if (h->sort_records && h->n_records > 1 && h->n_active_rows > 0) {
         // records by (time, channel): keys per record, one radix sort of the batch, k_pack writes to the sorted slots
         const i64 NR = h->n_records;
-        if (NR > 0xffffffffLL) return h->fail(WFS_E_CAPACITY, "more than 2^32 records in one batch");
+        if (NR > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "more than 2^31 records in one batch (the device sort takes an int count)");
         TRY(ensure(h, h->rec_key, (size_t)NR * 8)); TRY(ensure(h, h->rec_key2, (size_t)NR * 8));
         TRY(ensure(h, h->rec_val, (size_t)NR * 4)); TRY(ensure(h, h->rec_val2, (size_t)NR * 4)); TRY(ensure(h, h->rec_dest, (size_t)NR * 4));
         za.rec_key = h->rec_key.as<u64>(); za.rec_val = h->rec_val.as<u32>();

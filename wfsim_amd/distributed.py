@@ -10,6 +10,8 @@ Concatenating the shards in rank order gives the globally time-ordered stream.
 """
 import numpy as np
 
+from .config import afterpulse_switches
+
 
 def shard_clusters(cluster, weight, world_size, key=None, min_gap=None):
     """Contiguous ranges of whole clusters, balanced by ``weight`` (e.g. expected quanta per instruction).
@@ -46,13 +48,16 @@ def safe_cut_gap(config):
     its key: the S1 / S2 photon delays (tables end below ~40 lifetimes: 10 us), PMT afterpulse delays, and the reach of
     the electron afterpulses.  ``simulate_sharded`` verifies afterwards that no window crossed a cut."""
     reach = 20_000.0
-    if config.get('enable_pmt_afterpulses', False):
+    sw = afterpulse_switches(config)
+    if sw['pmt'] and config.get('uniform_to_pmt_ap'):
         for el in config['uniform_to_pmt_ap'].values():
             reach = max(reach, 20_000.0 + float(el['delaytime_bin_size']) * np.asarray(el['delaytime_cdf']).shape[-1])
-    if config.get('enable_electron_afterpulses', False):
+    if sw['electron']:
+        if config.get('uniform_to_ele_ap') is None:
+            raise ValueError('enable_electron_afterpulses (default: on, rawdata.py:194) needs uniform_to_ele_ap (the delay-time histogram)')
         h = config['uniform_to_ele_ap']
         reach += (float(h[1][-1]) if isinstance(h, (tuple, list)) else float(h.bin_edges[-1])) + 2 * config['drift_time_gate']
-    if config.get('enable_gate_afterpulses', False):
+    if sw['gate']:
         reach += config['photoelectric_t_center'] + 2 * config['drift_time_gate'] + 6 * config['photoelectric_t_spread']
     return float(config['right_raw_extension']) + reach
 

@@ -15,6 +15,8 @@ emitter offset ``(k + 1) << 20`` for its own photon Monte Carlo (include/wfsim_a
 """
 import numpy as np
 
+from .config import afterpulse_switches
+
 MAX_SECONDARIES_PER_PARENT = 4094          # emitter offsets (k + 1) << 20 must fit 32 bits
 
 
@@ -69,7 +71,8 @@ def plan_secondaries(parent, gid, n_photons, config, hist=None, grid=None):
     out = []
     if n_photons <= 0:
         return out                                                               # afterpulse.py:24-26
-    if config.get('enable_electron_afterpulses', True) and hist is not None:
+    sw = afterpulse_switches(config)
+    if sw['electron'] and hist is not None:
         rng = _rng(config, gid, 4)
         n_el = rng.poisson(hist.n * n_photons * config['photoionization_modifier'])          # afterpulse.py:37-39
         delay = hist.get_random(rng, n_el)
@@ -79,7 +82,7 @@ def plan_secondaries(parent, gid, n_photons, config, hist=None, grid=None):
         pick = rng.integers(0, n_photons, n)
         x, y = _positions(rng, n, config)
         out.append((4, pick, grid[idx], cnt.astype(np.int64), x, y))
-    if config.get('enable_gate_afterpulses', False):
+    if sw['gate']:
         rng = _rng(config, gid, 6)
         n = rng.poisson(config['photoelectric_p'] * n_photons * config['photoelectric_modifier'])   # afterpulse.py:108-110
         delay = np.clip(rng.normal(config['photoelectric_t_center'] + config['drift_time_gate'],

@@ -223,9 +223,9 @@ class Engine:
         rs = _arr(run_set, np.int32) if run_set is not None else None
         self._n_loaded = n
         self._n_run_sets = (int(rs.max()) + 1 if len(rs) else 0) if rs is not None else n
+        eb = _arr(em_base, np.uint32) if em_base is not None else None       # (a local: the converted copy must outlive the call)
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
-                                                   _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0),
-                                                   _p(_arr(em_base, np.uint32) if em_base is not None else None)))
+                                                   _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0), _p(eb)))
         if np.any(a[10] < 0):           # rows from the device pattern maps
             pxy = ip.get('pattern_xy')          # S2: the observed position under a field distortion model
             xyz = [_arr(ins['x'] if pxy is None else pxy[:, 0], np.float32), _arr(ins['y'] if pxy is None else pxy[:, 1], np.float32), _arr(ins['z'], np.float32)]

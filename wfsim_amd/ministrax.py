@@ -42,6 +42,11 @@ class Plugin:
             self.run_id = run_id
 
     def chunk(self, *, start, end, data, data_type=None, run_id=None):
+        # strax refuses a chunk whose data is not of the dtype the plugin declared (strax.Plugin.chunk -> Chunk.__init__)
+        if data_type is not None and hasattr(self, 'infer_dtype'):
+            want = self.infer_dtype()
+            want = want[data_type] if isinstance(want, dict) else want
+            assert np.dtype(data.dtype) == np.dtype(want), f'{data_type}: data of dtype {data.dtype}, declared {np.dtype(want)}'
         return Chunk(start=start, end=end, data=data, data_type=data_type, run_id=run_id or self.run_id)
 
     def setup(self):

@@ -19,6 +19,7 @@ import os
 
 import numpy as np
 
+from .config import afterpulse_switches
 from .dtypes import raw_record_dtype
 from .engine import Engine
 from .physics import instruction_params
@@ -44,9 +45,13 @@ class RawData:
         self.engine = Engine(config, self.resource, device=device, seed=seed)
         # electron afterpulses (afterpulse.py:14-139): secondaries are made in a pre-pass over the primaries
         self._pi_hist = self._pi_grid = None
-        if config.get('enable_electron_afterpulses', False):
+        if afterpulse_switches(config)['pmt'] and not hasattr(self.resource, 'uniform_to_pmt_ap'):
+            raise ValueError('enable_pmt_afterpulses (on unless the config says otherwise, rawdata.py:176) needs the afterpulse '
+                             'tables: config uniform_to_pmt_ap with enable_pmt_afterpulses set (load_resource.py:228)')
+        if afterpulse_switches(config)['electron']:
             if not hasattr(self.resource, 'uniform_to_ele_ap'):
-                raise ValueError('enable_electron_afterpulses needs resource.uniform_to_ele_ap (delay-time histogram, load_resource.py:233)')
+                raise ValueError('enable_electron_afterpulses (on unless the config says otherwise, rawdata.py:194) needs '
+                                 'resource.uniform_to_ele_ap, the delay-time histogram (load_resource.py:233)')
             self._pi_hist = ea.DelayHistogram.wrap(self.resource.uniform_to_ele_ap)
             self._pi_grid = ea.coarse_delay_grid(self._pi_hist, config)
         self.source_finished = False
@@ -252,7 +257,8 @@ class RawData:
 
     # ---- electron afterpulses (afterpulse.py:14-139, rawdata.py:192-202) ------------------------------
     def _has_electron_afterpulses(self):
-        return bool(self.config.get('enable_electron_afterpulses', False) or self.config.get('enable_gate_afterpulses', False))
+        sw = afterpulse_switches(self.config)
+        return sw['electron'] or sw['gate']
 
     def electron_afterpulse_instructions(self, instructions, gids, with_parent=False):
         """Pre-pass: photons of the primaries only (no pulses), then for every S2 pulse set its secondary instructions

@@ -173,6 +173,11 @@ class ChunkRawRecords(object):
                     rd.left, rd.right = int(left[stop - 1]), int(right[stop - 1])
                     src = rec[first[w]:first[stop]]
                     dst = buf[self.blevel:self.blevel + n_new]
+                    # cutting the buffer at chunk_time by bisection needs it time sorted: windows of a run do not overlap in time
+                    # and a batch is sorted on the device -- should a stretch ever start before the last committed record
+                    # (tiny right_raw_extension, forced cluster breaks), the chunks fall back to the reference's mask + sort
+                    if n_new and self.blevel and int(src['time'][0]) < int(buf['time'][self.blevel - 1]):
+                        self._sorted_stream = False
                     if n_new and src.ctypes.data != dst.ctypes.data:
                         dst[:] = src
                     self.blevel += n_new
@@ -198,6 +203,8 @@ class ChunkRawRecords(object):
                     # the reference skips pulse by pulse in the order it yields them; here whole records in time order
                     wrec = wrec[:max(L - self.blevel, 0)]
                 dst = buf[self.blevel:self.blevel + len(wrec)]
+                if len(wrec) and self.blevel and int(wrec['time'][0]) < int(buf['time'][self.blevel - 1]):
+                    self._sorted_stream = False
                 if len(wrec) and wrec.ctypes.data != dst.ctypes.data:
                     dst[:] = wrec
                 self.blevel += len(wrec)
@@ -322,8 +329,9 @@ class ChunkRawRecords(object):
         self.blevel = n_left
 
     def _truth_out_dtype(self):
-        """the truth buffer's dtype without the 'fill' flag (strax_interface.py:478)"""
-        return [d for d in self.truth_buffer.dtype.descr if (d[0][1] if isinstance(d[0], tuple) else d[0]) != 'fill']
+        """strax_interface.py:478: always instruction_dtype + the truth fields -- also when a plugin gave the truth buffer more
+        columns (the optical plugins add _first / _last, :730): those never leave the chunker"""
+        return instruction_dtype + self.truth_dtype
 
     def source_finished(self):
         return self.rawdata.source_finished
@@ -514,8 +522,10 @@ class RawRecordsFromFaxnVeto(RawRecordsFromFaxOpticalNT):
         c['channels_bottom'] = np.array([], np.int64)
 
     def infer_dtype(self):
+        # (the reference's class derives from RawRecordsFromMcChain: truth chunks are instruction_dtype + truth fields,
+        # strax_interface.py:910-914, without the optical _first / _last columns of the truth buffer)
         return {'raw_records_nv': raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH),
-                'truth_nv': instruction_dtype + optical_extra_dtype + self._truth_dtype}
+                'truth_nv': instruction_dtype + self._truth_dtype}
 
     def compute(self):
         try:
