@@ -620,6 +620,45 @@ def fixture_chunker(ref):
 
 
 
+def fixture_ele_ap_generators(ref):
+    """Draws of the reference's electron-afterpulse generators (afterpulse.py:29-92 photo-ionisation, :107-131 gate): for a
+    parent S2 with 4000 detected photons, 600 calls each -- instructions per call, electrons per call, and pooled over the
+    calls: drift-time grid (from z), electrons per instruction, radius^2, which photon was picked as time zero."""
+    cfg = base_config(enable_electron_afterpulses=True, enable_gate_afterpulses=True, photoelectric_p=0.002)
+    edges = np.linspace(0, 700e3, 141)
+    h = np.exp(-np.arange(140) / 30.0); h *= 4e-3 / h.sum()
+    hist = StubDelayHist(h, edges)
+    ref.load_resource._cached_configs.clear()
+    orig_get = ref.load_resource.straxen.get_resource
+    ref.load_resource.straxen.get_resource = lambda path, fmt='text': (hist if fmt in ('dill', 'pkl.gz') else orig_get(path, fmt=fmt))
+    cfg['ele_ap_pdfs'] = ''
+    try:
+        pi = ref.afterpulse.PhotoIonization_Electron(cfg)
+        pe = ref.afterpulse.PhotoElectric_Electron(cfg)
+    finally:
+        ref.load_resource.straxen.get_resource = orig_get
+    pi.resource.uniform_to_ele_ap = hist
+
+    class Parent:
+        _photon_timings = 5_000_000 + np.arange(4000, dtype=np.int64) * 3
+    parent_ins = make_instructions([dict(type=2, time=5_000_000, x=1, y=2, z=-30, amp=200)])
+    np.random.seed(606)
+    out = {}
+    for tag, gen, t_off in (('pi', pi, -cfg['drift_time_gate']), ('pe', pe, +cfg['drift_time_gate'])):
+        n_ins, n_el, z, amp, r2, pick = [], [], [], [], [], []
+        for _ in range(600):
+            ins = gen.generate_instruction(Parent, parent_ins)
+            n_ins.append(len(ins)); n_el.append(int(np.sum(ins['amp'])) if len(ins) else 0)
+            if len(ins):
+                z.append(ins['z']); amp.append(ins['amp']); r2.append(ins['x'].astype(np.float64) ** 2 + ins['y'].astype(np.float64) ** 2)
+                pick.append((ins['time'] - t_off - 5_000_000) // 3)
+        out[f'{tag}_n_ins'] = np.array(n_ins); out[f'{tag}_n_el'] = np.array(n_el)
+        out[f'{tag}_delay'] = -np.concatenate(z).astype(np.float64) / cfg['drift_velocity_liquid']
+        out[f'{tag}_amp'] = np.concatenate(amp); out[f'{tag}_r2'] = np.concatenate(r2); out[f'{tag}_pick'] = np.concatenate(pick)
+    out['n_photons'] = np.int64(4000); out['histogram'] = h; out['bin_edges'] = edges; out['photoelectric_p'] = np.float64(0.002)
+    np.savez_compressed(HERE + '/ele_ap_draws.npz', **out)
+
+
 def fixture_optical_adjustment(ref):
     """utils.optical_adjustment (host preparation of optical input): random photon lists, a third of the entries longer
     than PULSE_MAX_DURATION, some empty"""
@@ -797,7 +836,7 @@ def fixture_chain_stats(ref):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker']
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws']
     ref = import_reference_interface() if 'chunker' in which else import_reference()
     p = fixture_tables(ref)
     if 'add_current' in which:
@@ -820,6 +859,8 @@ if __name__ == '__main__':
         fixture_chain_stats(ref)
     if 'chunker' in which:
         fixture_chunker(ref)
+    if 'ele_ap_draws' in which or 'ele_ap' in which:
+        fixture_ele_ap_generators(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(('.npz', '.json')):
             print(f'{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:9.1f} KiB')
