@@ -2,13 +2,15 @@
 """Headline benchmark: photoelectrons/s (+ raw_records MB/s) of the photon -> raw_records hot path on a batch of
 10^6-PE S2 instructions (BASELINE.json config[2]), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--instructions M]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--instructions M] [--workload s2|mixed|nveto]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one pass of the whole hot path (S2 electron/photon Monte Carlo, SPE gains, template scatter-add,
 digitisation, ZLE, record packing) over one batch of synthetic instructions that is already resident in HBM,
 followed -- for N > 1 -- by the RCCL gather of the packed raw_records on rank 0 (weak scaling: every rank
 simulates its own M instructions; event clusters are independent).
+--workload s2 (default) is the headline; mixed = BASELINE configs[3] (S1 + S2 pairs, PMT afterpulses and noise on, synthetic
+tables), nveto = configs[4] (optical instructions at 1 MHz on 120 channels) run through the same step / gather code.
 Prints ONE JSON line (rank 0).
 """
 import argparse
@@ -42,6 +44,28 @@ def s2_batch(n, first_gid, t0=0):
     ins['recoil'] = 7
     ins['event_number'] = first_gid + np.arange(n)
     return ins
+
+
+def mixed_batch(n, first_gid):
+    """BASELINE config[3]: n / 2 events, an S1 (3000 quanta) and an S2 (1500 electrons) each, 1 ms apart, all over the TPC"""
+    n_ev = max(n // 2, 1)
+    rng = np.random.default_rng(4 + first_gid)
+    ins = np.zeros(2 * n_ev, dtype=instruction_dtype)
+    ins['type'] = np.tile([1, 2], n_ev)
+    ins['time'] = np.repeat(1_000_000 * (1 + np.arange(n_ev)), 2)
+    r, phi = 45 * np.sqrt(rng.random(n_ev)), rng.uniform(0, 2 * np.pi, n_ev)
+    ins['x'], ins['y'], ins['z'] = np.repeat(r * np.cos(phi), 2), np.repeat(r * np.sin(phi), 2), np.repeat(-rng.uniform(1, 95, n_ev), 2)
+    ins['amp'] = np.tile([3000, 1500], n_ev)
+    ins['recoil'] = 7
+    ins['event_number'] = first_gid + np.arange(2 * n_ev)
+    return ins
+
+
+def mixed_config(seed):
+    """synthetic PMT afterpulse tables and noise (the real resource files are private): tests/golden, made by make_golden.py"""
+    from tests.helpers import ap_tables_from_golden, golden
+    return xenonnt_test_config(seed=seed, enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap_tables_from_golden(),
+                               enable_noise=True, noise_data=golden('noise.npz')['noise'])
 
 
 def bench_config(seed):
@@ -95,7 +119,9 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--instructions', type=int, default=1000, help='S2 instructions per GPU per step')
+    ap.add_argument('--instructions', type=int, default=None, help='instructions per GPU per step (default: 1000 S2 / 10000 mixed / 200000 nveto)')
+    ap.add_argument('--workload', choices=['s2', 'mixed', 'nveto'], default='s2',
+                    help='s2: the headline batch (BASELINE configs[2]); mixed: configs[3]; nveto: configs[4]')
     ap.add_argument('--cpu-sample', type=int, default=60, help="S2 instructions timed on the CPU oracle, ~15 s (0: skip)")
     ap.add_argument('--no-gather', action='store_true', help='skip the RCCL gather of records (N > 1)')
     ap.add_argument('--sync-gather', action='store_true', help='do not overlap the gather with the next batch')
@@ -108,7 +134,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     cpu = None
-    if args.cpu_sample > 0 and world == 1:          # the CPU baseline is timed on rank 0 of the 1-GPU run only, before the GPU is touched
+    if args.instructions is None:
+        args.instructions = dict(s2=1000, mixed=10000, nveto=200000)[args.workload]
+    if args.cpu_sample > 0 and world == 1 and args.workload == 's2':          # the CPU baseline is timed on rank 0 of the 1-GPU run only, before the GPU is touched
         cpu = cpu_baseline(3, args.cpu_sample)
     import torch
     import torch.distributed as dist
@@ -127,16 +155,26 @@ def main():
             dist.init_process_group(backend)
 
     from wfsim_amd.engine import Engine
-    cfg = bench_config(seed=3)
-    res = Resource(cfg)
     M = args.instructions
-    ins = s2_batch(M, first_gid=rank * M)
-    order, key, cluster = schedule(ins, cfg)
-    s_ins = ins[order]
-    gid = (rank * M + order).astype(np.uint32)          # run-wide instruction ids: streams do not depend on the sharding
-    ip = instruction_params(s_ins, cfg, res)
-    eng = Engine(cfg, res, device=local_rank)
-    eng.load_instructions(s_ins, gid, cluster, key, ip)   # inputs resident in HBM before the timed region
+    if args.workload == 'nveto':
+        from tests.test_gpu_optical import nveto_config, optical_instructions
+        cfg = nveto_config(seed=31)
+        res = Resource(cfg)
+        ins, channels, timings = optical_instructions(M, 1000.0, 3 + rank)
+        order, key, cluster = schedule(ins, cfg)
+        eng = Engine(cfg, res, device=local_rank)
+        eng.load_optical(ins[order], (rank * M + order).astype(np.uint32), cluster, key, channels, timings, int(1e6))
+    else:
+        cfg = bench_config(seed=3) if args.workload == 's2' else mixed_config(seed=3)
+        res = Resource(cfg)
+        ins = s2_batch(M, first_gid=rank * M) if args.workload == 's2' else mixed_batch(M, first_gid=rank * M)
+        M = len(ins)
+        order, key, cluster = schedule(ins, cfg)
+        s_ins = ins[order]
+        gid = (rank * M + order).astype(np.uint32)          # run-wide instruction ids: streams do not depend on the sharding
+        ip = instruction_params(s_ins, cfg, res)
+        eng = Engine(cfg, res, device=local_rank)
+        eng.load_instructions(s_ins, gid, cluster, key, ip)   # inputs resident in HBM before the timed region
 
     pending = None        # gather of the previous step, still in flight
 
@@ -227,25 +265,46 @@ def main():
     dom = max(ktimes, key=lambda k: ktimes[k][0])
     dom_ms, dom_launches = ktimes[dom]
     b_alg = algorithmic_bytes(counts)
-    traffic = None          # HBM bytes per launch of the dominant kernel from the committed PMC profile of this command
-    try:
-        with open(os.path.join(ROOT, 'profiles', 'r1_traffic.json')) as f:
-            traffic = json.load(f)['kernels'][dom]['hbm_bytes'] if M == 1000 else None
-    except (OSError, KeyError):
-        pass
+    # HBM bytes per launch of the dominant kernel and what limits it, from the committed PMC profiles of this command
+    # (tools/profile_round.sh, tools/pmc_r2.sh -> profiles/r2_traffic.json, r2_counters.json); only for the profiled workload
+    traffic, limiter, valu_util = None, None, None
+    if args.workload == 's2' and M == 1000:
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as f:
+                traffic = json.load(f)['kernels'][dom]['hbm_bytes']
+        except (OSError, KeyError):
+            pass
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'r2_counters.json')) as f:
+                kc = json.load(f)['kernels'][dom]
+                limiter, valu_util = kc.get('limited_by'), kc.get('valu_busy')
+        except (OSError, KeyError):
+            pass
     achieved = b_alg / (dom_ms / dom_launches * 1e-3) / 1e9
+    # the dominant kernel's OWN algorithmic bytes (the pulse kernel reads every photon record once and adds into the raw
+    # accumulators once; the generator writes every photon record once): what "achieved" would be without crediting one
+    # kernel with the whole pipeline's bytes
+    own = {'k_pulse_dense': 8 * counts['n_photons'] + 4 * counts['n_raw_samples'], 'k_photon_fill': 8 * counts['n_photons']}.get(dom)
     out = dict(
         metric='photoelectrons/sec + raw_records MB/s, 10^6-PE S2 batch', value=total_pe * args.steps / elapsed,
         unit='photoelectrons/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
         higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f64', data='synthetic',
         raw_records_MB_per_s=total_rec * 244 * args.steps / elapsed / 1e6,
-        config=dict(workload=f'{M} S2 instructions per GPU, 1e4 electrons each (~1e6 PE), 494 PMTs, z=-10 cm, '
-                             f's2_secondary_sc_gain=100, noise/afterpulses off (BASELINE configs[2])',
-                    instructions_per_gpu=M, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
+        config=dict(workload={'s2': f'{M} S2 instructions per GPU, 1e4 electrons each (~1e6 PE), 494 PMTs, z=-10 cm, '
+                                    f's2_secondary_sc_gain=100, noise/afterpulses off (BASELINE configs[2])',
+                              'mixed': f'{M} instructions per GPU: S1 (3000 quanta) + S2 (1500 e-) pairs over the TPC, PMT afterpulses and '
+                                       f'noise on (synthetic tables), 494 PMTs (BASELINE configs[3])',
+                              'nveto': f'{M} optical nVeto instructions per GPU at 1 MHz, ~10 photons each, 120 channels '
+                                       f'(BASELINE configs[4])'}[args.workload],
+                    instructions_per_gpu=M, instructions_per_s=M * world * args.steps / elapsed, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
                     gather='none' if (world == 1 or args.no_gather) else (('rccl' if backend == 'nccl' else backend) + ' send/recv to rank 0' + ('' if args.sync_gather else ', overlapped with the next batch')),
                     ms_per_step_incl_d2h_of_records=pcie_ms, d2h='pinned host buffers, copy of batch k overlapped with batch k + 1' if pinned else 'pageable host buffers'),
+        # bound: the roofline these numbers are priced on (HBM bytes: there is no dense contraction for MFMA).  What actually
+        # limits the dominant kernel is in `limited_by` (SQ counters: f64 VALU issue + exposed latency, not HBM).
         roofline=dict(bound='hbm', kernel=dom, achieved=achieved, peak=HBM_PEAK_GBS, unit='GB/s', frac=achieved / HBM_PEAK_GBS,
                       traffic=traffic, algorithmic_bytes_per_launch=b_alg, kernel_ms=dom_ms / dom_launches,
+                      limited_by=limiter, valu_busy=valu_util,
+                      kernel_own_bytes=own, kernel_own_frac=(own / (dom_ms / dom_launches * 1e-3) / 1e9 / HBM_PEAK_GBS) if own else None,
                       pipeline_frac=b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       measured_copy_GBs=copy_gbs, frac_of_measured_copy=achieved / copy_gbs,
                       kernels_ms={k: round(v[0], 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}),

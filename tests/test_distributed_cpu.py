@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from wfsim_amd.distributed import shard_clusters, gather_records, wait_gather
+from wfsim_amd.distributed import shard_clusters, gather_records, wait_gather, gather_batches
 from wfsim_amd.dtypes import raw_record_dtype
 
 
@@ -73,3 +73,41 @@ def test_gather_records_gloo(tmp_path, world):
     ref = np.concatenate([_fake_records(r, n) for r, n in enumerate(sizes)])
     assert got.tobytes() == ref.tobytes()
     assert np.all(np.diff(got['time']) >= 0)
+
+
+def _batches_of(rank):
+    """rank r delivers r + 1 batches (rank 2: none) of a few fake records each, later batches later in time"""
+    n_batches = {0: 1, 1: 3, 2: 0}[rank]
+    out = []
+    for k in range(n_batches):
+        rec = _fake_records(rank, 3 + k)
+        rec['time'] += 1_000_000 * k
+        out.append(rec)
+    return out
+
+
+def _rounds_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    parts = gather_batches((torch.from_numpy(r.view(np.uint8).copy()) for r in _batches_of(rank)), dst=0, device=torch.device('cpu'))
+    if rank == 0:
+        np.save(out, np.concatenate([p.numpy().view(raw_record_dtype()) for p in parts]))
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_gather_batches_with_unequal_numbers_of_rounds(tmp_path, world):
+    """the multi-GPU product path (simulate_sharded): per-batch gathers, ranks with fewer batches keep taking part"""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'rounds.npy')
+    mp.spawn(_rounds_worker, args=(world, port, out), nprocs=world, join=True)
+    got = np.load(out)
+    ref = np.concatenate([r for rank in range(world) for r in _batches_of(rank)])
+    assert got.tobytes() == ref.tobytes() and np.all(np.diff(got['time']) >= 0)

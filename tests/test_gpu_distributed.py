@@ -22,29 +22,53 @@ def _case():
     return cfg, big
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, quanta=None):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from wfsim_amd.distributed import simulate_sharded
     cfg, ins = _case()
-    rec = simulate_sharded(cfg, ins, device=0)
+    rec = simulate_sharded(cfg, ins, device=0, max_batch_quanta=quanta)
     if rank == 0:
         np.save(out, rec)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_ranks_equal_single_process(tmp_path, world):
+@pytest.mark.parametrize('world,quanta', [(2, None), (3, None), (2, 20_000)])
+def test_sharded_ranks_equal_single_process(tmp_path, world, quanta):
+    """(quanta: small batches -- the ranks then run different numbers of gather rounds)"""
     import wfsim_amd
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / 'records.npy')
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, quanta), nprocs=world, join=True)
     got = np.load(out)
     cfg, ins = _case()
     ref = np.concatenate([w['records'] for w in wfsim_amd.RawData(cfg).iter_windows(ins)])
     assert len(ref) > 1000 and got.tobytes() == ref.tobytes()
+
+
+def test_device_resident_records_equal_host_records():
+    """RawData.iter_batches(device_records=True): what simulate_sharded sends over RCCL (a torch uint8 tensor filled from the
+    engine's record arena) == the host copy.  In a child process: torch.cuda has to be initialised before the HIP library."""
+    import subprocess
+    import sys
+    code = """
+import torch
+torch.cuda.init()
+import numpy as np, wfsim_amd
+from tests.test_gpu_random_mixes import _random_case
+cfg, ins, ap = _random_case(1008)
+rd = wfsim_amd.RawData(cfg); rd.engine.set_record_order(False); rd.max_batch_quanta = 30_000
+dev = [b['records'] for b in rd.iter_batches(ins, device_records=True)]
+assert len(dev) > 1 and all(t.is_cuda for t in dev)
+got = torch.cat(dev).cpu().numpy().tobytes()
+ref = np.concatenate([w['records'] for w in wfsim_amd.RawData(cfg).iter_windows(ins)]).tobytes()
+assert got == ref and len(ref) > 244 * 100
+print('device records ok', len(ref) // 244)
+"""
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0 and 'device records ok' in r.stdout, r.stderr[-2000:]

@@ -97,9 +97,46 @@ def wait_gather(handles):
         q.wait()
 
 
-def simulate_sharded(config, instructions, device=None, dst=0):
+def gather_batches(tensors, dst=0, device=None, group=None):
+    """Gathers a stream of per-batch record tensors from every rank on ``dst``: rank ``dst`` gets the list of non-empty
+    tensors in (rank, batch) order -- shard order is time order, and so is the batch order inside a shard --, the others
+    ``None``.  The ranks may have different numbers of batches: all run the same number of rounds (one small all-reduce
+    per round decides whether anybody has a batch left; a rank that is out sends nothing), and the transfer of round k is
+    only waited for after the producer has delivered batch k + 1, so that it overlaps that batch's kernels."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    it = iter(tensors)
+    rounds, pending = [], None
+    while True:
+        t = next(it, None)
+        more = torch.tensor([0 if t is None else 1], dtype=torch.int32, device=device)
+        dist.all_reduce(more, op=dist.ReduceOp.MAX, group=group)
+        if pending is not None:
+            wait_gather(pending)
+            pending = None
+        if int(more.item()) == 0:
+            break
+        if t is None:
+            t = torch.empty(0, dtype=torch.uint8, device=device)
+        bufs, pending = gather_records(t, dst=dst, group=group, async_op=True)
+        if rank == dst:
+            rounds.append(bufs)
+    if rank != dst:
+        return None
+    return [rounds[k][r] for r in range(world) for k in range(len(rounds)) if rounds[k][r].numel()]
+
+
+def simulate_sharded(config, instructions, device=None, dst=0, max_batch_quanta=None):
     """All ranks call this with the same instructions; rank ``dst`` gets the time-ordered raw_records of the whole
-    run (numpy structured array), the others ``None``.  One process per GPU (``LOCAL_RANK`` picks the device)."""
+    run (numpy structured array), the others ``None``.  One process per GPU (``LOCAL_RANK`` picks the device).
+
+    Every rank simulates its shard batch by batch; the packed records of a batch go from the engine's arena into a device
+    tensor and from there over RCCL to ``dst`` (no host hop), the transfer of batch k overlapping the kernels of batch
+    k + 1 -- the path ``bench.py --gpus N`` times.  Ranks run a common number of rounds (a rank that is out of batches
+    sends nothing).  Only ``dst`` moves records to the host, once, at the end: on an 8-GPU node that is 8 shards through ONE
+    PCIe link -- a consumer that can read per-rank output (strax writes per-plugin chunks) should rather run one
+    ChunkRawRecords per rank on its own time range and skip the gather."""
     import os
     import torch
     import torch.distributed as dist
@@ -108,6 +145,7 @@ def simulate_sharded(config, instructions, device=None, dst=0):
     from .scheduler import schedule
     rank, world = dist.get_rank(), dist.get_world_size()
     device = int(os.environ.get('LOCAL_RANK', rank)) if device is None else device
+    on_gpu = dist.get_backend() == 'nccl'
     order, key, cluster = schedule(instructions, config)
     s_ins = instructions[order]
     weight = np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15, s_ins['amp'] * float(config.get('s2_secondary_sc_gain', 30)))
@@ -117,11 +155,21 @@ def simulate_sharded(config, instructions, device=None, dst=0):
     rd = RawData(config, device=device)
     # run-wide instruction ids keep the RNG streams independent of the sharding
     rd.global_ids = order[b[rank]:b[rank + 1]]
-    recs, last_end = [], np.iinfo(np.int64).min
-    for w in rd.iter_windows(mine):
-        recs.append(w['records'])
-        last_end = max(last_end, (int(w['right']) - config['trigger_window']) * config['sample_duration'])
-    local = np.concatenate(recs) if recs else np.zeros(0, dtype=raw_record_dtype())
+    rd.engine.set_record_order(False)
+    if max_batch_quanta is not None:
+        rd.max_batch_quanta = int(max_batch_quanta)
+    coll = torch.device('cuda', device) if on_gpu else torch.device('cpu')
+    # RCCL: the records stay on the device; gloo (CPU collectives: tests, rehearsals on one card): host arrays
+    batches = rd.iter_batches(mine, device_records=on_gpu) if len(mine) else iter(())
+    last_end = np.iinfo(np.int64).min
+
+    def tensors():
+        nonlocal last_end
+        for batch in batches:
+            if len(batch['right']):
+                last_end = max(last_end, (int(np.max(batch['right'])) - config['trigger_window']) * config['sample_duration'])
+            yield batch['records'] if on_gpu else torch.from_numpy(np.ascontiguousarray(batch['records']).view(np.uint8).copy())
+    parts = gather_batches(tensors(), dst=dst, device=coll)
     # no digitise window may reach into the next shard (rawdata.py:96-98 applied across the cut)
     ends = [None] * world
     dist.all_gather_object(ends, int(last_end))
@@ -130,9 +178,8 @@ def simulate_sharded(config, instructions, device=None, dst=0):
         run_end = max(run_end, ends[r])
         if b[r + 1] < len(key) and b[r + 1] > b[r] and not (key[b[r + 1]] - run_end > config['right_raw_extension']):
             raise RuntimeError(f'a digitise window of shard {r} reaches into shard {r + 1}: the result would depend on the sharding')
-    dev = torch.device('cuda', device) if dist.get_backend() == 'nccl' else torch.device('cpu')
-    t = torch.from_numpy(local.view(np.uint8).copy()).to(dev)
-    bufs = gather_records(t, dst=dst)
     if rank != dst:
         return None
-    return np.concatenate([x.cpu().numpy().view(raw_record_dtype()) for x in bufs])
+    if not parts:
+        return np.zeros(0, dtype=raw_record_dtype())
+    return torch.cat(parts).cpu().numpy().view(raw_record_dtype())

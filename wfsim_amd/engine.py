@@ -88,6 +88,14 @@ def load_library():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise WfsError(f'{LIB_PATH} not found: the HIP extension is not built; there is no CPU fallback')
+        # torch ships its own HIP runtime: in a process that uses both (the multi-GPU gather keeps records in torch tensors),
+        # torch.cuda must be initialised BEFORE this library pulls in the system's libamdhip64 -- afterwards torch finds no GPU
+        import sys
+        if 'torch' in sys.modules:
+            try:
+                sys.modules['torch'].cuda.init()
+            except Exception:
+                pass
         lib = C.CDLL(LIB_PATH)
         for name in EXPORTS:
             getattr(lib, name)          # AttributeError if a declared symbol is missing
@@ -127,6 +135,7 @@ class Engine:
         for n, _ in WfsConfig._fields_:
             setattr(cfg, n, params[n])
         self._h = C.c_void_p(0)
+        self.device = int(device)
         self._pinned = []
         rc = self.lib.wfs_create(C.byref(cfg), C.c_int(device), C.byref(self._h))
         if rc != 0:

@@ -102,11 +102,12 @@ class RawData:
                 self._write_truth(table, rows[k:], truth_buffer)
         self.source_finished = True
 
-    def iter_batches(self, instructions, want_truth=False, record_sink=None, **kwargs):
+    def iter_batches(self, instructions, want_truth=False, record_sink=None, device_records=False, **kwargs):
         """The same stream batch by batch (what the chunker consumes): dict(left[], right[] of the batch's digitise windows
         in time order, first[] record offsets (one more than windows), records, truth_table + truth_rows + truth_before (row truth_rows[k] of the table belongs in
         front of window truth_before[k]; == number of windows: after the last), finished).  ``record_sink(n)`` may hand out
-        the array the records are copied into (device -> host without a staging copy)."""
+        the array the records are copied into (device -> host without a staging copy); ``device_records``: the records stay
+        on the GPU (``records`` is a torch uint8 tensor of n * 244 bytes)."""
         self.source_finished = False
         if len(instructions) == 0:
             self.source_finished = True
@@ -150,8 +151,10 @@ class RawData:
                 L = launched
                 ins, cl, n_emit, first, nonempty, ins_group, groups = L['ins'], L['cl'], L['n_emit'], L['first'], L['nonempty'], L['ins_group'], L['groups']
                 n_rec = int(first[n_emit])
-                out = record_sink(n_rec) if record_sink is not None else None
-                if out is None:
+                out = None
+                if record_sink is not None and not device_records:
+                    out = record_sink(n_rec)
+                if out is None and not device_records:
                     out = np.empty(n_rec, dtype=raw_record_dtype())
                 keep = np.where(nonempty[:n_emit])[0]
                 # window position of every emitted group: rows of a group go in front of its window, rows of a group without
@@ -165,7 +168,22 @@ class RawData:
                     truth_before = pos_of_group[grp[truth_rows]] if n_emit else np.zeros(0, dtype=np.int64)
                 # the records travel on the engine's copy stream: the next batch's kernels are started first, then the copy is
                 # awaited (the small copies above come first: behind 0.6 GB of records they would wait for them)
-                records = self.engine.records_into_async(out, n_rec)
+                if device_records:
+                    # the records stay on the GPU (a torch uint8 tensor of n_rec * 244 bytes): the multi-GPU gather sends them
+                    # from there (distributed.simulate_sharded)
+                    import torch
+                    if not torch.cuda.is_initialized():
+                        try:
+                            torch.cuda.init()
+                        except RuntimeError as e:
+                            raise RuntimeError('device_records needs torch.cuda initialised BEFORE the first wfsim_amd Engine of the process is '
+                                               'created (import torch; torch.cuda.init()): torch brings its own HIP runtime') from e
+                    records = torch.empty(n_rec * np.dtype(raw_record_dtype()).itemsize, dtype=torch.uint8,
+                                          device=torch.device('cuda', self.engine.device))
+                    if n_rec:
+                        self.engine.copy_records_to_device(records.data_ptr(), n_rec)
+                else:
+                    records = self.engine.records_into_async(out, n_rec)
                 batch = dict(left=groups['left'][keep], right=groups['right'][keep],
                              first=np.append(first[keep], first[n_emit]) if len(keep) else np.array([first[n_emit]]),
                              records=records, truth_table=truth_table, truth_rows=truth_rows, truth_before=truth_before, finished=L['b'] >= n)
