@@ -19,7 +19,8 @@ struct DevBuf {
 };
 struct Pmf { std::vector<double> p; long vmin = 0; };      // probability mass function of an integer delay term
 
-struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf; };
+struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf;
+                int delay_sorted = 0, amp_sorted = 0; };
 
 struct KernelTime { std::string name; hipEvent_t a, b; };
 
@@ -45,7 +46,7 @@ struct wfs_handle {
     DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_embase, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0, blk_desc;
-    DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles;
+    DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles, wave_tiles;
     DevBuf ph, ph_gain;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
@@ -62,7 +63,7 @@ struct wfs_handle {
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
     i64 h_scal[32] = {0};
-    i64 n_active_tiles = 0, n_tiny_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
+    i64 n_active_tiles = 0, n_tiny_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, n_wave_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
     double h_templates[WFS_DT * 22] = {0};
@@ -395,7 +396,7 @@ int wfs_destroy(wfs_handle *h)
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
-        &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
+        &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->wave_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
@@ -490,6 +491,13 @@ int wfs_set_ap_element(wfs_handle *h, int32_t e, int32_t n_bins_delay, int32_t n
     a.n_bins_delay = n_bins_delay; a.n_bins_amp = n_bins_amp; a.amp_2d = amp_2d; a.is_uniform = is_uniform; a.delay_bin = delay_bin; a.amp_bin = amp_bin;
     TRY(upload(h, a.delay_cdf, delay_cdf, sizeof(double) * (size_t)h->cfg.n_tpc * n_bins_delay));
     TRY(upload(h, a.amp_cdf, amp_cdf, sizeof(double) * (size_t)(amp_2d ? h->cfg.n_tpc : 1) * n_bins_amp));
+    // non-decreasing rows (every cumulative distribution is): np.argmin(|cdf - u|) by bisection on the device
+    auto rows_sorted = [](const double *c, size_t rows, int n) {
+        for (size_t r = 0; r < rows; r++) for (int k = 1; k < n; k++) if (!(c[r * n + k] >= c[r * n + k - 1])) return 0;
+        return 1;
+    };
+    a.delay_sorted = rows_sorted(delay_cdf, (size_t)h->cfg.n_tpc, n_bins_delay);
+    a.amp_sorted = rows_sorted(amp_cdf, (size_t)(amp_2d ? h->cfg.n_tpc : 1), n_bins_amp);
     h->dev.n_ap = std::max(h->dev.n_ap, e + 1);
     HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
@@ -895,7 +903,8 @@ static int run_generation(wfs_handle *h)
         ap.n = d.n_ap;
         for (int e = 0; e < d.n_ap; e++) {
             const ApElem &s = h->ap[e];
-            ap.el[e] = ApElemDev{s.n_bins_delay, s.n_bins_amp, s.amp_2d, s.is_uniform, s.delay_bin, s.amp_bin, s.delay_cdf.as<double>(), s.amp_cdf.as<double>()};
+            ap.el[e] = ApElemDev{s.n_bins_delay, s.n_bins_amp, s.amp_2d, s.is_uniform, s.delay_bin, s.amp_bin, s.delay_cdf.as<double>(), s.amp_cdf.as<double>(),
+                                 s.delay_sorted, s.amp_sorted};
         }
         TRY(ensure(h, h->ap_ins, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_ch, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_t, (size_t)ap_cap * 4));
         TRY(ensure(h, h->ap_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ph_gain, (size_t)ap_cap * 8));
@@ -972,7 +981,7 @@ int wfs_run(wfs_handle *h)
     TRY(fill64(h, h->row_lo, CG * d.n_tpc, I64_MAX)); TRY(fill64(h, h->row_hi, CG * d.n_tpc, I64_MIN));
     TRY(ensure(h, h->acc_len, (size_t)CG * d.n_tpc * 4)); HIPCHK(hipMemsetAsync(h->acc_len.p, 0, (size_t)CG * d.n_tpc * 4, h->stream));
     TRY(ensure(h, h->itv_cap, (size_t)CG * d.row_slots * 4)); TRY(ensure(h, h->active_rows, (size_t)CG * d.row_slots * 4));
-    TRY(ensure(h, h->active_tiles, (size_t)T * 4)); TRY(ensure(h, h->sparse_tiles, (size_t)T * 4)); TRY(ensure(h, h->dense_tiles, (size_t)T * 4));
+    TRY(ensure(h, h->active_tiles, (size_t)T * 4)); TRY(ensure(h, h->sparse_tiles, (size_t)T * 4)); TRY(ensure(h, h->dense_tiles, (size_t)T * 4)); TRY(ensure(h, h->wave_tiles, (size_t)T * 4));
     GeomArgs ga{};
     ga.n_sets = S; ga.n_tiles = T; ga.n_clusters = C; ga.n_gslots = CG;
     ga.tile_count = h->tile_count.as<i32>(); ga.tile_tmin = h->tile_tmin.as<i32>(); ga.tile_tmax = h->tile_tmax.as<i32>();
@@ -980,7 +989,7 @@ int wfs_run(wfs_handle *h)
     ga.cl_end = h->cl_end.as<i64>(); ga.cl_group = h->cl_group.as<i32>(); ga.grp_lo = h->grp_lo.as<i64>(); ga.grp_hi = h->grp_hi.as<i64>();
     ga.grp_left = h->grp_left.as<i64>(); ga.grp_right = h->grp_right.as<i64>(); ga.grp_ixrand = h->grp_ixrand.as<i64>(); ga.grp_gid = h->grp_gid.as<u32>();
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
-    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.sparse_tiles = h->sparse_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
+    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.sparse_tiles = h->sparse_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.wave_tiles = h->wave_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
     ga.noise_override = h->n_noise_override ? h->noise_override.as<i64>() : nullptr; ga.n_noise_override = h->n_noise_override;
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 1024)), dim3(1024), 0, h->stream, d, ga); }
     { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(GROUPS_TPB), 0, h->stream, d, ga); }
@@ -994,12 +1003,15 @@ int wfs_run(wfs_handle *h)
     if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
     h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5]; h->max_tile_dense = h->h_scal[15];
     h->n_dense_tiles = h->h_scal[11]; h->max_nb_dense = h->h_scal[12]; h->n_tiny_tiles = h->h_scal[16];
-    h->n_active_tiles = h->n_tiny_tiles + h->n_sparse_tiles + h->n_dense_tiles;
+    h->n_wave_tiles = h->h_scal[17];
+    h->n_active_tiles = h->n_tiny_tiles + h->n_sparse_tiles + h->n_dense_tiles + h->n_wave_tiles;
     // one work list: tiny tiles, then sparse, then dense
     if (h->n_sparse_tiles > 0)
         HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_tiny_tiles, h->sparse_tiles.p, (size_t)h->n_sparse_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
     if (h->n_dense_tiles > 0)
         HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles, h->dense_tiles.p, (size_t)h->n_dense_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
+    if (h->n_wave_tiles > 0)
+        HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles + h->n_dense_tiles, h->wave_tiles.p, (size_t)h->n_wave_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
     h->s_raw = h->h_scal[8]; h->n_itv_slots = h->h_scal[9];
     // deterministic processing order of the work lists (they were appended with atomics)
     // (results do not depend on it; sorting keeps profiles and debug dumps reproducible)
@@ -1050,6 +1062,14 @@ int wfs_run(wfs_handle *h)
         pt.desc = h->tile_desc.as<TileDesc>();
         Timer t(h, "k_pulse_tiny");
         hipLaunchKernelGGL(k_pulse_tiny, dim3(nblocks(h->n_tiny_tiles, 256)), dim3(256), 0, h->stream, d, pt, h->n_tiny_tiles);
+    }
+    if (h->n_wave_tiles > 0) {          // work list order: tiny | sparse | dense | wave
+        PulseArgs pw = pa;
+        const i64 first = h->n_tiny_tiles + h->n_sparse_tiles + h->n_dense_tiles;
+        pw.desc = h->tile_desc.as<TileDesc>() + first;
+        if (pw.cur_off) pw.cur_off += first;
+        Timer t(h, "k_pulse_wave");
+        hipLaunchKernelGGL(k_pulse_wave, dim3(nblocks(h->n_wave_tiles, 4)), dim3(256), 0, h->stream, d, pw, h->n_wave_tiles);
     }
     if (h->n_sparse_tiles > 0) {
         PulseArgs ps = pa;

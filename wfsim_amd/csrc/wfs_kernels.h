@@ -119,6 +119,7 @@ struct GeomArgs {
     i32 *active_tiles;   // tiny tiles (thread per tile); the other two lists are copied behind them by the host side
     i32 *sparse_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
     i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
+    i32 *wave_tiles;     // medium tiles (at most 64 photons, any width: wave per tile); scal[17] = their number
     i32 force_dense;     // debug: send every tile to the dense kernel
     i32 init_has; i64 init_runmax;      // last_pulse_end_time carried in from earlier batches
     const i64 *noise_override; i64 n_noise_override;
@@ -128,6 +129,8 @@ struct GeomArgs {
 #define SPARSE_MAX_BINS 64
 #define TINY_MAX_PHOTONS 4         // tiles of a few photons in a few start bins (the bulk of an S1): one THREAD per tile
 #define TINY_MAX_BINS 32
+#define WAVE_MAX_PHOTONS 64        // medium tiles: photons fit the lanes of one wave (any width): k_pulse_wave
+#define WAVE_MAX_BINS 16384
 
 __device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i32 tmax, i64 &left, i64 &right, i64 &bin0, i64 &nb)
 {
@@ -146,14 +149,15 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = tile < a.n_tiles && a.tile_count[tile] > 0;
-    int cls = 2; i64 nb = 0; i32 cnt = 0; i32 cl = -1; i64 end = I64_MIN;      // class 0 tiny, 1 sparse, 2 dense
+    int cls = 2; i64 nb = 0; i32 cnt = 0; i32 cl = -1; i64 end = I64_MIN;      // class 0 tiny, 1 sparse, 2 dense, 3 wave (medium)
     if (live) {
         const i64 set = tile / d.n_tpc;
         i64 left, right, bin0;
         tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
         cl = a.set_cluster[set]; end = right * d.dt;
         cnt = a.tile_count[tile];
-        if (!a.force_dense) cls = (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1 : 2);
+        if (!a.force_dense) cls = (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1
+                                  : ((cnt <= WAVE_MAX_PHOTONS && nb <= WAVE_MAX_BINS) ? 3 : 2));
     }
     {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
         const u64 ml = __ballot(live);
@@ -168,8 +172,8 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     }
     // work lists and maxima: aggregated per workgroup in LDS, then one global atomic per workgroup and counter
     // (76k wave-level atomics on one cache line cost ~3 ms; the counters all live in the same line of scal[])
-    __shared__ i32 s_n[3]; __shared__ i64 s_b[3], s_mx[4];
-    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; s_mx[3] = 0; }
+    __shared__ i32 s_n[4]; __shared__ i64 s_b[4], s_mx[4];
+    if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; s_mx[3] = 0; }
     __syncthreads();
     i32 rk = 0;
     if (live) {
@@ -181,13 +185,14 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
         s_b[0] = s_n[0] ? (i64)atomicAdd((u64 *)&a.scal[16], (u64)s_n[0]) : 0;
         s_b[1] = s_n[1] ? (i64)atomicAdd((u64 *)&a.scal[3], (u64)s_n[1]) : 0;
         s_b[2] = s_n[2] ? (i64)atomicAdd((u64 *)&a.scal[11], (u64)s_n[2]) : 0;
+        s_b[3] = s_n[3] ? (i64)atomicAdd((u64 *)&a.scal[17], (u64)s_n[3]) : 0;
         if (s_mx[0]) atomicMax(&a.scal[4], s_mx[0]);
         if (s_mx[1]) atomicMax(&a.scal[5], s_mx[1]);
         if (s_mx[2]) atomicMax(&a.scal[12], s_mx[2]);
         if (s_mx[3]) atomicMax(&a.scal[15], s_mx[3]);
     }
     __syncthreads();
-    if (live) (cls == 0 ? a.active_tiles : (cls == 1 ? a.sparse_tiles : a.dense_tiles))[s_b[cls] + rk] = (i32)tile;
+    if (live) (cls == 0 ? a.active_tiles : (cls == 1 ? a.sparse_tiles : (cls == 2 ? a.dense_tiles : a.wave_tiles)))[s_b[cls] + rk] = (i32)tile;
 }
 
 // Digitise groups.  The cache is digitised before cluster k when min(instruction key of k) - last_pulse_end_time > rext
@@ -733,6 +738,109 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
         if (a.currents) a.currents[a.cur_off[idx] + s] = cur;
         const i64 adc = -(i64)rint(cur * d.c2a);                 // rawdata.py:236
         if (adc != 0) atomicAdd(&dst[s], (i32)adc);
+    }
+}
+
+// Medium tiles: at most 64 photons over any number of start bins -- the tiles of a small S2 (a few hundred to a few thousand
+// electrons: ~30 photons per PMT over microseconds), far too wide for the counting-sort kernel below and far too empty for
+// the dense kernel, whose cost goes with the samples (~600 x 220 multiply-adds for 30 photons x 22).  One WAVE per tile, no
+// LDS traffic beyond the template table: lane = photon while the photons are loaded, sorted by time (bitonic network on
+// keys ns << 6 | lane) and merged (equal ns: the first of the run takes the summed gain, the others 0.0, which add nothing);
+// then lane = sample, block by block of 64: the photons that can reach the block are a contiguous range of the sorted
+// list, their (bin, ns remainder, gain) are broadcast one at a time from the lane that holds them, and every sample in
+// reach adds templates[r][k] * gain with a separate multiply and add, in ascending time: the arithmetic of add_current
+// (pulse.py:276-318), the same bits as the other kernels.
+__global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n_wave)
+{
+    constexpr int dt = WFS_DT, tlen = 22;
+    __shared__ double sT[dt * tlen];                      // templates[r][k]
+    __shared__ double s_cmax[dt];
+    for (int i = threadIdx.x; i < dt * tlen; i += blockDim.x) sT[i] = d.templates[i];
+    if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const i64 idx = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= n_wave) return;                            // wave-uniform
+    const TileDesc td = a.desc[idx];
+    const int n = td.n, L = td.L;
+    const int lead = d.store_before + d.samples_before;
+    const bool v = lane < n;
+    // ---- lane = photon
+    const PhotonRec rec = a.ph[td.off + (v ? lane : 0)];
+    const i32 ns0 = v ? (i32)(rec.t - td.rel0) : 0x7fffff;                  // ns relative to the tile's first start bin
+    const u32 code = v ? rec.code : 0u;
+    double g = 0.0;
+    if (td.mode != 0) { if (v) g = a.ph_gain[td.off + lane]; }
+    else {
+        const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? td.ch : 0) * 2001;
+        const double s1 = spe_row[code & 0xffffu], s2 = spe_row[code >> 16];
+        g = td.G * s1;                                                       // pulse.py:97-98
+        if (code >> 16) g += td.G * s2;                                      // pulse.py:101-103
+        if (!v) g = 0.0;
+    }
+    if (a.tile_truth) {        // pulse.py:229-271, photons in their order in the channel slice (= lane order)
+        const bool is_dpe = v && (code >> 16) != 0;
+        const i32 n_dpe = __popcll(__ballot(is_dpe));
+        const bool above = v && (g * s_cmax[v ? ns0 % dt : 0] * d.c2a > td.thr);
+        const i32 n_trig = __popcll(__ballot(above)), n_trig_dpe = __popcll(__ballot(above && lane < n_dpe));
+        const double tr = v ? (double)(ns0 + td.rel0) : 0.0;
+        double sg = g, sgt = above ? g : 0.0, st = tr, st2 = tr * tr;
+        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_down(sg, o, 64); sgt += __shfl_down(sgt, o, 64); st += __shfl_down(st, o, 64); st2 += __shfl_down(st2, o, 64); }
+        if (lane == 0) {
+            double *o = a.tile_truth + (i64)td.tile * 8;
+            o[0] = (double)n; o[1] = (double)n_dpe; o[2] = (double)n_trig; o[3] = (double)n_trig_dpe; o[4] = sg; o[5] = sgt; o[6] = st; o[7] = st2;
+        }
+    }
+    // ---- ascending time: bitonic sort of the keys ns << 6 | lane (unique: a deterministic order), then the gains follow
+    u32 key = ((u32)ns0 << 6) | (u32)lane;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const u32 other = (u32)__shfl_xor((int)key, j, 64);
+            const bool up = (lane & k) == 0, low = (lane & j) == 0;
+            key = (low == up) ? (key < other ? key : other) : (key > other ? key : other);
+        }
+    const int src = (int)(key & 63u);
+    i32 ns = (i32)(key >> 6);
+    g = __shfl(g, src, 64);
+    // runs of equal ns (pulse.py:303-313): the head of a run collects the gains of the run in order, the others become 0.0
+    {
+        const i32 prev = __shfl_up(ns, 1, 64);
+        const bool head = lane == 0 || prev != ns;
+        if (__any(!head && lane < n)) {
+            double tot = g;
+            for (int step = 1; step < 64; step++) {
+                const i32 nsq = __shfl_down(ns, step, 64); const double gq = __shfl_down(g, step, 64);
+                const bool same = lane + step < n && nsq == ns;
+                if (!__any(head && same)) break;
+                if (head && same) tot += gq;
+            }
+            g = head ? tot : 0.0;
+        }
+    }
+    const i32 bin = lane < n ? ns / dt : 0x3fffffff, r = lane < n ? ns - (ns / dt) * dt : 0;
+    const u32 g_lo = (u32)__double_as_longlong(g), g_hi = (u32)((u64)__double_as_longlong(g) >> 32);
+    // ---- lane = sample.  Live samples: s' = 0 .. nb + 20 (sample lead + s' of the tile sees the start bins s' - 21 .. s')
+    i32 *dst = a.raw + td.dst;
+    const int n_live = td.nb + tlen - 1;
+    if (a.currents) for (int s = lane; s < L; s += 64) if (s < lead || s >= lead + n_live) a.currents[a.cur_off[idx] + s] = 0.0;
+    for (int s0 = 0; s0 < n_live; s0 += 64) {
+        // sorted photons with a start bin in [s0 - 21, s0 + 63]: a contiguous range [q_lo, q_hi) of lanes
+        const int q_lo = __popcll(__ballot(bin < s0 - (tlen - 1))), q_hi = __popcll(__ballot(bin <= s0 + 63));
+        const int sp = s0 + lane;
+        double c = 0.0;
+        for (int q = q_lo; q < q_hi; q++) {
+            const int bq = __builtin_amdgcn_readlane(bin, q), rq = __builtin_amdgcn_readlane(r, q);
+            const double gq = __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane((int)g_hi, q) << 32) | (u32)__builtin_amdgcn_readlane((int)g_lo, q)));
+            const int kk = sp - bq;
+            if (kk >= 0 && kk < tlen) { const double prod = sT[rq * tlen + kk] * gq; c = c + prod; }
+        }
+        if (sp < n_live) {
+            if (a.currents) a.currents[a.cur_off[idx] + lead + sp] = c;
+            const i64 adc = -(i64)rint(c * d.c2a);             // rawdata.py:236
+            if (adc != 0) atomicAdd(&dst[lead + sp], (i32)adc);
+        }
     }
 }
 
@@ -1344,7 +1452,31 @@ __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double
 #define CDF_G 512                  // guide cells of the per-block channel search
 
 // PMT afterpulse element tables (afterpulse.py:181-186) and the staging list of generated afterpulse photons
-struct ApElemDev { i32 n_bins_delay, n_bins_amp, amp_2d, is_uniform; double delay_bin, amp_bin; const double *delay_cdf, *amp_cdf; };
+struct ApElemDev { i32 n_bins_delay, n_bins_amp, amp_2d, is_uniform; double delay_bin, amp_bin; const double *delay_cdf, *amp_cdf;
+                   i32 delay_sorted, amp_sorted; };     // the rows are non-decreasing (checked on the host): argmin by bisection
+
+// np.argmin(|cdf - u|) (afterpulse.py:222, 229): the FIRST index of the smallest distance.  On a non-decreasing row the
+// distance falls up to the first entry >= u and rises behind it, so the answer is that entry or the one in front of it
+// (lower index on a tie), moved to the start of its plateau of equal values -- two bisections instead of a scan of the row
+// (a scan costs every wave that holds one accepted photon ~n_bins iterations: 20 of 23 ms of the fill pass with
+// afterpulses on).  Rows that are not sorted (never seen; the host checks) keep the scan.
+__device__ __forceinline__ int argmin_abs_diff(const double *c, int n, double u, bool sorted)
+{
+    if (!sorted) {
+        int best = 0; double bd = fabs(c[0] - u);
+        for (int k = 1; k < n; k++) { const double dd = fabs(c[k] - u); if (dd < bd) { bd = dd; best = k; } }
+        return best;
+    }
+    int lo = 0, hi = n;                                  // first k with c[k] >= u (n: none)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] >= u) hi = mid; else lo = mid + 1; }
+    int best = lo;
+    if (lo == n) best = n - 1;
+    else if (lo > 0 && !(fabs(c[lo] - u) < fabs(c[lo - 1] - u))) best = lo - 1;
+    const double v = c[best];
+    int a = 0, b = best;                                 // first k with c[k] == v: first k with c[k] >= v
+    while (a < b) { const int mid = (a + b) >> 1; if (c[mid] >= v) b = mid; else a = mid + 1; }
+    return a;
+}
 struct ApArgs {
     i32 n; i32 pad;
     ApElemDev el[WFS_MAX_AP];
@@ -1410,12 +1542,10 @@ __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, c
             const u32x4 x = philox4x32_10(j, gid, m, SITE_AP_X + (u32)e, d.k0, d.k1);
             delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
         } else {
-            int best = 0; double bd = fabs(dc[0] - rU0);            // np.argmin(|cdf - u|): first minimum
-            for (int k = 1; k < el.n_bins_delay; k++) { const double dd = fabs(dc[k] - rU0); if (dd < bd) { bd = dd; best = k; } }
+            const int best = argmin_abs_diff(dc, el.n_bins_delay, rU0, el.delay_sorted != 0);      // np.argmin(|cdf - u|): first minimum
             delay = best * el.delay_bin - d.pmt_ap_t_modifier;
             const double *ac = el.amp_2d ? el.amp_cdf + (size_t)ch * el.n_bins_amp : el.amp_cdf;
-            int ba = 0; double bad = fabs(ac[0] - rU1);
-            for (int k = 1; k < el.n_bins_amp; k++) { const double dd = fabs(ac[k] - rU1); if (dd < bad) { bad = dd; ba = k; } }
+            const int ba = argmin_abs_diff(ac, el.n_bins_amp, rU1, el.amp_sorted != 0);
             amp = ba * el.amp_bin;
         }
         const double tf = (double)(itime + t) + delay;              // afterpulse.py:235, int64 + float
