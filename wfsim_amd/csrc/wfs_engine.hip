@@ -465,7 +465,12 @@ int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, in
     TRY(build_time_tables(h));         // the S2 delay table contains the luminescence term
     d.noise = nullptr; d.noise_len = 0; d.noise_channels = 0;
     if (noise && noise_len > 0 && noise_channels > 0) {
-        TRY(upload(h, h->t_noise, noise, sizeof(int16_t) * (size_t)noise_len * noise_channels));
+        // channel-major on the device ([channel][sample]; the reference's array is [sample][channel], rawdata.py:429): a row reads
+        // consecutive samples of ONE channel -- time-major that is one cache line per sample
+        std::vector<int16_t> nt((size_t)noise_len * noise_channels);
+        for (int64_t i = 0; i < noise_len; i++) for (int c = 0; c < noise_channels; c++) nt[(size_t)c * noise_len + i] = noise[(size_t)i * noise_channels + c];
+        TRY(upload(h, h->t_noise, nt.data(), sizeof(int16_t) * nt.size()));
+        HIPCHK(hipStreamSynchronize(h->stream));
         d.noise = h->t_noise.as<int16_t>(); d.noise_len = noise_len; d.noise_channels = noise_channels;
     }
     d.templates = h->t_templates.as<double>(); d.spe = h->t_spe.as<double>(); d.n_spe = n_spe; d.gains = h->t_gains.as<double>();

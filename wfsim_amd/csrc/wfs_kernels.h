@@ -1118,7 +1118,7 @@ __device__ __forceinline__ i32 finish_sample(const WfsDev &d, const i32 *acc, i6
     if (d.enable_noise && slot_ch < d.noise_channels) {
         i64 in = ix_rand + i;
         if (in >= d.noise_len) in -= (i64)d.noise_len * (in / d.noise_len);
-        v += d.noise[in * d.noise_channels + slot_ch];
+        v += d.noise[(i64)slot_ch * d.noise_len + in];          // channel-major copy (wfs_set_tables): consecutive samples, consecutive addresses
     }
     v += d.baseline;
     return v < 0 ? 0 : (i32)v;
@@ -1156,27 +1156,41 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
         const i32 plen = (i32)(rr - l + 1);                     // a row is shorter than 10^6 samples (k_group_final)
         return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
     };
-    i64 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;
-    for (i64 c0 = 0; c0 < len; c0 += 64) {
-        i64 i = c0 + lane;
-        i32 v = i < len ? finish_sample(d, acc, i, channel, he, ixr) : 0x7fffffff;
-        if (a.row_dbg && i < len) a.row_dbg[a.row_dbg_off[r] + i] = v;
-        bool hit = i < len && (i64)v < thr;
-        u64 mask = __ballot(hit);
-        u64 lt = (1ull << lane) - 1ull;
-        u64 below = mask & lt;
-        i64 prev = below ? c0 + 63 - __clzll(below) : carry_last;       // last hit before this sample
-        bool start = hit && (prev < 0 || i - prev > hold);
-        u64 smask = __ballot(start);
-        if (start) {
-            u64 sbelow = smask & lt;
-            i32 k = count + __popcll(sbelow);
-            i64 prev_left = sbelow ? c0 + 63 - __clzll(sbelow) : open_left;
-            if (k > 0) nrec += close_interval(k - 1, prev_left, prev);
+    i32 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;      // (a row is shorter than 10^6 samples: 32-bit indices)
+    const i32 len32 = (i32)len, hold32 = (i32)hold;
+    // chunks of 64 samples; the loads of ZLE_GROUP chunks are issued together (one dependent load per chunk leaves the wave
+    // waiting a memory round trip per 64 samples)
+    constexpr int ZLE_GROUP = 2;
+    for (i32 g0 = 0; g0 < len32; g0 += 64 * ZLE_GROUP) {
+        i32 vv[ZLE_GROUP];
+#pragma unroll
+        for (int u = 0; u < ZLE_GROUP; u++) {
+            const i32 i = g0 + 64 * u + lane;
+            vv[u] = i < len32 ? finish_sample(d, acc, i, channel, he, ixr) : 0x7fffffff;
+            if (a.row_dbg && i < len32) a.row_dbg[a.row_dbg_off[r] + i] = vv[u];
         }
-        count += __popcll(smask);
-        if (smask) open_left = c0 + 63 - __clzll(smask);
-        if (mask) carry_last = c0 + 63 - __clzll(mask);
+#pragma unroll
+        for (int u = 0; u < ZLE_GROUP; u++) {
+            const i32 c0 = g0 + 64 * u;
+            if (c0 >= len32) break;                             // wave-uniform
+            const i32 i = c0 + lane;
+            const bool hit = i < len32 && (i64)vv[u] < thr;
+            const u64 mask = __ballot(hit);
+            const u64 lt = (1ull << lane) - 1ull;
+            const u64 below = mask & lt;
+            const i32 prev = below ? c0 + 63 - __clzll(below) : carry_last;       // last hit before this sample
+            const bool start = hit && (prev < 0 || i - prev > hold32);
+            const u64 smask = __ballot(start);
+            if (start) {
+                const u64 sbelow = smask & lt;
+                const i32 k = count + __popcll(sbelow);
+                const i32 prev_left = sbelow ? c0 + 63 - __clzll(sbelow) : open_left;
+                if (k > 0) nrec += close_interval(k - 1, prev_left, prev);
+            }
+            count += __popcll(smask);
+            if (smask) open_left = c0 + 63 - __clzll(smask);
+            if (mask) carry_last = c0 + 63 - __clzll(mask);
+        }
     }
     if (lane == 0 && count > 0) nrec += close_interval(count - 1, open_left, carry_last);
     for (int o = 32; o > 0; o >>= 1) nrec += __shfl_down(nrec, o, 64);
@@ -1230,29 +1244,36 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
         const i64 left = a.itv_left[base + k]; const i32 plen = (i32)(a.itv_right[base + k] - left + 1);
         if (plen <= 0) continue;
         const i32 need = (plen + spr - 1) / spr;
-        for (i32 f = 0; f < need; f++, rec++) {
-            if (rec >= a.rec_capacity) return;
-            u32 *out = (u32 *)(a.records + (a.rec_dest ? (i64)a.rec_dest[rec] : rec) * (24 + 2 * (i64)spr));
-            const i64 time = (i64)d.dt * (left + spr * f);
-            const i32 length = (i32)((plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f);
-            for (int q = lane; q < rec_dwords; q += 64) {
+        // all dwords of the interval's records as one index space (record f, dword q of 61), four per lane in flight
+        const i32 n_dw = need * rec_dwords;
+        for (i32 t0 = lane; t0 < n_dw; t0 += 64 * 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const i32 t = t0 + 64 * u;
+                if (t >= n_dw) break;
+                const i32 f = t / rec_dwords, qd = t - f * rec_dwords;
+                if (rec + f >= a.rec_capacity) continue;
+                u32 *out = (u32 *)(a.records + (a.rec_dest ? (i64)a.rec_dest[rec + f] : rec + f) * (24 + 2 * (i64)spr));
+                const i64 time = (i64)d.dt * (left + spr * f);
+                const i32 length = (i32)((plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f);
                 u32 w;
-                if (q == 0) w = (u32)(u64)time;
-                else if (q == 1) w = (u32)((u64)time >> 32);
-                else if (q == 2) w = (u32)length;
-                else if (q == 3) w = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
-                else if (q == 4) w = (u32)plen;
-                else if (q == 5) w = (u32)(uint16_t)f;           // record_i, baseline = 0
+                if (qd == 0) w = (u32)(u64)time;
+                else if (qd == 1) w = (u32)((u64)time >> 32);
+                else if (qd == 2) w = (u32)length;
+                else if (qd == 3) w = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
+                else if (qd == 4) w = (u32)plen;
+                else if (qd == 5) w = (u32)(uint16_t)f;           // record_i, baseline = 0
                 else {
-                    int s0 = (q - 6) * 2;
-                    i64 i0 = (left - row_abs) + spr * f + s0;
-                    u32 lo = s0 < length ? (u32)(uint16_t)finish_sample(d, acc, i0, channel, he, ixr) : 0u;
-                    u32 hi = s0 + 1 < length ? (u32)(uint16_t)finish_sample(d, acc, i0 + 1, channel, he, ixr) : 0u;
+                    const int s0 = (qd - 6) * 2;
+                    const i64 i0 = (left - row_abs) + spr * f + s0;
+                    const u32 lo = s0 < length ? (u32)(uint16_t)finish_sample(d, acc, i0, channel, he, ixr) : 0u;
+                    const u32 hi = s0 + 1 < length ? (u32)(uint16_t)finish_sample(d, acc, i0 + 1, channel, he, ixr) : 0u;
                     w = lo | (hi << 16);
                 }
-                out[q] = w;
+                out[qd] = w;
             }
         }
+        rec += need;
     }
 }
 
