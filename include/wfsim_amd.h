@@ -138,6 +138,14 @@ int wfs_set_s1_propagation(wfs_handle *h, int32_t nz, int32_t nu, double u0, dou
  * S1 propagation the z cell of the spline grid and the normalised distance inside it (prop_zi -1 / NULL: none). */
 int wfs_set_instruction_models(wfs_handle *h, int64_t n, const int32_t *tab, const int32_t *tab_bottom,
                                const int32_t *prop_zi, const double *prop_zf);
+/* s2_luminescence_model 'garfield_gas_gap' (s2.py:413-483; resource s2_luminescence_gg, load_resource.py:284-291): the
+ * excitation-time inverse CDFs timing_inv_cdf[n_gas_gaps][n_points] once; then per batch, for every instruction, the table at
+ * or below the gas gap under it (np.digitize(gap, gas_gap) - 1; -1: the instruction does not use the model) and
+ * (gap - gas_gap[table]) / spacing.  Every photon draws its excitation time from the interpolated table; the mean over the
+ * instruction's photons is subtracted (s2.py:447) and the result truncated (s2.py:532).  Needs wfs_set_instruction_models
+ * for the same batch (the remaining delay terms come from its tables, base 3). */
+int wfs_set_gas_gap_model(wfs_handle *h, int32_t n_gas_gaps, int32_t n_points, const double *timing_inv_cdf);
+int wfs_set_instruction_gas_gap(wfs_handle *h, int64_t n, const int32_t *table, const double *weight);
 
 /* ---- pattern maps evaluated on the device ----------------------------------------------------------------
  * The hit pattern of an instruction is resource.s1_pattern_map(x, y, z) / s2_pattern_map(x, y) (s1.py:148, s2.py:640):

@@ -170,6 +170,9 @@ class Oracle:
         if sp is not None:
             lib().orc_set_s1_propagation(self._s, C.c_int32(len(sp['z'])), C.c_int32(sp['nu']), C.c_double(sp['u0']), C.c_double(sp['du']),
                                          _p(sp['top']), _p(sp['bottom']))
+        if models.gas_gap is not None:
+            inv = models.gas_gap['inv']
+            lib().orc_set_gas_gap_model(self._s, C.c_int32(inv.shape[0]), C.c_int32(inv.shape[1]), _p(inv))
 
     def _instruction_models(self, instructions, gid):
         if getattr(self, '_models', None) is None:
@@ -180,6 +183,9 @@ class Oracle:
             base, off, pmf, vmin = self._models.table_arrays()
             lib().orc_set_delay_models(self._s, C.c_int32(len(base)), _p(base), _p(off), _p(pmf), _p(vmin))
         lib().orc_set_instruction_models(self._s, C.c_int64(len(instructions)), *[_p(x) for x in self._im])
+        if self._models.gas_gap is not None:
+            self._igg = self._models.instruction_gas_gap(instructions)       # kept alive, as above
+            lib().orc_set_instruction_gas_gap(self._s, C.c_int64(len(instructions)), _p(self._igg[0]), _p(self._igg[1]))
 
     def simulate(self, instructions, gid, ip, em_base=None):
         n = len(instructions)
@@ -238,6 +244,12 @@ class Oracle:
         while k < n.value:
             k *= 2
         return pa[:k], pc[:k], int(vmin.value)
+
+    def sample_gas_gap(self, n, table, weight):
+        """the 'garfield_gas_gap' luminescence term of the n photons of one instruction (mean subtracted, truncated)"""
+        out = np.zeros(n, dtype=np.int64)
+        lib().orc_sample_gas_gap(self._s, C.c_int64(n), C.c_int32(table), C.c_double(weight), _p(out))
+        return out
 
     def sample_poisson(self, lam, n):
         out = np.zeros(n, dtype=np.int64)

@@ -103,6 +103,9 @@ typedef struct orc_session_s {
     orc_tab *xtab; i32 n_xtab;
     const i32 *ins_tab, *ins_tabb, *ins_pzi; const double *ins_pzf; i64 n_ins_models;
     double *prop_top, *prop_bot; i32 prop_nz, prop_nu; double prop_u0, prop_du;
+    /* s2_luminescence_model 'garfield_gas_gap' (s2.py:413-483): inverse CDFs of the excitation time per tabulated gas gap,
+     * per instruction the lower table and the interpolation weight towards the next one */
+    double *gg_inv; i32 gg_n, gg_L; const i32 *ins_gg; const double *ins_ggw; i64 n_ins_gg; i32 cur_gg; double cur_ggw;
     i32 cur_tab, cur_tabb, cur_pzi; double cur_pzf;   /* trunc()-ed delay variates: the individual terms and their sums, see TAB_* */    /* tests: ix_rand per digitise call instead of the Philox draw */
 } orc_session;
 
@@ -127,7 +130,8 @@ void orc_philox(const u32 *ctr, const u32 *key, u32 *out) { philox4x32_10(ctr[0]
  * index, double-PE flag, second SPE index.  SITE_PH, counter (0, gid, item): photons that arrive with time and channel
  * (optical input): x -> transit time, y -> gains.  SITE_PH_X, counter (emitter, gid, item): S1 optical propagation. */
 enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
-       SITE_DELAY = 16, SITE_CH = 17, SITE_GAIN = 18, SITE_PH = 19, SITE_PH_X = 20, SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
+       SITE_DELAY = 16, SITE_CH = 17, SITE_GAIN = 18, SITE_PH = 19, SITE_PH_X = 20, SITE_LUM = 21 /* P-indexed like SITE_DELAY: garfield gas gap excitation time */,
+       SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
 
 static inline void draw(const orc_session *s, u32 emitter, u32 gid, u32 item, u32 site, u32 w[4])
 {
@@ -189,7 +193,7 @@ orc_session *orc_new(const orc_config *c, const double *templates, const double 
                      const int16_t *noise)
 {
     orc_session *s = (orc_session *)calloc(1, sizeof(orc_session));
-    s->cur_tab = s->cur_tabb = s->cur_pzi = -1;
+    s->cur_tab = s->cur_tabb = s->cur_pzi = -1; s->cur_gg = -1;
     s->c = *c; s->templates = templates; s->spe = spe; s->gains = gains; s->thr_truth = thr_truth; s->thr_zle = thr_zle;
     s->lum_x = lum_x; s->lum_t = lum_t; s->noise = noise; s->save_full_truth = 1;
     tab_normal(s, TAB_TTS, c->tts_mean, c->tts_sigma); tab_exp(s, TAB_S1_EXP, c->s1_decay_time); tab_normal(s, TAB_S1_SPREAD, 0.0, c->s1_decay_spread);
@@ -230,7 +234,7 @@ void orc_free(orc_session *s)
     for (size_t i = 0; i < sizeof(ptrs) / sizeof(ptrs[0]); i++) free(*ptrs[i]);
     for (int q = 0; q < TAB_N; q++) { free(s->tab[q].cum); free(s->tab[q].thr); free(s->tab[q].alias); }
     for (i32 k = 0; k < s->n_xtab; k++) { free(s->xtab[k].cum); free(s->xtab[k].thr); free(s->xtab[k].alias); }
-    free(s->xtab); free(s->prop_top); free(s->prop_bot);
+    free(s->xtab); free(s->prop_top); free(s->prop_bot); free(s->gg_inv);
     free(s);
 }
 
@@ -688,8 +692,30 @@ void orc_set_instruction_models(orc_session *s, i64 n, const i32 *tab, const i32
 {
     s->n_ins_models = n; s->ins_tab = tab; s->ins_tabb = tabb; s->ins_pzi = pzi; s->ins_pzf = pzf;
 }
+/* garfield_gas_gap luminescence: timing_inv_cdf [n_gg][L] (load_resource.py:284-291); per instruction (same indexing as the
+ * arrays of the next orc_simulate* call) the index of the table at or below its gas gap (-1: not this model) and
+ * (gas gap - tabulated gas gap) / spacing (s2.py:474-476) */
+void orc_set_gas_gap_model(orc_session *s, i32 n_gg, i32 L, const double *inv)
+{
+    free(s->gg_inv); s->gg_inv = NULL; s->gg_n = n_gg; s->gg_L = L;
+    if (n_gg <= 0) return;
+    s->gg_inv = (double *)malloc((size_t)n_gg * L * 8); memcpy(s->gg_inv, inv, (size_t)n_gg * L * 8);
+}
+void orc_set_instruction_gas_gap(orc_session *s, i64 n, const i32 *idx, const double *w) { s->n_ins_gg = n; s->ins_gg = idx; s->ins_ggw = w; }
+/* excitation time of one photon, s2.py:443-446: a uniform position on the inverse CDF interpolated between the two tables */
+static double gg_time(const orc_session *s, i32 lo, double wgt, u32 w)
+{
+    const i32 L = s->gg_L, hi = lo + 1 < s->gg_n ? lo + 1 : s->gg_n - 1;
+    const double samples = ((double)w + 0.5) * (1.0 / 4294967296.0) * (double)(L - 2);
+    const double fl = floor(samples); const i32 i0 = (i32)fl, i1 = (i32)ceil(samples);
+    const double *A = s->gg_inv + (i64)lo * L, *B = s->gg_inv + (i64)hi * L;
+    const double t1 = (B[i0] - A[i0]) * wgt + A[i0], t2 = (B[i1] - A[i1]) * wgt + A[i1];
+    return (t2 - t1) * (samples - fl) + t1;
+}
+
 static void set_cur(orc_session *s, i64 i)
 {
+    s->cur_gg = (i < s->n_ins_gg && s->ins_gg && s->gg_inv) ? s->ins_gg[i] : -1; s->cur_ggw = s->cur_gg >= 0 ? s->ins_ggw[i] : 0.0;
     const int on = i < s->n_ins_models;
     s->cur_tab = on && s->ins_tab ? s->ins_tab[i] : -1; s->cur_tabb = on && s->ins_tabb ? s->ins_tabb[i] : s->cur_tab;
     s->cur_pzi = on && s->ins_pzi ? s->ins_pzi[i] : -1; s->cur_pzf = on && s->ins_pzf ? s->ins_pzf[i] : 0.0;
@@ -865,6 +891,7 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
 {
     const orc_config *c = &s->c;
     u64 T = bern_threshold(cy); u32 w[4]; i64 n0 = x->pb.t.n; u32 P = 0;       /* P: photons of this instruction so far */
+    vec_f64 lum; memset(&lum, 0, sizeof lum);                                   /* garfield gas gap: excitation time of every photon */
     for (i64 j = 0; j < amp; j++) {
         if ((j & 3) == 0) draw(s, em_base, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);
         if (!((u64)w[j & 3] < T)) continue;
@@ -882,10 +909,20 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
         VEC_PUSH(s->e_t, i64, et);
         for (i64 m = 0; m < nph; m++) {
             i64 t; int ch, dpe; double g;
+            if (s->cur_gg >= 0) { u32 Lw[4]; draw(s, em_base, gid, P >> 2, SITE_LUM, Lw); VEC_PUSH(lum, double, gg_time(s, s->cur_gg, s->cur_ggw, Lw[P & 3u])); }
             one_photon(s, 1, je, gid, (u32)m, em_base, P++, et, cdf, &t, &ch, &dpe, &g);
             ctx_push(x, t, ch, dpe, g, gid, (i64)je, m);
         }
     }
+    if (lum.n) {
+        /* s2.py:447-450: T - mean(T) over the instruction's photons, then the int64 cast of photon_timings (s2.py:532-533).
+         * The mean is taken in fixed point (2^-20 ns) so that it does not depend on the order of summation. */
+        i64 sum = 0;
+        for (i64 k = 0; k < lum.n; k++) sum += llrint(lum.p[k] * 1048576.0);
+        const double mean = (double)sum / (double)lum.n / 1048576.0;
+        for (i64 k = 0; k < lum.n; k++) x->pb.t.p[n0 + k] += (i64)(lum.p[k] - mean);
+    }
+    free(lum.p);
     return x->pb.t.n - n0;
 }
 /* the Pulse call over the collected photons (+ its PMT afterpulse call, rawdata.py:176-178) */
@@ -1131,3 +1168,13 @@ void orc_sample_delay(orc_session *s, i64 n, int is_s2, i32 tab, int bottom, i32
     }
 }
 void orc_sample_poisson(orc_session *s, double lam, i64 n, i64 *out) { for (i64 i = 0; i < n; i++) out[i] = poisson_draw(s, (u32)i, 12345u, lam); }
+
+/* the garfield gas gap luminescence term of n photons of one instruction exactly as gen_s2 adds it (tests) */
+void orc_sample_gas_gap(orc_session *s, i64 n, i32 lo, double wgt, i64 *out)
+{
+    double *T = (double *)malloc((size_t)(n ? n : 1) * 8); i64 sum = 0;
+    for (i64 k = 0; k < n; k++) { u32 w[4]; draw(s, 0, 515151u, (u32)(k >> 2), SITE_LUM, w); T[k] = gg_time(s, lo, wgt, w[k & 3]); sum += llrint(T[k] * 1048576.0); }
+    const double mean = n ? (double)sum / (double)n / 1048576.0 : 0.0;
+    for (i64 k = 0; k < n; k++) out[k] = (i64)(T[k] - mean);
+    free(T);
+}

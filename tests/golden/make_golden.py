@@ -659,6 +659,38 @@ def fixture_ele_ap_generators(ref):
     np.savez_compressed(HERE + '/ele_ap_draws.npz', **out)
 
 
+def gas_gap_resources():
+    """synthetic stand-ins for the private garfield gas gap files (load_resource.py:96-98): excitation-time inverse CDFs for 10
+    gas gaps 0.1 mm apart (a smooth S-shaped quantile function whose scale grows with the gap, plus a long last tail as in
+    the real tables) and a gas gap map linear in x"""
+    gas_gap = 0.20 + 0.01 * np.arange(10)
+    q = (np.arange(1000) + 0.5) / 1000
+    shape = 120.0 * q + 35.0 * np.log(q / (1 - q)) + 900.0 * q ** 12
+    inv = np.array([(0.6 + 2.2 * (g - 0.2) / 0.09) * shape + 40 * g for g in gas_gap])
+    return dict(gas_gap=gas_gap, timing_inv_cdf=inv)
+
+
+def fixture_gas_gap(ref):
+    """draws of the reference's 'garfield_gas_gap' luminescence (s2.py:413-483) for three instructions at different gas gaps"""
+    gg = gas_gap_resources()
+
+    class Res:
+        s2_luminescence_gg = gg
+
+        @staticmethod
+        def garfield_gas_gap_map(xy):
+            return 0.2 + 0.0009 * (np.asarray(xy)[:, 0] + 50.0)
+    xy = np.array([[-48.0, 3.0], [1.7, -20.0], [37.3, 11.0]])
+    n = np.array([250_000, 250_000, 250_000])
+    np.random.seed(717)
+    t = ref.s2.S2.luminescence_timings_garfield_gasgap(xy, n, Res).astype(np.int64)
+    out = dict(gas_gap=gg['gas_gap'], timing_inv_cdf=gg['timing_inv_cdf'], xy=xy, cont_gap=Res.garfield_gas_gap_map(xy))
+    for k in range(3):
+        v, c = np.unique(t[n[:k].sum():n[:k + 1].sum()], return_counts=True)
+        out[f'lum{k}_v'], out[f'lum{k}_c'] = v, c
+    np.savez_compressed(HERE + '/gas_gap.npz', **out)
+
+
 def fixture_optical_adjustment(ref):
     """utils.optical_adjustment (host preparation of optical input): random photon lists, a third of the entries longer
     than PULSE_MAX_DURATION, some empty"""
@@ -836,7 +868,7 @@ def fixture_chain_stats(ref):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws']
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap']
     ref = import_reference_interface() if 'chunker' in which else import_reference()
     p = fixture_tables(ref)
     if 'add_current' in which:
@@ -861,6 +893,8 @@ if __name__ == '__main__':
         fixture_chunker(ref)
     if 'ele_ap_draws' in which or 'ele_ap' in which:
         fixture_ele_ap_generators(ref)
+    if 'gas_gap' in which or 'models' in which:
+        fixture_gas_gap(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(('.npz', '.json')):
             print(f'{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:9.1f} KiB')

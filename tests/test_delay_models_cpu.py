@@ -164,3 +164,37 @@ def test_gas_gap_warping_tables(tag, x):
     assert tab[0] == tab[1] != tab[2] and tab[3] == -1 and np.array_equal(tab, tabb)
     orc.set_delay_models(models)                     # the tables of this batch
     _check(d, 's2_warp_' + tag, orc.sample_delay(N, True, tab=int(tab[0])))
+
+
+def gas_gap_resources(g=None):
+    """config entries of the 'garfield_gas_gap' luminescence: the synthetic tables tests/golden/gas_gap.npz was made with"""
+    g = g if g is not None else golden('gas_gap.npz')
+    return dict(s2_luminescence_gg=dict(gas_gap=g['gas_gap'], timing_inv_cdf=g['timing_inv_cdf']),
+                garfield_gas_gap_map=(lambda xy: 0.2 + 0.0009 * (np.asarray(xy)[:, 0] + 50.0)))
+
+
+@pytest.mark.parametrize('k', [0, 1, 2])
+def test_garfield_gas_gap_luminescence(k):
+    """s2.py:413-483 on the reference's own draws: three instructions under different gas gaps, 250k photons each
+    (inverse CDF interpolated between the two neighbouring tabulated gaps, the instruction's mean subtracted, truncated)"""
+    g = golden('gas_gap.npz')
+    cfg = dict(xenonnt_test_config(s2_luminescence_model='garfield_gas_gap', **gas_gap_resources(g)), seed=91 + k)
+    res = Resource(cfg)
+    models = DelayModels(cfg, res)
+    ins = one_instruction(2, x=float(g['xy'][k, 0]))
+    ins['y'] = g['xy'][k, 1]
+    idx, w = models.instruction_gas_gap(ins)
+    gaps = g['gas_gap']
+    assert idx[0] == np.digitize(g['cont_gap'][k], gaps) - 1 and np.isclose(gaps[idx[0]] + w[0] * (gaps[1] - gaps[0]), g['cont_gap'][k])
+    orc = make_oracle(cfg, resource=res)
+    x = orc.sample_gas_gap(250_000, int(idx[0]), float(w[0]))
+    _check(g, f'lum{k}', x)
+
+
+def test_garfield_gas_gap_needs_its_resources():
+    with pytest.raises(KeyError):
+        Resource(xenonnt_test_config(s2_luminescence_model='garfield_gas_gap'))
+    ins = one_instruction(1)
+    cfg = xenonnt_test_config(s2_luminescence_model='garfield_gas_gap', **gas_gap_resources())
+    idx, w = DelayModels(cfg, Resource(cfg)).instruction_gas_gap(ins)
+    assert idx[0] == -1                     # S1s carry no luminescence term

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from tests.helpers import make_engine, make_oracle, ap_tables_from_golden, golden
-from tests.test_delay_models_cpu import model_resources
+from tests.test_delay_models_cpu import model_resources, gas_gap_resources
 from wfsim_amd.config import xenonnt_test_config
 from wfsim_amd.dtypes import instruction_dtype
 from wfsim_amd.physics import instruction_params
@@ -18,7 +18,8 @@ pytestmark = pytest.mark.gpu
 
 S1_MODELS = ['custom', 'simple+custom', 'simple+optical_propagation', 'custom+optical_propagation', 'simple']
 S2_MODELS = [('simple', 'optical_propagation'), ('garfield', 'zero_delay'), ('garfield', 'optical_propagation'),
-             ('garfield', 's2_time_spread around zero'), ('simple', 's2_time_spread around zero')]
+             ('garfield', 's2_time_spread around zero'), ('simple', 's2_time_spread around zero'),
+             ('garfield_gas_gap', 'zero_delay'), ('garfield_gas_gap', 'optical_propagation')]
 
 
 def _case(seed):
@@ -28,6 +29,8 @@ def _case(seed):
     kw = dict(s1_model_type=S1_MODELS[(seed // len(S2_MODELS)) % len(S1_MODELS)], s2_luminescence_model=lum, s2_time_model=tm,
               led_pulse_length=float(rng.choice([12.5, 33.3])), s2_secondary_sc_gain=float(rng.choice([4.0, 21.3, 100.0])),
               seed=int(rng.integers(1, 10 ** 6)), **model_resources(d))
+    if lum == 'garfield_gas_gap':
+        kw.update(gas_gap_resources())
     if kw['s1_model_type'] == 'simple' and (lum, tm) == ('simple', 's2_time_spread around zero'):
         kw['s1_model_type'] = 'custom'          # never the all-default combination
     if lum == 'simple' and seed % 3 == 1:          # gas gap warping: a luminescence table per position (s2.py:360-378)
@@ -50,7 +53,7 @@ def _case(seed):
     return cfg, ins, ap
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS', 40)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS', 49)))))
 def test_model_variants_match_oracle(seed):
     cfg, ins, ap = _case(seed)
     res = Resource(cfg)
@@ -86,7 +89,7 @@ def test_models_change_the_result():
     assert out[0] != out[1]
 
 
-@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS_EAP', 10)))))
+@pytest.mark.parametrize('seed', list(range(int(os.environ.get('WFS_RANDOM_MODELS_EAP', 12)))))
 def test_model_variants_with_electron_afterpulses(seed):
     """RawData end to end with electron afterpulses: the pre-pass recomputes photon times (k_photon_times) from the same
     tables, batches are cut at random"""
@@ -96,10 +99,11 @@ def test_model_variants_with_electron_afterpulses(seed):
     d = golden('dists_models.npz')
     edges = np.linspace(0, 150e3, 141)
     hist = np.exp(-np.arange(140) / 30.0); hist *= 3e-3 / hist.sum()
-    lum, tm = S2_MODELS[seed % 4]
+    lum, tm = S2_MODELS[(0, 1, 5, 2, 6, 3)[seed % 6]]
+    extra = gas_gap_resources() if lum == 'garfield_gas_gap' else {}
     cfg = xenonnt_test_config(enable_electron_afterpulses=True, uniform_to_ele_ap=(hist, edges), seed=int(rng.integers(1, 10 ** 6)),
                               s2_secondary_sc_gain=60.0, s1_model_type=S1_MODELS[seed % 4], s2_luminescence_model=lum, s2_time_model=tm,
-                              led_pulse_length=20.0, **model_resources(d))
+                              led_pulse_length=20.0, **model_resources(d), **extra)
     n = int(rng.integers(3, 20))
     ins = np.zeros(n, dtype=instruction_dtype)
     ins['type'] = rng.choice([1, 2], n)

@@ -69,9 +69,7 @@ def kernel_params(config):
         assert part in ('', 'simple', 'custom', 'optical_propagation', 'nest'), f'Model type "{part}" not in the valid S1 model types'
         if part == 'nest':
             raise NotImplementedError('s1_model_type "nest" needs nestpy and is outside the MI355X hot path (SURVEY.md 2.1 row 2)')
-    if c.get('s2_luminescence_model', 'simple') not in ('simple', 'garfield'):
-        if c.get('s2_luminescence_model') == 'garfield_gas_gap':
-            raise NotImplementedError('s2_luminescence_model "garfield_gas_gap" is outside the MI355X hot path (delay_models.py)')
+    if c.get('s2_luminescence_model', 'simple') not in ('simple', 'garfield', 'garfield_gas_gap'):
         raise KeyError(f"{c['s2_luminescence_model']} is not valid! Use 'simple' or 'garfield' or 'garfield_gas_gap'")
     # same substring tests, in the same order, as s2.py:539-552; the propagation term itself is a delay table (delay_models.py)
     if 'optical_propagation' in c['s2_time_model'] or 'zero_delay' in c['s2_time_model']:

@@ -26,6 +26,7 @@ enum WfsSite : u32 {
     SITE_GAIN = 18,      // -> first SPE index, double-PE flag, second SPE index
     SITE_PH = 19,        // photons that arrive with time and channel (optical input), counter (0, gid, item): x -> transit time, y -> gains
     SITE_PH_X = 20,      // per photon (emitter, gid, item), S1 optical propagation only: x -> spline coordinate
+    SITE_LUM = 21,       // photon stream (as SITE_DELAY): position on the excitation-time inverse CDF ('garfield_gas_gap' luminescence)
     SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
 };
 

@@ -78,6 +78,7 @@ struct wfs_handle {
     std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
     DevBuf prop_top, prop_bot; i32 prop_nz = 0, prop_nu = 0; double prop_u0 = 0, prop_du = 1;
     DevBuf ins_tab, ins_tabb, ins_pzi, ins_pzf; bool ins_models = false;
+    DevBuf gg_inv, ins_gg, ins_ggw, ins_ggsum; i32 gg_n = 0, gg_L = 0; bool ins_gg_set = false;       // 'garfield_gas_gap' luminescence
     // pattern maps evaluated on the device
     struct PatternMap { bool set = false; i32 dims = 0, n[3] = {1, 1, 1}, w[3] = {0, 0, 0}, n_map_ch = 0; double lo[3] = {0, 0, 0}, hgrid[3] = {1, 1, 1}; DevBuf values; } pmap[2];
     std::vector<i32> dev_row_ins; std::vector<int8_t> h_ins_type; i64 n_host_rows = 0; bool dev_rows_pending = false;
@@ -392,7 +393,7 @@ int wfs_destroy(wfs_handle *h)
         hipFree(h->stamps.p);
     }
 #endif
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -613,7 +614,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     TRY(load_clusters(h, n, cluster, tmin, gid));
-    h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false; h->ins_models = false;
+    h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false; h->ins_models = false; h->ins_gg_set = false;
     return WFS_OK;
 }
 
@@ -755,6 +756,32 @@ int wfs_set_instruction_models(wfs_handle *h, int64_t n, const int32_t *tab, con
     return WFS_OK;
 }
 
+// ---- s2_luminescence_model 'garfield_gas_gap' (s2.py:413-483, load_resource.py:284-291) ----
+int wfs_set_gas_gap_model(wfs_handle *h, int32_t n_gas_gaps, int32_t n_points, const double *timing_inv_cdf)
+{
+    if (!h) return WFS_E_INVALID;
+    if (n_gas_gaps == 0) { h->gg_n = 0; return WFS_OK; }
+    if (n_gas_gaps < 1 || n_points < 3 || !timing_inv_cdf) return h->fail(WFS_E_INVALID, "wfs_set_gas_gap_model: at least one table of at least 3 points");
+    HIPCHK(hipSetDevice(h->device));
+    TRY(upload(h, h->gg_inv, timing_inv_cdf, (size_t)n_gas_gaps * n_points * 8));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->gg_n = n_gas_gaps; h->gg_L = n_points;
+    return WFS_OK;
+}
+
+int wfs_set_instruction_gas_gap(wfs_handle *h, int64_t n, const int32_t *table, const double *weight)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins || !table || !weight) return h->fail(WFS_E_STATE, "wfs_set_instruction_gas_gap follows wfs_load_instructions of the same batch");
+    if (h->gg_n < 1) return h->fail(WFS_E_STATE, "wfs_set_gas_gap_model first");
+    for (i64 i = 0; i < n; i++) if (table[i] < -1 || table[i] >= h->gg_n) return h->fail(WFS_E_INVALID, "gas gap table index out of range");
+    HIPCHK(hipSetDevice(h->device));
+    TRY(upload(h, h->ins_gg, table, (size_t)n * 4)); TRY(upload(h, h->ins_ggw, weight, (size_t)n * 8));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->ins_gg_set = true; h->gen_done = false;
+    return WFS_OK;
+}
+
 int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, const int64_t *set_tmin, const int64_t *set_off,
                      const int64_t *t, const int16_t *ch, const double *gain, const uint8_t *dpe)
 {
@@ -879,6 +906,10 @@ static int run_generation(wfs_handle *h)
         g.tabs = h->d_tabs.as<AliasTab>(); g.ins_tab = h->ins_tab.as<i32>(); g.ins_tabb = h->ins_tabb.as<i32>();
         g.ins_pzi = h->ins_pzi.as<i32>(); g.ins_pzf = h->ins_pzf.as<double>();
         if (h->prop_nz >= 2) { g.prop_top = h->prop_top.as<double>(); g.prop_bot = h->prop_bot.as<double>(); g.prop_nu = h->prop_nu; g.prop_u0 = h->prop_u0; g.prop_du = h->prop_du; }
+        if (h->ins_gg_set && h->gg_n >= 1) {
+            TRY(ensure(h, h->ins_ggsum, (size_t)(N + 1) * 8)); HIPCHK(hipMemsetAsync(h->ins_ggsum.p, 0, (size_t)(N + 1) * 8, h->stream));
+            g.gg_inv = h->gg_inv.as<double>(); g.gg_n = h->gg_n; g.gg_L = h->gg_L; g.ins_gg = h->ins_gg.as<i32>(); g.ins_ggw = h->ins_ggw.as<double>(); g.ins_ggsum = h->ins_ggsum.as<i64>();
+        }
     }
     { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }
     {
@@ -929,6 +960,7 @@ static int run_generation(wfs_handle *h)
         // cache lines of a tile (consecutive ranges, k_block_ranges) run close together in time on the same L2
         g.xcd_chunk = (nb + 7) / 8;
         const unsigned nbx = (unsigned)(g.xcd_chunk * 8);
+        if (g.gg_inv) { Timer t(h, "k_gg_sum"); hipLaunchKernelGGL(k_gg_sum, dim3(nb), dim3(256), 0, h->stream, d, g); }
         { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(COUNT_TPB), GEN_COUNT_LDS(d.n_tpc), h->stream, d, g); }
         { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));

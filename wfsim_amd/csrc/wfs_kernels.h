@@ -1323,6 +1323,10 @@ struct GenArgs {
     const i32 *ins_tab, *ins_tabb;        // [n_ins] table of the instruction's photons on top / bottom array channels
     const i32 *ins_pzi; const double *ins_pzf;    // [n_ins] S1 optical propagation: z cell of the spline grid and normalised distance in it (-1: none)
     const double *prop_top, *prop_bot; i32 prop_nu; double prop_u0, prop_du;      // spline node values [nz][nu], u grid
+    // 'garfield_gas_gap' luminescence (s2.py:413-483): inverse CDFs of the excitation time per tabulated gas gap [gg_n][gg_L];
+    // per instruction the table at or below its gas gap (-1: not this model), the interpolation weight towards the next
+    // table, and the sum of its photons' excitation times in units of 2^-20 ns (k_gg_sum; the mean is subtracted, s2.py:447)
+    const double *gg_inv; i32 gg_n, gg_L; const i32 *ins_gg; const double *ins_ggw; i64 *ins_ggsum;
 };
 
 // S1 optical propagation delay (s1.py:241-260): multilinear interpolation of the spline nodes, evaluated as scipy's
@@ -1340,6 +1344,24 @@ __device__ __forceinline__ double s1_propagation(const GenArgs &a, bool bottom, 
     v += r1[0] * (zf * (1.0 - uf));
     v += r1[1] * (zf * uf);
     return v;
+}
+
+// excitation time of one photon from the garfield gas gap tables (s2.py:436-446): a uniform position on the inverse CDF,
+// interpolated between the two tables that bracket the instruction's gas gap; same operation order as the oracle
+__device__ __forceinline__ double gg_time(const GenArgs &a, i32 lo, double wgt, u32 w)
+{
+    const i32 L = a.gg_L, hi = lo + 1 < a.gg_n ? lo + 1 : a.gg_n - 1;
+    const double samples = ((double)w + 0.5) * (1.0 / 4294967296.0) * (double)(L - 2);
+    const double fl = floor(samples); const i32 i0 = (i32)fl, i1 = (i32)ceil(samples);
+    const double *A = a.gg_inv + (i64)lo * L, *B = a.gg_inv + (i64)hi * L;
+    const double t1 = (B[i0] - A[i0]) * wgt + A[i0], t2 = (B[i1] - A[i1]) * wgt + A[i1];
+    return (t2 - t1) * (samples - fl) + t1;
+}
+// mean excitation time of an instruction's photons (fixed point sum -> independent of the order of summation)
+__device__ __forceinline__ double gg_mean(const GenArgs &a, i32 ins)
+{
+    const i64 n = a.ins_ph0[ins + 1] - a.ins_ph0[ins];
+    return n > 0 ? (double)a.ins_ggsum[ins] / (double)n / 1048576.0 : 0.0;
 }
 
 // Poisson: PTRS (Hoermann 1993) for lam >= 10, multiplication method below; same algorithm and uniforms as the oracle
@@ -1795,6 +1817,37 @@ __device__ __forceinline__ int photon_channel_global(const WfsDev &d, const GenA
 // in order, so that the blocks writing neighbouring ranges of a tile run close together in time behind the same L2.
 __device__ __forceinline__ i64 block_of_workgroup(const GenArgs &a) { return (i64)(blockIdx.x & 7) * a.xcd_chunk + (blockIdx.x >> 3); }
 
+// 'garfield_gas_gap' luminescence: sum of the excitation times of every instruction's photons (block by block like the count
+// pass; only launched when a loaded instruction uses the model)
+__global__ __launch_bounds__(256) void k_gg_sum(WfsDev d, GenArgs a)
+{
+    const i64 vb = blockIdx.x;
+    if (vb >= a.n_blocks) return;
+    const BlockDesc bd = a.blk_desc[vb];
+    const i64 p0 = vb * GEN_BLOCK;
+    const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
+    if (bd.ins >= 0) {
+        const i32 lo = a.ins_gg[bd.ins];
+        if (lo < 0) return;                                  // block-uniform
+        const double wgt = a.ins_ggw[bd.ins];
+        const u32 q0 = (u32)(bd.R0 >> 2); const int r = (int)(bd.R0 & 3);
+        i64 sum = 0;
+        for (int qi = threadIdx.x; 4 * qi - r < np; qi += 256) {
+            const u32x4 W = philox4x32_10(bd.eb, bd.gid, q0 + (u32)qi, SITE_LUM, d.k0, d.k1);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int pr = 4 * qi + k - r; if (pr >= 0 && pr < np) sum += __double2ll_rn(gg_time(a, lo, wgt, word_of(W, k)) * 1048576.0); }
+        }
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+        if ((threadIdx.x & 63) == 0 && sum) atomicAdd((u64 *)&a.ins_ggsum[bd.ins], (u64)sum);
+    } else {
+        for (int pr = threadIdx.x; pr < np; pr += 256) {
+            const PhotonId id = photon_id(a, p0 + pr, a.blk_e[2 * vb], a.blk_e[2 * vb + 1] + 1);
+            const i32 lo = a.ins_gg[id.ins];
+            if (lo >= 0) atomicAdd((u64 *)&a.ins_ggsum[id.ins], (u64)__double2ll_rn(gg_time(a, lo, a.ins_ggw[id.ins], photon_word(d, id, SITE_LUM)) * 1048576.0));
+        }
+    }
+}
+
 #define GEN_COUNT_LDS(nch) ((size_t)(nch) * 8 + (CDF_G + 8) * 2)
 
 __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
@@ -1895,6 +1948,8 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
             tab_t = a.tabs[a.ins_tab[bd.ins]]; tab_b = a.tabs[a.ins_tabb[bd.ins]];
             if (a.prop_top && !bd.is_s2) { pzi = a.ins_pzi[bd.ins]; pzf = a.ins_pzf[bd.ins]; }
         }
+        i32 gg_lo = -1; double gg_w = 0.0, gg_m = 0.0;       // garfield gas gap luminescence of this instruction
+        if (EXT && a.gg_inv && a.ins_gg[bd.ins] >= 0) { gg_lo = a.ins_gg[bd.ins]; gg_w = a.ins_ggw[bd.ins]; gg_m = gg_mean(a, bd.ins); }
 #define TAB_OF(c) (EXT ? ((c) >= d.n_top ? tab_b : tab_t) : tab)
         const i64 tbase = (i64)set_lo * nch;
         const i64 set_ph0 = a.tile_off[tbase];               // first photon slot of the set: per-channel offsets fit 32 bits
@@ -1945,6 +2000,8 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                 e[k] = TAB_OF(ch[k]).cell[cell[k]];
             }
             const u32x4 G = philox4x32_10(eb, gid, q0 + (u32)qi, SITE_GAIN, d.k0, d.k1);      // (under the latency of the table gathers)
+            u32x4 LW = u32x4{0u, 0u, 0u, 0u};
+            if (EXT && gg_lo >= 0) LW = philox4x32_10(eb, gid, q0 + (u32)qi, SITE_LUM, d.k0, d.k1);
             // emitter of the quad's first photon: last slot with win[slot] <= pr (emitters without photons are skipped);
             // photons are spread evenly over the block's emitters, so an interpolated guess lands within a step or two
             int slot;
@@ -1966,6 +2023,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                     const u32x4 X = philox4x32_10(j, gid, m, SITE_PH_X, d.k0, d.k1);
                     t += (i32)(i64)s1_propagation(a, c >= d.n_top, pzi, pzf, X.x);
                 }
+                if (EXT && gg_lo >= 0) t += (i32)(i64)(gg_time(a, gg_lo, gg_w, word_of(LW, k)) - gg_m);      // s2.py:447-450, the cast of :532
                 if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t);
                 atomicMin(&hmin[c], t); atomicMax(&hmax[c], t);
                 stage[hist[c] + atomicAdd(&cur[c], 1)] = PhotonRec{t, code};
@@ -1999,6 +2057,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                 const u32x4 X = philox4x32_10(id.j, id.gid, id.m, SITE_PH_X, d.k0, d.k1);
                 t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], X.x);
             }
+            if (EXT && a.gg_inv && a.ins_gg[ins] >= 0) t += (i64)(gg_time(a, a.ins_gg[ins], a.ins_ggw[ins], photon_word(d, id, SITE_LUM)) - gg_mean(a, ins));
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
             if (AP) ap_generate(d, a, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
@@ -2056,6 +2115,7 @@ __global__ void k_photon_times(WfsDev d, GenArgs a, i64 n, const i64 *index, i64
             const u32x4 X = philox4x32_10(id.j, id.gid, id.m, SITE_PH_X, d.k0, d.k1);
             t += (i64)s1_propagation(a, ch >= d.n_top, a.ins_pzi[ins], a.ins_pzf[ins], X.x);
         }
+        if (a.gg_inv && a.ins_gg[ins] >= 0) t += (i64)(gg_time(a, a.ins_gg[ins], a.ins_ggw[ins], photon_word(d, id, SITE_LUM)) - gg_mean(a, ins));
         out[i] = t;
         return;
     }

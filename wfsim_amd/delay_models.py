@@ -12,8 +12,11 @@ the default terms and samples the sum from one uniform (include/wfsim_amd.h: wfs
 * S1 ``optical_propagation`` (s1.py:185-188, 241-260) depends on z continuously: evaluated per photon on the device from
   the spline nodes (wfs_set_s1_propagation), not a table.
 
-``nest`` (needs nestpy) and ``garfield_gas_gap`` (subtracts the mean of each electron's own draws, s2.py:447-448: not a
-sum of independent terms) stay outside the path.
+* S2 ``garfield_gas_gap`` luminescence (s2.py:413-483) is NOT an independent term -- the mean of the instruction's own draws is
+  subtracted (s2.py:447-448): the device draws it per photon from the interpolated excitation-time tables and subtracts the
+  instruction's mean (wfs_set_gas_gap_model / wfs_set_instruction_gas_gap); the remaining terms come from a table.
+
+``nest`` (needs nestpy) stays outside the path.
 """
 import numpy as np
 
@@ -186,6 +189,7 @@ class DelayModels:
         self.s1_tables = {}                 # recoil class -> table
         self.s1_prop = None
         self.s2_rows = None                 # garfield: x grid of the rows
+        self.gas_gap = None                 # garfield_gas_gap: tabulated gas gaps, inverse CDFs, the (x, y) -> gas gap map
         self.s2_tables = None               # [n_rows or 1][2] table index per row and array
         if 'custom' in s1_model:
             for kind in RECOIL_CLASSES:
@@ -221,6 +225,13 @@ class DelayModels:
             for r in range(len(x)):
                 row = pmf_samples(t[r].astype(np.int64) - avgt)
                 self.s2_tables.append([self._add(3, row.conv(s2_prop[k]) if s2_prop else row) for k in range(2 if s2_prop else 1)])
+        elif lum_model == 'garfield_gas_gap':
+            gg = resource.s2_luminescence_gg
+            self.gas_gap = dict(gas_gap=np.asarray(gg['gas_gap'], dtype=np.float64), inv=np.ascontiguousarray(gg['timing_inv_cdf'], dtype=np.float64),
+                                map=resource.garfield_gas_gap_map)
+            assert self.gas_gap['inv'].ndim == 2 and len(self.gas_gap['gas_gap']) == len(self.gas_gap['inv']) >= 2
+            # everything but the luminescence: singlet / triplet + spread + transit time (base 3) (+ optical propagation)
+            self.s2_tables = [[self._add(3, s2_prop[k] if s2_prop else pmf_delta(0)) for k in range(2 if s2_prop else 1)]]
         elif lum_model != 'simple':
             raise NotImplementedError(f's2_luminescence_model "{lum_model}" is outside the MI355X hot path (delay_models.py)')
         elif s2_prop:
@@ -266,6 +277,22 @@ class DelayModels:
             rot = np.array(((np.cos(tilt), -np.sin(tilt)), (np.sin(tilt), np.cos(tilt))))
             distance = (np.matmul(xy, rot)[:, 1] + pitch / 2) % pitch - pitch / 2
         return np.array([np.argmin(np.abs(d - self.s2_rows)) for d in distance], dtype=np.int64)
+
+    def instruction_gas_gap(self, instructions):
+        """(table, weight) per instruction for wfs_set_instruction_gas_gap: s2.py:470-476 -- the tabulated gas gap at or below the
+        one under the instruction (np.digitize - 1) and the distance to it in units of the spacing; -1 for S1s"""
+        n = len(instructions)
+        idx, w = np.full(n, -1, dtype=np.int32), np.zeros(n, dtype=np.float64)
+        s2 = np.where(instructions['type'] != 1)[0]
+        if len(s2):
+            gaps = self.gas_gap['gas_gap']
+            d_gas_gap = gaps[1] - gaps[0]
+            xy = np.array([instructions['x'][s2], instructions['y'][s2]]).T
+            cont = np.asarray(self.gas_gap['map'](xy), dtype=np.float64).reshape(len(s2), -1)[:, 0]
+            draw = np.clip(np.digitize(cont, gaps) - 1, 0, len(gaps) - 1)      # (below the first gap the reference wraps to the last table)
+            idx[s2] = draw
+            w[s2] = (cont - gaps[draw]) / d_gas_gap
+        return idx, w
 
     def instruction_tables(self, instructions, gids=None):
         """(tab, tab_bottom, prop_zi, prop_zf) for wfs_set_instruction_models"""

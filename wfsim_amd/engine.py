@@ -79,7 +79,8 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_copy_photons', 'wfs_copy_truth', 'wfs_copy_truth_per_pmt', 'wfs_copy_instruction_photon_offsets', 'wfs_gather_photon_times', 'wfs_copy_electron_stats', 'wfs_set_window_carry', 'wfs_copy_cluster_groups', 'wfs_set_noise_offsets', 'wfs_set_debug', 'wfs_set_stream', 'wfs_synchronize',
            'wfs_kernel_times', 'wfs_set_profiling', 'wfs_set_delay_models', 'wfs_set_s1_propagation', 'wfs_set_instruction_models',
            'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range',
-           'wfs_copy_records_range_async', 'wfs_wait_records', 'wfs_host_register', 'wfs_host_unregister']
+           'wfs_copy_records_range_async', 'wfs_wait_records', 'wfs_host_register', 'wfs_host_unregister',
+           'wfs_set_gas_gap_model', 'wfs_set_instruction_gas_gap']
 
 
 def load_library():
@@ -200,6 +201,9 @@ class Engine:
             if sp is not None:
                 self._check(self.lib.wfs_set_s1_propagation(self._h, C.c_int32(len(sp['z'])), C.c_int32(sp['nu']), C.c_double(sp['u0']),
                                                             C.c_double(sp['du']), _p(sp['top']), _p(sp['bottom'])))
+            gg = self.models.gas_gap
+            if gg is not None:
+                self._check(self.lib.wfs_set_gas_gap_model(self._h, C.c_int32(gg['inv'].shape[0]), C.c_int32(gg['inv'].shape[1]), _p(gg['inv'])))
 
     # ------------------------------------------------------------------------------------------
     def _check(self, rc):
@@ -246,6 +250,9 @@ class Engine:
                 base, off, pmf, vmin = self.models.table_arrays()
                 self._check(self.lib.wfs_set_delay_models(self._h, C.c_int32(len(base)), _p(base), _p(off), _p(pmf), _p(vmin)))
             self._check(self.lib.wfs_set_instruction_models(self._h, C.c_int64(n), _p(tab), _p(tabb), _p(zi), _p(zf)))
+            if self.models.gas_gap is not None:
+                gi, gw = self.models.instruction_gas_gap(ins)
+                self._check(self.lib.wfs_set_instruction_gas_gap(self._h, C.c_int64(n), _p(gi), _p(gw)))
 
     def cdf_rows(self):
         """(cdf_row, cdf_table) of the loaded batch as the generator uses them, device-evaluated rows included"""

@@ -177,6 +177,15 @@ class Resource:
                 level = min(levels, key=lambda x: abs(x - (c['gate_to_anode_distance'] - c['elr_gas_gap_length'])))
                 lum = lum[lum['ll'] == level]
             self.s2_luminescence = dict(t=np.asarray(lum['t']), x=np.asarray(lum['x']))
+        if 'garfield_gas_gap' in c.get('s2_luminescence_model', ''):
+            # load_resource.py:284-291: excitation-time inverse CDFs per tabulated gas gap + the map (x, y) -> gas gap
+            gg = c['s2_luminescence_gg']
+            if isinstance(gg, str):
+                gg = np.load(gg, allow_pickle=True)
+                gg = gg['arr_0'] if hasattr(gg, 'files') and 'arr_0' in gg.files else gg
+            self.s2_luminescence_gg = dict(gas_gap=np.asarray(gg['gas_gap'], dtype=np.float64).reshape(-1),
+                                           timing_inv_cdf=np.ascontiguousarray(np.asarray(gg['timing_inv_cdf'], dtype=np.float64)))
+            self.garfield_gas_gap_map = make_map(c['garfield_gas_gap_map'])
         if c.get('enable_gas_gap_warping', False):
             self.gas_gap_length = make_map(c['gas_gap_map'])
         # SPE area distributions: dict(charge, pdf[, n_channels]) or dict(charge, pdfs[n_ch, n_bins]) or a CSV path
