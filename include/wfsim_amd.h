@@ -160,6 +160,32 @@ int wfs_set_instruction_gas_gap(wfs_handle *h, int64_t n, const int32_t *table, 
 int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
                         const float *values, int32_t n_map_channels);
 int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float *y, const float *z);
+/* The same for a map on an irregular coordinate system (a list of points: straxen queries a KD-tree for the 2 * dims
+ * nearest points): points f64[n_points][dims], values f32[n_points][n_map_channels]. */
+int wfs_set_pattern_map_points(wfs_handle *h, int32_t which, int32_t dims, int64_t n_points, const double *points,
+                               const float *values, int32_t n_map_channels);
+/* s2_aft_sigma / s2_aft_skewness (S2.photon_channels, s2.py:660-665): factor[i] = the skew-normal draw of instruction i
+ * (NaN: leave the pattern alone); on the rows the device evaluates the top-array fraction cur becomes
+ * new = clip(cur * factor, 0, 1), top channels are scaled by new / cur and the others by (1 - new) / (1 - cur).
+ * Call between wfs_load_instructions and wfs_eval_pattern_rows; factor = NULL clears it. */
+int wfs_set_instruction_aft(wfs_handle *h, int64_t n, const double *factor);
+
+/* ---- scalar maps evaluated on the device -------------------------------------------------------------------
+ * The per-instruction inputs of the generator that the reference reads from straxen InterpolatingMaps: S1 light yield
+ * (resource.s1_lce_correction_map, s1.py:125), S2 correction / single-electron gain (s2.py:193-196, 229-234), longitudinal
+ * diffusion (s2.py:170), field-distortion corrections (s2.py:41), all WeightedNearestNeighbors on a regular grid
+ * (wfs_scalar_map_grid) or a point list (wfs_scalar_map_points); and the field-dependence / COMSOL maps, which
+ * load_resource.py:316,326 builds with method RectBivariateSpline (wfs_scalar_map_spline: the knots tx[nx], ty[ny], degrees
+ * and coefficients c[(nx-kx-1)*(ny-ky-1)] of scipy's spline object; evaluated like its .ev(): FITPACK bispeu, arguments
+ * clamped to the knot range).  Each call registers a map for the lifetime of the handle and returns its id.
+ * wfs_scalar_map_eval: pos f64[n][dims] -> out f64[n].  Tolerance against the host evaluation: rtol 1e-6 (different
+ * summation order; the nearest neighbours of a position equidistant to several nodes may be chosen differently). */
+int wfs_scalar_map_grid(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
+                        const double *values, int32_t *map_id);
+int wfs_scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values, int32_t *map_id);
+int wfs_scalar_map_spline(wfs_handle *h, int32_t nx, const double *tx, int32_t ny, const double *ty, int32_t kx, int32_t ky,
+                          const double *c, int32_t *map_id);
+int wfs_scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out);
 int wfs_copy_cdf_rows(wfs_handle *h, int32_t *cdf_row, double *cdf_table, int64_t cap_rows);
 
 /* Order of the packed records of a batch: 0 (default) as the reference yields pulses (window, channel, interval,

@@ -691,6 +691,28 @@ def fixture_gas_gap(ref):
     np.savez_compressed(HERE + '/gas_gap.npz', **out)
 
 
+def fixture_aft_sigma(ref):
+    """S2.photon_channels with s2_aft_sigma / s2_aft_skewness (s2.py:660-665): photons on the top array per instruction, for
+    3000 instructions of 2000 photons at one position of a fixed pattern (top fraction 0.72: the clip at 1 is reached)"""
+    rng = np.random.default_rng(5)
+    p0 = rng.uniform(0.5, 1.5, N_TPC)
+    p0[:N_TOP] *= 0.72 / p0[:N_TOP].sum()
+    p0[N_TOP:] *= 0.28 / p0[N_TOP:].sum()
+
+    class Res:
+        @staticmethod
+        def s2_pattern_map(pos):
+            return np.tile(p0, (len(pos), 1))
+    n_ins, n_ph = 3000, 2000
+    cfg = base_config(s2_aft_sigma=0.15, s2_aft_skewness=2.0, turned_off_pmts=np.zeros(0, dtype=np.int64))
+    np.random.seed(99)
+    ch = ref.s2.S2.photon_channels(np.full(n_ins, 10), np.zeros(n_ins), np.zeros((n_ins, 2)), np.repeat(np.arange(n_ins), n_ph), cfg, Res)
+    top = (np.asarray(ch).reshape(n_ins, n_ph) < N_TOP).sum(axis=1)
+    # within the top array the relative pattern is untouched: pooled top-channel histogram
+    hist = np.bincount(np.asarray(ch)[np.asarray(ch) < N_TOP], minlength=N_TOP)
+    np.savez_compressed(HERE + '/aft_sigma.npz', pattern=p0, n_photons=n_ph, sigma=0.15, skewness=2.0, top_counts=top, top_hist=hist)
+
+
 def fixture_optical_adjustment(ref):
     """utils.optical_adjustment (host preparation of optical input): random photon lists, a third of the entries longer
     than PULSE_MAX_DURATION, some empty"""
@@ -868,7 +890,7 @@ def fixture_chain_stats(ref):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap']
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap', 'aft_sigma']
     ref = import_reference_interface() if 'chunker' in which else import_reference()
     p = fixture_tables(ref)
     if 'add_current' in which:
@@ -895,6 +917,8 @@ if __name__ == '__main__':
         fixture_ele_ap_generators(ref)
     if 'gas_gap' in which or 'models' in which:
         fixture_gas_gap(ref)
+    if 'aft_sigma' in which:
+        fixture_aft_sigma(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(('.npz', '.json')):
             print(f'{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:9.1f} KiB')

@@ -196,3 +196,35 @@ def test_correction_maps_derived_from_the_pattern_maps():
     ins['type'][:2] = 1
     ip = instruction_params(ins, cfg, res)
     assert np.all(ip['p_hit'] > 0) and np.all(ip['sc_gain'][2:] > 0)
+
+
+def test_aft_smearing_against_the_reference_draws():
+    """tests/golden/aft_sigma.npz: S2.photon_channels of the reference with s2_aft_sigma = 0.15, skewness 2 -- photons on the
+    top array for 3000 instructions of 2000 photons each.  Ours: the per-instruction top fraction of the smeared rows, with
+    the binomial counting noise of 2000 photons on top; two-sample KS and moments."""
+    from tests.helpers import golden
+    from tests.test_oracle_distributions import _ks, _ks_limit
+    d = golden('aft_sigma.npz')
+    p0, n_ph = d['pattern'], int(d['n_photons'])
+    cfg = xenonnt_test_config(s2_aft_sigma=float(d['sigma']), s2_aft_skewness=float(d['skewness']), seed=4)
+    n_top = cfg['n_top_pmts']
+
+    class Res:
+        @staticmethod
+        def s2_pattern_map(pos):
+            return np.tile(p0, (len(pos), 1))
+    n = 20000
+    p = s2_channel_probabilities(np.zeros((n, 2)), cfg, Res, gids=np.arange(n))
+    aft = p[:, :n_top].sum(axis=1)
+    assert np.allclose(p.sum(axis=1), 1.0) and aft.max() <= 1.0 + 1e-12
+    ours = np.random.default_rng(0).binomial(n_ph, np.clip(aft, 0, 1))
+    v, c = np.unique(d['top_counts'], return_counts=True)
+    assert _ks(v, c, ours) < _ks_limit(c.sum(), n)
+    ref = d['top_counts'] / n_ph
+    assert abs(ours.mean() / n_ph - ref.mean()) < 5 * ref.std() * np.sqrt(1 / n + 1 / len(ref))
+    assert abs(ours.std() / n_ph / ref.std() - 1) < 0.05
+    assert abs((aft > 1 - 1e-9).mean() - (ref == 1).mean()) < 0.004              # instructions clipped to the top array only
+    # inside the top array the pattern keeps its shape (pooled reference histogram against p0)
+    h = d['top_hist'] / d['top_hist'].sum()
+    q = p0[:n_top] / p0[:n_top].sum()
+    assert np.abs(h - q).max() < 5 * np.sqrt(q.max() / d['top_hist'].sum())

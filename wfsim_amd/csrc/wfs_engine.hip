@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -80,7 +81,12 @@ struct wfs_handle {
     DevBuf ins_tab, ins_tabb, ins_pzi, ins_pzf; bool ins_models = false;
     DevBuf gg_inv, ins_gg, ins_ggw, ins_ggsum; i32 gg_n = 0, gg_L = 0; bool ins_gg_set = false;       // 'garfield_gas_gap' luminescence
     // pattern maps evaluated on the device
-    struct PatternMap { bool set = false; i32 dims = 0, n[3] = {1, 1, 1}, w[3] = {0, 0, 0}, n_map_ch = 0; double lo[3] = {0, 0, 0}, hgrid[3] = {1, 1, 1}; DevBuf values; } pmap[2];
+    struct PatternMap { bool set = false; i32 dims = 0, n[3] = {1, 1, 1}, w[3] = {0, 0, 0}, n_map_ch = 0; double lo[3] = {0, 0, 0}, hgrid[3] = {1, 1, 1}; DevBuf values;
+                        i64 n_points = 0; DevBuf points; } pmap[2];
+    // scalar maps (kind 0: weighted nearest neighbours on a regular grid, 1: on a point list, 2: RectBivariateSpline)
+    struct ScalarMap { int kind = 0; PatternMap g; i32 nx = 0, ny = 0, kx = 0, ky = 0; DevBuf tx, ty, c; };
+    std::vector<std::unique_ptr<ScalarMap>> smaps;
+    DevBuf smap_pos, smap_out, smap_nb_idx, smap_nb_w, ins_aft; bool ins_aft_set = false;
     std::vector<i32> dev_row_ins; std::vector<int8_t> h_ins_type; i64 n_host_rows = 0; bool dev_rows_pending = false;
     DevBuf map_row_ins[2], map_row_id[2], map_x, map_y, map_z, map_nb_idx[2], map_nb_w[2];
 
@@ -402,6 +408,8 @@ int wfs_destroy(wfs_handle *h)
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
+    for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft}) if (b->p) hipFree(b->p);
+    for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
     for (auto &b : h->x_alias) if (b.p) hipFree(b.p);
     for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); }
@@ -579,7 +587,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     {
         std::vector<i32> rows(cdf_row, cdf_row + n);
         for (i64 i = 0; i < n; i++) if (rows[i] < 0) { rows[i] = (i32)(n_cdf + (i64)h->dev_row_ins.size()); h->dev_row_ins.push_back((i32)i); }
-        h->dev_rows_pending = !h->dev_row_ins.empty();
+        h->dev_rows_pending = !h->dev_row_ins.empty(); h->ins_aft_set = false;
         const size_t total = (size_t)n_cdf + h->dev_row_ins.size();
         TRY(ensure(h, h->cdf_table, total * h->cfg.n_tpc * 8)); TRY(ensure(h, h->cdf_guide, total * (CDF_G + 2) * 2));
         TRY(upload(h, h->ins_cdfrow, rows.data(), (size_t)n * 4)); HIPCHK(hipStreamSynchronize(h->stream));
@@ -646,6 +654,35 @@ int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, c
 }
 
 // ---- pattern maps evaluated on the device (make_patternmap, load_resource.py:403-435; WeightedNearestNeighbors) ----
+static int map_set_grid(wfs_handle *h, wfs_handle::PatternMap &m, int dims, int min_dims, const int32_t *n_nodes, const double *lo, const double *hi, size_t &nodes)
+{
+    if (dims < min_dims || dims > 3 || !n_nodes || !lo || !hi) return h->fail(WFS_E_INVALID, "map: bad number of dimensions / missing grid");
+    nodes = 1; double diag2 = 0;
+    for (int a = 0; a < 3; a++) { m.n[a] = 1; m.lo[a] = 0; m.hgrid[a] = 1; m.w[a] = 0; }
+    for (int a = 0; a < dims; a++) {
+        if (n_nodes[a] < 2 || !(hi[a] > lo[a])) return h->fail(WFS_E_INVALID, "map: every axis needs at least 2 nodes and hi > lo");
+        m.n[a] = n_nodes[a]; m.lo[a] = lo[a]; m.hgrid[a] = (hi[a] - lo[a]) / (n_nodes[a] - 1); nodes *= (size_t)n_nodes[a];
+        diag2 += m.hgrid[a] * m.hgrid[a];
+    }
+    // the 2 * dims nearest nodes lie within one cell diagonal (a cell has 2^dims >= 2 * dims corners): candidate block per axis
+    for (int a = 0; a < dims; a++) m.w[a] = (i32)ceil(sqrt(diag2) / m.hgrid[a]) + 1;
+    m.dims = dims; m.n_points = 0;
+    return WFS_OK;
+}
+
+static void map_args(const wfs_handle::PatternMap &pm, MapArgs &m)
+{
+    m.dims = pm.dims; for (int q = 0; q < 3; q++) { m.n[q] = pm.n[q]; m.w[q] = pm.w[q]; m.lo[q] = pm.lo[q]; m.h[q] = pm.hgrid[q]; }
+    m.n_points = pm.n_points; m.points = pm.n_points ? pm.points.as<double>() : nullptr;
+    m.values = pm.values.as<float>(); m.n_map_ch = pm.n_map_ch;
+}
+
+static void launch_neighbours(wfs_handle *h, const MapArgs &m)
+{
+    if (m.points) { Timer t(h, "k_map_neighbours_points"); hipLaunchKernelGGL(k_map_neighbours_points, dim3(nblocks(m.n_rows, 4)), dim3(256), 0, h->stream, m); }
+    else { Timer t(h, "k_map_neighbours"); hipLaunchKernelGGL(k_map_neighbours, dim3(nblocks(m.n_rows, 128)), dim3(128), 0, h->stream, m); }
+}
+
 int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
                         const float *values, int32_t n_map_channels)
 {
@@ -653,22 +690,115 @@ int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_
     if (which != 1 && which != 2) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: which = 1 (S1 map) or 2 (S2 map)");
     auto &m = h->pmap[which - 1];
     if (dims == 0) { m.set = false; return WFS_OK; }
-    if (dims < 2 || dims > 3 || !n_nodes || !lo || !hi || !values || n_map_channels <= 0 || n_map_channels > h->cfg.n_tpc)
-        return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: 2 or 3 dimensions, at most n_tpc channels");
+    if (!values || n_map_channels <= 0 || n_map_channels > h->cfg.n_tpc) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: at most n_tpc channels");
     HIPCHK(hipSetDevice(h->device));
-    size_t nodes = 1; double diag2 = 0;
-    for (int a = 0; a < 3; a++) { m.n[a] = 1; m.lo[a] = 0; m.hgrid[a] = 1; m.w[a] = 0; }
-    for (int a = 0; a < dims; a++) {
-        if (n_nodes[a] < 2 || !(hi[a] > lo[a])) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: every axis needs at least 2 nodes and hi > lo");
-        m.n[a] = n_nodes[a]; m.lo[a] = lo[a]; m.hgrid[a] = (hi[a] - lo[a]) / (n_nodes[a] - 1); nodes *= (size_t)n_nodes[a];
-        diag2 += m.hgrid[a] * m.hgrid[a];
-    }
-    // the 2 * dims nearest nodes lie within one cell diagonal (a cell has 2^dims >= 2 * dims corners): candidate block per axis
-    for (int a = 0; a < dims; a++) m.w[a] = (i32)ceil(sqrt(diag2) / m.hgrid[a]) + 1;
-    m.dims = dims; m.n_map_ch = n_map_channels;
+    size_t nodes = 0;
+    TRY(map_set_grid(h, m, dims, 2, n_nodes, lo, hi, nodes));
+    m.n_map_ch = n_map_channels;
     TRY(upload(h, m.values, values, nodes * (size_t)n_map_channels * 4));
     HIPCHK(hipStreamSynchronize(h->stream));
     m.set = true;
+    return WFS_OK;
+}
+
+// a pattern map on an irregular coordinate system (a list of points; straxen queries a KD-tree for the 2 * dims nearest)
+int wfs_set_pattern_map_points(wfs_handle *h, int32_t which, int32_t dims, int64_t n_points, const double *points, const float *values, int32_t n_map_channels)
+{
+    if (!h) return WFS_E_INVALID;
+    if (which != 1 && which != 2) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map_points: which = 1 (S1 map) or 2 (S2 map)");
+    auto &m = h->pmap[which - 1];
+    if (dims < 2 || dims > 3 || n_points < 2 * dims || !points || !values || n_map_channels <= 0 || n_map_channels > h->cfg.n_tpc)
+        return h->fail(WFS_E_INVALID, "wfs_set_pattern_map_points: 2 or 3 dimensions, at least 2 * dims points, at most n_tpc channels");
+    HIPCHK(hipSetDevice(h->device));
+    m.dims = dims; m.n_points = n_points; m.n_map_ch = n_map_channels;
+    TRY(upload(h, m.points, points, (size_t)n_points * dims * 8));
+    TRY(upload(h, m.values, values, (size_t)n_points * (size_t)n_map_channels * 4));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    m.set = true;
+    return WFS_OK;
+}
+
+// s2_aft_sigma (s2.py:660-665): the skew-normal factor of every instruction of the loaded batch (NaN: none), applied to the
+// rows the device evaluates.  Call between wfs_load_instructions and wfs_eval_pattern_rows.
+int wfs_set_instruction_aft(wfs_handle *h, int64_t n, const double *factor)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins) return h->fail(WFS_E_STATE, "wfs_set_instruction_aft follows wfs_load_instructions of the same batch");
+    if (!factor) { h->ins_aft_set = false; return WFS_OK; }
+    HIPCHK(hipSetDevice(h->device));
+    TRY(upload(h, h->ins_aft, factor, (size_t)n * 8));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->ins_aft_set = true;
+    return WFS_OK;
+}
+
+// ---- scalar maps on the device: LCE (s1.py:125), S2 correction / SE gain (s2.py:193-234), longitudinal diffusion (s2.py:170),
+// field-dependence splines (s2.py:150, 248), field distortion maps (s2.py:41, 66) ----
+static int smap_new(wfs_handle *h, std::unique_ptr<wfs_handle::ScalarMap> m, int32_t *map_id)
+{
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->smaps.push_back(std::move(m));
+    *map_id = (int32_t)h->smaps.size() - 1;
+    return WFS_OK;
+}
+
+int wfs_scalar_map_grid(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi, const double *values, int32_t *map_id)
+{
+    if (!h || !map_id || !values) return WFS_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    std::unique_ptr<wfs_handle::ScalarMap> m(new wfs_handle::ScalarMap()); size_t nodes = 0;
+    m->kind = 0;
+    TRY(map_set_grid(h, m->g, dims, 1, n_nodes, lo, hi, nodes));
+    TRY(upload(h, m->g.values, values, nodes * 8));
+    return smap_new(h, std::move(m), map_id);
+}
+
+int wfs_scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values, int32_t *map_id)
+{
+    if (!h || !map_id || !values || !points || dims < 1 || dims > 3 || n_points < 2 * dims) return h ? h->fail(WFS_E_INVALID, "wfs_scalar_map_points: 1..3 dimensions, at least 2 * dims points") : WFS_E_INVALID;
+    HIPCHK(hipSetDevice(h->device));
+    std::unique_ptr<wfs_handle::ScalarMap> m(new wfs_handle::ScalarMap());
+    m->kind = 1; m->g.dims = dims; m->g.n_points = n_points;
+    TRY(upload(h, m->g.points, points, (size_t)n_points * dims * 8));
+    TRY(upload(h, m->g.values, values, (size_t)n_points * 8));
+    return smap_new(h, std::move(m), map_id);
+}
+
+int wfs_scalar_map_spline(wfs_handle *h, int32_t nx, const double *tx, int32_t ny, const double *ty, int32_t kx, int32_t ky, const double *c, int32_t *map_id)
+{
+    if (!h || !map_id || !tx || !ty || !c) return WFS_E_INVALID;
+    if (kx < 1 || kx > 5 || ky < 1 || ky > 5 || nx < 2 * kx + 2 || ny < 2 * ky + 2) return h->fail(WFS_E_INVALID, "wfs_scalar_map_spline: degrees 1..5, at least 2 (k + 1) knots per axis");
+    HIPCHK(hipSetDevice(h->device));
+    std::unique_ptr<wfs_handle::ScalarMap> m(new wfs_handle::ScalarMap());
+    m->kind = 2; m->nx = nx; m->ny = ny; m->kx = kx; m->ky = ky;
+    TRY(upload(h, m->tx, tx, (size_t)nx * 8)); TRY(upload(h, m->ty, ty, (size_t)ny * 8));
+    TRY(upload(h, m->c, c, (size_t)(nx - kx - 1) * (size_t)(ny - ky - 1) * 8));
+    return smap_new(h, std::move(m), map_id);
+}
+
+int wfs_scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out)
+{
+    if (!h) return WFS_E_INVALID;
+    if (map_id < 0 || (size_t)map_id >= h->smaps.size() || n < 0 || (n && (!pos || !out))) return h->fail(WFS_E_INVALID, "wfs_scalar_map_eval: unknown map or missing arrays");
+    if (n == 0) return WFS_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const auto &sm = *h->smaps[map_id];
+    const int dims = sm.kind == 2 ? 2 : sm.g.dims;
+    TRY(upload(h, h->smap_pos, pos, (size_t)n * dims * 8)); TRY(ensure(h, h->smap_out, (size_t)n * 8));
+    if (sm.kind == 2) {
+        SplineArgs a{sm.nx, sm.ny, sm.kx, sm.ky, sm.tx.as<double>(), sm.ty.as<double>(), sm.c.as<double>(), n, h->smap_pos.as<double>(), h->smap_out.as<double>()};
+        Timer t(h, "k_map_spline"); hipLaunchKernelGGL(k_map_spline, dim3(nblocks(n, 128)), dim3(128), 0, h->stream, a);
+    } else {
+        TRY(ensure(h, h->smap_nb_idx, (size_t)n * MAP_K * 8)); TRY(ensure(h, h->smap_nb_w, (size_t)n * MAP_K * 8));
+        MapArgs m{};
+        map_args(sm.g, m);
+        m.n_rows = n; m.pos = h->smap_pos.as<double>(); m.nb_idx = h->smap_nb_idx.as<i64>(); m.nb_w = h->smap_nb_w.as<double>();
+        launch_neighbours(h, m);
+        { Timer t(h, "k_map_scalar"); hipLaunchKernelGGL(k_map_scalar, dim3(nblocks(n, 128)), dim3(128), 0, h->stream, m, sm.g.values.as<double>(), h->smap_out.as<double>()); }
+    }
+    HIPCHK(hipMemcpyAsync(out, h->smap_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipGetLastError());
     return WFS_OK;
 }
 
@@ -691,12 +821,13 @@ int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float 
         TRY(upload(h, h->map_row_ins[w], rows_of[w].data(), (size_t)nr * 4)); TRY(upload(h, h->map_row_id[w], row_id[w].data(), (size_t)nr * 8));
         TRY(ensure(h, h->map_nb_idx[w], (size_t)nr * MAP_K * 8)); TRY(ensure(h, h->map_nb_w[w], (size_t)nr * MAP_K * 8));
         MapArgs m{};
-        m.dims = pm.dims; for (int q = 0; q < 3; q++) { m.n[q] = pm.n[q]; m.w[q] = pm.w[q]; m.lo[q] = pm.lo[q]; m.h[q] = pm.hgrid[q]; }
-        m.values = pm.values.as<float>(); m.n_map_ch = pm.n_map_ch; m.n_rows = nr; m.row_ins = h->map_row_ins[w].as<i32>(); m.row_id = h->map_row_id[w].as<i64>();
+        map_args(pm, m);
+        m.n_rows = nr; m.row_ins = h->map_row_ins[w].as<i32>(); m.row_id = h->map_row_id[w].as<i64>();
+        m.aft = (w == 1 && h->ins_aft_set) ? h->ins_aft.as<double>() : nullptr; m.n_top = h->cfg.n_top;
         m.x = h->map_x.as<float>(); m.y = h->map_y.as<float>(); m.z = h->map_z.as<float>();
         m.nb_idx = h->map_nb_idx[w].as<i64>(); m.nb_w = h->map_nb_w[w].as<double>();
         m.cdf_table = h->cdf_table.as<double>(); m.cdf_guide = h->cdf_guide.as<unsigned short>(); m.gains = h->t_gains.as<double>();
-        { Timer t(h, "k_map_neighbours"); hipLaunchKernelGGL(k_map_neighbours, dim3(nblocks(nr, 128)), dim3(128), 0, h->stream, m); }
+        launch_neighbours(h, m);
         { Timer t(h, "k_map_rows"); hipLaunchKernelGGL(k_map_rows, dim3((unsigned)nr), dim3(256), (size_t)nch * 8, h->stream, m, nch); }
     }
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -1648,25 +1648,44 @@ __device__ __forceinline__ void block_excl_scan(i32 *v, int n, i32 *wtmp)
 // an instruction and one workgroup turns them into the instruction's channel CDF row and its guide table.
 #define MAP_K 6                    // 2 * dims neighbours, dims <= 3
 struct MapArgs {
-    i32 dims, n[3], w[3];          // nodes per axis; half-width of the candidate block per axis
+    i32 dims, n[3], w[3];          // regular grid: nodes per axis; half-width of the candidate block per axis
     double lo[3], h[3];            // first node and spacing per axis
-    const float *values;           // [n0 * n1 * n2][n_map_ch]
+    i64 n_points; const double *points;    // point-list map (an irregular coordinate system): [n_points][dims]; else nullptr
+    const float *values;           // [nodes][n_map_ch]
     i32 n_map_ch;                  // channels stored in the map; channels beyond get weight 1 (s2.py:648-650: top-only maps)
-    i64 n_rows;                    // instructions to evaluate
-    const i32 *row_ins;            // [n_rows] instruction of the row
-    const float *x, *y, *z;        // [n_ins] positions
+    i64 n_rows;                    // positions to evaluate
+    const i32 *row_ins;            // [n_rows] instruction of the row (pattern rows)
+    const float *x, *y, *z;        // [n_ins] positions of the instructions (pattern rows)
+    const double *pos;             // or: [n_rows][dims] positions (scalar maps)
     const i64 *row_id;             // [n_rows] cdf row to write
     i64 *nb_idx; double *nb_w;     // [n_rows][MAP_K]
     double *cdf_table; unsigned short *cdf_guide;
     const double *gains;           // [n_tpc] 0: turned-off PMT
+    const double *aft;             // [n_ins] s2_aft_sigma: factor on the top-array fraction of the instruction's pattern, or nullptr
+    i32 n_top;
 };
+
+__device__ __forceinline__ void map_position(const MapArgs &m, i64 r, double pos[3])
+{
+    if (m.pos) { for (int a = 0; a < 3; a++) pos[a] = a < m.dims ? m.pos[r * m.dims + a] : 0.0; return; }
+    const i32 ins = m.row_ins[r];
+    pos[0] = (double)m.x[ins]; pos[1] = (double)m.y[ins]; pos[2] = m.dims > 2 ? (double)m.z[ins] : 0.0;
+}
+
+__device__ __forceinline__ void map_store_neighbours(const MapArgs &m, i64 r, int K, const double *bd, const i64 *bi)
+{
+    for (int k = 0; k < MAP_K; k++) {
+        const double dist = k < K ? sqrt(bd[k]) : 0.0;
+        m.nb_idx[r * MAP_K + k] = k < K ? bi[k] : -1;
+        m.nb_w[r * MAP_K + k] = (k < K && bi[k] >= 0) ? 1.0 / (dist < 1e-6 ? 1e-6 : dist) : 0.0;
+    }
+}
 
 __global__ void k_map_neighbours(MapArgs m)
 {
     const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m.n_rows) return;
-    const i32 ins = m.row_ins[r];
-    const double pos[3] = {(double)m.x[ins], (double)m.y[ins], m.dims > 2 ? (double)m.z[ins] : 0.0};
+    double pos[3]; map_position(m, r, pos);
     i32 c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
     for (int a = 0; a < m.dims; a++) {
         i32 c = (i32)floor((pos[a] - m.lo[a]) / m.h[a]);
@@ -1692,11 +1711,105 @@ __global__ void k_map_neighbours(MapArgs m)
             }
         }
     }
-    for (int k = 0; k < MAP_K; k++) {
-        const double dist = sqrt(bd[k]);
-        m.nb_idx[r * MAP_K + k] = k < K ? bi[k] : -1;
-        m.nb_w[r * MAP_K + k] = (k < K && bi[k] >= 0) ? 1.0 / (dist < 1e-6 ? 1e-6 : dist) : 0.0;
+    map_store_neighbours(m, r, K, bd, bi);
+}
+
+// point-list maps (straxen.InterpolatingMap on an irregular coordinate system: a KD-tree query for the 2 * dims nearest
+// points): one wave per position, every lane scans a stride of the points keeping its own K best, then K rounds of a
+// wave-wide argmin merge the 64 lists (ties: the lower point index).
+__global__ __launch_bounds__(256) void k_map_neighbours_points(MapArgs m)
+{
+    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= m.n_rows) return;                              // the whole wave leaves
+    double pos[3]; map_position(m, r, pos);
+    const int K = 2 * m.dims;
+    double bd[MAP_K]; i64 bi[MAP_K];
+#pragma unroll
+    for (int k = 0; k < MAP_K; k++) { bd[k] = 1e300; bi[k] = 0x7fffffffffffffffLL; }
+    for (i64 q = lane; q < m.n_points; q += 64) {
+        double d2 = 0;
+        for (int a = 0; a < m.dims; a++) { const double d = pos[a] - m.points[q * m.dims + a]; d2 += d * d; }
+        if (!(d2 < bd[MAP_K - 1])) continue;
+        // insertion into the sorted list of MAP_K (only the first K are used); fixed trip counts keep the lists in registers
+        bool placed = false; double cd = d2; i64 ci = q;
+#pragma unroll
+        for (int k = 0; k < MAP_K; k++) {
+            if (placed || cd < bd[k]) { const double td = bd[k]; const i64 ti = bi[k]; bd[k] = cd; bi[k] = ci; cd = td; ci = ti; placed = true; }
+        }
     }
+    double od[MAP_K]; i64 oi[MAP_K];
+    for (int k = 0; k < MAP_K; k++) {
+        double d = bd[0]; i64 i = bi[0];
+        for (int o = 32; o > 0; o >>= 1) {
+            const double xd = __shfl_xor(d, o, 64); const i64 xi = __shfl_xor(i, o, 64);
+            if (xd < d || (xd == d && xi < i)) { d = xd; i = xi; }
+        }
+        if (bi[0] == i && i != 0x7fffffffffffffffLL) {     // the winner pops its head
+#pragma unroll
+            for (int q = 0; q < MAP_K - 1; q++) { bd[q] = bd[q + 1]; bi[q] = bi[q + 1]; }
+            bd[MAP_K - 1] = 1e300; bi[MAP_K - 1] = 0x7fffffffffffffffLL;
+        }
+        od[k] = d; oi[k] = i == 0x7fffffffffffffffLL ? -1 : i;
+    }
+    if (lane == 0) map_store_neighbours(m, r, K, od, oi);
+}
+
+// scalar maps (LCE, S2 correction, SE gain, longitudinal diffusion ...: s1.py:125, s2.py:170-234): the weighted average itself
+__global__ void k_map_scalar(MapArgs m, const double *values, double *out)
+{
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m.n_rows) return;
+    double num = 0, den = 0;
+    for (int k = 0; k < MAP_K; k++) {
+        const i64 i = m.nb_idx[r * MAP_K + k];
+        if (i < 0) continue;
+        const double w = m.nb_w[r * MAP_K + k];
+        num += values[i] * w; den += w;
+    }
+    out[r] = den > 0 ? num / den : __builtin_nan("");
+}
+
+// scipy.interpolate.RectBivariateSpline.ev (the field-dependence and COMSOL distortion maps, load_resource.py:316, 326): FITPACK's
+// bispeu on the spline's own knots and coefficients -- arguments clamped to the knot range, knot span by search, the
+// k + 1 non-zero B-splines by the stable recurrence of de Boor and Cox (fpbspl), coefficients summed in fpbisp's order.
+struct SplineArgs { i32 nx, ny, kx, ky; const double *tx, *ty, *c; i64 n; const double *pos; double *out; };
+
+__device__ __forceinline__ int spline_span(const double *t, int n, int k, double &x, double h[6])
+{
+    const int nk1 = n - k - 1;
+    const double tb = t[k], te = t[nk1];
+    if (x < tb) x = tb;
+    if (x > te) x = te;
+    int l = k;
+    while (!(x < t[l + 1]) && l + 1 != nk1) l++;
+    double hh[5];
+    h[0] = 1.0;
+    for (int j = 1; j <= k; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 0; i < j; i++) {
+            const int li = l + i + 1, lj = li - j;
+            if (t[li] == t[lj]) { h[i + 1] = 0.0; continue; }
+            const double f = hh[i] / (t[li] - t[lj]);
+            h[i] += f * (t[li] - x);
+            h[i + 1] = f * (x - t[lj]);
+        }
+    }
+    return l - k;
+}
+
+__global__ void k_map_spline(SplineArgs a)
+{
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n) return;
+    double x = a.pos[2 * r], y = a.pos[2 * r + 1], hx[6], hy[6];
+    const int lx = spline_span(a.tx, a.nx, a.kx, x, hx), ly = spline_span(a.ty, a.ny, a.ky, y, hy);
+    const int nky1 = a.ny - a.ky - 1;
+    double sp = 0;
+    for (int i = 0; i <= a.kx; i++)
+        for (int j = 0; j <= a.ky; j++) sp += a.c[(i64)(lx + i) * nky1 + ly + j] * hx[i] * hy[j];
+    a.out[r] = sp;
 }
 
 // one workgroup per row: weighted average of the neighbours' patterns, turned-off PMTs removed, normalised, cumulative sum,
@@ -1725,9 +1838,21 @@ __global__ __launch_bounds__(256) void k_map_rows(MapArgs m, int nch)
     __syncthreads();
     if (tid == 0) {
         const double tot = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+        // s2_aft_sigma (s2.py:660-665): the top-array fraction of the normalised pattern times the instruction's skew-normal
+        // factor, clipped to [0, 1]; top channels scaled by new / cur, the others by (1 - new) / (1 - cur)
+        double s_top = 1.0, s_bot = 1.0;
+        if (m.aft && tot > 0) {
+            double top = 0;
+            for (int c = 0; c < m.n_top; c++) top += p[c];
+            const double cur = top / tot, f = m.aft[m.row_ins[r]];
+            if (cur > 0 && cur < 1 && f == f) {
+                double nw = cur * f; nw = nw < 0 ? 0 : (nw > 1 ? 1 : nw);
+                s_top = nw / cur; s_bot = (1 - nw) / (1 - cur);
+            }
+        }
         // np.random.choice: cdf = cumsum(p / sum); cdf /= cdf[-1]  (sequential, as numpy's cumsum)
         double run = 0;
-        for (int c = 0; c < nch; c++) { run += tot > 0 ? p[c] / tot : 1.0 / nch; p[c] = run; }
+        for (int c = 0; c < nch; c++) { run += tot > 0 ? p[c] / tot * (c < m.n_top ? s_top : s_bot) : 1.0 / nch; p[c] = run; }
         s_sum = run;
     }
     __syncthreads();

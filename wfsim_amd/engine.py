@@ -80,7 +80,8 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_kernel_times', 'wfs_set_profiling', 'wfs_set_delay_models', 'wfs_set_s1_propagation', 'wfs_set_instruction_models',
            'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range',
            'wfs_copy_records_range_async', 'wfs_wait_records', 'wfs_host_register', 'wfs_host_unregister',
-           'wfs_set_gas_gap_model', 'wfs_set_instruction_gas_gap']
+           'wfs_set_gas_gap_model', 'wfs_set_instruction_gas_gap', 'wfs_set_pattern_map_points', 'wfs_set_instruction_aft',
+           'wfs_scalar_map_grid', 'wfs_scalar_map_points', 'wfs_scalar_map_spline', 'wfs_scalar_map_eval']
 
 
 def load_library():
@@ -178,8 +179,18 @@ class Engine:
                     if not (csys and isinstance(csys[0], (list, tuple)) and isinstance(csys[0][0], str) and 'map' in data):
                         continue
                     pm = InterpolatingMap({k: data[k] for k in ('coordinate_system', 'map')}, method=getattr(pm, 'method', 'WeightedNearestNeighbors'))
-                if not (pm.grid is not None and pm.dimensions == dims
-                        and pm.method == 'WeightedNearestNeighbors' and pm.map_names == ['map']):
+                if not (pm.dimensions == dims and pm.method == 'WeightedNearestNeighbors' and pm.map_names == ['map']):
+                    continue
+                if pm.grid is None:           # a point list (irregular coordinate system): brute-force neighbour search on the device
+                    vals = np.asarray(pm.data['map'])
+                    pts = np.ascontiguousarray(pm.coordinate_system, dtype=np.float64)
+                    if vals.ndim != 2 or len(vals) != len(pts) or vals.shape[1] > params['n_tpc'] or len(pts) < 2 * dims:
+                        continue
+                    if kind == 's2' and vals.shape[1] != params['n_tpc'] and (vals.shape[1] - 1) in np.asarray(config['channels_bottom']):
+                        continue
+                    v = np.ascontiguousarray(vals, dtype=np.float32)
+                    self._check(self.lib.wfs_set_pattern_map_points(self._h, C.c_int32(which), C.c_int32(dims), C.c_int64(len(pts)), _p(pts), _p(v), C.c_int32(v.shape[1])))
+                    self.device_maps.add(kind)
                     continue
                 grid, vals = pm.regular_grid()
                 if vals.ndim != dims + 1 or vals.shape[-1] > params['n_tpc']:
@@ -191,6 +202,16 @@ class Engine:
                 lo, hi = np.asarray([g[0] for g in grid], dtype=np.float64), np.asarray([g[-1] for g in grid], dtype=np.float64)
                 self._check(self.lib.wfs_set_pattern_map(self._h, C.c_int32(which), C.c_int32(dims), _p(nn), _p(lo), _p(hi), _p(v), C.c_int32(v.shape[1])))
                 self.device_maps.add(kind)
+        # s2_aft_sigma on device rows needs top = the first n_top channels and bottom = the rest (s2.py:660-665 scales exactly those)
+        cb = np.asarray(config['channels_bottom'])
+        self._aft_on_device = bool(len(cb)) and np.array_equal(cb, np.arange(params['n_top'], params['n_tpc']))
+        # scalar maps of the resource on the device: physics.instruction_params evaluates through this view
+        self._scalar_maps = []
+        if config.get('device_scalar_maps', True):
+            from .device_maps import DeviceResource
+            self.resource = DeviceResource(resource, self)
+        else:
+            self.resource = resource
         # model variants of the photon delays (S1 custom / optical propagation, S2 garfield / optical propagation)
         from .delay_models import DelayModels
         self.models = DelayModels(config, resource)
@@ -240,6 +261,10 @@ class Engine:
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
                                                    _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0), _p(eb)))
         if np.any(a[10] < 0):           # rows from the device pattern maps
+            aft = ip.get('aft_factor')
+            if aft is not None:
+                aft = _arr(aft, np.float64)
+                self._check(self.lib.wfs_set_instruction_aft(self._h, C.c_int64(n), _p(aft)))
             pxy = ip.get('pattern_xy')          # S2: the observed position under a field distortion model
             xyz = [_arr(ins['x'] if pxy is None else pxy[:, 0], np.float32), _arr(ins['y'] if pxy is None else pxy[:, 1], np.float32), _arr(ins['z'], np.float32)]
             self._check(self.lib.wfs_eval_pattern_rows(self._h, C.c_int64(n), *[_p(q) for q in xyz]))
@@ -253,6 +278,42 @@ class Engine:
             if self.models.gas_gap is not None:
                 gi, gw = self.models.instruction_gas_gap(ins)
                 self._check(self.lib.wfs_set_instruction_gas_gap(self._h, C.c_int64(n), _p(gi), _p(gw)))
+
+    def register_scalar_map(self, m, name='map'):
+        """one map of an itp_map.InterpolatingMap on the device: (map id, host result has a trailing axis) or None if it is not of
+        a kind the device evaluates (see device_maps.py)"""
+        mid = C.c_int32(-1)
+        if m.method == 'RectBivariateSpline' and name in m.splines:
+            spl = m.splines[name]
+            tx, ty, c = (np.ascontiguousarray(q, dtype=np.float64) for q in spl.tck)
+            kx, ky = spl.degrees
+            self._check(self.lib.wfs_scalar_map_spline(self._h, C.c_int32(len(tx)), _p(tx), C.c_int32(len(ty)), _p(ty), C.c_int32(kx), C.c_int32(ky), _p(c), C.byref(mid)))
+            return mid.value, False
+        if m.method != 'WeightedNearestNeighbors' or not 1 <= m.dimensions <= 3:
+            return None
+        v = np.asarray(m.data[name], dtype=np.float64)
+        n_points = len(m.coordinate_system)
+        if v.size != n_points:
+            return None                 # array valued: the pattern maps have their own path
+        trailing = (v.ndim > 1 and v.shape[0] == n_points) or v.ndim == m.dimensions + 1
+        v = np.ascontiguousarray(v.reshape(-1))
+        if m.grid is not None:
+            nn = np.asarray([len(g) for g in m.grid], dtype=np.int32)
+            lo, hi = np.asarray([g[0] for g in m.grid], dtype=np.float64), np.asarray([g[-1] for g in m.grid], dtype=np.float64)
+            self._check(self.lib.wfs_scalar_map_grid(self._h, C.c_int32(m.dimensions), _p(nn), _p(lo), _p(hi), _p(v), C.byref(mid)))
+        else:
+            if n_points < 2 * m.dimensions:
+                return None
+            pts = np.ascontiguousarray(m.coordinate_system, dtype=np.float64)
+            self._check(self.lib.wfs_scalar_map_points(self._h, C.c_int32(m.dimensions), C.c_int64(n_points), _p(pts), _p(v), C.byref(mid)))
+        return mid.value, bool(trailing)
+
+    def eval_scalar_map(self, map_id, positions):
+        pos = np.ascontiguousarray(positions, dtype=np.float64)
+        pos = pos.reshape(len(pos), -1)
+        out = np.empty(len(pos), dtype=np.float64)
+        self._check(self.lib.wfs_scalar_map_eval(self._h, C.c_int32(map_id), C.c_int64(len(pos)), _p(pos), _p(out)))
+        return out
 
     def cdf_rows(self):
         """(cdf_row, cdf_table) of the loaded batch as the generator uses them, device-evaluated rows included"""

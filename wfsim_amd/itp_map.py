@@ -74,6 +74,7 @@ class InterpolatingMap:
             self.dimensions = len(csys[0])
         self.coordinate_system = csys
         self.interpolators = {}
+        self.splines = {}                    # map name -> scipy RectBivariateSpline (method 'RectBivariateSpline')
         self.map_names = sorted(k for k in data.keys() if k not in METADATA_FIELDS)
         for name in self.map_names:
             m = np.array(data[name])
@@ -93,6 +94,7 @@ class InterpolatingMap:
                 from scipy.interpolate import RectBivariateSpline
                 assert self.dimensions == 2 and not array_valued, 'RectBivariateSpline: scalar maps on 2-D grids'
                 spl = RectBivariateSpline(self.grid[0], self.grid[1], m.reshape(shape), s=0)
+                self.splines[name] = spl
                 self.interpolators[name] = (lambda positions, spl=spl: spl.ev(np.asarray(positions)[:, 0], np.asarray(positions)[:, 1]))
             elif method in ('WeightedNearestNeighbors', 'RegularGridInterpolator', 'RectBivariateSpline'):
                 vals = m.reshape((len(csys), m.shape[-1])) if array_valued else m.reshape(-1)

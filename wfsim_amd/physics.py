@@ -114,21 +114,29 @@ def s2_channel_probabilities(positions, config, resource, gids=None):
     sum_pat = np.sum(pattern, axis=1).reshape(-1, 1)
     pattern = np.divide(pattern, sum_pat, out=np.zeros_like(pattern), where=sum_pat != 0)
     assert pattern.shape[1] == len(channels)
-    aft_sigma = config.get('s2_aft_sigma', 0.0)
-    if aft_sigma != 0:
-        from numpy.random import Generator, Philox
-        from scipy.stats import skewnorm
+    if config.get('s2_aft_sigma', 0.0) != 0:
         top_index = np.arange(config['n_top_pmts'])
-        g = np.arange(len(pattern)) if gids is None else np.asarray(gids)
+        factor = s2_aft_factors(len(pattern), config, gids)
         for i, pat in enumerate(pattern):
             if pat.sum() == 0:
                 continue
-            rs = Generator(Philox(key=[int(config.get('seed', 0) or 0), (int(g[i]) << 8) | 0x41]))
             cur_aft = np.sum(pat[top_index]) / np.sum(pat)
-            new_aft = np.clip(cur_aft * skewnorm.rvs(loc=1.0, scale=aft_sigma, a=config.get('s2_aft_skewness', 0.0), random_state=rs), 0, 1)
+            new_aft = np.clip(cur_aft * factor[i], 0, 1)
             pat[top_index] *= (new_aft / cur_aft)
             pat[bottom_index] *= (1 - new_aft) / (1 - cur_aft)
     return pattern
+
+
+def s2_aft_factors(n, config, gids=None):
+    """the skew-normal factor on the top-array fraction of every S2 instruction's pattern (s2.py:661: one
+    ``skewnorm.rvs(loc=1, scale=s2_aft_sigma, a=s2_aft_skewness)`` per instruction), from a host Philox stream keyed by
+    (seed, run-wide instruction id): independent of batching and of whether the rows are made on the host or the device"""
+    from numpy.random import Generator, Philox
+    from scipy.stats import skewnorm
+    g = np.arange(n) if gids is None else np.asarray(gids)
+    seed, sigma, skew = int(config.get('seed', 0) or 0), config['s2_aft_sigma'], config.get('s2_aft_skewness', 0.0)
+    return np.array([skewnorm.rvs(loc=1.0, scale=sigma, a=skew, random_state=Generator(Philox(key=[seed, (int(g[i]) << 8) | 0x41])))
+                     for i in range(n)], dtype=np.float64)
 
 
 def s2_observed_positions(instructions, config, resource):
@@ -163,7 +171,7 @@ def instruction_time(instructions, config):
     return instructions['time'] + (instructions['z'] / v * (instructions['type'] % 2 - 1)).astype(np.int64)
 
 
-def instruction_params(instructions, config, resource, gids=None, device_maps=()):
+def instruction_params(instructions, config, resource, gids=None, device_maps=(), device_aft=True):
     """Batch arrays for the device: hit/survival probability, drift parameters, secondary gain and the
     cumulative channel table of every instruction (rows de-duplicated).  ``device_maps``: kinds ('s1', 's2') whose pattern
     map lives on the device (Engine.device_maps): their instructions get ``cdf_row = -1`` and no host row."""
@@ -182,6 +190,7 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
     cdf_row = np.zeros(n, dtype=np.int32)
     pattern_xy = np.array([instructions['x'], instructions['y']], dtype=np.float64).T      # where the pattern map is evaluated
     outside = np.zeros(n, dtype=bool)         # S2 positions without a pattern (s2.py:598, see s2_channel_probabilities)
+    aft_factor = np.full(n, np.nan)
     for sel, kind in ((is_s1, 's1'), (is_s2, 's2')):
         if not sel.any():
             continue
@@ -210,9 +219,11 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
             if config.get('diffusion_constant_transverse', 0) > 0:
                 outside[idx] = np.sum(np.asarray(xy_obs, dtype=np.float64) ** 2, axis=1) > config['tpc_radius'] ** 2
             per_instruction = config.get('s2_aft_sigma', 0.0) != 0 or bool(outside[idx].any())
-        if kind in device_maps and not (kind == 's2' and config.get('s2_aft_sigma', 0.0) != 0):
+        if kind in device_maps and not (kind == 's2' and config.get('s2_aft_sigma', 0.0) != 0 and not device_aft):
             cdf_row[idx] = -1                  # the row comes from the device map; instructions without a pattern make no photons
             p_hit[idx[outside[idx]]] = 0.0
+            if kind == 's2' and config.get('s2_aft_sigma', 0.0) != 0:        # the device rescales its rows (wfs_set_instruction_aft)
+                aft_factor[idx] = s2_aft_factors(len(idx), config, sel_gids)
         elif isinstance(pmap, DummyMap) and not per_instruction:
             cdf_row[idx] = len(rows)           # a constant map: one shared row
             rows.append(choice_cdf(probs(1))[0])
@@ -226,4 +237,5 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
             rows.extend(list(choice_cdf(p)))
     cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.ones((1, n_ch))
     return dict(p_hit=p_hit, drift_mean=drift_mean, drift_spread=drift_spread, sc_gain=sc_gain,
-                cdf_row=cdf_row, cdf_table=cdf_table, pattern_xy=pattern_xy)
+                cdf_row=cdf_row, cdf_table=cdf_table, pattern_xy=pattern_xy,
+                aft_factor=None if np.all(np.isnan(aft_factor)) else aft_factor)

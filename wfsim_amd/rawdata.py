@@ -265,7 +265,7 @@ class RawData:
         return np.minimum(q, 5 * len(self.config.get('gains', np.zeros(494))) + q / 400)
 
     def _load_batch(self, ins, gid, cl, key):
-        ip = instruction_params(ins, self.config, self.resource, gids=gid, device_maps=self.engine.device_maps)
+        ip = instruction_params(ins, self.config, self.engine.resource, gids=gid, device_maps=self.engine.device_maps, device_aft=self.engine._aft_on_device)
         # one pulse set per instruction, or -- save_full_truth off -- per group of nearby S1s / S2s (rawdata.py:106-127)
         # ...; electron-afterpulse instructions (types 4 / 6) of a cluster always share one call
         plain = self.config.get('save_full_truth', True) and bool(np.all(ins['type'] <= 2))

@@ -52,6 +52,14 @@ def make_map(map_file, fmt=None, method='WeightedNearestNeighbors'):
     raise TypeError("Can't handle map_file except a string or a list")
 
 
+def rz_wrapper(rz_map):
+    """load_resource.py:335-338: a map in (r, z) called with (z, xy)"""
+    def wrapped(z, xy, **kwargs):
+        r = np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
+        return rz_map(np.array([r, z]).T, **kwargs)
+    return wrapped
+
+
 def make_patternmap(map_file, fmt=None, method='WeightedNearestNeighbors', pmt_mask=None):
     """Pattern maps with the PMT mask applied and the compressed / quantised storage undone (load_resource.py:403-435).
     Compression codecs: the ones python ships (bz2, zlib, lzma); strax's blosc / zstd / lz4 are not installed here."""
@@ -143,17 +151,11 @@ class Resource:
                 norm_dvel = fmap(np.array([[0], [- c['tpc_length']]]).T, map_name='drift_speed_map')[0] * 1e-4
                 self.drift_velocity_scaling = c['drift_velocity_liquid'] / norm_dvel
 
-            def rz_map(z, xy, **kwargs):           # load_resource.py:335-338
-                r = np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
-                return fmap(np.array([r, z]).T, **kwargs)
-            self.field_dependencies_map = rz_map
+            self.field_dependencies_rz = fmap      # the maps in (r, z); the reference keeps only the (z, xy) wrappers below
+            self.field_dependencies_map = rz_wrapper(fmap)
             if efd.get('diffusion_longitudinal_map', False):       # data-driven longitudinal diffusion (load_resource.py:340-347)
-                dmap = make_map(c['diffusion_longitudinal_map'])
-
-                def _rz_map(z, xy, **kwargs):
-                    r = np.sqrt(xy[:, 0] ** 2 + xy[:, 1] ** 2)
-                    return dmap(np.array([r, z]).T, **kwargs)
-                self.diffusion_longitudinal_map = _rz_map
+                self.diffusion_longitudinal_rz = make_map(c['diffusion_longitudinal_map'])
+                self.diffusion_longitudinal_map = rz_wrapper(self.diffusion_longitudinal_rz)
         # field distortion models of S2.__call__ (load_resource.py:310-315)
         if c.get('field_distortion_model', 'none') == 'inverse_fdc':
             self.fdc_3d = make_map(c['fdc_3d'])
