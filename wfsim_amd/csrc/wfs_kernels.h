@@ -257,13 +257,27 @@ __global__ __launch_bounds__(GROUPS_TPB) void k_groups(WfsDev d, GeomArgs a)
 __global__ void k_tile_rows(WfsDev d, GeomArgs a)
 {
     i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= a.n_tiles || a.tile_count[tile] <= 0) return;
-    i64 set = tile / d.n_tpc; i32 ch = (i32)(tile - set * d.n_tpc);
-    i64 left, right, bin0, nb;
-    tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
-    i64 g = a.cl_group[a.set_cluster[set]];
-    atomicMin(&a.row_lo[g * d.n_tpc + ch], left); atomicMax(&a.row_hi[g * d.n_tpc + ch], right);
-    atomicMin(&a.grp_lo[g], left); atomicMax(&a.grp_hi[g], right);
+    const bool live = tile < a.n_tiles && a.tile_count[tile] > 0;
+    i64 left = I64_MAX, right = I64_MIN, g = -1;
+    if (live) {
+        i64 set = tile / d.n_tpc; i32 ch = (i32)(tile - set * d.n_tpc);
+        i64 bin0, nb;
+        tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+        g = a.cl_group[a.set_cluster[set]];
+        atomicMin(&a.row_lo[g * d.n_tpc + ch], left); atomicMax(&a.row_hi[g * d.n_tpc + ch], right);
+    }
+    // the group's range: the 494 tiles of a pulse set all aim at one address -- reduce inside the wave first when its
+    // live lanes share the group (the usual case), one atomic pair per wave instead of 64
+    const u64 lm = __ballot(live);
+    if (lm == 0) return;
+    const i64 g0 = __shfl(g, __ffsll((long long)lm) - 1, 64);
+    if (__all(!live || g == g0)) {
+        for (int o = 32; o > 0; o >>= 1) {
+            const i64 l2 = __shfl_xor(left, o, 64), r2 = __shfl_xor(right, o, 64);
+            left = l2 < left ? l2 : left; right = r2 > right ? r2 : right;
+        }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&a.grp_lo[g0], left); atomicMax(&a.grp_hi[g0], right); }
+    } else if (live) { atomicMin(&a.grp_lo[g], left); atomicMax(&a.grp_hi[g], right); }
 }
 
 // per group: window (rawdata.py:215-224) and the noise offset (rawdata.py:407-417)
@@ -1884,16 +1898,17 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
         const i64 pa = a.ins_ph0[ins], pb = a.ins_ph0[ins + 1];     // photons [pa, pb) of the instruction
         if (pb <= pa) continue;
         const i64 b1 = (pb - 1) / GEN_BLOCK;
-        for (i64 b0 = pa / GEN_BLOCK; b0 <= b1; b0 += 8) {       // eight blocks at a time: their loads are in flight together
-            u32 cnt[8]; bool mine[8];
+        constexpr int NB = 8;                                    // blocks at a time: their loads are in flight together
+        for (i64 b0 = pa / GEN_BLOCK; b0 <= b1; b0 += NB) {
+            u32 cnt[NB]; bool mine[NB];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < NB; k++) {
                 const i64 b = b0 + k < b1 ? b0 + k : b1;
                 mine[k] = b0 + k <= b1 && a.blk_ins[b] == ins;
                 cnt[k] = a.blk_cnt[b * nch + c];
             }
 #pragma unroll
-            for (int k = 0; k < 8; k++) if (mine[k]) { a.blk_base[(b0 + k) * nch + c] = run; run += cnt[k]; }
+            for (int k = 0; k < NB; k++) if (mine[k]) { a.blk_base[(b0 + k) * nch + c] = run; run += cnt[k]; }
         }
     }
     a.tile_count[idx] = (i32)run;
