@@ -34,7 +34,7 @@ struct wfs_handle {
     std::string err;
     WfsDev dev;
     bool tables_set = false, batch_loaded = false, injected = false, optical = false, ran = false;
-    DevBuf set_gid, opt_t, opt_item;
+    DevBuf set_gid, opt_t, opt_item, opt_first, opt_last, opt_ch, opt_time;
     int keep_currents = 0, profiling = 0;
     bool gen_done = false;
     GenArgs gen_args{};           // the generator's view of the batch (kept for wfs_gather_photon_times)
@@ -399,7 +399,7 @@ int wfs_destroy(wfs_handle *h)
         hipFree(h->stamps.p);
     }
 #endif
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -973,33 +973,30 @@ int wfs_load_optical(wfs_handle *h, int64_t n, const int64_t *time, const uint32
     const int nch = h->cfg.n_tpc;
     h->n_ins = n; h->n_sets = n; h->n_tiles = n * nch; h->n_emitters = 0; h->ap_active = false;
     if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
-    std::vector<i32> count((size_t)h->n_tiles, 0);
-    for (i64 i = 0; i < n; i++) {
-        if (first[i] < 0 || last[i] < first[i] || last[i] > n_ph) return h->fail(WFS_E_INVALID, "_first/_last out of range");
-        for (i64 k = first[i]; k < last[i]; k++) {
-            if (timings[k] < 0 || timings[k] >= cutoff) continue;              // rawdata.py:485-486
-            if (channels[k] < 0 || channels[k] >= nch) return h->fail(WFS_E_INVALID, "photon channel out of range");
-            if (h->h_gains[channels[k]] == 0) continue;                      // turned-off PMT: no pulse (pulse.py:89-90)
-            if (timings[k] > 0x7ffffff0LL) return h->fail(WFS_E_CAPACITY, "photon time beyond 2^31 ns");
-            count[(size_t)(i * nch + channels[k])]++;
-        }
-    }
-    std::vector<i64> off((size_t)h->n_tiles + 1, 0);
-    for (i64 t = 0; t < h->n_tiles; t++) off[t + 1] = off[t] + count[t];
-    const i64 P = off[h->n_tiles];
-    h->n_photons = P;
-    std::vector<i32> rel((size_t)P); std::vector<u32> item((size_t)P); std::vector<i64> cur(off.begin(), off.end() - 1);
     for (i64 i = 0; i < n; i++)
-        for (i64 k = first[i]; k < last[i]; k++) {
-            if (timings[k] < 0 || timings[k] >= cutoff || h->h_gains[channels[k]] == 0) continue;
-            const i64 pos = cur[(size_t)(i * nch + channels[k])]++;
-            rel[pos] = (i32)timings[k]; item[pos] = (u32)(k - first[i]);
-        }
+        if (first[i] < 0 || last[i] < first[i] || last[i] > n_ph) return h->fail(WFS_E_INVALID, "_first/_last out of range");
+    // the photons are bucketed by (instruction, channel) on the device: count, scan, place (k_optical_bucket)
+    const i64 T = h->n_tiles;
     std::vector<i32> mode((size_t)n, 0);
     TRY(upload(h, h->set_cluster, cluster, (size_t)n * 4)); TRY(upload(h, h->set_t0, time, (size_t)n * 8)); TRY(upload(h, h->set_mode, mode.data(), (size_t)n * 4));
     TRY(upload(h, h->set_gid, gid, (size_t)n * 4)); TRY(upload(h, h->ins_time, time, (size_t)n * 8));
-    TRY(upload(h, h->tile_count, count.data(), count.size() * 4)); TRY(upload(h, h->tile_off, off.data(), off.size() * 8));
-    TRY(upload(h, h->opt_t, rel.data(), (size_t)P * 4)); TRY(upload(h, h->opt_item, item.data(), (size_t)P * 4));
+    TRY(upload(h, h->opt_first, first, (size_t)n * 4)); TRY(upload(h, h->opt_last, last, (size_t)n * 4));
+    TRY(upload(h, h->opt_ch, channels, (size_t)n_ph * 4)); TRY(upload(h, h->opt_time, timings, (size_t)n_ph * 8));
+    TRY(ensure(h, h->tile_count, (size_t)T * 4)); TRY(ensure(h, h->tile_cursor, (size_t)T * 4)); TRY(ensure(h, h->tile_off, (size_t)(T + 1) * 8));
+    TRY(ensure(h, h->opt_t, (size_t)n_ph * 4)); TRY(ensure(h, h->opt_item, (size_t)n_ph * 4));
+    HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (size_t)T * 4, h->stream)); HIPCHK(hipMemsetAsync(h->tile_cursor.p, 0, (size_t)T * 4, h->stream));
+    HIPCHK(hipMemsetAsync(h->scal.p, 0, 256, h->stream));
+    OptLoadArgs oa{n, h->opt_first.as<i32>(), h->opt_last.as<i32>(), h->opt_ch.as<i32>(), h->opt_time.as<i64>(), cutoff, h->t_gains.as<double>(),
+                   h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->tile_cursor.as<i32>(), h->opt_t.as<i32>(), h->opt_item.as<u32>(), h->scal.as<i64>()};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_optical_bucket<false>), dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->dev, oa);
+    TRY(scan_into(h, h->tile_count.as<i32>(), T, h->tile_off.as<i64>(), 7, 0));
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_optical_bucket<true>), dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->dev, oa);
+    TRY(read_scal(h));
+    HIPCHK(hipGetLastError());
+    if (h->h_scal[20] == 1) return h->fail(WFS_E_INVALID, "photon channel out of range");
+    if (h->h_scal[20] == 2) return h->fail(WFS_E_CAPACITY, "photon time beyond 2^31 ns");
+    const i64 P = h->h_scal[7];
+    h->n_photons = P;
     TRY(ensure(h, h->ph, (size_t)P * 8));
     TRY(ensure(h, h->tile_tmin, (size_t)h->n_tiles * 4)); TRY(ensure(h, h->tile_tmax, (size_t)h->n_tiles * 4));
     TRY(ensure(h, h->el_stat, (size_t)n * 32)); TRY(ensure(h, h->el_minmax, (size_t)n * 16));

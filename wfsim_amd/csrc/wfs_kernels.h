@@ -2268,6 +2268,31 @@ __global__ void k_photon_times(WfsDev d, GenArgs a, i64 n, const i64 *index, i64
 struct OpticalArgs { i64 n_tiles; const i32 *tile_count; const i64 *tile_off; i32 *tile_tmin, *tile_tmax; const u32 *set_gid;
                      const i32 *in_t; const u32 *in_item; PhotonRec *ph; i64 *scal; };
 
+// Bucketing of the supplied photons by (instruction, channel) -- one thread per instruction, which owns the instruction's tiles
+// (plain read-modify-write).  The host used to do this over dense per-tile arrays: 0.4 s of 0.5 s per 4 x 10^5 nVeto instructions.
+// rawdata.py:485-486: photons with a negative time or beyond the cutoff are dropped; pulse.py:89-90: so are those of turned-off PMTs.
+struct OptLoadArgs { i64 n; const i32 *first, *last, *channels; const i64 *timings; i64 cutoff; const double *gains;
+                     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *in_t; u32 *in_item; i64 *scal; };
+
+template <bool PLACE>
+__global__ void k_optical_bucket(WfsDev d, OptLoadArgs a)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const i32 f = a.first[i], l = a.last[i];
+    for (i32 k = f; k < l; k++) {
+        const i64 t = a.timings[k];
+        if (t < 0 || t >= a.cutoff) continue;
+        const i32 ch = a.channels[k];
+        if (ch < 0 || ch >= d.n_tpc) { atomicMax(&a.scal[20], (i64)1); continue; }      // photon channel out of range
+        if (a.gains[ch] == 0) continue;
+        if (t > 0x7ffffff0LL) { atomicMax(&a.scal[20], (i64)2); continue; }              // photon time beyond 2^31 ns
+        const i64 tile = i * d.n_tpc + ch;
+        if (!PLACE) a.tile_count[tile]++;
+        else { const i64 pos = a.tile_off[tile] + a.tile_cursor[tile]++; a.in_t[pos] = (i32)t; a.in_item[pos] = (u32)(k - f); }
+    }
+}
+
 __global__ void k_optical_finish(WfsDev d, OpticalArgs a)
 {
     const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
