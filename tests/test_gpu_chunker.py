@@ -187,3 +187,39 @@ def test_random_chunker_runs_identical_to_the_per_window_replay(seed):
             sim.record_buffer = sim.record_buffer[:buf].copy()
         return sim
     _assert_same(_chunks(factory, ins, False), _chunks(factory, ins, True))
+
+
+@pytest.mark.parametrize('hold', [True, False])
+def test_chunks_handed_out_without_a_copy_stay_intact(monkeypatch, hold):
+    """Large chunks leave as the page-locked buffer their records arrived in (ChunkRawRecords._hand_out); the chunker carries
+    on in a spare buffer.  Held by the consumer (hold) they are never overwritten -- when no spare buffer is left the chunker
+    copies as the reference does; dropped, their buffers go back to the pool.  Either way: the bytes of the copying path."""
+    import gc
+    from wfsim_amd import engine as eng
+    monkeypatch.setattr(wfsim_amd.ChunkRawRecords, 'zero_copy_min_records', 50)
+    gc.collect()                                # chunkers of earlier tests give their buffers back
+    cfg = xenonnt_test_config(seed=8, chunk_size=0.004, s2_secondary_sc_gain=60.0, high_energy_deamplification_factor=0)
+    ins = _mixed(120, 4)
+    ref_sim = wfsim_amd.ChunkRawRecords(dict(cfg, zero_copy_chunks=False))
+    ref_sim.rawdata.max_batch_quanta = 80_000
+    ref = [c['raw_records'].copy() for c in ref_sim(ins)]
+    assert len(ref) > 8
+    sim = wfsim_amd.ChunkRawRecords(cfg)
+    sim.rawdata.max_batch_quanta = 80_000
+    assert eng.is_pooled_record_buffer(sim.record_buffer)
+    held, leased, k = [], 0, 0
+    for c in sim(ins):
+        r = c['raw_records']
+        leased += not r.flags.owndata and len(r) > 0 and isinstance(r.base, memoryview)
+        if hold:
+            held.append(r)
+        else:
+            assert r.tobytes() == ref[k].tobytes()
+        k += 1
+        del r, c
+    assert k == len(ref) and leased >= (2 if hold else len([x for x in ref if len(x) >= 50]) // 2)
+    for a, b in zip(held, ref):               # every chunk still holds what it held when it was handed out
+        assert a.tobytes() == b.tobytes()
+    held.clear(); del sim, ref_sim
+    gc.collect()
+    assert not any(slot[1] for slot in eng._RECORD_BUFFERS)       # every pooled buffer is free again

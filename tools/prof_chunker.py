@@ -18,4 +18,4 @@ def run():
     return time.perf_counter() - t0, nrec
 print('warm', run())
 pr = cProfile.Profile(); pr.enable(); r = run(); pr.disable(); print('profiled', r)
-pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
+pstats.Stats(pr).sort_stats('tottime').print_stats(16)

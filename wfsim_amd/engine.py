@@ -36,19 +36,25 @@ def unpin_host(array):
 
 
 _RECORD_BUFFERS = []        # [array, in use]: page-locked record buffers, kept for the life of the process
+MAX_RECORD_BUFFERS = 4      # at most this many (1.2 GB each): beyond it the chunker copies instead of handing buffers out
 
 
-def acquire_record_buffer(length, dtype, pin=True):
+def acquire_record_buffer(length, dtype, pin=True, spare_only=False):
     """A record buffer for ChunkRawRecords (strax_interface.py:360-361: np.zeros(5000000, raw_record_dtype), 1.2 GB).
-    Page-locking that much memory takes a few hundred ms, so pinned buffers are recycled between instances."""
+    Page-locking that much memory takes a few hundred ms, so pinned buffers are recycled between instances.
+    ``spare_only``: a pooled buffer or None (a new one is made only while the pool is below MAX_RECORD_BUFFERS)."""
     dtype = np.dtype(dtype)
     for slot in _RECORD_BUFFERS:
         if not slot[1] and len(slot[0]) == length and slot[0].dtype == dtype:
             slot[1] = True
             return slot[0]
+    if spare_only and len(_RECORD_BUFFERS) >= MAX_RECORD_BUFFERS:
+        return None
     buf = np.zeros(length, dtype=dtype)
     if pin and pin_host(buf):
         _RECORD_BUFFERS.append([buf, True])
+    elif spare_only:
+        return None
     return buf
 
 
@@ -56,6 +62,20 @@ def release_record_buffer(buf):
     for slot in _RECORD_BUFFERS:
         if slot[0] is buf:
             slot[1] = False
+
+
+def is_pooled_record_buffer(buf):
+    return any(slot[0] is buf for slot in _RECORD_BUFFERS)
+
+
+def lease_record_buffer(buf, n):
+    """The first n records of a pooled buffer as an array the caller may hand out: the buffer stays taken until that array
+    and every view derived from it are gone, then it returns to the pool.  (The array is built on a memoryview, so numpy's
+    base chain of every derived view ends at it and not at the buffer: its finaliser runs when the last view dies.)"""
+    import weakref
+    arr = np.frombuffer(memoryview(buf.view(np.uint8).reshape(-1)), dtype=buf.dtype, count=n)
+    weakref.finalize(arr, release_record_buffer, buf)
+    return arr
 
 
 class WfsConfig(C.Structure):

@@ -60,20 +60,30 @@ class RawData:
         self.prefetch = os.environ.get('WFSIM_AMD_PREFETCH', '1') != '0'
         #: run-wide index of every instruction passed to __call__ (RNG stream ids); None: position in the input
         self.global_ids = None
+        #: chunk boundaries of the consumer (ns): batches end just behind them where that costs little (_batch_end)
+        self.cut_period, self.cut_origin = None, 0
 
     @staticmethod
     def symtype(ptype):
         return PULSE_TYPE_NAMES[ptype]
 
     # ------------------------------------------------------------------------------------------
-    def _batch_end(self, start, est_csum, cluster, scale=1, rec_csum=None):
-        """End of the batch starting at sorted index ``start``: whole clusters, bounded by expected quanta."""
+    def _batch_end(self, start, est_csum, cluster, scale=1, rec_csum=None, key=None):
+        """End of the batch starting at sorted index ``start``: whole clusters, bounded by expected quanta.
+        ``cut_period`` / ``cut_origin`` (set by the chunker): a batch that would run across the next chunk boundary ends just
+        behind it instead, when that does not make it much smaller -- the chunk then closes at the end of a batch and its
+        records leave as the buffer they arrived in (ChunkRawRecords._hand_out).  Results do not depend on the cuts."""
         n = len(cluster)
         limit = (est_csum[start - 1] if start else 0) + self.max_batch_quanta * scale
         stop = int(np.searchsorted(est_csum, limit, side='right'))
         if self.record_budget is not None and rec_csum is not None:
             rlimit = (rec_csum[start - 1] if start else 0) + self.record_budget * scale / self._rec_scale
             stop = min(stop, int(np.searchsorted(rec_csum, rlimit, side='right')))
+        if self.cut_period and key is not None and scale == 1 and stop < n:
+            boundary = self.cut_origin + (np.floor((int(key[start]) - self.cut_origin) / self.cut_period) + 1) * self.cut_period
+            s = int(np.searchsorted(key, boundary, side='right')) + 1        # one instruction beyond: its window closes the chunk
+            if start + (stop - start) // 2 <= s < stop:
+                stop = s
         stop = max(stop, start + 1)
         while stop < n and cluster[stop] == cluster[stop - 1]:      # never cut a cluster
             stop += 1
@@ -105,7 +115,7 @@ class RawData:
     def iter_batches(self, instructions, want_truth=False, record_sink=None, device_records=False, **kwargs):
         """The same stream batch by batch (what the chunker consumes): dict(left[], right[] of the batch's digitise windows
         in time order, first[] record offsets (one more than windows), records, truth_table + truth_rows + truth_before (row truth_rows[k] of the table belongs in
-        front of window truth_before[k]; == number of windows: after the last), finished).  ``record_sink(n)`` may hand out
+        front of window truth_before[k]; == number of windows: after the last), finished).  ``record_sink(n, first_left)`` may hand out
         the array the records are copied into (device -> host without a staging copy); ``device_records``: the records stay
         on the GPU (``records`` is a torch uint8 tensor of n * 244 bytes)."""
         self.source_finished = False
@@ -151,12 +161,13 @@ class RawData:
                 L = launched
                 ins, cl, n_emit, first, nonempty, ins_group, groups = L['ins'], L['cl'], L['n_emit'], L['first'], L['nonempty'], L['ins_group'], L['groups']
                 n_rec = int(first[n_emit])
+                keep = np.where(nonempty[:n_emit])[0]
                 out = None
                 if record_sink is not None and not device_records:
-                    out = record_sink(n_rec)
+                    # (the sink is told where the batch's first window starts: the chunker can tell a chunk that is about to close)
+                    out = record_sink(n_rec, int(groups['left'][keep[0]]) if len(keep) else None)
                 if out is None and not device_records:
                     out = np.empty(n_rec, dtype=raw_record_dtype())
-                keep = np.where(nonempty[:n_emit])[0]
                 # window position of every emitted group: rows of a group go in front of its window, rows of a group without
                 # pulses in front of the next window that has some
                 pos_of_group = np.searchsorted(keep, np.arange(n_emit), side='left')
@@ -215,7 +226,7 @@ class RawData:
         s_ins, gids, order, key, cluster, n = st['s_ins'], st['gids'], st['order'], st['key'], st['cluster'], st['n']
         scale = 1
         while True:
-            b = self._batch_end(a, st['est_csum'], cluster, scale, st.get('rec_csum'))
+            b = self._batch_end(a, st['est_csum'], cluster, scale, st.get('rec_csum'), key if self._all_run_sets is None else None)
             ins = s_ins[a:b]
             gid = gids[order[a:b]].astype(np.uint32)
             cl = (cluster[a:b] - cluster[a]).astype(np.int32)

@@ -57,6 +57,7 @@ def instruction_from_csv(filename):
 
 class ChunkRawRecords(object):
     record_buffer_length = 5000000          # strax_interface.py:360
+    zero_copy_min_records = 200_000         # chunks of at least this many records are handed out without a copy (_hand_out)
 
     def __init__(self, config, rawdata_generator=RawData, **kwargs):
         self.config = config
@@ -65,19 +66,25 @@ class ChunkRawRecords(object):
         # speed while the next batch's kernels run) and recycled between instances: pinning 1.2 GB takes a few hundred ms
         rdt = raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH)
         if hasattr(self.rawdata, 'iter_batches') and config.get('pin_record_buffer', True):
-            from .engine import acquire_record_buffer
+            from .engine import acquire_record_buffer, is_pooled_record_buffer
             self.record_buffer = acquire_record_buffer(self.record_buffer_length, rdt)
+            self._own_buffers = [self.record_buffer] if is_pooled_record_buffer(self.record_buffer) else []
         else:
             self.record_buffer = np.zeros(self.record_buffer_length, dtype=rdt)
         truth_per_n_pmts = self._n_channels if config.get('per_pmt_truth') else False
         self.truth_dtype = extra_truth_dtype_per_pmt(truth_per_n_pmts)
         self.truth_buffer = np.zeros(10000, dtype=instruction_dtype + self.truth_dtype + [('fill', bool)])
         self.blevel = 0
+        self._next_buffer = None
+        self._batch_leases = []
+
+    _own_buffers = ()           # pooled buffers this instance holds (the current one, a spare taken ahead)
 
     def __del__(self):
         try:
             from .engine import release_record_buffer
-            release_record_buffer(self.record_buffer)
+            for b in self._own_buffers:
+                release_record_buffer(b)
         except Exception:
             pass
 
@@ -119,6 +126,8 @@ class ChunkRawRecords(object):
             yield from self.final_results()
             self.chunk_time_pre = self.chunk_time
             self.chunk_time += self._cksz
+            if hasattr(self.rawdata, 'cut_origin'):
+                self.rawdata.cut_origin = self.chunk_time + self._rext
             return
         return
 
@@ -144,16 +153,31 @@ class ChunkRawRecords(object):
         found by bisection and everything in front of it is committed in one go.  The records of a batch are copied
         from the device straight into the record buffer (behind what is committed), ordered as strax.sort_by_time
         would order them -- final_results then only cuts the buffer at ``chunk_time``."""
-        rd, buf, dt = self.rawdata, self.record_buffer, self._dt
-        L = len(buf)
+        rd, dt = self.rawdata, self._dt
+        L = len(self.record_buffer)
         rd.engine.set_record_order(True)
         rd.record_budget = max(L // 2, 1)       # a batch's records go from the device straight into the buffer
+        rd.cut_period, rd.cut_origin = self._cksz, self.chunk_time + self._rext     # batches end where chunks do, if that is cheap
         self._sorted_stream = True
 
-        def sink(n):
-            return buf[self.blevel:self.blevel + n] if self.blevel + n <= L else None
+        def sink(n, first_left=None):
+            # (self.record_buffer: final_results may have handed the previous buffer to the consumer)
+            # A batch whose first window lies beyond the open chunk closes it before any of its records is committed, and every
+            # record in the buffer then belongs to that chunk: such a batch goes to the front of a spare buffer, the full one is
+            # handed to the consumer as it is (_hand_out) -- no record is copied on the host at all.
+            from .engine import acquire_record_buffer, is_pooled_record_buffer
+            if (first_left is not None and n <= L and self.blevel >= self.zero_copy_min_records and self._next_buffer is None
+                    and first_left * dt > self.chunk_time + self._rext and self.config.get('zero_copy_chunks', True)
+                    and is_pooled_record_buffer(self.record_buffer)):
+                spare = acquire_record_buffer(L, self.record_buffer.dtype, spare_only=True)
+                if spare is not None:
+                    self._next_buffer = spare
+                    self._own_buffers.append(spare)
+                    return spare[:n]
+            return self.record_buffer[self.blevel:self.blevel + n] if self.blevel + n <= L else None
 
         for batch in rd.iter_batches(instructions, want_truth=True, record_sink=sink, **kwargs):
+            self._batch_leases = []             # buffers handed out while this batch is worked on stay taken until it is done
             rec, first, left, right = batch['records'], batch['first'], batch['left'], batch['right']
             table, rows, before = batch['truth_table'], batch['truth_rows'], batch['truth_before']
             left_ns = left * dt
@@ -171,6 +195,7 @@ class ChunkRawRecords(object):
                         if r != self.current_digitized_right:
                             self.last_digitized_right, self.current_digitized_right = self.current_digitized_right, r
                     rd.left, rd.right = int(left[stop - 1]), int(right[stop - 1])
+                    buf = self.record_buffer
                     src = rec[first[w]:first[stop]]
                     dst = buf[self.blevel:self.blevel + n_new]
                     # cutting the buffer at chunk_time by bisection needs it time sorted: windows of a run do not overlap in time
@@ -202,6 +227,7 @@ class ChunkRawRecords(object):
                     log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
                     # the reference skips pulse by pulse in the order it yields them; here whole records in time order
                     wrec = wrec[:max(L - self.blevel, 0)]
+                buf = self.record_buffer
                 dst = buf[self.blevel:self.blevel + len(wrec)]
                 if len(wrec) and self.blevel and int(wrec['time'][0]) < int(buf['time'][self.blevel - 1]):
                     self._sorted_stream = False
@@ -213,6 +239,42 @@ class ChunkRawRecords(object):
                 rd._write_truth(table, rows[k:], self.truth_buffer)
             if batch['finished']:
                 rd.source_finished = True
+            self._drop_next_buffer()            # (a spare buffer this batch did not move into after all: its records were copied over)
+        self._batch_leases = []
+
+    def _drop_next_buffer(self):
+        if self._next_buffer is not None:
+            from .engine import release_record_buffer
+            release_record_buffer(self._next_buffer)
+            self._own_buffers = [b for b in self._own_buffers if b is not self._next_buffer]
+            self._next_buffer = None
+
+    def _hand_out(self, n_out):
+        """The first n_out records of the (time-sorted) record buffer as the chunk's array.  Large chunks are not copied: the
+        buffer itself goes to the consumer (it returns to the pool when the consumer drops the chunk) and the chunker carries
+        on in a spare page-locked buffer, into which only the records behind the cut are moved.  Without a spare buffer
+        (a consumer that keeps every chunk) or for small chunks: a copy, as the reference makes.  Returns (array, moved)."""
+        from .engine import acquire_record_buffer, is_pooled_record_buffer, lease_record_buffer
+        old = self.record_buffer
+        if (n_out < self.zero_copy_min_records or not self.config.get('zero_copy_chunks', True) or not is_pooled_record_buffer(old)):
+            return _copy_records(old[:n_out]), False
+        if self._next_buffer is not None and n_out == self.blevel:
+            new, self._next_buffer = self._next_buffer, None       # the batch in hand already lies at its front (sink)
+        elif self._next_buffer is not None:
+            return _copy_records(old[:n_out]), False               # (records stay behind the cut: not the case the spare was taken for)
+        else:
+            new = acquire_record_buffer(len(old), old.dtype, spare_only=True)
+            if new is None:
+                return _copy_records(old[:n_out]), False
+            self._own_buffers.append(new)
+        self._own_buffers = [b for b in self._own_buffers if b is not old]      # the lease's finaliser returns it to the pool
+        n_left = self.blevel - n_out
+        new[:n_left] = old[n_out:self.blevel]
+        out = lease_record_buffer(old, n_out)
+        if getattr(self, '_batch_leases', None) is not None:
+            self._batch_leases.append(out)      # records of the batch in hand may still be read from the old buffer
+        self.record_buffer, self.blevel = new, n_left
+        return out, True
 
     # ---- window granularity: records arrive packed from the GPU ------------------------------------
     def _run_windows(self, instructions, **kwargs):
@@ -306,20 +368,26 @@ class ChunkRawRecords(object):
         _truth.sort(order='time')
 
         det = self.config['detector']
+        moved = False
         if det == 'XENON1T' or det == 'XENONnT_neutron_veto':
-            yield dict(raw_records=_copy_records(records) if maska is None else records, truth=_truth)
+            if maska is None:
+                records, moved = self._hand_out(n_out)
+            yield dict(raw_records=records, truth=_truth)
         elif det == 'XENONnT':
             he = self.config['channel_map']['he']
             engine = getattr(self.rawdata, 'engine', None)
             if maska is None and engine is not None and not engine.emits_he_records:
-                # every record is a TPC record (no HE rows are digitised, row 800 is never emitted): one plain copy
+                # every record is a TPC record (no HE rows are digitised, row 800 is never emitted): the buffer's prefix as it is
                 empty = records[:0].copy()
-                yield dict(raw_records=_copy_records(records), raw_records_he=empty, raw_records_aqmon=empty.copy(), truth=_truth)
+                records, moved = self._hand_out(n_out)
+                yield dict(raw_records=records, raw_records_he=empty, raw_records_aqmon=empty.copy(), truth=_truth)
             else:
                 yield dict(raw_records=records[records['channel'] < he[0]],
                            raw_records_he=records[(records['channel'] >= he[0]) & (records['channel'] <= he[-1])],
                            raw_records_aqmon=records[records['channel'] == 800],
                            truth=_truth)
+        if moved:
+            return                  # _hand_out switched buffers and moved the records behind the cut
         if maska is None:
             n_left = self.blevel - n_out
             self.record_buffer[:n_left] = self.record_buffer[n_out:self.blevel]
