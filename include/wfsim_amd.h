@@ -288,6 +288,9 @@ int wfs_set_debug(wfs_handle *h, int32_t flags);
 /* parity tests: noise start index per digitise window (rawdata.py:417) instead of the Philox draw; entries < 0 keep the draw.
  * Indexed by the window number of wfs_copy_groups (host pointer, copied). n = 0 clears the override. */
 int wfs_set_noise_offsets(wfs_handle *h, const int64_t *ix_rand, int64_t n);
+/* A noise array of floats, f64[noise_len][noise_channels] (call after wfs_set_tables; replaces its int16 table): add_noise
+ * (rawdata.py:436, numba) adds noise_data[ix, ch] into the int64 row, which stores the truncated SUM. */
+int wfs_set_noise_float(wfs_handle *h, const double *noise, int32_t noise_len, int32_t noise_channels);
 int wfs_set_stream(wfs_handle *h, void *hip_stream);
 int wfs_synchronize(wfs_handle *h);
 /* HIP-event timing of the kernels of the last wfs_run: names (NUL separated) and milliseconds */

@@ -104,6 +104,10 @@ class Oracle:
         self._s = C.c_void_p(L.orc_new(C.byref(cfg), _p(t['templates']), _p(t['spe']), _p(t['gains']), _p(t['thr_truth']),
                                        _p(t['thr_zle']), _p(t['lum_x']), _p(t['lum_t']), _p(t['noise'])))
         self._keep = []
+        nz = tables.get('noise')
+        if nz is not None and np.asarray(nz).dtype.kind == 'f' and not np.array_equal(np.asarray(nz), np.trunc(nz)):
+            self._noise_f = _arr(nz, np.float64)                # a float noise array: the truncated sum is stored (rawdata.py:436)
+            L.orc_set_noise_float(self._s, _p(self._noise_f))
         if ap_tables:
             for e, (name, d) in enumerate(ap_tables.items()):
                 dc = _arr(d['delaytime_cdf'], np.float64)
@@ -286,6 +290,11 @@ def add_noise(data, mask, left, right, noise, ix_rand):
     data_c = np.ascontiguousarray(data, dtype=np.int64)
     assert data_c is data or data.size == 0 or np.shares_memory(data_c, data)
     m, l, r = _arr(mask, np.uint8), _arr(left, np.int64), _arr(right, np.int64)
+    if np.asarray(noise).dtype.kind == 'f':          # float noise: numba stores the truncated sum into the int64 row
+        nz = _arr(noise, np.float64)
+        lib().orc_add_noise_float(_p(data_c), C.c_int64(data.shape[0]), C.c_int64(data.shape[1]), _p(m), _p(l), _p(r), _p(nz),
+                                  C.c_int64(nz.shape[0]), C.c_int64(nz.shape[1]), C.c_int64(int(ix_rand)))
+        return
     nz = _arr(noise, np.int16)
     lib().orc_add_noise(_p(data_c), C.c_int64(data.shape[0]), C.c_int64(data.shape[1]), _p(m), _p(l), _p(r), _p(nz),
                         C.c_int64(nz.shape[0]), C.c_int64(nz.shape[1]), C.c_int64(int(ix_rand)))

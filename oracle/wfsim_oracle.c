@@ -77,6 +77,7 @@ typedef struct orc_session_s {
     const i64 *thr_zle;          /* [n_rows] baseline - thr - 1, rawdata.py:290-294  */
     const double *lum_x, *lum_t; /* [n_lum] normalised cdf, emission time, s2.py:333-338 */
     const int16_t *noise;        /* [noise_len][noise_channels] */
+    const double *noise_f;       /* float noise (orc_set_noise_float): the truncated sum is stored, rawdata.py:436 */
     orc_ap_element ap[8];
     double current_max[10];
 
@@ -217,6 +218,7 @@ void orc_set_ap_element(orc_session *s, int e, int n_bins_delay, int n_bins_amp,
     a->delay_bin = delay_bin; a->amp_bin = amp_bin; a->delay_cdf = delay_cdf; a->amp_cdf = amp_cdf;
 }
 
+void orc_set_noise_float(orc_session *s, const double *noise) { s->noise_f = noise; if (noise && !s->noise) s->noise = (const int16_t *)noise; }
 void orc_set_noise_override(orc_session *s, const i64 *ix, i64 n) { s->noise_override = ix; s->n_noise_override = n; }
 void orc_set_save_full_truth(orc_session *s, int on) { s->save_full_truth = on; }
 
@@ -376,6 +378,7 @@ i64 orc_find_intervals_below_threshold(const i64 *w, i64 n, i64 threshold, i64 h
 /* rawdata.py:398-437 add_noise, the part after ix_rand is drawn: per masked channel noise[(ix_rand + ix - ch_left) mod N, ch]
  * is added to the samples ch_left..ch_right that exist (the reference guards against ix >= row length), channels past the
  * noise columns are skipped. */
+static const double *g_noise_f = NULL;       /* set around add_noise_rows by the session that has a float noise array */
 static void add_noise_rows(i64 *raw, i64 R, i64 L, const uint8_t *mask, const i64 *ml, const i64 *mr,
                            const int16_t *noise, i64 N, i64 noise_channels, i64 ix_rand)
 {
@@ -385,7 +388,8 @@ static void add_noise_rows(i64 *raw, i64 R, i64 L, const uint8_t *mask, const i6
             if (ix >= L) continue;
             i64 in = ix_rand + ix - ml[ch];
             if (in >= N) in -= N * (in / N);
-            raw[ch * L + ix] += noise[in * noise_channels + ch];
+            if (g_noise_f) raw[ch * L + ix] = (i64)((double)raw[ch * L + ix] + g_noise_f[in * noise_channels + ch]);
+            else raw[ch * L + ix] += noise[in * noise_channels + ch];
         }
     }
 }
@@ -401,6 +405,13 @@ void orc_add_noise(i64 *raw, i64 R, i64 L, const uint8_t *mask, const i64 *ml, c
                    i64 noise_channels, i64 ix_rand)
 {
     add_noise_rows(raw, R, L, mask, ml, mr, noise, N, noise_channels, ix_rand);
+}
+void orc_add_noise_float(i64 *raw, i64 R, i64 L, const uint8_t *mask, const i64 *ml, const i64 *mr, const double *noise, i64 N,
+                         i64 noise_channels, i64 ix_rand)
+{
+    g_noise_f = noise;
+    add_noise_rows(raw, R, L, mask, ml, mr, (const int16_t *)noise, N, noise_channels, ix_rand);
+    g_noise_f = NULL;
 }
 
 /* rawdata.py:204-272 digitize_pulse_cache + :398-458 add_noise/add_baseline/digitizer_saturation, then
@@ -448,7 +459,9 @@ void orc_digitize_and_zle(orc_session *s, u32 noise_gid)
             if (high <= 0) ix_rand = 0;
             else { u32 w[4]; draw(s, 0, noise_gid, 0, SITE_NOISE, w); ix_rand = (i64)(u53(w[0], w[1]) * (double)high); }
             if (s->noise_override && s->dg_left.n < s->n_noise_override && s->noise_override[s->dg_left.n] >= 0) ix_rand = s->noise_override[s->dg_left.n];
+            g_noise_f = s->noise_f;
             add_noise_rows(raw, R, L, mask, ml, mr, s->noise, N, c->noise_channels, ix_rand);
+            g_noise_f = NULL;
         }
     }
     i64 dg = s->dg_left.n;

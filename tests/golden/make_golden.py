@@ -713,6 +713,22 @@ def fixture_aft_sigma(ref):
     np.savez_compressed(HERE + '/aft_sigma.npz', pattern=p0, n_photons=n_ph, sigma=0.15, skewness=2.0, top_counts=top, top_hist=hist)
 
 
+def fixture_noise_float(ref):
+    """RawData.add_noise (rawdata.py:398-437, numba) with a FLOAT noise array on int64 rows: what `data[ch, ix] += noise[ix, ch]`
+    stores.  Rows as long as the noise array (high = 0 -> ix_rand = 0, no random draw)."""
+    rng = np.random.default_rng(12)
+    n_ch, n = 3, 64
+    data = rng.integers(-40, 5, size=(n_ch, n)).astype(np.int64)
+    noise = rng.uniform(-3.0, 3.0, size=(n, n_ch))
+    noise[::7] = np.round(noise[::7])               # some exact integers, some exact halves
+    noise[3::11] = np.round(noise[3::11]) + 0.5
+    mask = np.zeros(n_ch, dtype=[('mask', '?'), ('left', 'i8'), ('right', 'i8')])
+    mask['mask'], mask['left'], mask['right'] = True, 0, n - 1
+    out = data.copy()
+    ref.rawdata.RawData.add_noise(out, mask, noise, n, n_ch)
+    np.savez_compressed(HERE + '/noise_float.npz', data=data, noise=noise, out=out)
+
+
 def fixture_optical_adjustment(ref):
     """utils.optical_adjustment (host preparation of optical input): random photon lists, a third of the entries longer
     than PULSE_MAX_DURATION, some empty"""
@@ -890,7 +906,7 @@ def fixture_chain_stats(ref):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap', 'aft_sigma']
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap', 'aft_sigma', 'noise_float']
     ref = import_reference_interface() if 'chunker' in which else import_reference()
     p = fixture_tables(ref)
     if 'add_current' in which:
@@ -919,6 +935,8 @@ if __name__ == '__main__':
         fixture_gas_gap(ref)
     if 'aft_sigma' in which:
         fixture_aft_sigma(ref)
+    if 'noise_float' in which:
+        fixture_noise_float(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(('.npz', '.json')):
             print(f'{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:9.1f} KiB')

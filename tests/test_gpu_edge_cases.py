@@ -5,6 +5,7 @@ import pytest
 
 import wfsim_amd
 from wfsim_amd.config import xenonnt_test_config
+from wfsim_amd.dtypes import instruction_dtype
 from wfsim_amd.engine import WfsError
 from tests.test_gpu_generation import _instructions, _run_both, _compare, MS
 
@@ -62,3 +63,35 @@ def test_window_longer_than_1e6_samples_is_an_error():
         list(rd(ins))
     # the engine stays usable afterwards
     assert len(list(rd(ins[:20]))) > 0
+
+
+def test_float_noise_array():
+    """a noise array of floats with non-integral values (rawdata.py:436 stores the truncated sum into the int64 row):
+    device == oracle, and different from the same array truncated on upload"""
+    import wfsim_amd
+    from tests.helpers import golden, make_engine, make_oracle
+    from wfsim_amd.physics import instruction_params
+    from wfsim_amd.resource import Resource
+    from wfsim_amd.scheduler import schedule
+    nz = golden('noise.npz')['noise']
+    rng = np.random.default_rng(3)
+    noise_f = nz.astype(np.float64) + rng.uniform(-0.9, 0.9, nz.shape)
+    ins = np.zeros(12, dtype=instruction_dtype)
+    ins['type'] = np.tile([1, 2], 6)
+    ins['time'] = 1_000_000 + 400_000 * np.arange(12)
+    ins['z'], ins['amp'], ins['recoil'], ins['event_number'] = -20.0, np.tile([3000, 200], 6), 7, np.arange(12)
+    out = {}
+    for tag, arr in (('float', noise_f), ('truncated', np.trunc(noise_f))):
+        cfg = xenonnt_test_config(seed=12, enable_noise=True, noise_data=arr)
+        res = Resource(cfg)
+        order, key, cluster = schedule(ins, cfg)
+        s_ins, gid = ins[order], order.astype(np.uint32)
+        ip = instruction_params(s_ins, cfg, res)
+        eng = make_engine(cfg, resource=res)
+        eng.load_instructions(s_ins, gid, cluster, key, ip)
+        eng.run()
+        orc = make_oracle(cfg, resource=res)
+        orc.simulate(s_ins, gid, ip)
+        out[tag] = eng.records().tobytes()
+        assert out[tag] == orc.pack_records().tobytes() and len(out[tag]) > 0
+    assert out['float'] != out['truncated']

@@ -54,3 +54,16 @@ def test_add_noise_skips_channels_without_noise_columns_and_unmasked_rows():
     O.add_noise(data, mask, left, right, noise, 11)
     assert np.array_equal(data, want)
     assert not data[1].any() and not data[3].any() and not data[4].any() and data[0].any() and data[2, 5:31].any()
+
+
+def test_float_noise_stores_the_truncated_sum_like_the_reference():
+    """tests/golden/noise_float.npz: the reference's add_noise (numba) run on int64 rows with a float noise array --
+    `data[ch, ix] += noise[ix, ch]` stores trunc(data + noise), not data + trunc(noise)"""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'noise_float.npz'))
+    data, noise, out = d['data'], d['noise'], d['out']
+    n_ch, n = data.shape
+    mine = data.copy()
+    O.add_noise(mine, np.ones(n_ch, dtype=np.uint8), np.zeros(n_ch, dtype=np.int64), np.full(n_ch, n - 1, dtype=np.int64), noise, 0)
+    assert np.array_equal(mine, out)
+    assert not np.array_equal(out, data + np.trunc(noise.T).astype(np.int64))        # the difference is visible in the fixture

@@ -136,4 +136,5 @@ struct WfsDev {
     const double *templates, *spe, *gains, *thr_truth, *lum_x, *lum_t;
     const i64 *thr_zle;
     const int16_t *noise;
+    const double *noise_f;       // a float noise array (wfs_set_noise_float): the sum is stored truncated (rawdata.py:436 into an int64 row)
 };

@@ -40,7 +40,7 @@ struct wfs_handle {
     GenArgs gen_args{};           // the generator's view of the batch (kept for wfs_gather_photon_times)
     int carry_has = 0; i64 carry_runmax = 0;
     // tables
-    DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise;
+    DevBuf t_templates, t_spe, t_gains, t_thr_truth, t_thr_zle, t_lumx, t_lumt, t_noise, t_noise_f;
     ApElem ap[WFS_MAX_AP];
     // instructions
     i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
@@ -399,7 +399,7 @@ int wfs_destroy(wfs_handle *h)
         hipFree(h->stamps.p);
     }
 #endif
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -432,6 +432,24 @@ int wfs_set_stream(wfs_handle *h, void *s)
 }
 
 int wfs_synchronize(wfs_handle *h) { if (!h) return WFS_E_INVALID; HIPCHK(hipStreamSynchronize(h->stream)); return WFS_OK; }
+// a noise array of floats (resource.noise_data of a float dtype with non-integral values): add_noise (rawdata.py:436) adds it into
+// the int64 row inside numba, which stores the TRUNCATED SUM -- not the sum with the truncated noise.  Replaces the int16 table.
+int wfs_set_noise_float(wfs_handle *h, const double *noise, int32_t noise_len, int32_t noise_channels)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
+    if (!noise || noise_len <= 0 || noise_channels <= 0) return h->fail(WFS_E_INVALID, "wfs_set_noise_float: empty noise array");
+    HIPCHK(hipSetDevice(h->device));
+    std::vector<double> nt((size_t)noise_len * noise_channels);
+    for (int64_t i = 0; i < noise_len; i++) for (int c = 0; c < noise_channels; c++) nt[(size_t)c * noise_len + i] = noise[(size_t)i * noise_channels + c];
+    TRY(upload(h, h->t_noise_f, nt.data(), sizeof(double) * nt.size()));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    WfsDev &d = h->dev;
+    d.noise_f = h->t_noise_f.as<double>(); d.noise = (const int16_t *)d.noise_f; d.noise_len = noise_len; d.noise_channels = noise_channels;
+    refresh_dev(h);
+    return WFS_OK;
+}
+
 int wfs_set_noise_offsets(wfs_handle *h, const int64_t *ix, int64_t n)
 {
     if (!h || n < 0 || (n > 0 && !ix)) return WFS_E_INVALID;
@@ -472,7 +490,7 @@ int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, in
         d.n_lum = n_lum; h->h_lum_x.assign(lum_x, lum_x + n_lum); h->h_lum_t.assign(lum_t, lum_t + n_lum);
     }
     TRY(build_time_tables(h));         // the S2 delay table contains the luminescence term
-    d.noise = nullptr; d.noise_len = 0; d.noise_channels = 0;
+    d.noise = nullptr; d.noise_f = nullptr; d.noise_len = 0; d.noise_channels = 0;
     if (noise && noise_len > 0 && noise_channels > 0) {
         // channel-major on the device ([channel][sample]; the reference's array is [sample][channel], rawdata.py:429): a row reads
         // consecutive samples of ONE channel -- time-major that is one cache line per sample

@@ -1132,7 +1132,9 @@ __device__ __forceinline__ i32 finish_sample(const WfsDev &d, const i32 *acc, i6
     if (d.enable_noise && slot_ch < d.noise_channels) {
         i64 in = ix_rand + i;
         if (in >= d.noise_len) in -= (i64)d.noise_len * (in / d.noise_len);
-        v += d.noise[(i64)slot_ch * d.noise_len + in];          // channel-major copy (wfs_set_tables): consecutive samples, consecutive addresses
+        // channel-major copy (wfs_set_tables): consecutive samples, consecutive addresses
+        if (d.noise_f) v = (i64)((double)v + d.noise_f[(i64)slot_ch * d.noise_len + in]);     // numba: int64 += float64 stores the truncated sum
+        else v += d.noise[(i64)slot_ch * d.noise_len + in];
     }
     v += d.baseline;
     return v < 0 ? 0 : (i32)v;

@@ -101,7 +101,7 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range',
            'wfs_copy_records_range_async', 'wfs_wait_records', 'wfs_host_register', 'wfs_host_unregister',
            'wfs_set_gas_gap_model', 'wfs_set_instruction_gas_gap', 'wfs_set_pattern_map_points', 'wfs_set_instruction_aft',
-           'wfs_scalar_map_grid', 'wfs_scalar_map_points', 'wfs_scalar_map_spline', 'wfs_scalar_map_eval']
+           'wfs_scalar_map_grid', 'wfs_scalar_map_points', 'wfs_scalar_map_spline', 'wfs_scalar_map_eval', 'wfs_set_noise_float']
 
 
 def load_library():
@@ -183,6 +183,12 @@ class Engine:
                     C.c_int32('Uniform' in name), C.c_double(d['delaytime_bin_size']), C.c_double(d['amplitude_bin_size']), _p(dc), _p(ac)))
 
         # HE records exist only when the HE rows can differ from a flat baseline (wfs_engine.hip refresh_dev): a non-zero
+        if t['noise'] is not None and np.asarray(resource.noise_data).dtype.kind == 'f' \
+                and not np.array_equal(np.asarray(resource.noise_data), np.trunc(resource.noise_data)):
+            # a float noise array with non-integral values: numba's `int64 row += float64 noise` (rawdata.py:436) stores the
+            # truncated SUM, which the int16 table cannot express -- the device then adds in f64 and truncates as well
+            nf = _arr(resource.noise_data, np.float64)
+            self._check(self.lib.wfs_set_noise_float(self._h, _p(nf), C.c_int32(nl), C.c_int32(nc)))
         # int(high_energy_deamplification_factor) (rawdata.py:242) or noise columns for the HE channels
         he_noise = bool(params['enable_noise']) and nc > params['he_first']
         self.emits_he_records = bool(params['detector_nt'] and params['n_top'] > 0 and (params['he_factor'] != 0 or he_noise))
