@@ -22,14 +22,16 @@ def _case():
     return cfg, big
 
 
-def _worker(rank, world, port, out, quanta=None):
+def _worker(rank, world, port, out, quanta=None, gather=True):
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from wfsim_amd.distributed import simulate_sharded
     cfg, ins = _case()
-    rec = simulate_sharded(cfg, ins, device=0, max_batch_quanta=quanta)
-    if rank == 0:
+    rec = simulate_sharded(cfg, ins, device=0, max_batch_quanta=quanta, gather=gather)
+    if not gather:
+        np.save(out + f'.{rank}.npy', rec)          # every rank keeps its own time range
+    elif rank == 0:
         np.save(out, rec)
     dist.barrier()
     dist.destroy_process_group()
@@ -49,6 +51,23 @@ def test_sharded_ranks_equal_single_process(tmp_path, world, quanta):
     cfg, ins = _case()
     ref = np.concatenate([w['records'] for w in wfsim_amd.RawData(cfg).iter_windows(ins)])
     assert len(ref) > 1000 and got.tobytes() == ref.tobytes()
+
+
+def test_sharded_without_the_gather_every_rank_keeps_its_time_range(tmp_path):
+    """gather=False (delivery stays sharded, nothing funnels through one PCIe link): the per-rank records,
+    concatenated in rank order, are the run"""
+    import wfsim_amd
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'records')
+    mp.spawn(_worker, args=(3, port, out, None, False), nprocs=3, join=True)
+    parts = [np.load(out + f'.{r}.npy') for r in range(3)]
+    cfg, ins = _case()
+    ref = np.concatenate([w['records'] for w in wfsim_amd.RawData(cfg).iter_windows(ins)])
+    assert all(len(p) for p in parts) and np.concatenate(parts).tobytes() == ref.tobytes()
+    assert all(parts[r]['time'].max() < parts[r + 1]['time'].min() for r in range(2))
 
 
 def test_device_resident_records_equal_host_records():

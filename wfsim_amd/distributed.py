@@ -127,7 +127,7 @@ def gather_batches(tensors, dst=0, device=None, group=None):
     return [rounds[k][r] for r in range(world) for k in range(len(rounds)) if rounds[k][r].numel()]
 
 
-def simulate_sharded(config, instructions, device=None, dst=0, max_batch_quanta=None):
+def simulate_sharded(config, instructions, device=None, dst=0, max_batch_quanta=None, gather=True):
     """All ranks call this with the same instructions; rank ``dst`` gets the time-ordered raw_records of the whole
     run (numpy structured array), the others ``None``.  One process per GPU (``LOCAL_RANK`` picks the device).
 
@@ -135,8 +135,9 @@ def simulate_sharded(config, instructions, device=None, dst=0, max_batch_quanta=
     tensor and from there over RCCL to ``dst`` (no host hop), the transfer of batch k overlapping the kernels of batch
     k + 1 -- the path ``bench.py --gpus N`` times.  Ranks run a common number of rounds (a rank that is out of batches
     sends nothing).  Only ``dst`` moves records to the host, once, at the end: on an 8-GPU node that is 8 shards through ONE
-    PCIe link -- a consumer that can read per-rank output (strax writes per-plugin chunks) should rather run one
-    ChunkRawRecords per rank on its own time range and skip the gather."""
+    PCIe link.  ``gather=False``: no record leaves its rank -- every rank gets the records of ITS time range (ranges are
+    contiguous in time and disjoint: concatenated in rank order they are the run); what a consumer that can write per-rank
+    output should use.  The check that no digitise window reaches into the next shard is made either way."""
     import os
     import torch
     import torch.distributed as dist
@@ -169,7 +170,10 @@ def simulate_sharded(config, instructions, device=None, dst=0, max_batch_quanta=
             if len(batch['right']):
                 last_end = max(last_end, (int(np.max(batch['right'])) - config['trigger_window']) * config['sample_duration'])
             yield batch['records'] if on_gpu else torch.from_numpy(np.ascontiguousarray(batch['records']).view(np.uint8).copy())
-    parts = gather_batches(tensors(), dst=dst, device=coll)
+    if gather:
+        parts = gather_batches(tensors(), dst=dst, device=coll)
+    else:
+        parts = [t for t in tensors() if t.numel()]
     # no digitise window may reach into the next shard (rawdata.py:96-98 applied across the cut)
     ends = [None] * world
     dist.all_gather_object(ends, int(last_end))
@@ -178,7 +182,7 @@ def simulate_sharded(config, instructions, device=None, dst=0, max_batch_quanta=
         run_end = max(run_end, ends[r])
         if b[r + 1] < len(key) and b[r + 1] > b[r] and not (key[b[r + 1]] - run_end > config['right_raw_extension']):
             raise RuntimeError(f'a digitise window of shard {r} reaches into shard {r + 1}: the result would depend on the sharding')
-    if rank != dst:
+    if gather and rank != dst:
         return None
     if not parts:
         return np.zeros(0, dtype=raw_record_dtype())
