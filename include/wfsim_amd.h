@@ -169,6 +169,13 @@ int wfs_set_pattern_map_points(wfs_handle *h, int32_t which, int32_t dims, int64
  * new = clip(cur * factor, 0, 1), top channels are scaled by new / cur and the others by (1 - new) / (1 - cur).
  * Call between wfs_load_instructions and wfs_eval_pattern_rows; factor = NULL clears it. */
 int wfs_set_instruction_aft(wfs_handle *h, int64_t n, const double *factor);
+/* diffusion_constant_transverse with enable_field_dependencies['diffusion_transverse_map'] (S2.s2_pattern_map_diffuse,
+ * s2.py:560-613): the pattern of an S2 instruction is the average of the pattern map over its surviving electrons, each
+ * displaced by N(0, sigma_r[i]) along the radius and N(0, sigma_a[i]) across it (cm; sqrt(2 D t) from the field maps, NaN: not
+ * this path); electrons that end outside tpc_radius do not count.  Evaluated inside wfs_run, behind the electron survival
+ * draws.  Needs the S2 pattern map as a regular grid (wfs_set_pattern_map) and the instruction loaded with cdf_row = -1;
+ * call between wfs_load_instructions and wfs_eval_pattern_rows (which still supplies the positions). */
+int wfs_set_instruction_diffusion(wfs_handle *h, int64_t n, const double *sigma_r, const double *sigma_a, double tpc_radius);
 
 /* ---- scalar maps evaluated on the device -------------------------------------------------------------------
  * The per-instruction inputs of the generator that the reference reads from straxen InterpolatingMaps: S1 light yield

@@ -249,6 +249,12 @@ class Oracle:
             k *= 2
         return pa[:k], pc[:k], int(vmin.value)
 
+    def sample_diffusion(self, gid, em_base, amp, p_survive):
+        """(survive[amp], z_radial[amp], z_azimuthal[amp]) of the candidate electrons of one S2 instruction"""
+        sv, z0, z1 = np.zeros(amp, dtype=np.uint8), np.zeros(amp), np.zeros(amp)
+        lib().orc_sample_diffusion(self._s, C.c_uint32(gid), C.c_uint32(em_base), C.c_int64(amp), C.c_double(p_survive), _p(sv), _p(z0), _p(z1))
+        return sv.astype(bool), z0, z1
+
     def sample_gas_gap(self, n, table, weight):
         """the 'garfield_gas_gap' luminescence term of the n photons of one instruction (mean subtracted, truncated)"""
         out = np.zeros(n, dtype=np.int64)

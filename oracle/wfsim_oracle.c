@@ -131,6 +131,7 @@ void orc_philox(const u32 *ctr, const u32 *key, u32 *out) { philox4x32_10(ctr[0]
  * index, double-PE flag, second SPE index.  SITE_PH, counter (0, gid, item): photons that arrive with time and channel
  * (optical input): x -> transit time, y -> gains.  SITE_PH_X, counter (emitter, gid, item): S1 optical propagation. */
 enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
+       SITE_EL_DIFF = 6 /* per electron: Box-Muller pair -> radial / azimuthal transverse diffusion, s2.py:588-589 */,
        SITE_DELAY = 16, SITE_CH = 17, SITE_GAIN = 18, SITE_PH = 19, SITE_PH_X = 20, SITE_LUM = 21 /* P-indexed like SITE_DELAY: garfield gas gap excitation time */,
        SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
 
@@ -1181,6 +1182,19 @@ void orc_sample_delay(orc_session *s, i64 n, int is_s2, i32 tab, int bottom, i32
     }
 }
 void orc_sample_poisson(orc_session *s, double lam, i64 n, i64 *out) { for (i64 i = 0; i < n; i++) out[i] = poisson_draw(s, (u32)i, 12345u, lam); }
+
+/* electrons of one S2 instruction as gen_s2 and the device see them (tests of the transverse diffusion, s2.py:560-613): survival flag
+ * (s2.py:254) and the two standard normals of the radial / azimuthal displacement */
+void orc_sample_diffusion(orc_session *s, u32 gid, u32 em_base, i64 amp, double cy, uint8_t *survive, double *z0, double *z1)
+{
+    const u64 T = bern_threshold(cy); u32 w[4];
+    for (i64 j = 0; j < amp; j++) {
+        if ((j & 3) == 0) draw(s, em_base, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);
+        survive[j] = (u64)w[j & 3] < T;
+        u32 B[4]; draw(s, em_base + (u32)j, gid, 0, SITE_EL_DIFF, B);
+        box_muller(B, &z0[j], &z1[j]);
+    }
+}
 
 /* the garfield gas gap luminescence term of n photons of one instruction exactly as gen_s2 adds it (tests) */
 void orc_sample_gas_gap(orc_session *s, i64 n, i32 lo, double wgt, i64 *out)

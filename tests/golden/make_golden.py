@@ -729,6 +729,42 @@ def fixture_noise_float(ref):
     np.savez_compressed(HERE + '/noise_float.npz', data=data, noise=noise, out=out)
 
 
+def diffusion_case():
+    """inputs of the transverse-diffusion fixture: a smooth synthetic S2 pattern map on a regular grid (the one of
+    tests/test_gpu_pattern_maps.map_config(0)), constant radial / azimuthal diffusion maps, four S2 positions (one at the edge)"""
+    rng = np.random.default_rng(0)
+    gx = np.linspace(-66, 66, 31)
+    pmt = rng.uniform(-60, 60, (N_TPC, 2))
+    d2 = (gx[:, None, None] - pmt[None, None, :, 0]) ** 2 + (gx[None, :, None] - pmt[None, None, :, 1]) ** 2
+    s2 = (1.0 / (1.0 + d2 / 40.0)).astype(np.float32)
+    pattern = dict(coordinate_system=[['x', [-66, 66, 31]], ['y', [-66, 66, 31]]], map=s2)
+    xy = np.array([[3.0, -7.0], [-30.0, 22.0], [40.0, 45.0], [0.5, 62.5]])
+    z = np.array([-20.0, -60.0, -110.0, -140.0])
+    return pattern, xy, z, dict(d_r=900.0, d_a=300.0, tpc_radius=64.0, v=6.77e-5)      # cm^2/s, cm, cm/ns
+
+
+def fixture_diffusion(ref):
+    """S2.s2_pattern_map_diffuse (s2.py:560-613) with diffusion_transverse_map: averaged patterns of four instructions of
+    20000 electrons each"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_itp_map', os.path.join(os.path.dirname(os.path.dirname(HERE)), 'wfsim_amd', 'itp_map.py'))
+    itp = importlib.util.module_from_spec(spec); spec.loader.exec_module(itp)
+    pattern, xy, z, par = diffusion_case()
+
+    class Res:
+        s2_pattern_map = itp.InterpolatingMap(pattern)
+
+        @staticmethod
+        def field_dependencies_map(z, xy, map_name='map'):
+            return np.full(len(z), dict(diffusion_radial_map=par['d_r'], diffusion_azimuthal_map=par['d_a'])[map_name], dtype=np.float64)
+    cfg = base_config(tpc_radius=par['tpc_radius'], drift_velocity_liquid=par['v'], diffusion_constant_transverse=1.0,
+                      enable_field_dependencies=dict(diffusion_transverse_map=True, drift_speed_map=False))
+    ne = np.full(len(z), 20000)
+    np.random.seed(404)
+    pat = ref.s2.S2.s2_pattern_map_diffuse(ne, z, xy, cfg, Res)
+    np.savez_compressed(HERE + '/diffusion.npz', patterns=pat, n_electron=ne)
+
+
 def fixture_optical_adjustment(ref):
     """utils.optical_adjustment (host preparation of optical input): random photon lists, a third of the entries longer
     than PULSE_MAX_DURATION, some empty"""
@@ -906,7 +942,7 @@ def fixture_chain_stats(ref):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap', 'aft_sigma', 'noise_float']
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap', 'aft_sigma', 'noise_float', 'diffusion']
     ref = import_reference_interface() if 'chunker' in which else import_reference()
     p = fixture_tables(ref)
     if 'add_current' in which:
@@ -937,6 +973,8 @@ if __name__ == '__main__':
         fixture_aft_sigma(ref)
     if 'noise_float' in which:
         fixture_noise_float(ref)
+    if 'diffusion' in which:
+        fixture_diffusion(ref)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(('.npz', '.json')):
             print(f'{f:28s} {os.path.getsize(os.path.join(HERE, f)) / 1024:9.1f} KiB')

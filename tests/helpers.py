@@ -126,3 +126,20 @@ def canonical_intervals(group, ch, left, right, data_off, data):
         out.append((int(group[k]), int(ch[k]), int(left[k]), int(right[k]),
                     np.asarray(data[data_off[k]:data_off[k + 1]], dtype=np.int64).tobytes()))
     return sorted(out)
+
+
+def host_diffuse_patterns(orc, pattern_map, xy, gids, amps, p_survive, sigma_r, sigma_a, tpc_radius, em_base=0):
+    """S2.s2_pattern_map_diffuse (s2.py:583-611) on the host with the electrons the oracle / the device draw: per instruction
+    (averaged pattern of the surviving electrons inside the TPC, number of them, per-channel standard error of that average)"""
+    out, n_in, err = [], [], []
+    for i in range(len(xy)):
+        sv, z0, z1 = orc.sample_diffusion(int(gids[i]), em_base, int(amps[i]), float(p_survive[i]))
+        th = np.arctan2(xy[i, 1], xy[i, 0])
+        hr, ha = z0[sv] * sigma_r[i], z1[sv] * sigma_a[i]
+        pos = np.array([xy[i, 0] + np.cos(th) * hr - np.sin(th) * ha, xy[i, 1] + np.sin(th) * hr + np.cos(th) * ha]).T
+        pos = pos[np.sum(pos ** 2, axis=1) <= tpc_radius ** 2]
+        p = np.asarray(pattern_map(pos), dtype=np.float64) if len(pos) else np.zeros((0, 1))
+        out.append(p.mean(axis=0) if len(pos) else None)
+        n_in.append(len(pos))
+        err.append(p.std(axis=0) / np.sqrt(max(len(pos), 1)) if len(pos) else None)
+    return out, n_in, err

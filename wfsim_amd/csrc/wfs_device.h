@@ -20,6 +20,7 @@ typedef unsigned int u32;
 
 enum WfsSite : u32 {
     SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
+    SITE_EL_DIFF = 6,    // per electron (emitter, gid, 0): Box-Muller pair -> radial / azimuthal transverse diffusion (s2.py:588-589)
     // photon streams, counter (em_base, gid, P >> 2, site), P = index of the photon among its instruction's photons; photon P owns word P & 3
     SITE_DELAY = 16,     // -> summed delay (alias table)
     SITE_CH = 17,        // -> channel

@@ -87,6 +87,8 @@ struct wfs_handle {
     struct ScalarMap { int kind = 0; PatternMap g; i32 nx = 0, ny = 0, kx = 0, ky = 0; DevBuf tx, ty, c; };
     std::vector<std::unique_ptr<ScalarMap>> smaps;
     DevBuf smap_pos, smap_out, smap_nb_idx, smap_nb_w, ins_aft; bool ins_aft_set = false;
+    // transverse diffusion with field maps: instructions whose pattern is averaged over their electrons (k_diffuse_patterns)
+    DevBuf ins_sigr, ins_siga, diff_row_ins, diff_row_id, diff_pre; std::vector<uint8_t> ins_diff; i64 n_diff_rows = 0; double diff_r2 = 0;
     std::vector<i32> dev_row_ins; std::vector<int8_t> h_ins_type; i64 n_host_rows = 0; bool dev_rows_pending = false;
     DevBuf map_row_ins[2], map_row_id[2], map_x, map_y, map_z, map_nb_idx[2], map_nb_w[2];
 
@@ -408,7 +410,7 @@ int wfs_destroy(wfs_handle *h)
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
-    for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft}) if (b->p) hipFree(b->p);
+    for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft, &h->ins_sigr, &h->ins_siga, &h->diff_row_ins, &h->diff_row_id, &h->diff_pre}) if (b->p) hipFree(b->p);
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
     for (auto &b : h->x_alias) if (b.p) hipFree(b.p);
@@ -605,7 +607,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     {
         std::vector<i32> rows(cdf_row, cdf_row + n);
         for (i64 i = 0; i < n; i++) if (rows[i] < 0) { rows[i] = (i32)(n_cdf + (i64)h->dev_row_ins.size()); h->dev_row_ins.push_back((i32)i); }
-        h->dev_rows_pending = !h->dev_row_ins.empty(); h->ins_aft_set = false;
+        h->dev_rows_pending = !h->dev_row_ins.empty(); h->ins_aft_set = false; h->n_diff_rows = 0; h->ins_diff.clear();
         const size_t total = (size_t)n_cdf + h->dev_row_ins.size();
         TRY(ensure(h, h->cdf_table, total * h->cfg.n_tpc * 8)); TRY(ensure(h, h->cdf_guide, total * (CDF_G + 2) * 2));
         TRY(upload(h, h->ins_cdfrow, rows.data(), (size_t)n * 4)); HIPCHK(hipStreamSynchronize(h->stream));
@@ -750,6 +752,35 @@ int wfs_set_instruction_aft(wfs_handle *h, int64_t n, const double *factor)
     return WFS_OK;
 }
 
+// diffusion_constant_transverse with enable_field_dependencies['diffusion_transverse_map'] (S2.s2_pattern_map_diffuse, s2.py:560-613):
+// sigma_r[i], sigma_a[i] = sqrt(2 D t) of instruction i along / across the radius (cm; NaN: not this path).  The pattern of such an
+// instruction is averaged over its surviving electrons inside wfs_run (k_diffuse_patterns), not by wfs_eval_pattern_rows.
+// Needs the S2 pattern map on the device as a regular grid and the instruction loaded with cdf_row = -1.
+int wfs_set_instruction_diffusion(wfs_handle *h, int64_t n, const double *sigma_r, const double *sigma_a, double tpc_radius)
+{
+    if (!h) return WFS_E_INVALID;
+    if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins || !sigma_r || !sigma_a) return h->fail(WFS_E_STATE, "wfs_set_instruction_diffusion follows wfs_load_instructions of the same batch");
+    const auto &pm = h->pmap[1];
+    if (!pm.set || pm.n_points || pm.dims != 2) return h->fail(WFS_E_STATE, "wfs_set_instruction_diffusion needs a regular-grid S2 pattern map on the device (wfs_set_pattern_map)");
+    HIPCHK(hipSetDevice(h->device));
+    h->ins_diff.assign((size_t)n, 0);
+    std::vector<char> is_dev((size_t)n, 0);
+    for (i32 i : h->dev_row_ins) is_dev[i] = 1;
+    std::vector<i32> rows; std::vector<i64> ids;
+    for (size_t k = 0; k < h->dev_row_ins.size(); k++) {
+        const i32 i = h->dev_row_ins[k];
+        if (h->h_ins_type[i] == 1 || !(sigma_r[i] == sigma_r[i]) || !(sigma_a[i] == sigma_a[i])) continue;
+        h->ins_diff[i] = 1; rows.push_back(i); ids.push_back(h->n_host_rows + (i64)k);
+    }
+    for (i64 i = 0; i < n; i++)
+        if (h->h_ins_type[i] != 1 && sigma_r[i] == sigma_r[i] && !is_dev[i]) return h->fail(WFS_E_STATE, "transverse diffusion: the instruction must take its pattern from the device map (cdf_row = -1)");
+    h->n_diff_rows = (i64)rows.size(); h->diff_r2 = tpc_radius * tpc_radius;
+    TRY(upload(h, h->ins_sigr, sigma_r, (size_t)n * 8)); TRY(upload(h, h->ins_siga, sigma_a, (size_t)n * 8));
+    TRY(upload(h, h->diff_row_ins, rows.data(), rows.size() * 4)); TRY(upload(h, h->diff_row_id, ids.data(), ids.size() * 8));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return WFS_OK;
+}
+
 // ---- scalar maps on the device: LCE (s1.py:125), S2 correction / SE gain (s2.py:193-234), longitudinal diffusion (s2.py:170),
 // field-dependence splines (s2.py:150, 248), field distortion maps (s2.py:41, 66) ----
 static int smap_new(wfs_handle *h, std::unique_ptr<wfs_handle::ScalarMap> m, int32_t *map_id)
@@ -831,7 +862,10 @@ int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float 
     i64 first = h->n_host_rows;
     // rows were numbered in instruction order; evaluate them map by map, each over its own (ordered) subset
     std::vector<i32> rows_of[2]; std::vector<i64> row_id[2];
-    for (size_t k = 0; k < h->dev_row_ins.size(); k++) { const int w = h->h_ins_type[h->dev_row_ins[k]] == 1 ? 0 : 1; rows_of[w].push_back(h->dev_row_ins[k]); row_id[w].push_back(first + (i64)k); }
+    for (size_t k = 0; k < h->dev_row_ins.size(); k++) {
+        if (!h->ins_diff.empty() && h->ins_diff[h->dev_row_ins[k]]) continue;       // averaged over its electrons inside wfs_run
+        const int w = h->h_ins_type[h->dev_row_ins[k]] == 1 ? 0 : 1; rows_of[w].push_back(h->dev_row_ins[k]); row_id[w].push_back(first + (i64)k);
+    }
     for (int w = 0; w < 2; w++) {
         if (rows_of[w].empty()) continue;
         const auto &pm = h->pmap[w];
@@ -1063,6 +1097,22 @@ static int run_generation(wfs_handle *h)
         TRY(ensure(h, h->eblk_ins, (size_t)(neb + 1) * 4)); g.eblk_ins = h->eblk_ins.as<i32>();
         { Timer t(h, "k_emitter_blocks"); hipLaunchKernelGGL(k_emitter_blocks, dim3(nblocks(neb + 1, 256)), dim3(256), 0, h->stream, g, neb); }
         Timer t(h, "k_s2_electrons"); hipLaunchKernelGGL(k_s2_electrons, dim3(nblocks(E, 256)), dim3(256), 0, h->stream, d, g);
+    }
+    if (h->n_diff_rows > 0) {
+        // transverse diffusion maps: the pattern of these instructions is the average over their surviving electrons (s2.py:560-613)
+        const auto &pm = h->pmap[1];
+        const i64 nr = h->n_diff_rows;
+        TRY(ensure(h, h->diff_pre, (size_t)nr * pm.n_map_ch * 8));
+        MapArgs m{};
+        map_args(pm, m);
+        m.n_rows = nr; m.row_ins = h->diff_row_ins.as<i32>(); m.row_id = h->diff_row_id.as<i64>();
+        m.x = h->map_x.as<float>(); m.y = h->map_y.as<float>(); m.z = h->map_z.as<float>();
+        m.cdf_table = h->cdf_table.as<double>(); m.cdf_guide = h->cdf_guide.as<unsigned short>(); m.gains = h->t_gains.as<double>();
+        m.aft = h->ins_aft_set ? h->ins_aft.as<double>() : nullptr; m.n_top = h->cfg.n_top;
+        DiffArgs q{nr, m.row_ins, h->ins_sigr.as<double>(), h->ins_siga.as<double>(), h->diff_r2, h->diff_pre.as<double>()};
+        { Timer t(h, "k_diffuse_patterns"); hipLaunchKernelGGL(k_diffuse_patterns, dim3((unsigned)nr), dim3(256), 0, h->stream, d, g, m, q); }
+        m.pre = h->diff_pre.as<double>();
+        { Timer t(h, "k_map_rows"); hipLaunchKernelGGL(k_map_rows, dim3((unsigned)nr), dim3(256), (size_t)d.n_tpc * 8, h->stream, m, d.n_tpc); }
     }
     TRY(scan(h, h->em_nph.as<i32>(), E, h->em_ph_off, 6));
     TRY(read_scal(h));

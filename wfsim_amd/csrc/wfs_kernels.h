@@ -1679,6 +1679,7 @@ struct MapArgs {
     const double *gains;           // [n_tpc] 0: turned-off PMT
     const double *aft;             // [n_ins] s2_aft_sigma: factor on the top-array fraction of the instruction's pattern, or nullptr
     i32 n_top;
+    const double *pre;             // [n_rows][n_map_ch] patterns already averaged (k_diffuse_patterns) instead of neighbour lists, or nullptr
 };
 
 __device__ __forceinline__ void map_position(const MapArgs &m, i64 r, double pos[3])
@@ -1697,11 +1698,9 @@ __device__ __forceinline__ void map_store_neighbours(const MapArgs &m, i64 r, in
     }
 }
 
-__global__ void k_map_neighbours(MapArgs m)
+// the K = 2 * dims nearest nodes of a regular grid (squared distances ascending in bd, node indices in bi)
+__device__ __forceinline__ void grid_nearest(const MapArgs &m, const double *pos, double *bd, i64 *bi)
 {
-    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= m.n_rows) return;
-    double pos[3]; map_position(m, r, pos);
     i32 c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
     for (int a = 0; a < m.dims; a++) {
         i32 c = (i32)floor((pos[a] - m.lo[a]) / m.h[a]);
@@ -1710,7 +1709,6 @@ __global__ void k_map_neighbours(MapArgs m)
         c1[a] = c + m.w[a] > m.n[a] - 1 ? m.n[a] - 1 : c + m.w[a];
     }
     const int K = 2 * m.dims;
-    double bd[MAP_K]; i64 bi[MAP_K];
     for (int k = 0; k < MAP_K; k++) { bd[k] = 1e300; bi[k] = -1; }
     for (i32 i = c0[0]; i <= c1[0]; i++) {
         const double dx = pos[0] - (m.lo[0] + i * m.h[0]);
@@ -1727,7 +1725,16 @@ __global__ void k_map_neighbours(MapArgs m)
             }
         }
     }
-    map_store_neighbours(m, r, K, bd, bi);
+}
+
+__global__ void k_map_neighbours(MapArgs m)
+{
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m.n_rows) return;
+    double pos[3]; map_position(m, r, pos);
+    double bd[MAP_K]; i64 bi[MAP_K];
+    grid_nearest(m, pos, bd, bi);
+    map_store_neighbours(m, r, 2 * m.dims, bd, bi);
 }
 
 // point-list maps (straxen.InterpolatingMap on an irregular coordinate system: a KD-tree query for the 2 * dims nearest
@@ -1769,6 +1776,67 @@ __global__ __launch_bounds__(256) void k_map_neighbours_points(MapArgs m)
         od[k] = d; oi[k] = i == 0x7fffffffffffffffLL ? -1 : i;
     }
     if (lane == 0) map_store_neighbours(m, r, K, od, oi);
+}
+
+// Transverse diffusion with field maps (S2.s2_pattern_map_diffuse, s2.py:560-613): the pattern of an instruction is the average
+// of the pattern map over its SURVIVING electrons' positions, each displaced by N(0, sigma_r) along the radius and N(0, sigma_a)
+// across it; electrons that end outside tpc_radius do not count.  One workgroup per instruction, after k_s2_electrons: batches of
+// 256 electrons -- a thread displaces one electron and finds its 4 grid neighbours (LDS), then the threads, one or two
+// channels each, add the 256 weighted patterns in electron order (a fixed order: reproducible sums).  An instruction without an
+// electron inside gets no pattern: its electrons make no photons (the reference's NaN pattern sends them to channel -1).
+struct DiffArgs { i64 n_rows; const i32 *row_ins; const double *sig_r, *sig_a; double r2max; double *pre; };
+
+__global__ __launch_bounds__(256) void k_diffuse_patterns(WfsDev d, GenArgs a, MapArgs m, DiffArgs q)
+{
+    __shared__ i32 s_idx[256][4]; __shared__ double s_w[256][4]; __shared__ i32 s_n, s_wn[4];
+    const i64 r = blockIdx.x; const int tid = threadIdx.x;
+    const i32 ins = q.row_ins[r];
+    const double x0 = (double)m.x[ins], y0 = (double)m.y[ins];
+    const double th = atan2(y0, x0), ct = cos(th), st = sin(th);
+    const double sr = q.sig_r[ins], sa = q.sig_a[ins];
+    const i64 e0 = a.em_off[ins], e1 = a.em_off[ins + 1];
+    const u32 jb = a.ins_embase[ins], gid = a.ins_gid[ins];
+    double acc[2] = {0.0, 0.0};
+    i64 n_in = 0;
+    for (i64 base = e0; base < e1; base += 256) {
+        const i64 e = base + tid;
+        bool ok = e < e1 && a.em_time[e] != I64_MIN;
+        double w[4] = {0, 0, 0, 0}, ws = 1; i64 bi[MAP_K];
+        if (ok) {
+            const u32x4 B = philox4x32_10(jb + (u32)(e - e0), gid, 0, SITE_EL_DIFF, d.k0, d.k1);
+            double z0, z1;
+            box_muller(B, z0, z1);
+            const double hr = z0 * sr, ha = z1 * sa;
+            const double pos[3] = {x0 + (ct * hr - st * ha), y0 + (st * hr + ct * ha), 0.0};
+            ok = pos[0] * pos[0] + pos[1] * pos[1] <= q.r2max;
+            if (ok) {
+                double bd[MAP_K];
+                grid_nearest(m, pos, bd, bi);
+                ws = 0;
+                for (int k = 0; k < 4; k++) { const double dist = sqrt(bd[k]); w[k] = bi[k] >= 0 ? 1.0 / (dist < 1e-6 ? 1e-6 : dist) : 0.0; ws += w[k]; }
+            }
+        }
+        // slots in electron order (ballot ranks): the sums below run in a fixed order
+        const u64 mask = __ballot(ok);
+        if ((tid & 63) == 0) s_wn[tid >> 6] = __popcll(mask);
+        __syncthreads();
+        int slot = __popcll(mask & ((1ull << (tid & 63)) - 1ull));
+        for (int v = 0; v < (tid >> 6); v++) slot += s_wn[v];
+        if (ok) for (int k = 0; k < 4; k++) { s_idx[slot][k] = bi[k] >= 0 ? (i32)bi[k] : 0; s_w[slot][k] = w[k] / ws; }
+        if (tid == 0) s_n = s_wn[0] + s_wn[1] + s_wn[2] + s_wn[3];
+        __syncthreads();
+        const int nb = s_n;
+        n_in += nb;
+        for (int c = tid, u = 0; c < m.n_map_ch && u < 2; c += 256, u++) {
+            double sum = acc[u];
+            for (int p = 0; p < nb; p++)
+                for (int k = 0; k < 4; k++) sum += s_w[p][k] * (double)m.values[(i64)s_idx[p][k] * m.n_map_ch + c];
+            acc[u] = sum;
+        }
+        __syncthreads();
+    }
+    for (int c = tid, u = 0; c < m.n_map_ch && u < 2; c += 256, u++) q.pre[r * m.n_map_ch + c] = n_in > 0 ? acc[u] / (double)n_in : 0.0;
+    if (n_in == 0) for (i64 e = e0 + tid; e < e1; e += 256) a.em_nph[e] = 0;
 }
 
 // scalar maps (LCE, S2 correction, SE gain, longitudinal diffusion ...: s1.py:125, s2.py:170-234): the weighted average itself
@@ -1837,11 +1905,12 @@ __global__ __launch_bounds__(256) void k_map_rows(MapArgs m, int nch)
     __shared__ double s_part[4]; __shared__ double s_sum;
     const i64 r = blockIdx.x; const int tid = threadIdx.x;
     double w[MAP_K]; i64 idx[MAP_K]; double wsum = 0;
-    for (int k = 0; k < MAP_K; k++) { w[k] = m.nb_w[r * MAP_K + k]; idx[k] = m.nb_idx[r * MAP_K + k]; wsum += w[k]; }
+    for (int k = 0; k < MAP_K; k++) { w[k] = m.pre ? 0.0 : m.nb_w[r * MAP_K + k]; idx[k] = m.pre ? -1 : m.nb_idx[r * MAP_K + k]; wsum += w[k]; }
     double part = 0;
     for (int c = tid; c < nch; c += 256) {
         double v = 1.0;
-        if (c < m.n_map_ch) {
+        if (c < m.n_map_ch && m.pre) v = m.pre[r * m.n_map_ch + c];
+        else if (c < m.n_map_ch) {
             double acc = 0;
             for (int k = 0; k < MAP_K; k++) if (idx[k] >= 0) acc += w[k] * (double)m.values[idx[k] * m.n_map_ch + c];
             v = acc / wsum;

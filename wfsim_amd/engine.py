@@ -101,7 +101,7 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range',
            'wfs_copy_records_range_async', 'wfs_wait_records', 'wfs_host_register', 'wfs_host_unregister',
            'wfs_set_gas_gap_model', 'wfs_set_instruction_gas_gap', 'wfs_set_pattern_map_points', 'wfs_set_instruction_aft',
-           'wfs_scalar_map_grid', 'wfs_scalar_map_points', 'wfs_scalar_map_spline', 'wfs_scalar_map_eval', 'wfs_set_noise_float']
+           'wfs_scalar_map_grid', 'wfs_scalar_map_points', 'wfs_scalar_map_spline', 'wfs_scalar_map_eval', 'wfs_set_noise_float', 'wfs_set_instruction_diffusion']
 
 
 def load_library():
@@ -291,6 +291,10 @@ class Engine:
             if aft is not None:
                 aft = _arr(aft, np.float64)
                 self._check(self.lib.wfs_set_instruction_aft(self._h, C.c_int64(n), _p(aft)))
+            ds = ip.get('diff_sigma')
+            if ds is not None:                  # diffusion_transverse_map: those rows are averaged over the electrons inside wfs_run
+                sr, sa = _arr(ds[0], np.float64), _arr(ds[1], np.float64)
+                self._check(self.lib.wfs_set_instruction_diffusion(self._h, C.c_int64(n), _p(sr), _p(sa), C.c_double(float(self.config['tpc_radius']))))
             pxy = ip.get('pattern_xy')          # S2: the observed position under a field distortion model
             xyz = [_arr(ins['x'] if pxy is None else pxy[:, 0], np.float32), _arr(ins['y'] if pxy is None else pxy[:, 1], np.float32), _arr(ins['z'], np.float32)]
             self._check(self.lib.wfs_eval_pattern_rows(self._h, C.c_int64(n), *[_p(q) for q in xyz]))

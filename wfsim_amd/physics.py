@@ -97,7 +97,8 @@ def s2_channel_probabilities(positions, config, resource, gids=None):
     ``diffusion_constant_transverse > 0`` sends the reference through s2_pattern_map_diffuse (s2.py:560-613), which reads
     the constant with ``getattr(config, ...)`` on a dict and therefore always diffuses by 0: every electron sits at the
     instruction's xy and the averaged pattern IS the pattern at xy (instructions outside ``tpc_radius`` get no pattern).
-    Only with the private ``diffusion_transverse_map`` field maps is there a real spread; that branch is not provided.
+    Only with the ``diffusion_transverse_map`` field maps is there a real spread: that average over the surviving electrons
+    is made on the device (``s2_transverse_sigmas``, wfs_set_instruction_diffusion) and needs the pattern map there.
     ``s2_aft_sigma``: the top-array fraction of every instruction's pattern is rescaled by a skew-normal factor
     (s2.py:660-665); the draw comes from a host Philox stream keyed by (seed, run-wide instruction id)."""
     channels = np.arange(config['n_tpc_pmts']).astype(np.int64)
@@ -105,7 +106,8 @@ def s2_channel_probabilities(positions, config, resource, gids=None):
     pattern = np.array(resource.s2_pattern_map(positions), dtype=np.float64)
     if config.get('diffusion_constant_transverse', 0) > 0:
         if config.get('enable_field_dependencies', {}).get('diffusion_transverse_map', False):
-            raise NotImplementedError('diffusion_transverse_map (private field maps, s2.py:575-579) is not on the MI355X path')
+            raise NotImplementedError('diffusion_transverse_map (s2.py:575-579) averages the pattern over the electrons the GPU draws: '
+                                      'it needs the S2 pattern map on the device as a regular grid (an InterpolatingMap, device_pattern_maps)')
         outside = np.sum(np.asarray(positions, dtype=np.float64) ** 2, axis=1) > config['tpc_radius'] ** 2     # s2.py:598
         pattern[outside] = 0
     if pattern.shape[1] - 1 not in bottom_index:
@@ -125,6 +127,22 @@ def s2_channel_probabilities(positions, config, resource, gids=None):
             pat[top_index] *= (new_aft / cur_aft)
             pat[bottom_index] *= (1 - new_aft) / (1 - cur_aft)
     return pattern
+
+
+def s2_transverse_sigmas(z_obs, xy_obs, config, resource):
+    """(sigma_radial, sigma_azimuthal) in cm of every instruction's electron cloud at the liquid surface,
+    S2.s2_pattern_map_diffuse (s2.py:572-589) with the ``diffusion_transverse_map`` field maps: sqrt(2 D t), D from the
+    radial / azimuthal diffusion maps (cm^2/s) at the observed position, t = -z / v with get_avg_drift_velocity (s2.py:139-155)"""
+    z_obs = np.asarray(z_obs, dtype=np.float64)
+    assert np.all(z_obs < 0), 'All S2 in liquid should have z < 0'
+    if config['enable_field_dependencies'].get('drift_speed_map', False):
+        v = resource.field_dependencies_map(z_obs, xy_obs, map_name='drift_speed_map') * 1e-4 * resource.drift_velocity_scaling
+    else:
+        v = config['drift_velocity_liquid']
+    d_r = resource.field_dependencies_map(z_obs, xy_obs, map_name='diffusion_radial_map') * 1e-9          # cm^2 / ns
+    d_a = resource.field_dependencies_map(z_obs, xy_obs, map_name='diffusion_azimuthal_map') * 1e-9
+    t = - z_obs / v
+    return np.sqrt(2 * d_r * t), np.sqrt(2 * d_a * t)
 
 
 def s2_aft_factors(n, config, gids=None):
@@ -191,6 +209,7 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
     pattern_xy = np.array([instructions['x'], instructions['y']], dtype=np.float64).T      # where the pattern map is evaluated
     outside = np.zeros(n, dtype=bool)         # S2 positions without a pattern (s2.py:598, see s2_channel_probabilities)
     aft_factor = np.full(n, np.nan)
+    diff_sigma = (np.full(n, np.nan), np.full(n, np.nan))      # diffusion_transverse_map: the pattern is averaged over the electrons on the device
     for sel, kind in ((is_s1, 's1'), (is_s2, 's2')):
         if not sel.any():
             continue
@@ -216,7 +235,14 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
 
             def probs(k):
                 return s2_channel_probabilities(xy_obs[:k], config, resource, None if sel_gids is None else sel_gids[:k])
-            if config.get('diffusion_constant_transverse', 0) > 0:
+            transverse_maps = (config.get('diffusion_constant_transverse', 0) > 0
+                               and config.get('enable_field_dependencies', {}).get('diffusion_transverse_map', False))
+            if transverse_maps:
+                if 's2' not in device_maps:
+                    raise NotImplementedError('diffusion_transverse_map (s2.py:575-579) needs the S2 pattern map on the device (regular grid)')
+                z_obs = s2_observed_positions(ins, config, resource)[0] if config.get('field_distortion_model', 'none') in ('inverse_fdc', 'comsol') else ins['z']
+                diff_sigma[0][idx], diff_sigma[1][idx] = s2_transverse_sigmas(z_obs, np.asarray(xy_obs, dtype=np.float64), config, resource)
+            elif config.get('diffusion_constant_transverse', 0) > 0:
                 outside[idx] = np.sum(np.asarray(xy_obs, dtype=np.float64) ** 2, axis=1) > config['tpc_radius'] ** 2
             per_instruction = config.get('s2_aft_sigma', 0.0) != 0 or bool(outside[idx].any())
         if kind in device_maps and not (kind == 's2' and config.get('s2_aft_sigma', 0.0) != 0 and not device_aft):
@@ -238,4 +264,5 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
     cdf_table = np.ascontiguousarray(np.stack(rows)) if rows else np.ones((1, n_ch))
     return dict(p_hit=p_hit, drift_mean=drift_mean, drift_spread=drift_spread, sc_gain=sc_gain,
                 cdf_row=cdf_row, cdf_table=cdf_table, pattern_xy=pattern_xy,
-                aft_factor=None if np.all(np.isnan(aft_factor)) else aft_factor)
+                aft_factor=None if np.all(np.isnan(aft_factor)) else aft_factor,
+                diff_sigma=None if np.all(np.isnan(diff_sigma[0])) else diff_sigma)
