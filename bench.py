@@ -266,7 +266,7 @@ def main():
     dom_ms, dom_launches = ktimes[dom]
     b_alg = algorithmic_bytes(counts)
     # HBM bytes per launch of the dominant kernel and what limits it, from the committed PMC profiles of this command
-    # (tools/profile_round.sh, tools/pmc_r2.sh -> profiles/r2_traffic.json, r2_counters.json); only for the profiled workload
+    # (tools/profile_round.sh + tools/make_profiles.py -> profiles/r2_traffic.json, r2_counters.json); only for the profiled workload
     traffic, limiter, valu_util = None, None, None
     if args.workload == 's2' and M == 1000:
         try:
