@@ -2191,9 +2191,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
         for (int q = 0; q < CPT; q++) {
             const int c = tid + q * TPB;
             if (c < nch) {
-                const i32 b0 = hist[c], b1 = hist[c + 1];
-                hoff[c] = toff_r[q] + (i32)base_r[q] - b0;
-                for (i32 k = b0; k < b1; k++) chmap[k] = (unsigned short)c;
+                hoff[c] = toff_r[q] + (i32)base_r[q] - hist[c];      // (the channel of every bucket position is noted when its photon is staged)
             }
         }
         STAMP(d, 1);
@@ -2237,7 +2235,8 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                 if (EXT && gg_lo >= 0) t += (i32)(i64)(gg_time(a, gg_lo, gg_w, word_of(LW, k)) - gg_m);      // s2.py:447-450, the cast of :532
                 if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t);
                 atomicMin(&hmin[c], t); atomicMax(&hmax[c], t);
-                stage[hist[c] + atomicAdd(&cur[c], 1)] = PhotonRec{t, code};
+                const int pos = hist[c] + atomicAdd(&cur[c], 1);
+                stage[pos] = PhotonRec{t, code}; chmap[pos] = (unsigned short)c;
             }
         }
         STAMP(d, 2);
