@@ -53,6 +53,8 @@ class DeviceMap:
         return out[:, None] if reg[1] else out
 
     def __getattr__(self, k):               # data, method, map_names, scale_coordinates ...
+        if k in ('host', 'engine', 'ids'):      # (not yet set: copy / pickle probing an empty instance)
+            raise AttributeError(k)
         return getattr(self.host, k)
 
 
@@ -76,4 +78,6 @@ class DeviceResource:
                 self.diffusion_longitudinal_map = rz_wrapper(dm)
 
     def __getattr__(self, k):
+        if k == '_resource':
+            raise AttributeError(k)
         return getattr(self._resource, k)
