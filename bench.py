@@ -111,6 +111,10 @@ def cpu_baseline(seed, n_sample, all_cores=True):
         wall = time.perf_counter() - t0
         out['all_cores'] = dict(value=sum(p[0] for p in parts) / wall, unit='photoelectrons/s', cores=cores,
                                 sample=f'{cores} processes x {per} instructions, {wall:.1f} s wall incl. process start')
+    # for context only (not measured on this box: the reference cannot travel): the reference's own Python path in no-JIT mode
+    # ran the same S2 shape at 5.7e5 PE/s on one core of the build container; its numba mode cannot be
+    # timed offline (numba does not initialise with the installed numpy)
+    out['reference_python_nojit_note'] = dict(value=5.7e5, unit='photoelectrons/s', cores=1, where='build container, SURVEY.md 6, not this box')
     return out
 
 
