@@ -1131,7 +1131,7 @@ __device__ __forceinline__ i32 finish_sample(const WfsDev &d, const i32 *acc, i6
     if (he) v *= d.he_factor;                                   // rawdata.py:242-246
     if (d.enable_noise && slot_ch < d.noise_channels) {
         i64 in = ix_rand + i;
-        if (in >= d.noise_len) in -= (i64)d.noise_len * (in / d.noise_len);
+        while (in >= d.noise_len) in -= d.noise_len;            // (= in mod noise_len, rawdata.py:433-434; a 64-bit division here costs more than the row)
         // channel-major copy (wfs_set_tables): consecutive samples, consecutive addresses
         if (d.noise_f) v = (i64)((double)v + d.noise_f[(i64)slot_ch * d.noise_len + in]);     // numba: int64 += float64 stores the truncated sum
         else v += d.noise[(i64)slot_ch * d.noise_len + in];
