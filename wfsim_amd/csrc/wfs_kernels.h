@@ -1146,6 +1146,29 @@ __device__ __forceinline__ void row_of_slot(const WfsDev &d, i64 idx, i64 &g, i3
     he = slot >= d.n_tpc; acc_ch = he ? slot - d.n_tpc : slot; channel = he ? d.he_first + acc_ch : slot;
 }
 
+// The same in two steps, for loops that want ALL their loads in flight before the first use: with the load inside finish_sample
+// the compiler waits for every load right behind it (a branch follows), and a wave spends one memory round trip per load.
+// A row no longer than the noise array wraps at most once (ix_rand < noise_len, i < len <= noise_len): no loop on the load path.
+struct RawSample { i32 acc; i32 nz; double nzf; };
+__device__ __forceinline__ RawSample load_sample(const WfsDev &d, const i32 *acc, i64 i, i64 noise_row, bool noisy, i64 ix_rand)
+{
+    RawSample s; s.acc = acc[i]; s.nz = 0; s.nzf = 0.0;
+    if (noisy) {                                                // (wave-uniform)
+        i64 in = ix_rand + i;
+        in = in >= d.noise_len ? in - d.noise_len : in;
+        if (d.noise_f) s.nzf = d.noise_f[noise_row + in]; else s.nz = d.noise[noise_row + in];
+    }
+    return s;
+}
+__device__ __forceinline__ i32 finish_loaded(const WfsDev &d, const RawSample &s, bool he, bool noisy)
+{
+    i64 v = s.acc;
+    if (he) v *= d.he_factor;
+    if (noisy) { if (d.noise_f) v = (i64)((double)v + s.nzf); else v += s.nz; }
+    v += d.baseline;
+    return v < 0 ? 0 : (i32)v;
+}
+
 // one wave per row: find_intervals_below_threshold (utils.py:13-58) in its parallel form: consecutive
 // hit samples a < b belong to one interval iff b - a <= max(holdoff, 1); then the window of rawdata.py:302-308.
 __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
@@ -1174,16 +1197,27 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     };
     i32 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;      // (a row is shorter than 10^6 samples: 32-bit indices)
     const i32 len32 = (i32)len, hold32 = (i32)hold;
+    const bool noisy = d.enable_noise && channel < d.noise_channels;
+    const bool fast_loads = len32 >= 1 && (!noisy || len32 <= d.noise_len);
+    const i64 noise_row = (i64)channel * d.noise_len;
     // chunks of 64 samples; the loads of ZLE_GROUP chunks are issued together (one dependent load per chunk leaves the wave
     // waiting a memory round trip per 64 samples)
     constexpr int ZLE_GROUP = 2;
     for (i32 g0 = 0; g0 < len32; g0 += 64 * ZLE_GROUP) {
         i32 vv[ZLE_GROUP];
+        if (fast_loads) {                                       // (wave-uniform) every load of the group first, then the arithmetic
+            RawSample rs[ZLE_GROUP];
 #pragma unroll
-        for (int u = 0; u < ZLE_GROUP; u++) {
-            const i32 i = g0 + 64 * u + lane;
-            vv[u] = i < len32 ? finish_sample(d, acc, i, channel, he, ixr) : 0x7fffffff;
-            if (a.row_dbg && i < len32) a.row_dbg[a.row_dbg_off[r] + i] = vv[u];
+            for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; rs[u] = load_sample(d, acc, i < len32 ? i : len32 - 1, noise_row, noisy, ixr); }
+#pragma unroll
+            for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; vv[u] = i < len32 ? finish_loaded(d, rs[u], he, noisy) : 0x7fffffff; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; vv[u] = i < len32 ? finish_sample(d, acc, i, channel, he, ixr) : 0x7fffffff; }
+        }
+        if (a.row_dbg) {
+#pragma unroll
+            for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; if (i < len32) a.row_dbg[a.row_dbg_off[r] + i] = vv[u]; }
         }
 #pragma unroll
         for (int u = 0; u < ZLE_GROUP; u++) {
