@@ -52,7 +52,12 @@ __global__ __launch_bounds__(SCAN_TPB) void k_scan_reduce(const i32 *__restrict_
     __shared__ i64 sh[SCAN_TPB / 64];
     i64 base = (i64)blockIdx.x * SCAN_TILE;
     i64 s = 0;
-    for (int k = 0; k < SCAN_IPT; k++) { i64 i = base + (i64)k * SCAN_TPB + threadIdx.x; if (i < n) s += in[i]; }
+    // (branch-free loads: behind `if (i < n)` every load is waited for before the next is issued)
+    i32 x[SCAN_IPT];
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { const i64 i = base + (i64)k * SCAN_TPB + threadIdx.x; x[k] = in[i < n ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { const i64 i = base + (i64)k * SCAN_TPB + threadIdx.x; s += i < n ? x[k] : 0; }
     s = block_reduce_sum(s, sh);
     if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
 }
@@ -89,7 +94,9 @@ __global__ __launch_bounds__(SCAN_TPB) void k_scan_down(const i32 *__restrict__ 
     i64 base = (i64)blockIdx.x * SCAN_TILE + (i64)threadIdx.x * SCAN_IPT;
     i64 v[SCAN_IPT], s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_IPT; k++) { i64 i = base + k; v[k] = i < n ? in[i] : 0; s += v[k]; }
+    for (int k = 0; k < SCAN_IPT; k++) { const i64 i = base + k; v[k] = in[i < n ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) { if (base + k >= n) v[k] = 0; s += v[k]; }
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 1; o < SCAN_TPB; o <<= 1) {
@@ -466,7 +473,13 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             const PhotonRec rec = a.ph[off + (v ? p : 0)];            // branch-free: tiles on the work list have n >= 1
             r_ns[k] = v ? (i32)(rec.t - rel0) : -1;
             code[k] = v ? rec.code : 0u;
-            r_gain[k] = (v && mode != 0) ? a.ph_gain[off + p] : 0.0;
+            r_gain[k] = 0.0;
+        }
+        // explicit gains (afterpulse / injected photons) in a loop of their own: a conditional load inside the loop above makes
+        // the compiler wait for every photon load before the branch -- eight memory round trips in a row instead of one
+        if (mode != 0) {
+#pragma unroll
+            for (int k = 0; k < DENSE_PPT; k++) { const i32 p = tid + k * TPB; const double g = a.ph_gain[off + (p < n ? p : 0)]; r_gain[k] = p < n ? g : 0.0; }
         }
         {
             i32 c = 0;
@@ -583,7 +596,11 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
                 code[k] = v ? rec.code : 0u;
                 const i64 jw = (i64)(ns[k] / dt) - b_lo;
                 use[k] = v && (first || (jw >= 0 && jw < HROWS));      // chunk 0 needs every photon (truth), the others only their own
-                gain[k] = (use[k] && mode != 0) ? a.ph_gain[off + p] : 0.0;
+                gain[k] = 0.0;
+            }
+            if (mode != 0) {                                 // (a loop of its own: see the resident form)
+#pragma unroll
+                for (int k = 0; k < DENSE_PPT; k++) { const i32 p = base + tid + k * TPB; const double g = a.ph_gain[off + (p < n ? p : 0)]; gain[k] = use[k] ? g : 0.0; }
             }
             if (first && one_batch) {                // (one batch, several workgroups per tile)
                 i32 c = 0;
@@ -2009,8 +2026,9 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
 #pragma unroll
             for (int k = 0; k < NB; k++) {
                 const i64 b = b0 + k < b1 ? b0 + k : b1;
-                mine[k] = b0 + k <= b1 && a.blk_ins[b] == ins;
+                const i32 bi = a.blk_ins[b];                     // (unconditional: a load behind && is waited for before the next one)
                 cnt[k] = a.blk_cnt[b * nch + c];
+                mine[k] = b0 + k <= b1 && bi == ins;
             }
 #pragma unroll
             for (int k = 0; k < NB; k++) if (mine[k]) { a.blk_base[(b0 + k) * nch + c] = run; run += cnt[k]; }
