@@ -310,3 +310,19 @@ def test_config3_shape_csv_instructions_afterpulses_noise(tmp_path):
     b = ref[np.lexsort((ref['channel'], ref['time']))]
     assert a.tobytes() == b.tobytes()
     assert len(np.concatenate([c.data for c in out['truth']])) == len(ins)
+
+
+def test_reference_invariant_totals_equal_per_pmt_sums():
+    """the one numerical invariant the reference's own integration test holds for this path (tests/test_wfsim.py:140-142):
+    with per_pmt_truth, truth[f] == sum(truth[f + '_per_pmt']) for n_pe, n_photon, raw_area; and records are non-empty with
+    a positive data sum (tests/test_wfsim.py:24-27)"""
+    cfg = dict(xenonnt_test_config(seed=23, enable_pmt_afterpulses=False), per_pmt_truth=True)
+    ins = _mixed_instructions()
+    sim = wfsim_amd.ChunkRawRecords(cfg)
+    chunks = list(sim(ins))
+    truth = np.concatenate([c['truth'] for c in chunks])
+    rr = np.concatenate([c['raw_records'] for c in chunks])
+    assert len(rr) > 0 and rr['data'].sum() > 0
+    for field in 'n_pe n_photon raw_area'.split():
+        assert np.all(np.isclose(truth[field], np.sum(truth[field + '_per_pmt'], axis=1))), field
+    assert truth['n_photon'].sum() > 0
