@@ -184,6 +184,31 @@ static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam)
     }
 }
 
+/* Photons per electron (s2.py:308): the Poisson distribution of the instruction's secondary gain is tabulated once per gain --
+ * pmf(k) = exp(k ln(lam) - lam - lgamma(k + 1)) on the 256 values from floor(lam - 8 sqrt(lam)) - 4 on, summed in order, normalised --
+ * and inverted with ONE uniform by bisection (the device: k_poisson_tables / poisson_table_draw); gains above POIS_LAM_MAX keep PTRS. */
+#define POIS_W 256
+#define POIS_LAM_MAX 217.0
+static double g_pois_lam = -1.0, g_pois_cdf[POIS_W]; static i64 g_pois_kmin = 0;
+static i64 poisson_any(const orc_session *s, u32 emitter, u32 gid, double lam)
+{
+    if (!(lam > 0)) return 0;
+    if (lam > POIS_LAM_MAX) return poisson_draw(s, emitter, gid, lam);
+    if (lam != g_pois_lam) {
+        i64 k0 = (i64)floor(lam - 8.0 * sqrt(lam)) - 4; if (k0 < 0) k0 = 0;
+        double run = 0;
+        for (int j = 0; j < POIS_W; j++) { const double k = (double)(k0 + j); run += exp(k * log(lam) - lam - lgamma(k + 1.0)); g_pois_cdf[j] = run; }
+        const double tot = g_pois_cdf[POIS_W - 1];
+        for (int j = 0; j < POIS_W; j++) g_pois_cdf[j] = g_pois_cdf[j] / tot;
+        g_pois_lam = lam; g_pois_kmin = k0;
+    }
+    u32 w[4]; draw(s, emitter, gid, 0, SITE_EL_POIS, w);
+    const double u = u53(w[0], w[1]);
+    int lo = 0, hi = POIS_W - 1;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (u < g_pois_cdf[mid]) hi = mid; else lo = mid + 1; }
+    return g_pois_kmin + lo;
+}
+
 enum { TAB_TTS = 0, TAB_S1_EXP, TAB_S1_SPREAD, TAB_T1, TAB_T3, TAB_S2_SPREAD, TAB_LUM, TAB_S1_TOTAL, TAB_S2_TOTAL, TAB_S2_NOLUM, TAB_N };
 static void tab_exp(struct orc_session_s *s, int slot, double tau);
 static void tab_totals(struct orc_session_s *s);
@@ -917,7 +942,7 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
         double timing = -log(1.0 - u53(A[0], A[1])) * c->trap_time;
         timing += drift_mean + drift_spread * z_drift;
         i64 et = time + (i64)timing;
-        i64 nph = poisson_draw(s, je, gid, sc_gain);
+        i64 nph = poisson_any(s, je, gid, sc_gain);
         nph += (i64)(0.0 + c->gain_spread * z_gain);
         if (nph < 0) nph = 0;
         VEC_PUSH(s->e_t, i64, et);
@@ -1181,7 +1206,7 @@ void orc_sample_delay(orc_session *s, i64 n, int is_s2, i32 tab, int bottom, i32
         out[i] = t;
     }
 }
-void orc_sample_poisson(orc_session *s, double lam, i64 n, i64 *out) { for (i64 i = 0; i < n; i++) out[i] = poisson_draw(s, (u32)i, 12345u, lam); }
+void orc_sample_poisson(orc_session *s, double lam, i64 n, i64 *out) { for (i64 i = 0; i < n; i++) out[i] = poisson_any(s, (u32)i, 12345u, lam); }
 
 /* electrons of one S2 instruction as gen_s2 and the device see them (tests of the transverse diffusion, s2.py:560-613): survival flag
  * (s2.py:254) and the two standard normals of the radial / azimuthal displacement */

@@ -159,3 +159,20 @@ def test_s2_photon_times_and_survival():
     assert _ks(v, c, t) < _ks_limit(20000, ne.sum(), 2.5)
     m, s = _moments(v, c)
     assert abs(t.mean() - m) < 6 * s / np.sqrt(ne.sum()) and abs(t.std() / s - 1) < 0.03
+
+
+@pytest.mark.parametrize('lam', [0.3, 9.9, 17.5, 82.03, 216.9, 400.0])
+def test_photons_per_electron_are_poisson(orc, lam):
+    """the per-instruction Poisson table (gains up to 217) and PTRS (above) against scipy's exact pmf: chi-square over the
+    populated values, mean and variance"""
+    from scipy.stats import poisson, chisquare
+    n = 400_000
+    k = orc.sample_poisson(lam, n)
+    assert k.min() >= 0
+    assert abs(k.mean() - lam) < 5 * np.sqrt(lam / n) and abs(k.var() / lam - 1) < 0.02
+    vals, cnt = np.unique(k, return_counts=True)
+    exp = poisson.pmf(vals, lam) * n
+    keep = exp > 20
+    obs, ex = cnt[keep].astype(float), exp[keep]
+    ex *= obs.sum() / ex.sum()
+    assert chisquare(obs, ex).pvalue > 1e-4

@@ -44,7 +44,7 @@ struct wfs_handle {
     ApElem ap[WFS_MAX_AP];
     // instructions
     i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
-    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, ins_embase, ins_set, set_ins_off, set_ins_list;
+    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, em_zg, ins_embase, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0, blk_desc;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles, wave_tiles;
@@ -79,6 +79,7 @@ struct wfs_handle {
     std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
     DevBuf prop_top, prop_bot; i32 prop_nz = 0, prop_nu = 0; double prop_u0 = 0, prop_du = 1;
     DevBuf ins_tab, ins_tabb, ins_pzi, ins_pzf; bool ins_models = false;
+    DevBuf pois_cdf, pois_kmin; bool any_ptrs = false;         // Poisson tables of the secondary gain per instruction (k_poisson_tables)
     DevBuf gg_inv, ins_gg, ins_ggw, ins_ggsum; i32 gg_n = 0, gg_L = 0; bool ins_gg_set = false;       // 'garfield_gas_gap' luminescence
     // pattern maps evaluated on the device
     struct PatternMap { bool set = false; i32 dims = 0, n[3] = {1, 1, 1}, w[3] = {0, 0, 0}, n_map_ch = 0; double lo[3] = {0, 0, 0}, hgrid[3] = {1, 1, 1}; DevBuf values;
@@ -403,7 +404,7 @@ int wfs_destroy(wfs_handle *h)
 #endif
     DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
-        &h->em_off, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
+        &h->em_off, &h->em_zg, &h->pois_cdf, &h->pois_kmin, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->wave_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
@@ -567,6 +568,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     HIPCHK(hipSetDevice(h->device));
     std::vector<i64> em_off((size_t)n + 1);
     em_off[0] = 0;
+    bool any_ptrs = false;
     for (i64 i = 0; i < n; i++) {
         if (type[i] != 1 && type[i] != 2 && type[i] != 4 && type[i] != 6)      // 4 / 6: electron afterpulses, simulated like an S2 (afterpulse.py:14, 94)
             return h->fail(WFS_E_INVALID, "instruction types: 1 (S1), 2 (S2), 4 / 6 (photo-ionisation / photo-electric electrons)");
@@ -575,6 +577,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
         if (cdf_row[i] == -1 && !h->pmap[type[i] == 1 ? 0 : 1].set) return h->fail(WFS_E_STATE, "cdf_row -1 needs wfs_set_pattern_map for the instruction type");
         if (type[i] != 1 && h->dev.n_lum < 2) return h->fail(WFS_E_STATE, "S2 instructions need the luminescence table");
         em_off[i + 1] = em_off[i] + (type[i] == 1 ? 1 : (i64)amp[i]);
+        if (type[i] != 1 && sc_gain[i] > 217.0) any_ptrs = true;          // POIS_LAM_MAX: the electrons of such an instruction draw with PTRS (k_s2_photons)
     }
     // pulse sets (one Pulse.__call__ each, rawdata.py:108-127): the caller's run sets, by default one per instruction
     std::vector<i32> ins_set((size_t)n);
@@ -595,6 +598,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     // PMT afterpulses are a second pulse set per primary set (rawdata.py:176-178): set PS + q belongs to set q
     h->ap_active = h->cfg.enable_pmt_ap && h->dev.n_ap > 0;
     const i64 S = h->ap_active ? 2 * PS : PS;
+    h->any_ptrs = any_ptrs;
     h->n_ins = n; h->n_psets = PS; h->n_sets = S; h->n_emitters = em_off[n]; h->n_tiles = S * h->cfg.n_tpc;
     h->h_rs_off = set_off; h->h_rs_list = set_list;
     if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
@@ -1091,12 +1095,17 @@ static int run_generation(wfs_handle *h)
             g.gg_inv = h->gg_inv.as<double>(); g.gg_n = h->gg_n; g.gg_L = h->gg_L; g.ins_gg = h->ins_gg.as<i32>(); g.ins_ggw = h->ins_ggw.as<double>(); g.ins_ggsum = h->ins_ggsum.as<i64>();
         }
     }
+    TRY(ensure(h, h->em_zg, (size_t)E * 8)); HIPCHK(hipMemsetAsync(h->em_zg.p, 0xff, (size_t)E * 8, h->stream)); g.em_zg = h->em_zg.as<double>();
     { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }
     {
         const i64 neb = (E + 255) / 256;
         TRY(ensure(h, h->eblk_ins, (size_t)(neb + 1) * 4)); g.eblk_ins = h->eblk_ins.as<i32>();
         { Timer t(h, "k_emitter_blocks"); hipLaunchKernelGGL(k_emitter_blocks, dim3(nblocks(neb + 1, 256)), dim3(256), 0, h->stream, g, neb); }
-        Timer t(h, "k_s2_electrons"); hipLaunchKernelGGL(k_s2_electrons, dim3(nblocks(E, 256)), dim3(256), 0, h->stream, d, g);
+        TRY(ensure(h, h->pois_cdf, (size_t)N * POIS_W * 8)); TRY(ensure(h, h->pois_kmin, (size_t)N * 4));
+        g.pois_cdf = h->pois_cdf.as<double>(); g.pois_kmin = h->pois_kmin.as<i32>();
+        { Timer t(h, "k_poisson_tables"); hipLaunchKernelGGL(k_poisson_tables, dim3((unsigned)N), dim3(POIS_W), 0, h->stream, g, h->pois_cdf.as<double>(), h->pois_kmin.as<i32>()); }
+        { Timer t(h, "k_s2_electrons"); hipLaunchKernelGGL(k_s2_electrons, dim3(nblocks(E, 256)), dim3(256), 0, h->stream, d, g); }
+        if (h->any_ptrs) { Timer t(h, "k_s2_photons"); hipLaunchKernelGGL(k_s2_photons, dim3(nblocks(E, 256)), dim3(256), 0, h->stream, d, g); }
     }
     if (h->n_diff_rows > 0) {
         // transverse diffusion maps: the pattern of these instructions is the average over their surviving electrons (s2.py:560-613)

@@ -1371,6 +1371,8 @@ struct GenArgs {
     const unsigned short *cdf_guide;      // [n_cdf][CDF_G + 2] guide table of every CDF row (host)
     const i64 *em_off;            // [n_ins + 1] first emitter of each instruction
     i64 *em_time; i32 *em_nph; i32 *em_ins; const i64 *em_ph_off;
+    double *em_zg;                // [n_emitters] gain-spread normal of a surviving electron whose photon number k_s2_photons draws (PTRS), NaN elsewhere
+    const double *pois_cdf; const i32 *pois_kmin;     // [n_ins][POIS_W] cumulative Poisson table of the instruction's secondary gain, first k (-1: PTRS, -2: gain <= 0)
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
     PhotonRec *ph;
     i64 n_blocks;
@@ -1481,6 +1483,37 @@ __global__ __launch_bounds__(256) void k_s1_hits(WfsDev d, GenArgs a)
     if (lane == 0) { i64 e = a.em_off[i]; a.em_nph[e] = hits; a.em_time[e] = a.ins_time[i]; a.em_ins[e] = (i32)i; }
 }
 
+// Photons per electron, Poisson(sc_gain) (s2.py:308).  The secondary gain is a property of the INSTRUCTION, so its Poisson
+// distribution is tabulated once per instruction -- pmf(k) = exp(k ln(lam) - lam - lgamma(k + 1)) on the 256 values from
+// floor(lam - 8 sqrt(lam)) - 4 on (what lies outside is below 1e-15), summed in order, normalised -- and an electron inverts it with
+// ONE uniform (bisection, 8 steps).  numpy's PTRS rejection loop with its logs and lgamma per trial cost 2000 VALU instructions per
+// electron (every wave takes the slow path and the longest loop of its 64 lanes) and 198 VGPRs; it is kept, in a kernel of its own,
+// for gains above POIS_LAM_MAX.  Same distribution (tests: KS against np.random.poisson draws of the reference).
+#define POIS_W 256
+#define POIS_LAM_MAX 217.0
+__global__ __launch_bounds__(POIS_W) void k_poisson_tables(GenArgs a, double *cdf, i32 *kmin)
+{
+    __shared__ double p[POIS_W];
+    const i64 i = blockIdx.x; const int t = threadIdx.x;
+    const double lam = a.ins_sc[i];
+    if (a.ins_type[i] == 1 || !(lam > 0) || lam > POIS_LAM_MAX) { if (t == 0) kmin[i] = (a.ins_type[i] != 1 && !(lam > 0)) ? -2 : -1; return; }
+    i64 k0 = (i64)floor(lam - 8.0 * sqrt(lam)) - 4; if (k0 < 0) k0 = 0;
+    const double k = (double)(k0 + t);
+    p[t] = exp(k * log(lam) - lam - lgamma(k + 1.0));
+    __syncthreads();
+    if (t == 0) { double run = 0; for (int j = 0; j < POIS_W; j++) { run += p[j]; p[j] = run; } kmin[i] = (i32)k0; }
+    __syncthreads();
+    cdf[i * POIS_W + t] = p[t] / p[POIS_W - 1];
+}
+__device__ __forceinline__ i64 poisson_table_draw(const WfsDev &d, const double *cdf, i32 kmin, u32 emitter, u32 gid)
+{
+    const u32x4 w = philox4x32_10(emitter, gid, 0, SITE_EL_POIS, d.k0, d.k1);
+    const double u = u53(w.x, w.y);
+    int lo = 0, hi = POIS_W - 1;                         // first j with u < cdf[j] (cdf[POIS_W - 1] == 1)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (u < cdf[mid]) hi = mid; else lo = mid + 1; }
+    return (i64)kmin + lo;
+}
+
 // S2: one thread per candidate electron (s2.py:254, 258-286, 308-310)
 // instruction of the first emitter of every 256-emitter block of k_s2_electrons (+ a sentinel: the last instruction)
 __global__ void k_emitter_blocks(GenArgs a, i64 n_blocks)
@@ -1521,10 +1554,15 @@ __global__ __launch_bounds__(256) void k_s2_electrons(WfsDev d, GenArgs a)
             double timing = -log(1.0 - u53(A.x, A.y)) * d.trap_time;
             timing += a.ins_dm[i] + a.ins_ds[i] * z_drift;
             i64 et = a.ins_time[i] + (i64)timing;                         // s2.py:282
-            i64 nph = poisson_draw(d, j, gid, a.ins_sc[i]);
-            nph += (i64)(0.0 + d.gain_spread * z_gain);                   // s2.py:309
-            if (nph < 0) nph = 0;
-            a.em_nph[e] = (i32)nph; a.em_time[e] = et;
+            a.em_time[e] = et;
+            const i32 pk = a.pois_kmin[i];
+            if (pk == -1) a.em_zg[e] = z_gain;                             // gain above POIS_LAM_MAX: k_s2_photons (PTRS)
+            else {
+                i64 nph = pk >= 0 ? poisson_table_draw(d, a.pois_cdf + i * POIS_W, pk, j, gid) : 0;
+                nph += (i64)(0.0 + d.gain_spread * z_gain);               // s2.py:309
+                if (nph < 0) nph = 0;
+                a.em_nph[e] = (i32)nph;
+            }
             double tr = (double)(et - a.ins_time[i]);
             st_n = 1; st_t = tr; st_t2 = tr * tr; st_min = et; st_max = et;
         }
@@ -1545,6 +1583,22 @@ __global__ __launch_bounds__(256) void k_s2_electrons(WfsDev d, GenArgs a)
         atomicAdd(&a.el_stat[i * 4 + 0], st_n); atomicAdd(&a.el_stat[i * 4 + 1], st_t); atomicAdd(&a.el_stat[i * 4 + 2], st_t2);
         atomicMin(&a.el_minmax[i * 2], st_min); atomicMax(&a.el_minmax[i * 2 + 1], st_max);
     }
+}
+
+// photons of the surviving electrons of instructions with a gain above POIS_LAM_MAX: numpy's PTRS + int(N(0, gain_spread)) (s2.py:308-310)
+__global__ __launch_bounds__(256) void k_s2_photons(WfsDev d, GenArgs a)
+{
+    const i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.n_emitters) return;
+    if (a.em_time[e] == I64_MIN) return;                     // did not survive (em_nph = 0 already); S1 emitters are not touched: em_zg is NaN
+    const double zg = a.em_zg[e];
+    if (!(zg == zg)) return;
+    const i32 i = a.em_ins[e];
+    const u32 j = a.ins_embase[i] + (u32)(e - a.em_off[i]);
+    i64 nph = poisson_draw(d, j, a.ins_gid[i], a.ins_sc[i]);
+    nph += (i64)(0.0 + d.gain_spread * zg);                  // s2.py:309
+    if (nph < 0) nph = 0;
+    a.em_nph[e] = (i32)nph;
 }
 
 __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double u)
