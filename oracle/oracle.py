@@ -249,6 +249,19 @@ class Oracle:
             k *= 2
         return pa[:k], pc[:k], int(vmin.value)
 
+    def chan_alias_pmf(self, cdf_row):
+        """the channel probabilities the alias cells of a cumulative row encode"""
+        row = _arr(cdf_row, np.float64)
+        out = np.zeros(len(row))
+        lib().orc_chan_alias_pmf(self._s, _p(row), _p(out))
+        return out
+
+    def sample_channels(self, cdf_row, n):
+        row = _arr(cdf_row, np.float64)
+        out = np.zeros(n, dtype=np.int32)
+        lib().orc_sample_channels(self._s, _p(row), C.c_int64(n), _p(out))
+        return out
+
     def sample_diffusion(self, gid, em_base, amp, p_survive):
         """(survive[amp], z_radial[amp], z_azimuthal[amp]) of the candidate electrons of one S2 instruction"""
         sv, z0, z1 = np.zeros(amp, dtype=np.uint8), np.zeros(amp), np.zeros(amp)

@@ -785,7 +785,7 @@ typedef struct { vec_i64 t; vec_i16 ch; vec_u8 dpe; vec_f64 gain; vec_i32 g1, g2
 
 /* np.random.choice(channels, p=...) == searchsorted(cdf, u, side='right') on the normalised cumulative sum
  * (s1.py:154-158, s2.py:673-677); cdf row prepared by the host exactly as numpy does. */
-static int channel_from_cdf(const double *cdf, int n, double u)
+__attribute__((unused)) static int channel_from_cdf(const double *cdf, int n, double u)
 {
     int lo = 0, hi = n;
     while (lo < hi) { int mid = (lo + hi) >> 1; if (u < cdf[mid]) hi = mid; else lo = mid + 1; }
@@ -819,13 +819,40 @@ static inline void gain_code(const orc_session *s, u32 w, int *g1, int *g2)
  * s1.py:180-194 (simple) or s2.py:504-557 (luminescence simple + singlet/triplet + spread + electron time).
  * Every term is truncated to int64 on its own before it is added: the sum is drawn from the table of the sum.
  * RNG spec v6: photon P of its instruction owns word P & 3 of the calls (em_base, gid, P >> 2, SITE_CH / _DELAY / _GAIN). */
+/* Channel of a photon: Walker's alias method over the 2^lg >= n_tpc cells of the instruction's cumulative row, built by alias_build
+ * exactly as the device builds its cells (k_chan_alias) -- RNG spec v8.  The row is that of the instruction in hand (chan_row_set). */
+static orc_tab g_chan_tab;
+static void chan_row_set(const orc_session *s, const double *cdf)
+{
+    g_chan_tab.cum = (double *)cdf; g_chan_tab.n = s->c.n_tpc; g_chan_tab.vmin = 0;
+    alias_build(&g_chan_tab);
+}
+
+/* the distribution the channel alias cells of a cumulative row encode (tests), and draws from it exactly as one_photon() makes them */
+void orc_chan_alias_pmf(const orc_session *s, const double *cdf, double *pmf_alias)
+{
+    chan_row_set(s, cdf);
+    const i64 K = 1ll << g_chan_tab.lg;
+    for (i64 i = 0; i < s->c.n_tpc; i++) pmf_alias[i] = 0.0;
+    for (i64 i = 0; i < K; i++) {
+        const double pa = g_chan_tab.alias[i] == (u32)i ? 1.0 : (double)g_chan_tab.thr[i] / 4294967296.0;
+        if (i < s->c.n_tpc) pmf_alias[i] += pa / (double)K;
+        if (g_chan_tab.alias[i] < (u32)s->c.n_tpc) pmf_alias[g_chan_tab.alias[i]] += (1.0 - pa) / (double)K;
+    }
+}
+void orc_sample_channels(const orc_session *s, const double *cdf, i64 n, i32 *out)
+{
+    chan_row_set(s, cdf);
+    for (i64 i = 0; i < n; i++) { u32 C[4]; draw(s, 0, 777777u, (u32)(i >> 2), SITE_CH, C); out[i] = (i32)alias_sample(&g_chan_tab, C[i & 3]); }
+}
+
 static void one_photon(const orc_session *s, int is_s2, u32 emitter, u32 gid, u32 item, u32 em_base, u32 P, i64 t0,
                        const double *cdf, i64 *t_out, int *ch_out, int *dpe_out, double *gain_out)
 {
     const orc_config *c = &s->c;
     u32 C[4], D[4], G[4];
     draw(s, em_base, gid, P >> 2, SITE_CH, C); draw(s, em_base, gid, P >> 2, SITE_DELAY, D); draw(s, em_base, gid, P >> 2, SITE_GAIN, G);
-    int ch = channel_from_cdf(cdf, c->n_tpc, (double)C[P & 3u] * (1.0 / 4294967296.0));
+    int ch = (int)alias_sample(&g_chan_tab, C[P & 3u]);
     int g1, g2; gain_code(s, G[P & 3u], &g1, &g2);
     int is_dpe = g2 != 0;
     i64 t;                                                /* all delay terms from one table, see tab_totals / orc_set_delay_models */
@@ -911,6 +938,7 @@ static void ctx_push(call_ctx *x, i64 t, int ch, int dpe, double g, u32 gid, i64
 static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, double p_hit, const double *cdf)
 {
     u64 T = bern_threshold(p_hit); i64 n_hits = 0; u32 w[4];
+    chan_row_set(s, cdf);
     for (i64 j = 0; j < amp; j++) {                   /* s1.py:133 Binomial(amp, ly) as a sum of Bernoulli trials */
         if ((j & 3) == 0) draw(s, 0, gid, (u32)(j >> 2), SITE_S1_HIT, w);
         n_hits += (u64)w[j & 3] < T;
@@ -930,6 +958,7 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
 {
     const orc_config *c = &s->c;
     u64 T = bern_threshold(cy); u32 w[4]; i64 n0 = x->pb.t.n; u32 P = 0;       /* P: photons of this instruction so far */
+    chan_row_set(s, cdf);
     vec_f64 lum; memset(&lum, 0, sizeof lum);                                   /* garfield gas gap: excitation time of every photon */
     for (i64 j = 0; j < amp; j++) {
         if ((j & 3) == 0) draw(s, em_base, gid, (u32)(j >> 2), SITE_S2_SURVIVE, w);

@@ -176,3 +176,28 @@ def test_photons_per_electron_are_poisson(orc, lam):
     obs, ex = cnt[keep].astype(float), exp[keep]
     ex *= obs.sum() / ex.sum()
     assert chisquare(obs, ex).pvalue > 1e-4
+
+
+def test_channel_alias_cells_sample_the_row(orc):
+    """photon channels are drawn with Walker's alias method over the instruction's cumulative row (np.random.choice's
+    distribution, s1.py:154-158 / s2.py:673-677): the cells encode the row's probabilities to 2^-32 per channel -- also with
+    channels of probability zero (turned-off PMTs) and a very uneven row -- and draws follow them (chi-square)"""
+    from scipy.stats import chisquare
+    rng = np.random.default_rng(6)
+    nch = 494
+    for kind in ('uniform', 'uneven'):
+        p = np.ones(nch) if kind == 'uniform' else rng.gamma(0.3, 1.0, nch)
+        p[[3, 260, 493]] = 0.0
+        p /= p.sum()
+        cdf = np.cumsum(p); cdf /= cdf[-1]
+        pa = orc.chan_alias_pmf(cdf)
+        pc = np.diff(cdf, prepend=0.0)
+        assert abs(pa.sum() - 1) < 1e-12 and np.abs(pa - pc).max() < 2.0 ** -31
+        assert np.all(pa[[3, 260, 493]] < 2.0 ** -31)
+        n = 2_000_000
+        ch = orc.sample_channels(cdf, n)
+        cnt = np.bincount(ch, minlength=nch)
+        assert cnt[[3, 260, 493]].sum() == 0
+        keep = pc * n > 20
+        ex = pc[keep] * n
+        assert chisquare(cnt[keep], ex * cnt[keep].sum() / ex.sum()).pvalue > 1e-4

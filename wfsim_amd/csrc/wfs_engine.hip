@@ -44,7 +44,7 @@ struct wfs_handle {
     ApElem ap[WFS_MAX_AP];
     // instructions
     i64 n_ins = 0, n_psets = 0, n_sets = 0, n_clusters = 0, n_emitters = 0, n_photons = 0, n_tiles = 0;
-    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, em_off, em_zg, ins_embase, ins_set, set_ins_off, set_ins_list;
+    DevBuf ins_type, ins_time, ins_amp, ins_gid, ins_p, ins_dm, ins_ds, ins_sc, ins_cdfrow, cdf_table, cdf_guide, chan_alias, em_off, em_zg, ins_embase, ins_set, set_ins_off, set_ins_list;
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0, blk_desc;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles, wave_tiles;
@@ -403,7 +403,7 @@ int wfs_destroy(wfs_handle *h)
     }
 #endif
     DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
-        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
+        &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->chan_alias, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->em_zg, &h->pois_cdf, &h->pois_kmin, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
         &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->wave_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
@@ -1165,11 +1165,18 @@ static int run_generation(wfs_handle *h)
         // cache lines of a tile (consecutive ranges, k_block_ranges) run close together in time on the same L2
         g.xcd_chunk = (nb + 7) / 8;
         const unsigned nbx = (unsigned)(g.xcd_chunk * 8);
+        {   // alias cells of every channel CDF row (host rows + rows from the device maps, the electron-averaged ones included)
+            const i64 n_rows = h->n_host_rows + (i64)h->dev_row_ins.size();
+            int lg = 1; while ((1 << lg) < d.n_tpc) lg++;
+            TRY(ensure(h, h->chan_alias, (size_t)n_rows * ((size_t)8 << lg)));
+            g.chan_alias = h->chan_alias.as<uint2>(); g.ch_lg = lg;
+            Timer t(h, "k_chan_alias"); hipLaunchKernelGGL(k_chan_alias, dim3((unsigned)n_rows), dim3(64), 0, h->stream, g.cdf_table, d.n_tpc, lg, h->chan_alias.as<uint2>());
+        }
         if (g.gg_inv) { Timer t(h, "k_gg_sum"); hipLaunchKernelGGL(k_gg_sum, dim3(nb), dim3(256), 0, h->stream, d, g); }
-        { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(COUNT_TPB), GEN_COUNT_LDS(d.n_tpc), h->stream, d, g); }
+        { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(COUNT_TPB), GEN_COUNT_LDS(d.n_tpc, g.ch_lg), h->stream, d, g); }
         { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
-        const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, ap_on).total;
+        const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, g.ch_lg, ap_on).total;
         { Timer t(h, "k_photon_fill");
           if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);
           else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);

@@ -1368,7 +1368,8 @@ struct GenArgs {
     const i64 *set_t0;            // [n_sets] time origin of the set's photon times
     const int8_t *ins_type; const i64 *ins_time; const i32 *ins_amp; const u32 *ins_gid;
     const double *ins_p, *ins_dm, *ins_ds, *ins_sc; const i32 *ins_cdfrow; const double *cdf_table;
-    const unsigned short *cdf_guide;      // [n_cdf][CDF_G + 2] guide table of every CDF row (host)
+    const unsigned short *cdf_guide;      // [n_cdf][CDF_G + 2] guide table of every CDF row (host; no longer used by the generator)
+    const uint2 *chan_alias; i32 ch_lg;   // [n_cdf][1 << ch_lg] Walker alias cells of every channel CDF row (k_chan_alias): {threshold, alias channel}
     const i64 *em_off;            // [n_ins + 1] first emitter of each instruction
     i64 *em_time; i32 *em_nph; i32 *em_ins; const i64 *em_ph_off;
     double *em_zg;                // [n_emitters] gain-spread normal of a surviving electron whose photon number k_s2_photons draws (PTRS), NaN elsewhere
@@ -2100,11 +2101,54 @@ __device__ __forceinline__ u32 cdf_threshold(double c)
     const double x = ceil(c * 4294967296.0);
     return x >= 4294967296.0 ? 0xffffffffu : (x >= 1.0 ? (u32)x - 1u : 0u);
 }
-__device__ __forceinline__ int channel_lookup(const u32 *T, const unsigned short *cguide, int nch, u32 w)
+// Channel of a photon from its 32-bit word: Walker's alias method over the 2^lg >= n_tpc cells of the instruction's row (built by
+// k_chan_alias from the cumulative row, identically in the oracle): the top lg bits pick the cell, the remaining bits, left-aligned,
+// are compared with the cell's threshold -- ONE 8-byte look-up instead of a guide read and a threshold search (RNG spec v8; the
+// probabilities are those of np.random.choice's row to 2^-32, as with the thresholds before).
+__device__ __forceinline__ int channel_lookup(const uint2 *A, int lg, u32 w)
 {
-    int ch = cguide[w >> 23];                      // CDF_G = 512 cells
-    while (ch < nch - 1 && w > T[ch]) ch++;
-    return ch;
+    const u32 cell = w >> (32 - lg);
+    const uint2 e = A[cell];
+    return (int)(((w << lg) < e.x) ? cell : e.y);
+}
+
+// Alias cells of every channel CDF row.  One workgroup per row, thread 0 runs Vose's construction exactly as the host does for the
+// delay tables (build_alias: cells below 1 and the others on two stacks, ascending fill, last in first out) so that the oracle,
+// which restates it in C, gets the same cells bit for bit (IEEE adds and compares only).
+__global__ __launch_bounds__(64) void k_chan_alias(const double *cdf_table, int nch, int lg, uint2 *out)
+{
+    __shared__ double q[WFS_MAX_CH];
+    __shared__ unsigned short st_small[WFS_MAX_CH], st_large[WFS_MAX_CH];
+    __shared__ uint2 cell[WFS_MAX_CH];                     // (built in LDS, written out together: the sequential part touches no global memory)
+    const i64 r = blockIdx.x; const int K = 1 << lg;
+    const double *cum = cdf_table + r * nch;
+    // the two stacks, filled in ascending cell order by the whole wave (ballot ranks), then the sequential pairing on lane 0 with the
+    // open "large" cell kept in registers
+    int ns = 0, nl = 0;
+    for (int i0 = 0; i0 < K; i0 += 64) {
+        const int i = i0 + threadIdx.x;
+        const double qi = i < nch ? (cum[i] - (i ? cum[i - 1] : 0.0)) * (double)K : 0.0;
+        q[i] = qi; cell[i] = uint2{0xffffffffu, (u32)i};
+        const bool sm = qi < 1.0;
+        const u64 ms = __ballot(sm), below = (1ull << threadIdx.x) - 1ull;
+        if (sm) st_small[ns + __popcll(ms & below)] = (unsigned short)i; else st_large[nl + __popcll(~ms & below)] = (unsigned short)i;
+        ns += __popcll(ms); nl += 64 - __popcll(ms);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && ns > 0 && nl > 0) {
+        int l = st_large[nl - 1]; double ql = q[l];
+        for (;;) {
+            const int sidx = st_small[--ns];
+            const double qs = q[sidx];
+            const double t = qs * 4294967296.0;
+            cell[sidx] = uint2{t >= 4294967295.0 ? 0xffffffffu : (u32)t, (u32)l};
+            ql = (ql + qs) - 1.0;
+            if (ql < 1.0) { q[l] = ql; nl--; st_small[ns++] = (unsigned short)l; if (nl == 0) break; l = st_large[nl - 1]; ql = q[l]; }
+            if (ns == 0) break;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < K; i += 64) out[r * K + i] = cell[i];
 }
 __device__ __forceinline__ u32 word_of(const u32x4 &W, int k) { return k == 0 ? W.x : (k == 1 ? W.y : (k == 2 ? W.z : W.w)); }
 
@@ -2124,7 +2168,7 @@ __device__ __forceinline__ u32 photon_word(const WfsDev &d, const PhotonId &id, 
 }
 __device__ __forceinline__ int photon_channel_global(const WfsDev &d, const GenArgs &a, const PhotonId &id)
 {
-    return channel_from_cdf(a.cdf_table + (size_t)a.ins_cdfrow[id.ins] * d.n_tpc, d.n_tpc, (double)photon_word(d, id, SITE_CH) * (1.0 / 4294967296.0));
+    return channel_lookup(a.chan_alias + ((size_t)a.ins_cdfrow[id.ins] << a.ch_lg), a.ch_lg, photon_word(d, id, SITE_CH));
 }
 
 #define COUNT_TPB (GEN_BLOCK / 8)
@@ -2165,23 +2209,23 @@ __global__ __launch_bounds__(256) void k_gg_sum(WfsDev d, GenArgs a)
     }
 }
 
-#define GEN_COUNT_LDS(nch) ((size_t)(nch) * 8 + (CDF_G + 8) * 2)
+#define GEN_COUNT_LDS(nch, lg) ((size_t)(8u << (lg)) + (size_t)(nch) * 4)
 
 __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nch = d.n_tpc, tid = threadIdx.x;
-    u32 *T = (u32 *)smem;                                           // [nch]
-    i32 *hist = (i32 *)(smem + (size_t)nch * 4);                    // [nch]
-    unsigned short *cguide = (unsigned short *)(smem + (size_t)nch * 8);
+    const int lg = a.ch_lg, K = 1 << lg;
+    uint2 *A = (uint2 *)smem;                                       // [K] alias cells of the instruction's channel row
+    i32 *hist = (i32 *)(smem + (size_t)K * 8);                      // [nch]
     const i64 vb = block_of_workgroup(a);
     if (vb >= a.n_blocks) return;                            // block-uniform (padding of the XCD order)
     const BlockDesc bd = a.blk_desc[vb];                     // block-uniform: scalar loads
     const i64 p0 = vb * GEN_BLOCK;
     const int np = (int)((p0 + GEN_BLOCK < a.n_photons) ? GEN_BLOCK : a.n_photons - p0);
     if (bd.ins >= 0) {
-        for (int c = tid; c < nch; c += COUNT_TPB) { hist[c] = 0; T[c] = cdf_threshold(a.cdf_table[(size_t)bd.row * nch + c]); }
-        for (int c = tid; c <= CDF_G; c += COUNT_TPB) cguide[c] = a.cdf_guide[(size_t)bd.row * (CDF_G + 2) + c];
+        for (int c = tid; c < nch; c += COUNT_TPB) hist[c] = 0;
+        for (int c = tid; c < K; c += COUNT_TPB) A[c] = a.chan_alias[((size_t)bd.row << lg) + c];
         __syncthreads();
         const u32 q0 = (u32)(bd.R0 >> 2); const int r = (int)(bd.R0 & 3);
         for (int qi = tid; 4 * qi - r < np; qi += COUNT_TPB) {  // quad qi of the block: photons 4 * qi - r .. + 3 (block-relative)
@@ -2189,7 +2233,7 @@ __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int pr = 4 * qi + k - r;
-                if (pr >= 0 && pr < np) atomicAdd(&hist[channel_lookup(T, cguide, nch, word_of(W, k))], 1);
+                if (pr >= 0 && pr < np) atomicAdd(&hist[channel_lookup(A, lg, word_of(W, k))], 1);
             }
         }
         __syncthreads();
@@ -2205,21 +2249,20 @@ __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
 
 // LDS layout of the fill pass (byte offsets; plain integer offsets: a pointer that went through an integer cast loses its
 // LDS address space)
-struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, cguide, stage, ap, total; };
-__host__ __device__ inline GenFillLds gen_fill_lds(int nch, bool with_ap)
+struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, stage, ap, total; };
+__host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap)
 {
     const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
     GenFillLds o;
     o.wtime = GEN_WIN * 4;                                    // win i32[GEN_WIN] at 0: first photon of the block's emitters, relative to the block
     o.T = o.wtime + GEN_WIN * 4;                              // wtime i32[GEN_WIN]: emitter times relative to the set's origin
-    o.hist = o.T + nch * 4;                                   // T u32[nch]; hist i32[nch1]: photons per channel, then their prefix sums
+    o.hist = o.T + (8 << lg);                                 // T: uint2[2^lg] alias cells of the channel row; hist i32[nch1]: photons per channel, then their prefix sums
     o.cur = o.hist + nch1 * 4;                                // i32[nch]: rank counters
     o.hmin = o.cur + nch * 4;                                 // i32[nch], i32[nch]: earliest / latest photon of the block per channel
     o.hmax = o.hmin + nch * 4;
     o.hoff = o.hmax + nch * 4;                                // i32[nch]: slot of bucket position 0 of every channel, relative to the set's first photon
     o.chmap = o.hoff + nch * 4;                               // u16[GEN_BLOCK]: channel of every bucket position
-    o.cguide = o.chmap + GEN_BLOCK * 2;                       // u16[CDF_G + 8]
-    o.stage = (o.cguide + (CDF_G + 8) * 2 + 7) & ~7;          // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
+    o.stage = (o.chmap + GEN_BLOCK * 2 + 7) & ~7;             // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
     o.ap = o.stage + GEN_BLOCK * 8;                           // afterpulse staging
     o.total = o.ap + (with_ap ? AP_STAGE * 20 : 0) + 16;
     return o;
@@ -2232,12 +2275,13 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TPB = FILL_TPB, CPT = (WFS_MAX_CH + TPB - 1) / TPB;      // channels per thread
     const int nch = d.n_tpc, tid = threadIdx.x;
-    const GenFillLds o = gen_fill_lds(nch, AP);
+    const int lg = a.ch_lg;
+    const GenFillLds o = gen_fill_lds(nch, lg, AP);
     i32 *win = (i32 *)smem, *wtime = (i32 *)(smem + o.wtime);
-    u32 *T = (u32 *)(smem + o.T);
+    uint2 *T = (uint2 *)(smem + o.T);                        // alias cells of the block's channel row
     i32 *hist = (i32 *)(smem + o.hist), *cur = (i32 *)(smem + o.cur), *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
     i32 *hoff = (i32 *)(smem + o.hoff);
-    unsigned short *chmap = (unsigned short *)(smem + o.chmap), *cguide = (unsigned short *)(smem + o.cguide);
+    unsigned short *chmap = (unsigned short *)(smem + o.chmap);
     PhotonRec *stage = (PhotonRec *)(smem + o.stage);
     __shared__ i32 s_wtmp[TPB / 64];
     ApStage aps;
@@ -2277,11 +2321,11 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
         for (int q = 0; q < CPT; q++) {
             const int c = tid + q * TPB;
             if (c < nch) {
-                T[c] = cdf_threshold(a.cdf_table[(size_t)bd.row * nch + c]); toff_r[q] = (i32)(a.tile_off[tbase + c] - set_ph0);
+                toff_r[q] = (i32)(a.tile_off[tbase + c] - set_ph0);
                 hist[c] = cnt_r[q]; cur[c] = 0; hmin[c] = 0x7fffffff; hmax[c] = (i32)0x80000000;
             }
         }
-        for (int c = tid; c <= CDF_G; c += TPB) cguide[c] = a.cdf_guide[(size_t)bd.row * (CDF_G + 2) + c];
+        for (int c = tid; c < (1 << lg); c += TPB) T[c] = a.chan_alias[((size_t)bd.row << lg) + c];
         for (int k = tid; k < nwin; k += TPB) {
             win[k] = (i32)(a.em_ph_off[bd.e_lo + k] - p0);
             // the block's own emitters only (slot nwin - 1 is the sentinel behind them); I64_MIN: an electron that did not survive (no photons)
@@ -2310,7 +2354,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
             int ch[4]; u32 cell[4]; uint2 e[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {                    // (photons outside the block: harmless values, nothing stored)
-                ch[k] = channel_lookup(T, cguide, nch, word_of(C, k));
+                ch[k] = channel_lookup(T, lg, word_of(C, k));
                 cell[k] = alias_cell(TAB_OF(ch[k]), word_of(D, k));
                 e[k] = TAB_OF(ch[k]).cell[cell[k]];
             }
