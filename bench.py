@@ -118,6 +118,33 @@ def cpu_baseline(seed, n_sample, all_cores=True):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: N child processes with the environment torch.distributed.run would give
+    them (one rank per GPU, rendezvous on 127.0.0.1), started before this process has initialised anything on the GPU -- children,
+    never an exec.  Rank 0's stdout (the JSON line) is relayed; the exit code is the first non-zero one of the ranks."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):       # a rank died: the others would wait in a collective for ever
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+        time.sleep(0.2)
+    sys.stdout.write(procs[0].stdout.read().decode())
+    sys.stdout.flush()
+    return next((p.returncode for p in procs if p.returncode), 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -134,9 +161,11 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if world == 1 and args.gpus > 1:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (nothing has touched the GPU yet) and relay rank 0's line
+        raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     cpu = None
     if args.instructions is None:
         args.instructions = dict(s2=1000, mixed=10000, nveto=200000)[args.workload]

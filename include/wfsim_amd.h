@@ -8,8 +8,9 @@
  * reference maintainer would add.
  *
  * Conventions
- *   - plain C types only; no exceptions cross the ABI.  Every function returns 0 on success or a negative
- *     WFS_E_* code; wfs_last_error(h) gives the message.
+ *   - plain C types only; no exceptions cross the ABI: every entry point is a function-try-block that turns a C++
+ *     exception of the host-side containers into a code (std::bad_alloc -> WFS_E_NOMEM, anything else -> WFS_E_INVALID)
+ *     and a message.  Every function returns 0 on success or a negative WFS_E_* code; wfs_last_error(h) gives the message.
  *   - a handle owns one GPU (hipSetDevice at creation) and one HIP stream; it is not thread safe.
  *   - "host" pointers are ordinary CPU memory (numpy buffers), copied by the call; "dev" pointers are HBM
  *     addresses on the handle's GPU (e.g. torch tensors' data_ptr()).
@@ -30,6 +31,7 @@ extern "C" {
 #define WFS_E_HIP (-2)       /* HIP runtime error (message has the call)                  */
 #define WFS_E_CAPACITY (-3)  /* caller buffer too small, or the 10^6-sample window assert */
 #define WFS_E_STATE (-4)     /* call order (tables / batch not loaded)                    */
+#define WFS_E_NOMEM (-5)     /* host allocation failed inside the library (std::bad_alloc) */
 
 typedef struct wfs_handle wfs_handle;
 
@@ -290,7 +292,9 @@ int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t capacity_sets
 /* ---- instrumentation ---------------------------------------------------------------------------------- */
 /* flags: bit 0 keep f64 tile currents and finished rows for wfs_copy_currents / wfs_copy_rows; bit 1 send every tile
  * to the dense pulse kernel (both kernels give the same bits; used by the parity tests); bit 2 wfs_run stops after the
- * photon generation (enough for wfs_copy_set_photon_counts / wfs_gather_photon_times: the electron-afterpulse pre-pass) */
+ * photon generation (enough for wfs_copy_set_photon_counts / wfs_gather_photon_times: the electron-afterpulse pre-pass);
+ * bit 3 check every kernel launch on the spot (hipGetLastError + stream synchronisation after each one: a failed launch or a
+ * faulting kernel is reported under its own name by wfs_run; slow, for debugging) */
 int wfs_set_debug(wfs_handle *h, int32_t flags);
 /* parity tests: noise start index per digitise window (rawdata.py:417) instead of the Philox draw; entries < 0 keep the draw.
  * Indexed by the window number of wfs_copy_groups (host pointer, copied). n = 0 clears the override. */

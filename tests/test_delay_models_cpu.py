@@ -198,3 +198,15 @@ def test_garfield_gas_gap_needs_its_resources():
     cfg = xenonnt_test_config(s2_luminescence_model='garfield_gas_gap', **gas_gap_resources())
     idx, w = DelayModels(cfg, Resource(cfg)).instruction_gas_gap(ins)
     assert idx[0] == -1                     # S1s carry no luminescence term
+
+
+def test_gas_gap_below_the_first_table_warns_and_uses_the_first_table():
+    """the reference's np.digitize(...) - 1 = -1 wraps to the LAST table (s2.py:476-477, numpy's negative index); here the first
+    table is used, with a warning -- the documented deviation"""
+    res = gas_gap_resources()
+    res['garfield_gas_gap_map'] = lambda xy: np.full(len(xy), float(res['s2_luminescence_gg']['gas_gap'][0]) - 0.01)
+    cfg = xenonnt_test_config(s2_luminescence_model='garfield_gas_gap', **res)
+    models = DelayModels(cfg, Resource(cfg))
+    with pytest.warns(UserWarning, match='below the first tabulated'):
+        idx, w = models.instruction_gas_gap(one_instruction(2))
+    assert idx[0] == 0 and w[0] < 0

@@ -95,3 +95,30 @@ def test_float_noise_array():
         out[tag] = eng.records().tobytes()
         assert out[tag] == orc.pack_records().tobytes() and len(out[tag]) > 0
     assert out['float'] != out['truncated']
+
+
+def small_array_config(n, **kw):
+    """a detector of n PMTs (upper half = top array): fewer channels than a wave has lanes"""
+    c = xenonnt_test_config(**kw)
+    c['gains'] = np.full(n, 2e6)
+    c['n_tpc_pmts'], c['n_top_pmts'] = n, n // 2
+    c['channels_bottom'] = np.arange(n // 2, n, dtype=np.int64)
+    c['channel_map'] = dict(tpc=(0, n - 1), he=(500, 500 + n // 2 - 1), sum_signal=800)
+    c['photon_area_distribution'] = dict(c['photon_area_distribution'], n_channels=n)
+    c['s1_pattern_map'] = ['constant dummy', 0.00014 * 494 / n, [n]]
+    c['s2_pattern_map'] = ['constant dummy', 0.0003 * 494 / n, [n]]
+    return c
+
+
+@pytest.mark.parametrize('n_pmts', [8, 20, 33])
+def test_fewer_channels_than_lanes(n_pmts):
+    """the alias cells of a channel row with 2^lg < 64 cells (k_chan_alias): photons must stay inside the n_pmts channels and
+    agree with the oracle photon by photon"""
+    cfg = small_array_config(n_pmts, seed=50 + n_pmts)
+    rows = [dict(type=1, time=MS * (i + 1), x=3, y=-2, z=-30, amp=3000) for i in range(4)]
+    rows += [dict(type=2, time=MS * (i + 1), x=3, y=-2, z=-30, amp=150) for i in range(4)]
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows))
+    _compare(orc, o, eng, counts, s_ins)
+    ph = eng.photons()
+    assert counts['n_photons'] > 5000 and ph['ch'].min() >= 0 and ph['ch'].max() < n_pmts
+    assert len(np.unique(ph['ch'])) == n_pmts

@@ -93,6 +93,7 @@ struct wfs_handle {
     std::vector<i32> dev_row_ins; std::vector<int8_t> h_ins_type; i64 n_host_rows = 0; bool dev_rows_pending = false;
     DevBuf map_row_ins[2], map_row_id[2], map_x, map_y, map_z, map_nb_idx[2], map_nb_w[2];
 
+    std::string launch_err;      // first failed launch of the current call (wfs_set_debug bit 3: every launch is checked)
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
 
@@ -122,9 +123,12 @@ int upload(wfs_handle *h, DevBuf &b, const void *src, size_t bytes)
 
 #define TRY(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+// Brackets one kernel launch: HIP events when profiling is on; with wfs_set_debug bit 3 the launch is checked on the spot
+// (hipGetLastError + a stream synchronisation), so that a failed launch or a faulting kernel is reported under its own name
+// instead of ~25 launches later at the end of wfs_run.
 struct Timer {
-    wfs_handle *h; bool on;
-    Timer(wfs_handle *h_, const char *name) : h(h_), on(h_->profiling != 0)
+    wfs_handle *h; bool on; const char *name;
+    Timer(wfs_handle *h_, const char *name_) : h(h_), on(h_->profiling != 0), name(name_)
     {
         if (!on) return;
         KernelTime kt; kt.name = name;
@@ -132,8 +136,17 @@ struct Timer {
         hipEventRecord(kt.a, h->stream);
         h->times.push_back(kt);
     }
-    ~Timer() { if (on) hipEventRecord(h->times.back().b, h->stream); }
+    ~Timer()
+    {
+        if (on) hipEventRecord(h->times.back().b, h->stream);
+        if (h->keep_currents & 8) {
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e != hipSuccess && h->launch_err.empty()) { try { h->launch_err = std::string(name) + ": " + hipGetErrorString(e); } catch (...) {} }
+        }
+    }
 };
+#define CHECK_LAUNCHES() do { if (!h->launch_err.empty()) { const std::string m_ = h->launch_err; h->launch_err.clear(); return h->fail(WFS_E_HIP, m_); } } while (0)
 
 // grid size for n items; never 0 (a launch with an empty grid is an error, every kernel bounds-checks its index)
 inline unsigned nblocks(i64 n, int tpb) { return n > 0 ? (unsigned)((n + tpb - 1) / tpb) : 1u; }
@@ -177,6 +190,7 @@ int read_scal(wfs_handle *h)
 {
     HIPCHK(hipMemcpyAsync(h->h_scal, h->scal.p, sizeof(h->h_scal), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (!h->launch_err.empty()) { const std::string m = h->launch_err; h->launch_err.clear(); return h->fail(WFS_E_HIP, m); }     // (wfs_set_debug bit 3)
     return WFS_OK;
 }
 
@@ -344,12 +358,28 @@ void refresh_dev(wfs_handle *h)
 
 }  // namespace
 
+
+// Exception firewall of the C ABI: every extern "C" entry point is a function-try-block, so that a std::bad_alloc /
+// std::length_error from the host-side containers becomes an error code + wfs_last_error instead of std::terminate.
+static int wfs_caught(wfs_handle *h, const char *fn) noexcept
+{
+    int code = WFS_E_INVALID; const char *what = "unknown C++ exception";
+    char buf[256];
+    try { throw; }
+    catch (const std::bad_alloc &) { code = WFS_E_NOMEM; what = "out of host memory (std::bad_alloc)"; }
+    catch (const std::exception &e) { snprintf(buf, sizeof buf, "%s", e.what()); what = buf; }
+    catch (...) {}
+    if (h) { try { h->err = std::string(fn) + ": " + what; } catch (...) {} }
+    return code;
+}
+#define WFS_CATCH(h) catch (...) { return wfs_caught((h), __func__); }
+
 extern "C" {
 
-int wfs_device_count(int *n) { return hipGetDeviceCount(n) == hipSuccess ? WFS_OK : WFS_E_HIP; }
+int wfs_device_count(int *n) try { return hipGetDeviceCount(n) == hipSuccess ? WFS_OK : WFS_E_HIP; } WFS_CATCH(nullptr)
 
 int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
-{
+try {
     if (!cfg || !out) return WFS_E_INVALID;
     if (cfg->n_tpc <= 0 || cfg->n_tpc > WFS_MAX_CH || cfg->dt != WFS_DT || cfg->tlen != 22) return WFS_E_INVALID;   // kernels are specialised for 10 ns samples and 22-tap templates
     int ndev = 0;
@@ -385,10 +415,10 @@ int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
     hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
     return WFS_OK;
-}
+} WFS_CATCH(nullptr)
 
 int wfs_destroy(wfs_handle *h)
-{
+try {
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
@@ -422,23 +452,23 @@ int wfs_destroy(wfs_handle *h)
     for (int q = 0; q < 2; q++) if (h->rec_copied[q]) hipEventDestroy(h->rec_copied[q]);
     delete h;
     return WFS_OK;
-}
+} WFS_CATCH(nullptr)
 
 const char *wfs_last_error(const wfs_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
 int wfs_set_stream(wfs_handle *h, void *s)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (h->own_stream) { hipStreamSynchronize(h->stream); hipStreamDestroy(h->stream); h->own_stream = false; }
     h->stream = (hipStream_t)s;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
-int wfs_synchronize(wfs_handle *h) { if (!h) return WFS_E_INVALID; HIPCHK(hipStreamSynchronize(h->stream)); return WFS_OK; }
+int wfs_synchronize(wfs_handle *h) try { if (!h) return WFS_E_INVALID; HIPCHK(hipStreamSynchronize(h->stream)); return WFS_OK; } WFS_CATCH(h)
 // a noise array of floats (resource.noise_data of a float dtype with non-integral values): add_noise (rawdata.py:436) adds it into
 // the int64 row inside numba, which stores the TRUNCATED SUM -- not the sum with the truncated noise.  Replaces the int16 table.
 int wfs_set_noise_float(wfs_handle *h, const double *noise, int32_t noise_len, int32_t noise_channels)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
     if (!noise || noise_len <= 0 || noise_channels <= 0) return h->fail(WFS_E_INVALID, "wfs_set_noise_float: empty noise array");
@@ -451,30 +481,30 @@ int wfs_set_noise_float(wfs_handle *h, const double *noise, int32_t noise_len, i
     d.noise_f = h->t_noise_f.as<double>(); d.noise = (const int16_t *)d.noise_f; d.noise_len = noise_len; d.noise_channels = noise_channels;
     refresh_dev(h);
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_set_noise_offsets(wfs_handle *h, const int64_t *ix, int64_t n)
-{
+try {
     if (!h || n < 0 || (n > 0 && !ix)) return WFS_E_INVALID;
     h->n_noise_override = n;
     if (n) { TRY(upload(h, h->noise_override, ix, (size_t)n * 8)); HIPCHK(hipStreamSynchronize(h->stream)); }
     return WFS_OK;
-}
-int wfs_set_window_carry(wfs_handle *h, int32_t has, int64_t t) { if (!h) return WFS_E_INVALID; h->carry_has = has; h->carry_runmax = t; return WFS_OK; }
+} WFS_CATCH(h)
+int wfs_set_window_carry(wfs_handle *h, int32_t has, int64_t t) try { if (!h) return WFS_E_INVALID; h->carry_has = has; h->carry_runmax = t; return WFS_OK; } WFS_CATCH(h)
 int wfs_copy_cluster_groups(wfs_handle *h, int32_t *group, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (cap < h->n_clusters) return h->fail(WFS_E_CAPACITY, "cluster buffer too small");
     HIPCHK(hipMemcpy(group, h->cl_group.p, (size_t)h->n_clusters * 4, hipMemcpyDeviceToHost));
     return WFS_OK;
-}
-int wfs_set_debug(wfs_handle *h, int32_t keep) { if (!h) return WFS_E_INVALID; h->keep_currents = keep; return WFS_OK; }
-int wfs_set_profiling(wfs_handle *h, int32_t on) { if (!h) return WFS_E_INVALID; h->profiling = on; return WFS_OK; }
+} WFS_CATCH(h)
+int wfs_set_debug(wfs_handle *h, int32_t keep) try { if (!h) return WFS_E_INVALID; h->keep_currents = keep; return WFS_OK; } WFS_CATCH(h)
+int wfs_set_profiling(wfs_handle *h, int32_t on) try { if (!h) return WFS_E_INVALID; h->profiling = on; return WFS_OK; } WFS_CATCH(h)
 
 int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, int32_t n_spe, const double *gains,
                    const double *thr_truth, const int64_t *thr_zle, const double *lum_x, const double *lum_t, int32_t n_lum,
                    const int16_t *noise, int32_t noise_len, int32_t noise_channels)
-{
+try {
     if (!h || !templates || !spe || !gains || !thr_truth || !thr_zle || n_spe < 1) return h ? h->fail(WFS_E_INVALID, "wfs_set_tables: null table") : WFS_E_INVALID;
     if (n_spe != 1 && n_spe < h->cfg.n_tpc) return h->fail(WFS_E_INVALID, "wfs_set_tables: n_spe must be 1 or >= n_tpc");
     HIPCHK(hipSetDevice(h->device));
@@ -516,11 +546,11 @@ int wfs_set_tables(wfs_handle *h, const double *templates, const double *spe, in
     HIPCHK(hipStreamSynchronize(h->stream));
     h->tables_set = true;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_set_ap_element(wfs_handle *h, int32_t e, int32_t n_bins_delay, int32_t n_bins_amp, int32_t amp_2d, int32_t is_uniform,
                        double delay_bin, double amp_bin, const double *delay_cdf, const double *amp_cdf)
-{
+try {
     if (!h || e < 0 || e >= WFS_MAX_AP || !delay_cdf || !amp_cdf) return WFS_E_INVALID;
     ApElem &a = h->ap[e];
     a.n_bins_delay = n_bins_delay; a.n_bins_amp = n_bins_amp; a.amp_2d = amp_2d; a.is_uniform = is_uniform; a.delay_bin = delay_bin; a.amp_bin = amp_bin;
@@ -536,7 +566,7 @@ int wfs_set_ap_element(wfs_handle *h, int32_t e, int32_t n_bins_delay, int32_t n
     h->dev.n_ap = std::max(h->dev.n_ap, e + 1);
     HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // ---------------------------------------------------------------------------------------------- batch input
 static int load_clusters(wfs_handle *h, i64 n, const int32_t *cluster, const int64_t *tmin, const uint32_t *gid)
@@ -560,7 +590,7 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
                           const int32_t *cluster, const int64_t *tmin, const double *p_hit, const double *drift_mean,
                           const double *drift_spread, const double *sc_gain, const int32_t *cdf_row, const double *cdf_table, int32_t n_cdf,
                           const int32_t *run_set, int64_t n_run_sets, const uint32_t *em_base)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
     if (n <= 0 || !type || !time || !amp || !gid || !cluster || !tmin || !p_hit || !drift_mean || !drift_spread || !sc_gain || !cdf_row || !cdf_table || n_cdf <= 0)
@@ -648,13 +678,13 @@ int wfs_load_instructions(wfs_handle *h, int64_t n, const int8_t *type, const in
     TRY(load_clusters(h, n, cluster, tmin, gid));
     h->injected = false; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false; h->ins_models = false; h->ins_gg_set = false;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // ---- model variants of the photon delays: S1 'custom' recoil models and optical propagation (s1.py:162-260), S2 garfield
 // luminescence and optical propagation (s2.py:380-557).  Each adds one independent integer-truncated term; the host builds
 // its probability mass function, the table of the sum is the convolution with the terms wfs_config describes.
 int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, const int64_t *pmf_off, const double *pmf, const int32_t *vmin)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
     if (n_tables < 0 || n_tables > 65536 || (n_tables > 0 && (!base || !pmf_off || !pmf || !vmin))) return h->fail(WFS_E_INVALID, "wfs_set_delay_models: bad arguments");
@@ -675,7 +705,7 @@ int wfs_set_delay_models(wfs_handle *h, int32_t n_tables, const int32_t *base, c
     TRY(upload(h, h->d_tabs, h->h_tabs.data(), h->h_tabs.size() * sizeof(AliasTab)));
     HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // ---- pattern maps evaluated on the device (make_patternmap, load_resource.py:403-435; WeightedNearestNeighbors) ----
 static int map_set_grid(wfs_handle *h, wfs_handle::PatternMap &m, int dims, int min_dims, const int32_t *n_nodes, const double *lo, const double *hi, size_t &nodes)
@@ -709,7 +739,7 @@ static void launch_neighbours(wfs_handle *h, const MapArgs &m)
 
 int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
                         const float *values, int32_t n_map_channels)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (which != 1 && which != 2) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map: which = 1 (S1 map) or 2 (S2 map)");
     auto &m = h->pmap[which - 1];
@@ -723,11 +753,11 @@ int wfs_set_pattern_map(wfs_handle *h, int32_t which, int32_t dims, const int32_
     HIPCHK(hipStreamSynchronize(h->stream));
     m.set = true;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // a pattern map on an irregular coordinate system (a list of points; straxen queries a KD-tree for the 2 * dims nearest)
 int wfs_set_pattern_map_points(wfs_handle *h, int32_t which, int32_t dims, int64_t n_points, const double *points, const float *values, int32_t n_map_channels)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (which != 1 && which != 2) return h->fail(WFS_E_INVALID, "wfs_set_pattern_map_points: which = 1 (S1 map) or 2 (S2 map)");
     auto &m = h->pmap[which - 1];
@@ -740,12 +770,12 @@ int wfs_set_pattern_map_points(wfs_handle *h, int32_t which, int32_t dims, int64
     HIPCHK(hipStreamSynchronize(h->stream));
     m.set = true;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // s2_aft_sigma (s2.py:660-665): the skew-normal factor of every instruction of the loaded batch (NaN: none), applied to the
 // rows the device evaluates.  Call between wfs_load_instructions and wfs_eval_pattern_rows.
 int wfs_set_instruction_aft(wfs_handle *h, int64_t n, const double *factor)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins) return h->fail(WFS_E_STATE, "wfs_set_instruction_aft follows wfs_load_instructions of the same batch");
     if (!factor) { h->ins_aft_set = false; return WFS_OK; }
@@ -754,14 +784,14 @@ int wfs_set_instruction_aft(wfs_handle *h, int64_t n, const double *factor)
     HIPCHK(hipStreamSynchronize(h->stream));
     h->ins_aft_set = true;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // diffusion_constant_transverse with enable_field_dependencies['diffusion_transverse_map'] (S2.s2_pattern_map_diffuse, s2.py:560-613):
 // sigma_r[i], sigma_a[i] = sqrt(2 D t) of instruction i along / across the radius (cm; NaN: not this path).  The pattern of such an
 // instruction is averaged over its surviving electrons inside wfs_run (k_diffuse_patterns), not by wfs_eval_pattern_rows.
 // Needs the S2 pattern map on the device as a regular grid and the instruction loaded with cdf_row = -1.
 int wfs_set_instruction_diffusion(wfs_handle *h, int64_t n, const double *sigma_r, const double *sigma_a, double tpc_radius)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins || !sigma_r || !sigma_a) return h->fail(WFS_E_STATE, "wfs_set_instruction_diffusion follows wfs_load_instructions of the same batch");
     const auto &pm = h->pmap[1];
@@ -783,7 +813,7 @@ int wfs_set_instruction_diffusion(wfs_handle *h, int64_t n, const double *sigma_
     TRY(upload(h, h->diff_row_ins, rows.data(), rows.size() * 4)); TRY(upload(h, h->diff_row_id, ids.data(), ids.size() * 8));
     HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // ---- scalar maps on the device: LCE (s1.py:125), S2 correction / SE gain (s2.py:193-234), longitudinal diffusion (s2.py:170),
 // field-dependence splines (s2.py:150, 248), field distortion maps (s2.py:41, 66) ----
@@ -796,7 +826,7 @@ static int smap_new(wfs_handle *h, std::unique_ptr<wfs_handle::ScalarMap> m, int
 }
 
 int wfs_scalar_map_grid(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi, const double *values, int32_t *map_id)
-{
+try {
     if (!h || !map_id || !values) return WFS_E_INVALID;
     HIPCHK(hipSetDevice(h->device));
     std::unique_ptr<wfs_handle::ScalarMap> m(new wfs_handle::ScalarMap()); size_t nodes = 0;
@@ -804,10 +834,10 @@ int wfs_scalar_map_grid(wfs_handle *h, int32_t dims, const int32_t *n_nodes, con
     TRY(map_set_grid(h, m->g, dims, 1, n_nodes, lo, hi, nodes));
     TRY(upload(h, m->g.values, values, nodes * 8));
     return smap_new(h, std::move(m), map_id);
-}
+} WFS_CATCH(h)
 
 int wfs_scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values, int32_t *map_id)
-{
+try {
     if (!h || !map_id || !values || !points || dims < 1 || dims > 3 || n_points < 2 * dims) return h ? h->fail(WFS_E_INVALID, "wfs_scalar_map_points: 1..3 dimensions, at least 2 * dims points") : WFS_E_INVALID;
     HIPCHK(hipSetDevice(h->device));
     std::unique_ptr<wfs_handle::ScalarMap> m(new wfs_handle::ScalarMap());
@@ -815,10 +845,10 @@ int wfs_scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const d
     TRY(upload(h, m->g.points, points, (size_t)n_points * dims * 8));
     TRY(upload(h, m->g.values, values, (size_t)n_points * 8));
     return smap_new(h, std::move(m), map_id);
-}
+} WFS_CATCH(h)
 
 int wfs_scalar_map_spline(wfs_handle *h, int32_t nx, const double *tx, int32_t ny, const double *ty, int32_t kx, int32_t ky, const double *c, int32_t *map_id)
-{
+try {
     if (!h || !map_id || !tx || !ty || !c) return WFS_E_INVALID;
     if (kx < 1 || kx > 5 || ky < 1 || ky > 5 || nx < 2 * kx + 2 || ny < 2 * ky + 2) return h->fail(WFS_E_INVALID, "wfs_scalar_map_spline: degrees 1..5, at least 2 (k + 1) knots per axis");
     HIPCHK(hipSetDevice(h->device));
@@ -827,10 +857,10 @@ int wfs_scalar_map_spline(wfs_handle *h, int32_t nx, const double *tx, int32_t n
     TRY(upload(h, m->tx, tx, (size_t)nx * 8)); TRY(upload(h, m->ty, ty, (size_t)ny * 8));
     TRY(upload(h, m->c, c, (size_t)(nx - kx - 1) * (size_t)(ny - ky - 1) * 8));
     return smap_new(h, std::move(m), map_id);
-}
+} WFS_CATCH(h)
 
 int wfs_scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (map_id < 0 || (size_t)map_id >= h->smaps.size() || n < 0 || (n && (!pos || !out))) return h->fail(WFS_E_INVALID, "wfs_scalar_map_eval: unknown map or missing arrays");
     if (n == 0) return WFS_OK;
@@ -853,10 +883,10 @@ int wfs_scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float *y, const float *z)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins || !x || !y || !z) return h->fail(WFS_E_STATE, "wfs_eval_pattern_rows follows wfs_load_instructions of the same batch");
     if (h->dev_row_ins.empty()) return WFS_OK;
@@ -890,11 +920,11 @@ int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float 
     HIPCHK(hipGetLastError());
     h->dev_rows_pending = false; h->gen_done = false;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // channel CDF rows of the loaded batch as the generator sees them (host rows followed by the device-evaluated ones)
 int wfs_copy_cdf_rows(wfs_handle *h, int32_t *cdf_row, double *cdf_table, int64_t cap_rows)
-{
+try {
     if (!h || !h->batch_loaded || h->injected || h->optical) return WFS_E_STATE;
     if (h->dev_rows_pending) return h->fail(WFS_E_STATE, "wfs_eval_pattern_rows has not been called for this batch");
     const i64 total = h->n_host_rows + (i64)h->dev_row_ins.size();
@@ -903,10 +933,10 @@ int wfs_copy_cdf_rows(wfs_handle *h, int32_t *cdf_row, double *cdf_table, int64_
     if (cdf_row) HIPCHK(hipMemcpy(cdf_row, h->ins_cdfrow.p, (size_t)h->n_ins * 4, hipMemcpyDeviceToHost));
     if (cdf_table) HIPCHK(hipMemcpy(cdf_table, h->cdf_table.p, (size_t)total * h->cfg.n_tpc * 8, hipMemcpyDeviceToHost));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_set_s1_propagation(wfs_handle *h, int32_t nz, int32_t nu, double u0, double du, const double *top, const double *bottom)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (nz == 0) { h->prop_nz = 0; return WFS_OK; }
     if (nz < 2 || nu < 2 || !(du > 0) || !top || !bottom) return h->fail(WFS_E_INVALID, "wfs_set_s1_propagation: needs a grid of at least 2 x 2 nodes");
@@ -915,10 +945,10 @@ int wfs_set_s1_propagation(wfs_handle *h, int32_t nz, int32_t nu, double u0, dou
     HIPCHK(hipStreamSynchronize(h->stream));
     h->prop_nz = nz; h->prop_nu = nu; h->prop_u0 = u0; h->prop_du = du;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_set_instruction_models(wfs_handle *h, int64_t n, const int32_t *tab, const int32_t *tab_bottom, const int32_t *prop_zi, const double *prop_zf)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins) return h->fail(WFS_E_STATE, "wfs_set_instruction_models follows wfs_load_instructions of the same batch");
     if (h->d_tabs.p == nullptr) TRY(wfs_set_delay_models(h, 0, nullptr, nullptr, nullptr, nullptr));
@@ -941,11 +971,11 @@ int wfs_set_instruction_models(wfs_handle *h, int64_t n, const int32_t *tab, con
     HIPCHK(hipStreamSynchronize(h->stream));
     h->ins_models = true; h->gen_done = false;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // ---- s2_luminescence_model 'garfield_gas_gap' (s2.py:413-483, load_resource.py:284-291) ----
 int wfs_set_gas_gap_model(wfs_handle *h, int32_t n_gas_gaps, int32_t n_points, const double *timing_inv_cdf)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (n_gas_gaps == 0) { h->gg_n = 0; return WFS_OK; }
     if (n_gas_gaps < 1 || n_points < 3 || !timing_inv_cdf) return h->fail(WFS_E_INVALID, "wfs_set_gas_gap_model: at least one table of at least 3 points");
@@ -954,10 +984,10 @@ int wfs_set_gas_gap_model(wfs_handle *h, int32_t n_gas_gaps, int32_t n_points, c
     HIPCHK(hipStreamSynchronize(h->stream));
     h->gg_n = n_gas_gaps; h->gg_L = n_points;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_set_instruction_gas_gap(wfs_handle *h, int64_t n, const int32_t *table, const double *weight)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins || !table || !weight) return h->fail(WFS_E_STATE, "wfs_set_instruction_gas_gap follows wfs_load_instructions of the same batch");
     if (h->gg_n < 1) return h->fail(WFS_E_STATE, "wfs_set_gas_gap_model first");
@@ -967,11 +997,11 @@ int wfs_set_instruction_gas_gap(wfs_handle *h, int64_t n, const int32_t *table, 
     HIPCHK(hipStreamSynchronize(h->stream));
     h->ins_gg_set = true; h->gen_done = false;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, const int64_t *set_tmin, const int64_t *set_off,
                      const int64_t *t, const int16_t *ch, const double *gain, const uint8_t *dpe)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
     if (n_sets <= 0 || !set_cluster || !set_tmin || !set_off) return h->fail(WFS_E_INVALID, "wfs_load_photons: null or empty input");
@@ -1016,11 +1046,11 @@ int wfs_load_photons(wfs_handle *h, int64_t n_sets, const int32_t *set_cluster, 
     TRY(load_clusters(h, n_sets, set_cluster, set_tmin, nullptr));
     h->injected = true; h->optical = false; h->batch_loaded = true; h->ran = false; h->gen_done = false;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_load_optical(wfs_handle *h, int64_t n, const int64_t *time, const uint32_t *gid, const int32_t *cluster, const int64_t *tmin,
                      const int32_t *first, const int32_t *last, const int32_t *channels, const int64_t *timings, int64_t n_ph, int64_t cutoff)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
     if (n <= 0 || !time || !gid || !cluster || !tmin || !first || !last || (n_ph > 0 && (!channels || !timings)))
@@ -1061,7 +1091,7 @@ int wfs_load_optical(wfs_handle *h, int64_t n, const int64_t *time, const uint32
     TRY(load_clusters(h, n, cluster, tmin, gid));
     h->injected = false; h->optical = true; h->batch_loaded = true; h->ran = false; h->gen_done = false;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // ---------------------------------------------------------------------------------------------- run
 static int run_generation(wfs_handle *h)
@@ -1199,7 +1229,7 @@ static int run_generation(wfs_handle *h)
 }
 
 int wfs_run(wfs_handle *h)
-{
+try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded) return h->fail(WFS_E_STATE, "no batch loaded");
     if (h->dev_rows_pending && !h->injected && !h->optical) return h->fail(WFS_E_STATE, "instructions with cdf_row -1: call wfs_eval_pattern_rows before wfs_run");
@@ -1433,12 +1463,13 @@ int wfs_run(wfs_handle *h)
     }
     TRY(read_scal(h));
     HIPCHK(hipGetLastError());
+    CHECK_LAUNCHES();
     h->ran = true;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_get_counts(wfs_handle *h, wfs_counts *out)
-{
+try {
     if (!h || !out) return WFS_E_INVALID;
     if (!h->ran) return h->fail(WFS_E_STATE, "wfs_run has not completed");
     wfs_counts c{};
@@ -1448,38 +1479,38 @@ int wfs_get_counts(wfs_handle *h, wfs_counts *out)
     c.n_intervals = h->h_scal[20]; c.n_pe = h->h_scal[21];          // reduced on the device at the end of wfs_run (k_counts)
     *out = c; h->counts = c;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 const void *wfs_records_dev_ptr(wfs_handle *h) { return h ? h->records_buf().p : nullptr; }
 
 int wfs_copy_records(wfs_handle *h, void *dst, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (cap < h->n_records) return h->fail(WFS_E_CAPACITY, "record buffer too small");
     if (h->n_records) HIPCHK(hipMemcpy(dst, h->records_buf().p, (size_t)h->n_records * 244, hipMemcpyDeviceToHost));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_records_range(wfs_handle *h, void *dst, int64_t first, int64_t count)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (first < 0 || count < 0 || first + count > h->n_records) return h->fail(WFS_E_INVALID, "record range outside the batch");
     if (count) HIPCHK(hipMemcpy(dst, (const uint8_t *)h->records_buf().p + (size_t)first * 244, (size_t)count * 244, hipMemcpyDeviceToHost));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // Pinned host memory + the copy stream: the records of a batch travel to the host while the next batch's kernels run
 // (strax_interface.py:360-364: the caller owns the record buffer; pinning it once removes the staging copy of pageable
 // transfers -- 15 GB/s -- and lets the transfer overlap).  wfs_run leaves the records of the last TWO batches intact.
 int wfs_host_register(void *ptr, int64_t bytes)
-{
+try {
     if (!ptr || bytes <= 0) return WFS_E_INVALID;
     return hipHostRegister(ptr, (size_t)bytes, hipHostRegisterDefault) == hipSuccess ? WFS_OK : WFS_E_HIP;
-}
-int wfs_host_unregister(void *ptr) { return (ptr && hipHostUnregister(ptr) == hipSuccess) ? WFS_OK : WFS_E_HIP; }
+} WFS_CATCH(nullptr)
+int wfs_host_unregister(void *ptr) try { return (ptr && hipHostUnregister(ptr) == hipSuccess) ? WFS_OK : WFS_E_HIP; } WFS_CATCH(nullptr)
 
 int wfs_copy_records_range_async(wfs_handle *h, void *dst, int64_t first, int64_t count)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (first < 0 || count < 0 || first + count > h->n_records) return h->fail(WFS_E_INVALID, "record range outside the batch");
     HIPCHK(hipSetDevice(h->device));
@@ -1487,35 +1518,37 @@ int wfs_copy_records_range_async(wfs_handle *h, void *dst, int64_t first, int64_
     HIPCHK(hipEventRecord(h->rec_copied[h->rec_cur], h->copy_stream));
     h->rec_pending[h->rec_cur] = true;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_wait_records(wfs_handle *h)
-{
+try {
     if (!h) return WFS_E_INVALID;
-    HIPCHK(hipStreamSynchronize(h->copy_stream));
-    h->rec_pending[0] = h->rec_pending[1] = false;
+    // May be called from the consumer's thread while a worker thread is inside wfs_run for the next batch (RawData.iter_batches):
+    // it only waits for the copy stream and leaves the handle's state alone -- rec_pending stays with the thread that runs and copies
+    // (wfs_run's own wait on an event that has completed returns at once).
+    if (hipStreamSynchronize(h->copy_stream) != hipSuccess) return WFS_E_HIP;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_records_dev(wfs_handle *h, void *dst, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (cap < h->n_records) return h->fail(WFS_E_CAPACITY, "record buffer too small");
     if (h->n_records) { HIPCHK(hipMemcpyAsync(dst, h->records_buf().p, (size_t)h->n_records * 244, hipMemcpyDeviceToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 // records of a batch in the order strax.sort_by_time gives them ((time, channel); strax_interface.py:453) instead of the
 // order the reference yields pulses (window, channel, interval)
 int wfs_set_record_order(wfs_handle *h, int32_t by_time)
-{
+try {
     if (!h) return WFS_E_INVALID;
     h->sort_records = by_time != 0;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_groups(wfs_handle *h, int64_t *left, int64_t *right, int64_t *first_record, int64_t *ix_rand)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     const i64 G = h->n_groups;
     if (left) HIPCHK(hipMemcpy(left, h->grp_left.p, (size_t)G * 8, hipMemcpyDeviceToHost));
@@ -1524,10 +1557,10 @@ int wfs_copy_groups(wfs_handle *h, int64_t *left, int64_t *right, int64_t *first
     if (first_record && G > 0)      // rec_off[g * row_slots]: a strided copy of one value per window (the whole array is 6 KB per cluster)
         HIPCHK(hipMemcpy2D(first_record, 8, h->rec_off.p, (size_t)h->dev.row_slots * 8, 8, (size_t)G, hipMemcpyDeviceToHost));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_intervals(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right, int64_t *data_off, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     const WfsDev &d = h->dev;
     const i64 RS = (h->n_clusters + 1) * d.row_slots;
@@ -1551,10 +1584,10 @@ int wfs_copy_intervals(wfs_handle *h, int32_t *group, int32_t *channel, int64_t 
     }
     if (k < cap) data_off[k] = doff;
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_interval_data(wfs_handle *h, int16_t *data, int64_t cap)
-{
+try {
     // unpack the records: fragments of one interval are consecutive
     if (!h || !h->ran) return WFS_E_STATE;
     std::vector<uint8_t> rec((size_t)h->n_records * 244);
@@ -1567,10 +1600,10 @@ int wfs_copy_interval_data(wfs_handle *h, int16_t *data, int64_t cap)
         k += len;
     }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_pulses(wfs_handle *h, int32_t *set, int32_t *channel, int64_t *left, int64_t *right, int64_t *nph, int64_t *cur_off, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     const WfsDev &d = h->dev;
     const i64 A = h->n_active_tiles;
@@ -1591,19 +1624,19 @@ int wfs_copy_pulses(wfs_handle *h, int32_t *set, int32_t *channel, int64_t *left
         nph[k] = cnt[tile]; cur_off[k] = off; off += right[k] - left[k] + 1;
     }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_currents(wfs_handle *h, double *cur, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (!(h->keep_currents & 1)) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
     if (cap < h->cur_total) return h->fail(WFS_E_CAPACITY, "current buffer too small");
     if (h->cur_total) HIPCHK(hipMemcpy(cur, h->currents.p, (size_t)h->cur_total * 8, hipMemcpyDeviceToHost));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_rows(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left, int64_t *right, int64_t *data_off, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (!(h->keep_currents & 1)) return h->fail(WFS_E_STATE, "wfs_set_debug(h, 1) before wfs_run");
     const WfsDev &d = h->dev;
@@ -1623,18 +1656,18 @@ int wfs_copy_rows(wfs_handle *h, int32_t *group, int32_t *channel, int64_t *left
         data_off[k] = off; off += right[k] - left[k] + 1;
     }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_row_data(wfs_handle *h, int32_t *data, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     if (cap < h->row_dbg_total) return h->fail(WFS_E_CAPACITY, "row data buffer too small");
     if (h->row_dbg_total) HIPCHK(hipMemcpy(data, h->row_dbg.p, (size_t)h->row_dbg_total * 4, hipMemcpyDeviceToHost));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, double *gain, uint8_t *dpe, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     const WfsDev &d = h->dev;
     const i64 P = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0), T = h->n_tiles;
@@ -1662,10 +1695,10 @@ int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, d
         }
     }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t cap)
-{
+try {
     if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
     const i64 N = h->n_ins;
     if (cap < N + 1) return h->fail(WFS_E_CAPACITY, "offset buffer too small");
@@ -1674,10 +1707,10 @@ int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t cap
     HIPCHK(hipMemcpy(epo.data(), h->em_ph_off.p, epo.size() * 8, hipMemcpyDeviceToHost));
     for (i64 i = 0; i <= N; i++) off[i] = epo[(size_t)emo[i]];
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_gather_photon_times(wfs_handle *h, int64_t n, const int64_t *index, int64_t *t_out)
-{
+try {
     if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
     if (n <= 0) return WFS_OK;
     if (!index || !t_out) return h->fail(WFS_E_INVALID, "wfs_gather_photon_times: null argument");
@@ -1688,10 +1721,10 @@ int wfs_gather_photon_times(wfs_handle *h, int64_t n, const int64_t *index, int6
     HIPCHK(hipMemcpyAsync(t_out, h->gather_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     const i64 S = h->n_sets;
     if (cap < S) return h->fail(WFS_E_CAPACITY, "truth buffer too small");
@@ -1708,10 +1741,10 @@ int wfs_copy_truth(wfs_handle *h, double *acc12, double *tstat5, int64_t cap)
         tstat5[s * 5 + 4] = n > 0 ? sqrt(var > 0 ? var : 0) : NAN;
     }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_truth_per_pmt(wfs_handle *h, double *acc6, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     const i64 S = h->n_sets, nch = h->cfg.n_tpc, T = S * nch;
     if (cap < S) return h->fail(WFS_E_CAPACITY, "per-PMT truth buffer too small");
@@ -1726,10 +1759,10 @@ int wfs_copy_truth_per_pmt(wfs_handle *h, double *acc6, int64_t cap)
         o[0] = p[0]; o[1] = p[0] + p[1]; o[2] = p[2]; o[3] = p[2] + p[3]; o[4] = p[4] / G; o[5] = p[5] / G;       // pulse.py:259-271
     }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t cap)
-{
+try {
     if (!h || !h->ran) return WFS_E_STATE;
     const i64 N = h->n_ins;
     if (h->optical) { for (i64 i = 0; i < N && i < cap; i++) { estat5[i * 5] = 0; for (int q = 1; q < 5; q++) estat5[i * 5 + q] = NAN; } return WFS_OK; }
@@ -1757,10 +1790,10 @@ int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t cap)
         estat5[q * 5 + 4] = n > 0 ? sqrt(var > 0 ? var : 0) : NAN;
     }
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 int wfs_kernel_times(wfs_handle *h, char *names, int64_t names_cap, float *ms, int32_t *n_launches, int32_t *n_kernels)
-{
+try {
     if (!h) return WFS_E_INVALID;
     HIPCHK(hipStreamSynchronize(h->stream));
     std::vector<std::string> uniq; std::vector<float> tot; std::vector<int> cnt;
@@ -1778,6 +1811,6 @@ int wfs_kernel_times(wfs_handle *h, char *names, int64_t names_cap, float *ms, i
     }
     *n_kernels = (int32_t)uniq.size();
     return WFS_OK;
-}
+} WFS_CATCH(h)
 
 }  // extern "C"

@@ -303,7 +303,9 @@ __global__ void k_group_final(WfsDev d, GeomArgs a)
         i64 N = d.noise_len, high = (N - nr + nl - 1 < 0) ? N - 1 : N - nr + nl - 1;
         if (high <= 0) ix = 0;
         else { u32x4 w = philox4x32_10(0, a.cl_gid[a.grp_gid[g]], 0, SITE_NOISE, d.k0, d.k1); ix = (i64)(u53(w.x, w.y) * (double)high); }
-        if (a.noise_override && g < a.n_noise_override && a.noise_override[g] >= 0) ix = a.noise_override[g];
+        // (reduced modulo the noise length: add_noise wraps the index, rawdata.py:433-434, and the single-subtract wrap of
+        // load_sample relies on ix < noise_len)
+        if (a.noise_override && g < a.n_noise_override && a.noise_override[g] >= 0) ix = N > 0 ? a.noise_override[g] % N : 0;
     }
     a.grp_ixrand[g] = ix;
 }
@@ -2127,12 +2129,15 @@ __global__ __launch_bounds__(64) void k_chan_alias(const double *cdf_table, int 
     int ns = 0, nl = 0;
     for (int i0 = 0; i0 < K; i0 += 64) {
         const int i = i0 + threadIdx.x;
+        // (K = 2^lg can be below the wave width: lanes behind the last cell take no part -- phantom zero-mass cells on the small
+        // stack would drain the large ones and leave the row uniform over all K cells, channels >= n_tpc included)
+        const bool valid = i < K;
         const double qi = i < nch ? (cum[i] - (i ? cum[i - 1] : 0.0)) * (double)K : 0.0;
-        q[i] = qi; cell[i] = uint2{0xffffffffu, (u32)i};
-        const bool sm = qi < 1.0;
-        const u64 ms = __ballot(sm), below = (1ull << threadIdx.x) - 1ull;
-        if (sm) st_small[ns + __popcll(ms & below)] = (unsigned short)i; else st_large[nl + __popcll(~ms & below)] = (unsigned short)i;
-        ns += __popcll(ms); nl += 64 - __popcll(ms);
+        if (valid) { q[i] = qi; cell[i] = uint2{0xffffffffu, (u32)i}; }
+        const bool sm = valid && qi < 1.0, lgc = valid && !(qi < 1.0);
+        const u64 ms = __ballot(sm), ml = __ballot(lgc), below = (1ull << threadIdx.x) - 1ull;
+        if (sm) st_small[ns + __popcll(ms & below)] = (unsigned short)i; else if (lgc) st_large[nl + __popcll(ml & below)] = (unsigned short)i;
+        ns += __popcll(ms); nl += __popcll(ml);
     }
     __syncthreads();
     if (threadIdx.x == 0 && ns > 0 && nl > 0) {

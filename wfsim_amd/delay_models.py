@@ -289,7 +289,14 @@ class DelayModels:
             d_gas_gap = gaps[1] - gaps[0]
             xy = np.array([instructions['x'][s2], instructions['y'][s2]]).T
             cont = np.asarray(self.gas_gap['map'](xy), dtype=np.float64).reshape(len(s2), -1)[:, 0]
-            draw = np.clip(np.digitize(cont, gaps) - 1, 0, len(gaps) - 1)      # (below the first gap the reference wraps to the last table)
+            draw = np.digitize(cont, gaps) - 1
+            if np.any(draw < 0):
+                # s2.py:476-477: index -1 wraps to the LAST table with the distance taken from gaps[-1] -- an artefact of numpy's
+                # negative indexing, not physics; here such positions use the first table (distance < 0: extrapolated)
+                import warnings
+                warnings.warn(f'garfield_gas_gap: {int(np.sum(draw < 0))} instruction(s) with a gas gap below the first tabulated value '
+                              f'({gaps[0]}): the first table is used where the reference wraps to the last one (s2.py:476)')
+            draw = np.clip(draw, 0, len(gaps) - 1)
             idx[s2] = draw
             w[s2] = (cont - gaps[draw]) / d_gas_gap
         return idx, w

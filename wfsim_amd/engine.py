@@ -35,21 +35,28 @@ def unpin_host(array):
     load_library().wfs_host_unregister(C.c_void_p(np.asarray(array).ctypes.data))
 
 
-_RECORD_BUFFERS = []        # [array, in use]: page-locked record buffers, kept for the life of the process
-MAX_RECORD_BUFFERS = 4      # at most this many (1.2 GB each): beyond it the chunker copies instead of handing buffers out
+_RECORD_BUFFERS = []        # [array, in use]: page-locked record buffers, recycled between chunkers
+MAX_RECORD_BUFFERS = 4      # ceiling of the page-locked pool (1.2 GB each by default): beyond it buffers are pageable / the chunker copies
 
 
 def acquire_record_buffer(length, dtype, pin=True, spare_only=False):
     """A record buffer for ChunkRawRecords (strax_interface.py:360-361: np.zeros(5000000, raw_record_dtype), 1.2 GB).
-    Page-locking that much memory takes a few hundred ms, so pinned buffers are recycled between instances.
-    ``spare_only``: a pooled buffer or None (a new one is made only while the pool is below MAX_RECORD_BUFFERS)."""
+    Page-locking that much memory takes a few hundred ms, so pinned buffers are recycled between instances.  The pool never
+    holds more than MAX_RECORD_BUFFERS page-locked buffers (a free one of another size is unpinned to make room); past the
+    ceiling the caller gets an ordinary pageable array (``spare_only``: None) -- copies into it still work, staged by the driver."""
     dtype = np.dtype(dtype)
     for slot in _RECORD_BUFFERS:
         if not slot[1] and len(slot[0]) == length and slot[0].dtype == dtype:
             slot[1] = True
             return slot[0]
-    if spare_only and len(_RECORD_BUFFERS) >= MAX_RECORD_BUFFERS:
-        return None
+    if len(_RECORD_BUFFERS) >= MAX_RECORD_BUFFERS:
+        for k, slot in enumerate(_RECORD_BUFFERS):
+            if not slot[1]:
+                unpin_host(slot[0])
+                del _RECORD_BUFFERS[k]
+                break
+    if len(_RECORD_BUFFERS) >= MAX_RECORD_BUFFERS:
+        return None if spare_only else np.zeros(length, dtype=dtype)
     buf = np.zeros(length, dtype=dtype)
     if pin and pin_host(buf):
         _RECORD_BUFFERS.append([buf, True])
@@ -182,6 +189,8 @@ class Engine:
                     self._h, C.c_int32(e), C.c_int32(dc.shape[1]), C.c_int32(ac.shape[-1]), C.c_int32(ac.ndim == 2),
                     C.c_int32('Uniform' in name), C.c_double(d['delaytime_bin_size']), C.c_double(d['amplitude_bin_size']), _p(dc), _p(ac)))
 
+        if os.environ.get('WFS_CHECK_LAUNCHES', '0') not in ('', '0'):
+            self.set_debug(False)          # every launch checked from the first run on
         # HE records exist only when the HE rows can differ from a flat baseline (wfs_engine.hip refresh_dev): a non-zero
         if t['noise'] is not None and np.asarray(resource.noise_data).dtype.kind == 'f' \
                 and not np.array_equal(np.asarray(resource.noise_data), np.trunc(resource.noise_data)):
@@ -371,8 +380,13 @@ class Engine:
         self.counts = {n: getattr(c, n) for n, _ in WfsCounts._fields_}
         return self.counts
 
-    def set_debug(self, on=True, force_dense=False, generate_only=False):
-        self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(bool(on)) | (2 if force_dense else 0) | (4 if generate_only else 0))))
+    def set_debug(self, on=True, force_dense=False, generate_only=False, check_launches=None):
+        """check_launches (default: the environment variable WFS_CHECK_LAUNCHES): every kernel launch of wfs_run is checked and
+        synchronised on the spot, so that a failing kernel is reported under its own name (slow; debugging only)"""
+        if check_launches is None:
+            check_launches = os.environ.get('WFS_CHECK_LAUNCHES', '0') not in ('', '0')
+        self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(bool(on)) | (2 if force_dense else 0) | (4 if generate_only else 0)
+                                                              | (8 if check_launches else 0))))
 
     def generate(self):
         """photon generation only (no pulses / records): the pre-pass of the electron afterpulses"""

@@ -150,7 +150,8 @@ class RawData:
         st = dict(s_ins=s_ins, gids=gids, order=order, key=key, cluster=cluster, em_base=em_base, est_csum=est_csum, rec_csum=rec_csum,
                   cl_min_key=cl_min_key, n=n)
         # the kernels of the next batch run (from a worker thread: the engine calls drop the GIL) while the consumer works on
-        # this one; the engine is only ever used by one thread at a time
+        # this one.  The worker owns the engine meanwhile; the one call the consumer's thread makes during that time is
+        # engine.wait_records(), which only waits for the copy stream and touches no state of the handle (wfs_wait_records)
         pool = None
         if self.prefetch and n > 1:
             from concurrent.futures import ThreadPoolExecutor
