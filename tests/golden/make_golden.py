@@ -787,6 +787,114 @@ def fixture_optical_adjustment(ref):
                         ins_out=out, timings_out=timings, channels_out=channels)
 
 
+class _FakeBranch:
+    """what uproot hands the reference for one branch of the Geant4 tree: .array(library='np') -> (object) array per event"""
+
+    def __init__(self, values):
+        self.values = values
+
+    def array(self, library='np'):
+        return self.values
+
+
+def synthetic_g4_events(rng, n_events, ch_lo, ch_hi, with_energy):
+    """array-backed stand-in for the Geant4 optical tree (strax_interface.py:292-322 reads these branches)"""
+    nhit = rng.integers(0, 40, n_events); nhit[::9] = 0
+
+    def ragged(make):
+        out = np.empty(n_events, dtype=object)
+        for i in range(n_events):
+            out[i] = make(int(nhit[i]))
+        return out
+    ev = dict(eventid=np.arange(100, 100 + n_events, dtype=np.int64),
+              pmthitID=ragged(lambda k: rng.integers(ch_lo - 3, ch_hi + 4, k).astype(np.int64)),          # a few ids outside the array
+              pmthitTime=ragged(lambda k: np.where(rng.random(k) < 0.1, rng.uniform(1.5e-6, 6e-6, k), rng.uniform(0, 4e-7, k))),   # s; some > 1 us: split pulses
+              xp_pri=rng.uniform(-600, 600, n_events), yp_pri=rng.uniform(-600, 600, n_events), zp_pri=rng.uniform(-1400, 0, n_events))
+    if with_energy:
+        ev['pmthitEnergy'] = ragged(lambda k: np.where(rng.random(k) < 0.05, 0.9, rng.uniform(2.0, 4.5, k)))       # eV; 0.9 eV -> 1378 nm: outside the table
+    return ev
+
+
+def fixture_optical_frontend(ref):
+    """the host front end of the optical / nVeto path run on the REFERENCE -- _read_optical_nveto + read_optical
+    (strax_interface.py:234-333) on an array-backed stand-in for the Geant4 tree (uproot is not installed: `uproot.open` is
+    pointed at it), and RawRecordsFromMcChain.set_timing (:824-863) on a bare object.  The random draws come from numpy's
+    legacy global generator, seeded: a RandomState with the same seed reproduces them in the test."""
+    import types
+    si = ref.strax_interface
+    out = {}
+    rng = np.random.default_rng(2024)
+    ch_lo, ch_hi = 2000, 2119
+    wl = np.arange(250.0, 701.0, 10.0)
+    qe = {str(c): (35.0 * np.exp(-0.5 * ((wl - 400.0 - (c % 7) * 3) / 80.0) ** 2)).tolist() for c in range(ch_lo, ch_hi + 1)}
+    qe_data = dict(nv_pmt_qe_wavelength=wl.tolist(), nv_pmt_qe=qe)
+    out['qe_wavelength'] = wl
+    out['qe_table'] = np.array([qe[str(c)] for c in range(ch_lo, ch_hi + 1)])
+    cases = [('nveto', 'XENONnT_neutron_veto', True, dict(nv_pmt_ce_factor=0.8), 501),
+             ('nveto_noqe', 'XENONnT_neutron_veto', False, dict(entry_start=105, entry_stop=140), 502),
+             ('tpc', 'XENONnT', None, dict(entry_start=110), 503)]
+    for tag, detector, use_qe, extra, seed in cases:
+        lo, hi = (ch_lo, ch_hi) if detector != 'XENONnT' else (0, 493)
+        ev = synthetic_g4_events(rng, 64, lo, hi, with_energy=detector != 'XENONnT')
+        if detector == 'XENONnT':
+            ev['pmthitID'] = np.array([np.clip(h, 0, 493) for h in ev['pmthitID']] + [None], dtype=object)[:-1]
+        config = dict(detector=detector, channel_map=dict(nveto=(ch_lo, ch_hi), tpc=(0, 493)), fax_file='stand-in', tag=tag, **extra)
+        fake = {k: _FakeBranch(v) for k, v in ev.items()}
+        sys.modules['uproot'].open = lambda path, _f=fake: types.SimpleNamespace(get=lambda name: _f)
+        si.uproot = sys.modules['uproot']
+        si.wfsim.load_config = lambda cfg, _q=(qe_data if use_qe else None): types.SimpleNamespace(nv_pmt_qe=_q)
+        si._cached_wavelength_to_qe_arr.clear()
+        np.random.seed(seed)
+        ins, channels, timings = si.read_optical(config)
+        for k, v in ev.items():
+            if v.dtype == object:
+                out[f'{tag}_{k}_flat'] = np.concatenate([np.asarray(x) for x in v]) if len(v) else np.zeros(0)
+                out[f'{tag}_{k}_len'] = np.array([len(x) for x in v], dtype=np.int64)
+            else:
+                out[f'{tag}_{k}'] = v
+        out[f'{tag}_seed'] = np.int64(seed)
+        out[f'{tag}_entry'] = np.array([config.get('entry_start', 0), config['entry_stop']], dtype=np.int64)
+        out[f'{tag}_ce'] = np.float64(extra.get('nv_pmt_ce_factor', 1.0))
+        out[f'{tag}_ins'], out[f'{tag}_channels'], out[f'{tag}_timings'] = ins, channels, timings
+        print(tag, len(ins), 'instructions', len(channels), 'photons kept of', int(out[f'{tag}_pmthitID_len'].sum()))
+    # ---- RawRecordsFromMcChain.set_timing on a bare object
+    for tag, targets, entry, seed in [('both', ('tpc', 'nveto'), (None, None), 601), ('nv_only', ('nveto',), (3, 40), 602), ('tpc_only', ('tpc',), (None, None), 603)]:
+        obj = object.__new__(si.RawRecordsFromMcChain)
+        obj.config = dict(targets=targets, event_rate=1000.0, entry_start=entry[0] if entry[0] is not None else 0, entry_stop=entry[1])
+        g4 = []
+        if 'tpc' in targets:
+            n = 90
+            epix = np.zeros(n, dtype=instruction_dtype)
+            epix['g4id'] = np.sort(rng.integers(2, 45, n))
+            epix['time'] = rng.integers(0, 2_000_000, n)          # physical delays inside the event
+            epix['time'][::17] += 3_000_000_000                   # far too late: removed
+            epix['type'] = rng.integers(1, 3, n)
+            epix['amp'] = rng.integers(1, 500, n)
+            obj.instructions_epix = epix
+            g4.append(epix['g4id'])
+            out[f'timing_{tag}_epix_in'] = epix.copy()
+        if 'nveto' in targets:
+            n = 40
+            nv = np.zeros(n, dtype=instruction_dtype + optical_extra_dtype)
+            nv['g4id'] = np.sort(rng.choice(np.arange(3, 40), n))
+            nv['time'] = rng.integers(0, 500, n)
+            nv['type'] = 1
+            obj.instructions_nveto = nv
+            g4.append(nv['g4id'])
+            out[f'timing_{tag}_nveto_in'] = nv.copy()
+        obj.g4id = np.unique(np.concatenate(g4))
+        np.random.seed(seed)
+        si.RawRecordsFromMcChain.set_timing(obj)
+        out[f'timing_{tag}_seed'] = np.int64(seed)
+        out[f'timing_{tag}_entry_in'] = np.array([-1 if e is None else e for e in entry], dtype=np.int64)
+        out[f'timing_{tag}_entry_out'] = np.array([obj.config['entry_start'], obj.config['entry_stop']], dtype=np.int64)
+        if 'tpc' in targets:
+            out[f'timing_{tag}_epix_out'] = obj.instructions_epix
+        if 'nveto' in targets:
+            out[f'timing_{tag}_nveto_out'] = obj.instructions_nveto
+    np.savez_compressed(HERE + '/optical_frontend.npz', **out)
+
+
 def hist(x):
     v, c = np.unique(np.asarray(x, dtype=np.int64), return_counts=True)
     return v.astype(np.int64), c.astype(np.int64)
@@ -942,8 +1050,8 @@ def fixture_chain_stats(ref):
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap', 'aft_sigma', 'noise_float', 'diffusion']
-    ref = import_reference_interface() if 'chunker' in which else import_reference()
+    which = sys.argv[1:] or ['tables', 'add_current', 'chains', 'dists', 'models', 'stats', 'chunker', 'ele_ap_draws', 'gas_gap', 'aft_sigma', 'noise_float', 'diffusion', 'frontend']
+    ref = import_reference_interface() if ('chunker' in which or 'frontend' in which) else import_reference()
     p = fixture_tables(ref)
     if 'add_current' in which:
         fixture_add_current(ref, p)
@@ -957,6 +1065,8 @@ if __name__ == '__main__':
         fixture_chain_electron_ap(ref)
     if 'optical' in which or 'tables' in which:
         fixture_optical_adjustment(ref)
+    if 'frontend' in which:
+        fixture_optical_frontend(ref)
     if 'dists' in which:
         fixture_distributions(ref)
     if 'models' in which:

@@ -121,6 +121,27 @@ def test_mc_chain_plugin_tpc_and_nveto():
     ev_t = plugin.event_times
     for g in (0, 7, 39):
         assert np.abs(rr['time'] - ev_t[g]).min() < 2000 and np.abs(rr_nv['time'] - ev_t[g]).min() < 2000
+    # ---- the records of both detectors are the oracle's for the synchronised instructions (a chunk is sorted by time, ties by channel)
+    from wfsim_amd.dtypes import raw_record_dtype
+    from wfsim_amd.physics import instruction_params
+    from wfsim_amd.resource import Resource
+    from wfsim_amd.scheduler import schedule
+
+    def by_time(x):
+        return x[np.lexsort((x['channel'], x['time']))]
+    epix = plugin.instructions_epix
+    order, key, cluster = schedule(epix, plugin.config)
+    orc = make_oracle(plugin.config)
+    orc.simulate(epix[order], order.astype(np.uint32), instruction_params(epix[order], plugin.config, Resource(plugin.config)))
+    ref = np.frombuffer(orc.pack_records(), dtype=raw_record_dtype())
+    assert by_time(rr).tobytes() == by_time(ref).tobytes()
+    nvi = plugin.instructions_nveto
+    assert np.array_equal(nvi['time'], ev_t[nvi['g4id'] - plugin.config['entry_start']])       # the event time replaces the (zero) nVeto instruction time
+    orc_nv = make_oracle(plugin.config_nveto)
+    orc_nv.simulate_optical(nvi, np.arange(len(nvi), dtype=np.uint32), plugin.nveto_channels, plugin.nveto_timings, int(1e6))
+    ref_nv = np.frombuffer(orc_nv.pack_records(), dtype=raw_record_dtype()).copy()
+    ref_nv['channel'] += 2000
+    assert by_time(rr_nv).tobytes() == by_time(ref_nv).tobytes()
     # TPC only
     plugin = wfsim_amd.RawRecordsFromMcChain(dict(cfg, targets=('tpc',), entry_stop=None))
     out2 = ministrax.run_plugin(plugin)

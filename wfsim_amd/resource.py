@@ -12,25 +12,20 @@ import numpy as np
 
 
 class DummyMap:
-    """Constant map; the output's first dimension matches the input, the rest is ``shape``.
-
-    Same behaviour as /root/reference/wfsim/load_resource.py:438-457.
-    """
+    """A map that is the same everywhere: called with n positions it returns an array of shape (n, *shape) filled with
+    ``const`` (the behaviour of load_resource.py:438-457, which the bundled test config relies on)."""
 
     def __init__(self, const, shape=()):
-        self.const = const
-        self.shape = shape
+        self.const, self.shape = const, shape
 
     def __call__(self, x, **kwargs):
-        shape = [len(x)] + list(self.shape)
-        return np.ones(shape) * self.const
+        return np.full((len(x), *self.shape), self.const, dtype=np.float64)
 
     def reduce_last_dim(self):
+        """the map summed over its last axis (kept with length 1): ``shape[-1]`` equal entries"""
         assert len(self.shape) >= 1, 'Need at least 1 dim to reduce further'
-        const = self.const * self.shape[-1]
-        shape = list(self.shape)
-        shape[-1] = 1
-        return DummyMap(const, shape)
+        *lead, last = self.shape
+        return DummyMap(self.const * last, [*lead, 1])
 
 
 def make_map(map_file, fmt=None, method='WeightedNearestNeighbors'):

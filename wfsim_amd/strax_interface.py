@@ -46,13 +46,14 @@ def _copy_records(src, threads=8, min_records=200_000):
 
 
 def instruction_from_csv(filename):
-    """strax_interface.py:336-350"""
-    import pandas as pd
-    df = pd.read_csv(filename)
-    recs = np.zeros(len(df), dtype=instruction_dtype)
-    for column in df.columns:
-        recs[column] = df[column]
-    return recs
+    """Instructions from a csv whose columns are named after instruction_dtype fields (strax_interface.py:336-350); fields
+    without a column stay zero, a column that is no field is an error (numpy's, as in the reference)."""
+    import pandas
+    table = pandas.read_csv(filename)
+    out = np.zeros(table.shape[0], dtype=instruction_dtype)
+    for name in table.columns:
+        out[name] = table[name].to_numpy()
+    return out
 
 
 class ChunkRawRecords(object):
@@ -60,8 +61,7 @@ class ChunkRawRecords(object):
     zero_copy_min_records = 200_000         # chunks of at least this many records are handed out without a copy (_hand_out)
 
     def __init__(self, config, rawdata_generator=RawData, **kwargs):
-        self.config = config
-        self.rawdata = rawdata_generator(self.config, **kwargs)
+        self.config, self.rawdata = config, rawdata_generator(config, **kwargs)
         # strax_interface.py:360-361; page-locked when the HIP generator fills it (the records of a batch then arrive at PCIe
         # speed while the next batch's kernels run) and recycled between instances: pinning 1.2 GB takes a few hundred ms
         rdt = raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH)
@@ -71,9 +71,9 @@ class ChunkRawRecords(object):
             self._own_buffers = [self.record_buffer] if is_pooled_record_buffer(self.record_buffer) else []
         else:
             self.record_buffer = np.zeros(self.record_buffer_length, dtype=rdt)
-        truth_per_n_pmts = self._n_channels if config.get('per_pmt_truth') else False
-        self.truth_dtype = extra_truth_dtype_per_pmt(truth_per_n_pmts)
-        self.truth_buffer = np.zeros(10000, dtype=instruction_dtype + self.truth_dtype + [('fill', bool)])
+        # strax_interface.py:363-366: truth rows wait in a 10^4-row buffer ('fill' marks the rows in use)
+        self.truth_dtype = extra_truth_dtype_per_pmt(len(config.get('gains', [])) if config.get('per_pmt_truth') else False)
+        self.truth_buffer = np.zeros(10_000, dtype=instruction_dtype + self.truth_dtype + [('fill', bool)])
         self.blevel = 0
         self._next_buffer = None
         self._batch_leases = []
@@ -88,24 +88,22 @@ class ChunkRawRecords(object):
         except Exception:
             pass
 
-    @property
-    def _n_channels(self):
-        return len(self.config.get('gains', []))
-
     # ------------------------------------------------------------------------------------------
     def __call__(self, instructions, time_zero=None, **kwargs):
-        samples_per_record = DEFAULT_RECORD_LENGTH
-        if len(instructions) == 0:
-            yield from np.array([], dtype=raw_record_dtype(samples_per_record=samples_per_record))
+        """Generator of chunks (strax_interface.py:368-440): dicts of record arrays + truth rows; ``chunk_time_pre`` / ``chunk_time``
+        are the bounds of the chunk just yielded."""
+        if not len(instructions):               # nothing to simulate: no chunk at all (:370-373)
             self.rawdata.source_finished = True
             return
-        self._dt = dt = self.config['sample_duration']
-        self._rext = int(self.config['right_raw_extension'])
-        self._cksz = int(self.config['chunk_size'] * 1e9)
+        c = self.config
+        self._dt, self._rext, self._cksz = c['sample_duration'], int(c['right_raw_extension']), int(c['chunk_size'] * 1e9)
+        dt = self._dt
         self.blevel = 0
-        self.chunk_time_pre = time_zero - self._rext if time_zero else np.min(instructions['time']) - self._rext
+        # the first chunk opens right_raw_extension before time_zero (a falsy time_zero: before the first instruction), :378-380
+        origin = time_zero if time_zero else np.min(instructions['time'])
+        self.chunk_time_pre = origin - self._rext
         self.chunk_time = self.chunk_time_pre + self._cksz
-        self.current_digitized_right = self.last_digitized_right = 0
+        self.last_digitized_right = self.current_digitized_right = 0
         self._sorted_stream = False
         if hasattr(self.rawdata, 'iter_batches') and not os.environ.get('WFSIM_AMD_SCALAR_CHUNKER'):
             yield from self._run_batches(instructions, **kwargs)
@@ -113,38 +111,38 @@ class ChunkRawRecords(object):
             yield from self._run_windows(instructions, **kwargs)
         else:
             yield from self._run_pulses(instructions, **kwargs)
+        # the last chunk ends behind the last digitised window, and is at least one sample long (:438-440)
         self.last_digitized_right = self.current_digitized_right
-        self.chunk_time = max((self.last_digitized_right + 1) * dt, self.chunk_time_pre + dt)
+        end_of_data = (self.last_digitized_right + 1) * dt
+        self.chunk_time = end_of_data if end_of_data > self.chunk_time_pre + dt else self.chunk_time_pre + dt
         yield from self.final_results()
 
     def _maybe_close_chunk(self):
         """strax_interface.py:398-407: the window being emitted starts beyond the current chunk."""
-        dt = self._dt
-        if self.rawdata.left * dt > self.chunk_time + self._rext:
-            if (self.last_digitized_right + 1) * dt > self.chunk_time:
-                self.chunk_time += (self.last_digitized_right + 1) * dt - self.chunk_time
-            yield from self.final_results()
-            self.chunk_time_pre = self.chunk_time
-            self.chunk_time += self._cksz
-            if hasattr(self.rawdata, 'cut_origin'):
-                self.rawdata.cut_origin = self.chunk_time + self._rext
+        if not (self.rawdata.left * self._dt > self.chunk_time + self._rext):
             return
-        return
+        # a chunk never ends inside the window digitised before this one: its end moves behind that window
+        self.chunk_time = max(self.chunk_time, (self.last_digitized_right + 1) * self._dt)
+        yield from self.final_results()
+        self._open_next_chunk()
+        if hasattr(self.rawdata, 'cut_origin'):
+            self.rawdata.cut_origin = self.chunk_time + self._rext
+
+    def _open_next_chunk(self):
+        self.chunk_time_pre, self.chunk_time = self.chunk_time, self.chunk_time + self._cksz
 
     def _buffer_full_flush(self):
         """strax_interface.py:409-418"""
-        log.warning('Chunck size too large, insufficient record buffer \n'
-                    'No longer in sync if simulating nVeto with TPC \n'
-                    'Consider reducing the chunk size')
+        log.warning('record buffer full before the chunk is: the chunk ends early (a TPC and an nVeto simulation no longer share '
+                    'chunk boundaries); reduce chunk_size')
         self.chunk_time = (self.last_digitized_right + 1) * self._dt
         yield from self.final_results()
-        self.chunk_time_pre = self.chunk_time
-        self.chunk_time += self._cksz
+        self._open_next_chunk()
 
     def _track_window(self):
-        if self.rawdata.right != self.current_digitized_right:        # strax_interface.py:394-396
-            self.last_digitized_right = self.current_digitized_right
-            self.current_digitized_right = self.rawdata.right
+        now = self.rawdata.right                 # a new window: remember where the one before it ended (strax_interface.py:394-396)
+        if now != self.current_digitized_right:
+            self.last_digitized_right, self.current_digitized_right = self.current_digitized_right, now
 
     # ---- batch granularity: the GPU hands over whole batches of windows, records already ordered by (time, channel) ----
     def _run_batches(self, instructions, **kwargs):
@@ -278,7 +276,7 @@ class ChunkRawRecords(object):
 
     # ---- window granularity: records arrive packed from the GPU ------------------------------------
     def _run_windows(self, instructions, **kwargs):
-        buffer_length = len(self.record_buffer)
+        capacity = len(self.record_buffer)
         for w in self.rawdata.iter_windows(instructions, truth_buffer=self.truth_buffer, **kwargs):
             rec = w['records']
             n_pulses = int(np.count_nonzero(rec['record_i'] == 0))
@@ -288,14 +286,14 @@ class ChunkRawRecords(object):
             while closed < n_pulses and self.rawdata.left * self._dt > self.chunk_time + self._rext:
                 yield from self._maybe_close_chunk()
                 closed += 1
-            if self.blevel + len(rec) > buffer_length:
+            if self.blevel + len(rec) > capacity:
                 yield from self._buffer_full_flush()
-            if self.blevel + len(rec) > buffer_length:
+            if self.blevel + len(rec) > capacity:
                 # the reference skips pulses one at a time here; keep whole pulses that fit
                 keep = 0
                 starts = np.where(rec['record_i'] == 0)[0]
                 for s, e in zip(starts, np.append(starts[1:], len(rec))):
-                    if self.blevel + e > buffer_length:
+                    if self.blevel + e > capacity:
                         break
                     keep = e
                 log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
@@ -304,31 +302,35 @@ class ChunkRawRecords(object):
             self.blevel += len(rec)
 
     # ---- pulse granularity: any generator with the RawData protocol (strax_interface.py:388-436) ---
+    def _pulse_records(self, channel, left, data):
+        """one ZLE pulse as raw_records: fragments of DEFAULT_RECORD_LENGTH samples, the last one zero padded (:425-435)"""
+        spr, n = DEFAULT_RECORD_LENGTH, len(data)
+        n_frag = (n + spr - 1) // spr
+        frag = np.arange(n_frag)
+        rec = np.zeros(n_frag, dtype=self.record_buffer.dtype)
+        rec['time'] = self._dt * (left + spr * frag)
+        rec['length'] = np.minimum(n - spr * frag, spr)
+        rec['dt'], rec['channel'], rec['pulse_length'], rec['record_i'] = self._dt, channel, n, frag
+        samples = np.zeros(n_frag * spr, dtype=rec['data'].dtype)
+        samples[:n] = data
+        rec['data'] = samples.reshape(n_frag, spr)
+        return rec
+
     def _run_pulses(self, instructions, **kwargs):
-        samples_per_record = DEFAULT_RECORD_LENGTH
-        dt = self._dt
-        buffer_length = len(self.record_buffer)
+        """a generator that yields (channel, left, right, data) pulse by pulse -- the reference's own RawData or a replay of
+        it (tests/test_chunker_reference.py); the product's generators deliver batches or windows (above)"""
+        room = len(self.record_buffer)
         for channel, left, right, data in self.rawdata(instructions=instructions, truth_buffer=self.truth_buffer, **kwargs):
-            pulse_length = right - left + 1
-            records_needed = int(np.ceil(pulse_length / samples_per_record))
+            rec = self._pulse_records(channel, left, data[:right - left + 1])
             self._track_window()
             yield from self._maybe_close_chunk()
-            if self.blevel + records_needed > buffer_length:
+            if self.blevel + len(rec) > room:
                 yield from self._buffer_full_flush()
-            if self.blevel + records_needed > buffer_length:
-                log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
-                continue
-            s = slice(self.blevel, self.blevel + records_needed)
-            self.record_buffer[s]['channel'] = channel
-            self.record_buffer[s]['dt'] = dt
-            self.record_buffer[s]['time'] = dt * (left + samples_per_record * np.arange(records_needed))
-            self.record_buffer[s]['length'] = [min(pulse_length, samples_per_record * (i + 1))
-                                               - samples_per_record * i for i in range(records_needed)]
-            self.record_buffer[s]['pulse_length'] = pulse_length
-            self.record_buffer[s]['record_i'] = np.arange(records_needed)
-            self.record_buffer[s]['data'] = np.pad(data, (0, records_needed * samples_per_record - pulse_length),
-                                                   'constant').reshape((-1, samples_per_record))
-            self.blevel += records_needed
+                if self.blevel + len(rec) > room:           # longer than the whole buffer: dropped (:419-422)
+                    log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
+                    continue
+            self.record_buffer[self.blevel:self.blevel + len(rec)] = rec
+            self.blevel += len(rec)
 
     # ------------------------------------------------------------------------------------------
     def final_results(self):
@@ -347,53 +349,54 @@ class ChunkRawRecords(object):
             n_out = lo
             if os.environ.get('WFSIM_AMD_CHECK_SORTED'):
                 assert np.array_equal(records[:n_out], sort_by_time(records[records['time'] <= self.chunk_time]))
-            maska = None
+            in_chunk = None
             records = records[:n_out]
         else:
-            maska = records['time'] <= self.chunk_time
-            records = records[maska]
-            records = sort_by_time(records)
+            in_chunk = records['time'] <= self.chunk_time
+            records = sort_by_time(records[in_chunk])
 
+        # truth rows whose first photon (or, without photons, whose instruction time) lies in the chunk leave the buffer
+        # (strax_interface.py:458-483): ordered by instruction time, stamped with the first photon's time, ordered again
         tb = self.truth_buffer
-        maskb = (tb['fill'] & ((tb['t_first_photon'] <= self.chunk_time)
-                               | (np.isnan(tb['t_first_photon']) & (tb['time'] <= self.chunk_time))))
-        truth = tb[maskb]
-        tb['fill'][maskb] = False
-        truth.sort(order='time')
-        _truth = np.zeros(len(truth), dtype=self._truth_out_dtype())
-        for name in _truth.dtype.names:
-            _truth[name] = truth[name]
-        ok = ~np.isnan(_truth['t_first_photon'])
-        _truth['time'][ok] = _truth['t_first_photon'][ok].astype(int)
+        tfp = tb['t_first_photon']
+        no_photon = np.isnan(tfp)
+        due = tb['fill'] & np.where(no_photon, tb['time'] <= self.chunk_time, tfp <= self.chunk_time)
+        leaving = tb[due]
+        tb['fill'][due] = False
+        leaving.sort(order='time')
+        _truth = np.zeros(len(leaving), dtype=self._truth_out_dtype())
+        for column in _truth.dtype.names:
+            _truth[column] = leaving[column]
+        seen = ~np.isnan(_truth['t_first_photon'])
+        _truth['time'][seen] = _truth['t_first_photon'][seen].astype(int)
         _truth.sort(order='time')
 
         det = self.config['detector']
         moved = False
         if det == 'XENON1T' or det == 'XENONnT_neutron_veto':
-            if maska is None:
+            if in_chunk is None:
                 records, moved = self._hand_out(n_out)
             yield dict(raw_records=records, truth=_truth)
         elif det == 'XENONnT':
             he = self.config['channel_map']['he']
             engine = getattr(self.rawdata, 'engine', None)
-            if maska is None and engine is not None and not engine.emits_he_records:
+            if in_chunk is None and engine is not None and not engine.emits_he_records:
                 # every record is a TPC record (no HE rows are digitised, row 800 is never emitted): the buffer's prefix as it is
                 empty = records[:0].copy()
                 records, moved = self._hand_out(n_out)
                 yield dict(raw_records=records, raw_records_he=empty, raw_records_aqmon=empty.copy(), truth=_truth)
             else:
-                yield dict(raw_records=records[records['channel'] < he[0]],
-                           raw_records_he=records[(records['channel'] >= he[0]) & (records['channel'] <= he[-1])],
-                           raw_records_aqmon=records[records['channel'] == 800],
-                           truth=_truth)
+                ch = records['channel']
+                yield dict(raw_records=records[ch < he[0]], raw_records_he=records[(ch >= he[0]) & (ch <= he[-1])],
+                           raw_records_aqmon=records[ch == 800], truth=_truth)
         if moved:
             return                  # _hand_out switched buffers and moved the records behind the cut
-        if maska is None:
+        if in_chunk is None:
             n_left = self.blevel - n_out
             self.record_buffer[:n_left] = self.record_buffer[n_out:self.blevel]
         else:
-            n_left = int(np.sum(~maska))
-            self.record_buffer[:n_left] = self.record_buffer[:self.blevel][~maska]
+            n_left = int(np.sum(~in_chunk))
+            self.record_buffer[:n_left] = self.record_buffer[:self.blevel][~in_chunk]
         self.blevel = n_left
 
     def _truth_out_dtype(self):
@@ -430,10 +433,9 @@ class SimulatorPlugin(_Plugin):
         self.device = device
 
     def setup(self):
-        self.set_config()
-        self.get_instructions()
-        self.check_instructions()
-        self._setup()
+        """strax calls this once per run: config, instructions, sanity checks, then the chunk iterator (strax_interface.py:553-563)"""
+        for stage in (self.set_config, self.get_instructions, self.check_instructions, self._setup):
+            stage()
 
     def set_config(self):
         """strax_interface.py:566-608 without the CMT / straxen look-ups: gains must be in the config (or to_pe)."""
@@ -461,32 +463,31 @@ class SimulatorPlugin(_Plugin):
         pass
 
     def _sort_check(self, results):
-        """strax_interface.py:622-640"""
-        if not isinstance(results, list):
-            results = [results]
-        last_chunk_time = self.last_chunk_time
-        for result in results:
-            if len(result) == 0:
+        """What strax relies on (strax_interface.py:622-640): every record array of a chunk is time sorted and starts at least
+        1 us behind the last record time noted so far.  As in the reference a one-record array is only checked for the spacing,
+        and the time noted is that of the last array with two or more records."""
+        noted = self.last_chunk_time
+        for data in (results if isinstance(results, list) else [results]):
+            if not len(data):
                 continue
-            if result['time'][0] < self.last_chunk_time + 1000:
-                raise RuntimeError("Simulator returned chunks with insufficient spacing. "
-                                   f"Last chunk's max time was {self.last_chunk_time}, "
-                                   f"this chunk's first time is {result['time'][0]}.")
-            if len(result) == 1:
-                continue
-            if np.diff(result['time']).min() < 0:
-                raise RuntimeError("Simulator returned non-sorted records!")
-            last_chunk_time = max(result['time'].max(), self.last_chunk_time)
-        self.last_chunk_time = last_chunk_time
+            t = data['time']
+            if t[0] < self.last_chunk_time + 1000:
+                raise RuntimeError(f'Simulator returned chunks with insufficient spacing: the last chunk reached {self.last_chunk_time}, '
+                                   f'this one starts at {t[0]}')
+            if len(t) >= 2:
+                if np.any(t[1:] < t[:-1]):
+                    raise RuntimeError('Simulator returned non-sorted records!')
+                noted = max(t.max(), self.last_chunk_time)
+        self.last_chunk_time = noted
 
     def is_ready(self, chunk_i):
-        if 'ready' not in self.__dict__:
-            self.ready = False
-        self.ready ^= True
+        """strax polls a source plugin before every chunk; the answer alternates, starting with True (strax_interface.py:642-649)"""
+        self.ready = not getattr(self, 'ready', False)
         return self.ready
 
     def source_finished(self):
-        return self.sim.source_finished()
+        sim = self.sim
+        return sim.source_finished()
 
     @property
     def _n_channels(self):
@@ -509,39 +510,42 @@ class RawRecordsFromFaxNT(SimulatorPlugin):
         if self.config.get('instructions') is not None:           # in-memory instructions (tests, benchmarks)
             self.instructions = np.asarray(self.config['instructions'])
         elif self.config['fax_file']:
-            assert self.config['fax_file'].endswith('csv'), 'Only csv input is supported'
-            self.instructions = instruction_from_csv(self.config['fax_file'])
+            path = self.config['fax_file']
+            assert path.endswith('csv'), 'Only csv input is supported'
+            self.instructions = instruction_from_csv(path)
         else:
             raise NotImplementedError('rand_instructions needs nestpy (SURVEY.md 2.1 row 7): pass instructions or a csv')
 
     def check_instructions(self):
-        c = self.config
-        m = (self.instructions['z'] < - c['tpc_length']) & (self.instructions['type'] == 2)
-        self.instructions = self.instructions[~m]
-        r_instr = np.sqrt(self.instructions['x'] ** 2 + self.instructions['y'] ** 2)
-        assert np.all((r_instr < c['tpc_radius']) | np.isclose(r_instr, c['tpc_radius'])), \
-            "Interaction is outside the TPC (radius)"
-        assert np.all(self.instructions['z'] < 0.25), "Interaction is outside the TPC (in Z)"
-        assert np.all(self.instructions['amp'] > 0), "Interaction has zero size"
+        """strax_interface.py:687-700: S2s below the cathode are dropped (S1s there pass); everything else must lie inside the TPC"""
+        c, ins = self.config, self.instructions
+        ins = ins[~((ins['type'] == 2) & (ins['z'] < -c['tpc_length']))]
+        radius = np.hypot(ins['x'], ins['y'])
+        assert np.all((radius < c['tpc_radius']) | np.isclose(radius, c['tpc_radius'])), 'Interaction is outside the TPC (radius)'
+        assert np.all(ins['z'] < 0.25), 'Interaction is outside the TPC (in Z)'
+        assert np.all(ins['amp'] > 0), 'Interaction has zero size'
+        self.instructions = ins
 
     def infer_dtype(self):
-        dtype = {data_type: raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH)
-                 for data_type in self.provides if data_type != 'truth'}
-        dtype['truth'] = instruction_dtype + self._truth_dtype
-        return dtype
+        records = raw_record_dtype(samples_per_record=DEFAULT_RECORD_LENGTH)
+        return {t: (instruction_dtype + self._truth_dtype) if t == 'truth' else records for t in self.provides}
 
     def compute(self):
-        try:
-            result = next(self.sim_iter)
-        except StopIteration:
-            raise RuntimeError("Bug in chunk count computation")
+        result = next(self.sim_iter, None)
+        if result is None:
+            raise RuntimeError('Bug in chunk count computation')         # strax asked for a chunk behind the last one
         self._sort_check(result[self.provides[0]])
-        return {data_type: self.chunk(start=self.sim.chunk_time_pre, end=self.sim.chunk_time,
-                                      data=result[data_type], data_type=data_type) for data_type in self.provides}
+        start, end = self.sim.chunk_time_pre, self.sim.chunk_time
+        return {t: self.chunk(start=start, end=end, data=result[t], data_type=t) for t in self.provides}
 
 
 class RawRecordsFromFax1T(RawRecordsFromFaxNT):
     provides = ('raw_records', 'truth')
+
+
+def _optical_truth_buffer(truth_dtype):
+    """the truth buffer of an optical chunker carries the instructions' _first / _last columns (strax_interface.py:730, 899)"""
+    return np.zeros(10_000, dtype=instruction_dtype + optical_extra_dtype + truth_dtype + [('fill', bool)])
 
 
 class RawRecordsFromFaxOpticalNT(RawRecordsFromFaxNT):
@@ -552,8 +556,7 @@ class RawRecordsFromFaxOpticalNT(RawRecordsFromFaxNT):
     def _setup(self):
         self.sim = ChunkRawRecords(self.config, rawdata_generator=RawDataOptical, channels=self.channels,
                                    timings=self.timings, device=self.device)
-        self.sim.truth_buffer = np.zeros(10000, dtype=instruction_dtype + optical_extra_dtype
-                                         + self._truth_dtype + [('fill', bool)])
+        self.sim.truth_buffer = _optical_truth_buffer(self._truth_dtype)
         self.sim_iter = self.sim(self.instructions)
 
     def get_instructions(self):
@@ -596,10 +599,9 @@ class RawRecordsFromFaxnVeto(RawRecordsFromFaxOpticalNT):
                 'truth_nv': instruction_dtype + self._truth_dtype}
 
     def compute(self):
-        try:
-            result = next(self.sim_iter)
-        except StopIteration:
-            raise RuntimeError("Bug in chunk count computation")
+        result = next(self.sim_iter, None)
+        if result is None:
+            raise RuntimeError('Bug in chunk count computation')
         rr = result['raw_records'].copy()
         rr['channel'] += self.config['channel_map']['nveto'][0]           # strax_interface.py:937
         self._sort_check(rr)
@@ -704,7 +706,7 @@ class RawRecordsFromMcChain(SimulatorPlugin):
         if 'nveto' in c['targets']:
             self.sim_nv = ChunkRawRecords(self.config_nveto, rawdata_generator=RawDataOptical, channels=self.nveto_channels,
                                           timings=self.nveto_timings, device=self.device)
-            self.sim_nv.truth_buffer = np.zeros(10000, dtype=instruction_dtype + optical_extra_dtype + self._truth_dtype + [('fill', bool)])
+            self.sim_nv.truth_buffer = _optical_truth_buffer(self._truth_dtype)
             self.sim_nv_iter = self.sim_nv(self.instructions_nveto, time_zero=time_zero)
 
     def infer_dtype(self):
@@ -716,46 +718,44 @@ class RawRecordsFromMcChain(SimulatorPlugin):
         targets = self.config['targets']
         dt = self.infer_dtype()
         result, result_nv = None, None
+        def depleted(sim):
+            if not sim.source_finished():
+                raise RuntimeError('Bug in getting source finished')            # the iterator ended before its source did
         if 'tpc' in targets:
-            try:
-                result = next(self.sim_iter)
-            except StopIteration:
-                if not self.sim.source_finished():
-                    raise RuntimeError("Bug in getting source finished")
+            result = next(self.sim_iter, None)
+            if result is None:
+                depleted(self.sim)
                 result = {t: np.zeros(0, dt[t]) for t in self.provides if 'nv' not in t}
                 if 'nveto' in targets:
                     self.sim.chunk_time, self.sim.chunk_time_pre = self.sim_nv.chunk_time, self.sim_nv.chunk_time_pre
         if 'nveto' in targets:
-            try:
-                result_nv = next(self.sim_nv_iter)
-                result_nv = dict(result_nv, raw_records=result_nv['raw_records'].copy())
-                result_nv['raw_records']['channel'] += self.config['channel_map']['nveto'][0]
-            except StopIteration:
-                if not self.sim_nv.source_finished():
-                    raise RuntimeError("Bug in getting source finished")
+            result_nv = next(self.sim_nv_iter, None)
+            if result_nv is not None:
+                shifted = result_nv['raw_records'].copy()
+                shifted['channel'] += self.config['channel_map']['nveto'][0]
+                result_nv = dict(result_nv, raw_records=shifted)
+            else:
+                depleted(self.sim_nv)
                 result_nv = {t[:-3]: np.zeros(0, dt[t]) for t in self.provides if 'nv' in t}
                 if 'tpc' in targets:
                     self.sim_nv.chunk_time, self.sim_nv.chunk_time_pre = self.sim.chunk_time, self.sim.chunk_time_pre
         exist_tpc = result is not None and any(len(result[t]) > 0 for t in self.provides if 'nv' not in t)
         exist_nv = result_nv is not None and any(len(result_nv[t[:-3]]) > 0 for t in self.provides if 'nv' in t)
-        chunk = {}
+        out = {}
         for t in self.provides:
             mine, other = (exist_nv, exist_tpc) if 'nv' in t else (exist_tpc, exist_nv)
             sim_mine, sim_other = (getattr(self, 'sim_nv', None), getattr(self, 'sim', None)) if 'nv' in t else (getattr(self, 'sim', None), getattr(self, 'sim_nv', None))
             if mine:
                 data = result_nv[t[:-3]] if 'nv' in t else result[t]
-                chunk[t] = self.chunk(start=sim_mine.chunk_time_pre, end=sim_mine.chunk_time, data=data, data_type=t)
+                out[t] = self.chunk(start=sim_mine.chunk_time_pre, end=sim_mine.chunk_time, data=data, data_type=t)
             elif other:
-                chunk[t] = self.chunk(start=sim_other.chunk_time_pre, end=sim_other.chunk_time, data=np.zeros(0, dt[t]), data_type=t)
+                out[t] = self.chunk(start=sim_other.chunk_time_pre, end=sim_other.chunk_time, data=np.zeros(0, dt[t]), data_type=t)
             else:
-                chunk[t] = self.chunk(start=0, end=0, data=np.zeros(0, dt[t]), data_type=t)
-        self._sort_check([chunk[t].data for t in self.provides])
-        return chunk
+                out[t] = self.chunk(start=0, end=0, data=np.zeros(0, dt[t]), data_type=t)
+        self._sort_check([out[t].data for t in self.provides])
+        return out
 
     def source_finished(self):
-        done = True
-        if 'tpc' in self.config['targets']:
-            done &= self.sim.source_finished()
-        if 'nveto' in self.config['targets']:
-            done &= self.sim_nv.source_finished()
-        return done
+        sims = [sim for target, sim in (('tpc', getattr(self, 'sim', None)), ('nveto', getattr(self, 'sim_nv', None)))
+                if target in self.config['targets']]
+        return all(sim.source_finished() for sim in sims)
