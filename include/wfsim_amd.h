@@ -58,6 +58,11 @@ typedef struct wfs_config {
     int32_t s1_simple;         /* 'simple' in s1_model_type                         s1.py:191        */
     int32_t s2_time_model;     /* 0 zero_delay, 1 "s2_time_spread around zero"      s2.py:545-550    */
     int32_t enable_pmt_ap;     /* enable_pmt_afterpulses                            rawdata.py:176   */
+    int32_t tile_gen;          /* 1: primary S2s whose tiles fit a pulse workgroup draw their photons there (tile-local generation,
+                                  RNG spec v9): Poisson(n_e g p_ch) photons per (instruction, channel), a uniform surviving
+                                  electron per photon -- the distribution of s2.py:308 + :673 when s2_gain_spread == 0.  0: every
+                                  photon comes from the per-electron generator (needed by the electron-afterpulse pre-pass)   */
+    int32_t reserved0;         /* keeps the doubles 8-byte aligned                                   */
     double c2a;                /* current_2_adc                                     pulse.py:33-35   */
     double tts_mean, tts_sigma;/* pmt_transit_time_mean, spread/2.35482             pulse.py:53-56   */
     double p_dpe;              /* p_double_pe_emision                               pulse.py:76      */
@@ -294,7 +299,8 @@ int wfs_copy_electron_stats(wfs_handle *h, double *estat5, int64_t capacity_sets
  * to the dense pulse kernel (both kernels give the same bits; used by the parity tests); bit 2 wfs_run stops after the
  * photon generation (enough for wfs_copy_set_photon_counts / wfs_gather_photon_times: the electron-afterpulse pre-pass);
  * bit 3 check every kernel launch on the spot (hipGetLastError + stream synchronisation after each one: a failed launch or a
- * faulting kernel is reported under its own name by wfs_run; slow, for debugging) */
+ * faulting kernel is reported under its own name by wfs_run; slow, for debugging); bit 4 the photons of tile-generated instructions
+ * (wfs_config.tile_gen) are also stored for wfs_copy_photons -- by default they only ever exist in registers */
 int wfs_set_debug(wfs_handle *h, int32_t flags);
 /* parity tests: noise start index per digitise window (rawdata.py:417) instead of the Philox draw; entries < 0 keep the draw.
  * Indexed by the window number of wfs_copy_groups (host pointer, copied). n = 0 clears the override. */

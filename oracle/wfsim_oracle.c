@@ -35,7 +35,7 @@ typedef struct {
     i32 n_spe_channels, noise_len, noise_channels, enable_noise;
     /* models */
     i32 s1_simple, s2_time_model /*0 zero_delay, 1 spread around zero*/, n_lum, enable_pmt_ap, n_ap_elements;
-    i32 pad0;
+    i32 tile_gen;                                   /* tile-local generation of eligible S2s (RNG spec v9): see gen_s2 */
     double c2a;                                     /* current_2_adc, pulse.py:33-35 */
     double tts_mean, tts_sigma, p_dpe;
     double s1_decay_time, s1_decay_spread;
@@ -133,6 +133,9 @@ void orc_philox(const u32 *ctr, const u32 *key, u32 *out) { philox4x32_10(ctr[0]
 enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_EL_POIS = 5,
        SITE_EL_DIFF = 6 /* per electron: Box-Muller pair -> radial / azimuthal transverse diffusion, s2.py:588-589 */,
        SITE_DELAY = 16, SITE_CH = 17, SITE_GAIN = 18, SITE_PH = 19, SITE_PH_X = 20, SITE_LUM = 21 /* P-indexed like SITE_DELAY: garfield gas gap excitation time */,
+       /* tile-local generation (spec v9): counter (em_base + channel, gid, item, site) */
+       SITE_TILE_N = 24 /* photons of the tile: Poisson, item = iteration */, SITE_TILE_E = 25 /* item = P >> 2, word P & 3 -> surviving electron */,
+       SITE_TILE_DELAY = 26, SITE_TILE_GAIN = 27,
        SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
 
 static inline void draw(const orc_session *s, u32 emitter, u32 gid, u32 item, u32 site, u32 w[4])
@@ -156,14 +159,16 @@ static inline void box_muller(const u32 w[4], double *z0, double *z1)
 
 /* Poisson: Hoermann PTRS for lam >= 10, Knuth multiplication below (the two algorithms numpy's legacy
  * generator uses, s2.py:308 draws np.random.poisson).  Uniform pairs come from SITE_EL_POIS items. */
-static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam)
+static i64 poisson_site(const orc_session *s, u32 emitter, u32 gid, u32 site, double lam);
+static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam) { return poisson_site(s, emitter, gid, SITE_EL_POIS, lam); }
+static i64 poisson_site(const orc_session *s, u32 emitter, u32 gid, u32 site, double lam)
 {
     u32 w[4]; u32 it = 0;
-    if (lam <= 0) return 0;
+    if (!(lam > 0)) return 0;
     if (lam < 10) {
         double enlam = exp(-lam), prod = 1.0; i64 x = 0;
         for (;;) {
-            draw(s, emitter, gid, it++, SITE_EL_POIS, w);
+            draw(s, emitter, gid, it++, site, w);
             prod *= u53(w[0], w[1]);
             if (prod > enlam) x++; else return x;
             prod *= u53(w[2], w[3]);
@@ -174,7 +179,7 @@ static i64 poisson_draw(const orc_session *s, u32 emitter, u32 gid, double lam)
     double b = 0.931 + 2.53 * slam, a = -0.059 + 0.02483 * b;
     double invalpha = 1.1239 + 1.1328 / (b - 3.4), vr = 0.9277 - 3.6224 / (b - 2);
     for (;;) {
-        draw(s, emitter, gid, it++, SITE_EL_POIS, w);
+        draw(s, emitter, gid, it++, site, w);
         double U = u53(w[0], w[1]) - 0.5, V = u53(w[2], w[3]);
         double us = 0.5 - fabs(U);
         i64 k = (i64)floor((2 * a / us + b) * U + lam + 0.43);
@@ -953,11 +958,28 @@ static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, doubl
 /* s2.py:73-136 S2.__call__ (luminescence 'simple') for one instruction.  Candidate electron j < amp survives with
  * probability cy (s2.py:254 Binomial as Bernoulli trials); survivors draw s2.py:280-282 arrival time and
  * s2.py:308-310 photon count; photons as one_photon(). */
-static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
+#define TILE_MAX_PHOTONS 2048
+/* Tile-local generation (RNG spec v9; device: wfs_tilegen.h).  With one secondary gain for all electrons (s2_gain_spread == 0) the
+ * photon counts per (electron, channel) are independent Poisson(g p_ch) variates (Poisson splitting of s2.py:308 + the
+ * np.random.choice of :673), so a tile (instruction, channel) holds Poisson(n_surviving g p_ch) photons, each from a uniformly
+ * drawn surviving electron -- the same joint distribution, drawn tile by tile.  The rule below is evaluated identically on the device. */
+static int fuse_eligible(const orc_session *s, int type, u32 em_base, i64 amp, double sc_gain, const double *cdf)
+{
+    const orc_config *c = &s->c;
+    if (!c->tile_gen || c->gain_spread != 0.0 || c->enable_pmt_ap || s->n_ins_models > 0 || !s->save_full_truth) return 0;
+    if (type != 2 || em_base != 0u || amp <= 0 || !(sc_gain > 0)) return 0;
+    double pmax = 0.0;
+    for (int ch = 0; ch < c->n_tpc; ch++) { const double p = cdf[ch] - (ch ? cdf[ch - 1] : 0.0); pmax = p > pmax ? p : pmax; }
+    const double lam = (double)amp * sc_gain * pmax;
+    return lam + 8.0 * sqrt(lam) + 8.0 <= (double)TILE_MAX_PHOTONS;
+}
+static i64 gen_s2(orc_session *s, call_ctx *x, int type, u32 gid, u32 em_base, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
                   double sc_gain, const double *cdf)
 {
     const orc_config *c = &s->c;
     u64 T = bern_threshold(cy); u32 w[4]; i64 n0 = x->pb.t.n; u32 P = 0;       /* P: photons of this instruction so far */
+    const int fused = fuse_eligible(s, type, em_base, amp, sc_gain, cdf);
+    vec_i64 surv; memset(&surv, 0, sizeof surv);                                /* fused: arrival times of the surviving electrons, in candidate order */
     chan_row_set(s, cdf);
     vec_f64 lum; memset(&lum, 0, sizeof lum);                                   /* garfield gas gap: excitation time of every photon */
     for (i64 j = 0; j < amp; j++) {
@@ -971,6 +993,7 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
         double timing = -log(1.0 - u53(A[0], A[1])) * c->trap_time;
         timing += drift_mean + drift_spread * z_drift;
         i64 et = time + (i64)timing;
+        if (fused) { VEC_PUSH(s->e_t, i64, et); VEC_PUSH(surv, i64, et); continue; }
         i64 nph = poisson_any(s, je, gid, sc_gain);
         nph += (i64)(0.0 + c->gain_spread * z_gain);
         if (nph < 0) nph = 0;
@@ -981,6 +1004,29 @@ static i64 gen_s2(orc_session *s, call_ctx *x, u32 gid, u32 em_base, i64 time, i
             one_photon(s, 1, je, gid, (u32)m, em_base, P++, et, cdf, &t, &ch, &dpe, &g);
             ctx_push(x, t, ch, dpe, g, gid, (i64)je, m);
         }
+    }
+    if (fused) {
+        const orc_tab *tab = &s->tab[TAB_S2_TOTAL];
+        for (int ch = 0; ch < c->n_tpc && surv.n > 0; ch++) {
+            const double p = cdf[ch] - (ch ? cdf[ch - 1] : 0.0);
+            const double lam = (double)(i32)surv.n * sc_gain * p;
+            const u32 c0 = em_base + (u32)ch;
+            i64 N = poisson_site(s, c0, gid, SITE_TILE_N, lam);
+            if (N > TILE_MAX_PHOTONS) N = TILE_MAX_PHOTONS;
+            int sc = c->n_spe_channels > ch ? ch : 0;
+            const double *row = s->spe + (i64)sc * 2001;
+            for (i64 q = 0; q < N; q++) {                                       /* photon q of the tile: word q & 3 of three calls */
+                u32 E[4], D[4], G[4];
+                draw(s, c0, gid, (u32)(q >> 2), SITE_TILE_E, E); draw(s, c0, gid, (u32)(q >> 2), SITE_TILE_DELAY, D); draw(s, c0, gid, (u32)(q >> 2), SITE_TILE_GAIN, G);
+                const u32 e = (u32)(((u64)E[q & 3] * (u64)(u32)surv.n) >> 32);
+                const i64 t = surv.p[e] + alias_sample(tab, D[q & 3]);
+                int g1, g2; gain_code(s, G[q & 3], &g1, &g2);
+                double gain = s->gains[ch] * row[g1];
+                if (g2) gain += s->gains[ch] * row[g2];
+                ctx_push(x, t, ch, g2 != 0, gain, gid, 0, q);
+            }
+        }
+        free(surv.p);
     }
     if (lum.n) {
         /* s2.py:447-450: T - mean(T) over the instruction's photons, then the int64 cast of photon_timings (s2.py:532-533).
@@ -1103,7 +1149,7 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
                 set_cur(s, i);
                 if (ptype == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
-                else gen_s2(s, &x, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+                else gen_s2(s, &x, ptype, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
                 open = 1; last_key = ord[k].t;
             }
             if (open) finish_call(s, ptype == 6 ? 5 : ptype, runset++, &x);      /* call kinds: 1 S1, 2 S2, 3 PMT afterpulse, 4 PI electrons, 5 gate electrons */
@@ -1141,7 +1187,7 @@ void orc_simulate_scheduled(orc_session *s, i64 n, const int8_t *type, const i64
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
                 set_cur(s, i);
                 if (type[i] == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
-                else gen_s2(s, &x, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+                else gen_s2(s, &x, -1 /* explicit run sets: never tile by tile (the device: run_sets_given) */, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
             }
             finish_call(s, type[k] == 6 ? 5 : type[k], run_set[k], &x);
             k = e;

@@ -73,7 +73,7 @@ def replay_chain_on_oracle(orc, d):
 # ------------------------------------------------------------------------------------------------ device side
 def make_engine(config, seed=None, resource=None):
     from wfsim_amd.engine import Engine
-    return Engine(config, resource or Resource(config), device=0, seed=seed)
+    return Engine(config, resource or Resource(config), device=0, seed=seed, keep_photons=True)      # (photons(): tests compare photon by photon)
 
 
 def chain_union(d):

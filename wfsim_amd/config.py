@@ -59,6 +59,20 @@ def afterpulse_switches(config):
                 gate=bool(config.get('enable_gate_afterpulses', False)))
 
 
+def tile_local_generation(config):
+    """Whether primary S2s may draw their photons tile by tile inside the pulse workgroup (RNG spec v9; switch:
+    config['tile_local_generation'], default on).  Off wherever something needs the photons of an instruction in generation order
+    or electron by electron: the electron-afterpulse pre-pass (photon counts and picked photon times per parent S2), Pulse calls
+    that cover several instructions (save_full_truth=False) and the transverse-diffusion field maps (the pattern of an instruction
+    is then known only after its electrons).  The per-instruction conditions (s2_gain_spread == 0, PMT afterpulses off, default
+    delay table, tile size) are checked where the instructions are: wfs_tilegen.h fuse_eligible and the oracle's twin."""
+    sw = afterpulse_switches(config)
+    transverse_maps = (config.get('diffusion_constant_transverse', 0) > 0
+                       and config.get('enable_field_dependencies', {}).get('diffusion_transverse_map', False))
+    return bool(config.get('tile_local_generation', True) and not sw['electron'] and not sw['gate']
+                and config.get('save_full_truth', True) and not transverse_maps)
+
+
 def kernel_params(config):
     """Scalars of the hot path, named as the fields of ``wfs_config`` (include/wfsim_amd.h)."""
     c = config
@@ -101,6 +115,7 @@ def kernel_params(config):
         s1_simple=int('simple' in s1_model),
         s2_time_model=s2_time_model,
         enable_pmt_ap=int(afterpulse_switches(c)['pmt']),
+        tile_gen=int(tile_local_generation(c)), reserved0=0,
         c2a=float(current_2_adc(c)),
         tts_mean=float(c['pmt_transit_time_mean']),
         tts_sigma=float(c['pmt_transit_time_spread'] / 2.35482),          # pulse.py:52-56

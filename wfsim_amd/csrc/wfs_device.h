@@ -28,6 +28,11 @@ enum WfsSite : u32 {
     SITE_PH = 19,        // photons that arrive with time and channel (optical input), counter (0, gid, item): x -> transit time, y -> gains
     SITE_PH_X = 20,      // per photon (emitter, gid, item), S1 optical propagation only: x -> spline coordinate
     SITE_LUM = 21,       // photon stream (as SITE_DELAY): position on the excitation-time inverse CDF ('garfield_gas_gap' luminescence)
+    // tile-local generation (spec v9, wfs_tilegen.h): counter (em_base + channel, gid, item, site)
+    SITE_TILE_N = 24,    // photons of the tile: Poisson draw, item = iteration of the sampler
+    SITE_TILE_E = 25,    // item = P >> 2 (P: photon of the tile), word P & 3 -> surviving electron
+    SITE_TILE_DELAY = 26,    // -> summed delay (alias table)
+    SITE_TILE_GAIN = 27,     // -> SPE indices and double-PE flag
     SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
 };
 

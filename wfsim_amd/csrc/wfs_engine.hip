@@ -2,6 +2,7 @@
 // stage orchestration on one HIP stream.  gfx950 (MI355X) only.
 #include <hipcub/hipcub.hpp>
 #include "wfs_kernels.h"
+#include "wfs_tilegen.h"
 #include "../../include/wfsim_amd.h"
 
 #include <algorithm>
@@ -92,6 +93,12 @@ struct wfs_handle {
     DevBuf ins_sigr, ins_siga, diff_row_ins, diff_row_id, diff_pre; std::vector<uint8_t> ins_diff; i64 n_diff_rows = 0; double diff_r2 = 0;
     std::vector<i32> dev_row_ins; std::vector<int8_t> h_ins_type; i64 n_host_rows = 0; bool dev_rows_pending = false;
     DevBuf map_row_ins[2], map_row_id[2], map_x, map_y, map_z, map_nb_idx[2], map_nb_w[2];
+
+    // tile-local generation (wfs_tilegen.h): S2 instructions whose photons are made inside the pulse workgroup
+    DevBuf ins_fused, ins_nsurv, ins_bcap, ins_bcap_all, ins_boff, et32, ftiles, tbuf, row_cnt, row_tile;
+    bool fuse_on = false, fuse_full = false, run_sets_given = false, any_s2 = false;
+    i64 n_fused_tiles = 0, p_fused = 0, s_raw_direct = 0;
+    FuseArgs fuse_args{};
 
     std::string launch_err;      // first failed launch of the current call (wfs_set_debug bit 3: every launch is checked)
     int fail(int code, const std::string &msg) { err = msg; return code; }
@@ -411,6 +418,8 @@ try {
     hipFuncSetAttribute((const void *)k_photon_fill<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_s2_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_s2_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
@@ -439,7 +448,8 @@ try {
         &h->active_tiles, &h->sparse_tiles, &h->dense_tiles, &h->wave_tiles, &h->ph, &h->ph_gain, &h->grp_lo, &h->grp_hi, &h->grp_left, &h->grp_right, &h->grp_ixrand,
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
-        &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal};
+        &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal,
+        &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft, &h->ins_sigr, &h->ins_siga, &h->diff_row_ins, &h->diff_row_id, &h->diff_pre}) if (b->p) hipFree(b->p);
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
@@ -629,6 +639,8 @@ try {
     h->ap_active = h->cfg.enable_pmt_ap && h->dev.n_ap > 0;
     const i64 S = h->ap_active ? 2 * PS : PS;
     h->any_ptrs = any_ptrs;
+    h->run_sets_given = run_set != nullptr;
+    h->any_s2 = false; for (i64 i = 0; i < n; i++) if (type[i] == 2) { h->any_s2 = true; break; }
     h->n_ins = n; h->n_psets = PS; h->n_sets = S; h->n_emitters = em_off[n]; h->n_tiles = S * h->cfg.n_tpc;
     h->h_rs_off = set_off; h->h_rs_list = set_list;
     if (h->n_tiles > 0x7fffffffLL) return h->fail(WFS_E_CAPACITY, "too many tiles in one batch");
@@ -1126,6 +1138,25 @@ static int run_generation(wfs_handle *h)
         }
     }
     TRY(ensure(h, h->em_zg, (size_t)E * 8)); HIPCHK(hipMemsetAsync(h->em_zg.p, 0xff, (size_t)E * 8, h->stream)); g.em_zg = h->em_zg.as<double>();
+    // tile-local generation (wfs_tilegen.h): which instructions take it is decided before the electrons are drawn -- theirs get no
+    // photon numbers.  Debug modes that need the per-photon arrays (currents, generation only) run the generation half alone.
+    const bool ap_cfg = h->ap_active;
+    h->fuse_on = h->cfg.tile_gen && h->any_s2 && !ext && !ap_cfg && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
+    h->fuse_full = h->fuse_on && !(h->keep_currents & 5);
+    h->n_fused_tiles = 0; h->p_fused = 0;
+    FuseArgs f{};
+    if (h->fuse_on) {
+        f.n_ins = N; f.nch = d.n_tpc; f.table_span = (i32)(1u << (32 - d.tab_s2.shift));
+        f.ins_type = g.ins_type; f.ins_amp = g.ins_amp; f.ins_sc = g.ins_sc; f.ins_embase = g.ins_embase; f.ins_gid = g.ins_gid; f.ins_cdfrow = g.ins_cdfrow;
+        f.cdf_table = g.cdf_table; f.ins_time = g.ins_time; f.em_off = g.em_off; f.em_time = g.em_time; f.el_minmax = g.el_minmax; f.scal = g.scal;
+        TRY(ensure(h, h->ins_fused, (size_t)N * 4)); TRY(ensure(h, h->ins_nsurv, (size_t)N * 4)); TRY(ensure(h, h->ins_bcap, (size_t)N * 4));
+        TRY(ensure(h, h->ins_bcap_all, (size_t)N * 4)); TRY(ensure(h, h->et32, (size_t)E * 4));
+        HIPCHK(hipMemsetAsync(h->ins_bcap.p, 0, (size_t)N * 4, h->stream)); HIPCHK(hipMemsetAsync(h->ins_bcap_all.p, 0, (size_t)N * 4, h->stream));
+        f.ins_fused = h->ins_fused.as<i32>(); f.ins_nsurv = h->ins_nsurv.as<i32>(); f.ins_bcap = h->ins_bcap.as<i32>(); f.ins_bcap_all = h->ins_bcap_all.as<i32>();
+        f.et32 = h->et32.as<i32>();
+        { Timer t(h, "k_fuse_decide"); hipLaunchKernelGGL(k_fuse_decide, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, f); }
+        g.ins_fused = f.ins_fused;
+    }
     { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }
     {
         const i64 neb = (E + 255) / 256;
@@ -1153,19 +1184,28 @@ static int run_generation(wfs_handle *h)
         m.pre = h->diff_pre.as<double>();
         { Timer t(h, "k_map_rows"); hipLaunchKernelGGL(k_map_rows, dim3((unsigned)nr), dim3(256), (size_t)d.n_tpc * 8, h->stream, m, d.n_tpc); }
     }
-    TRY(scan(h, h->em_nph.as<i32>(), E, h->em_ph_off, 6));
-    TRY(read_scal(h));
-    const i64 P = h->h_scal[6];
-    h->n_photons = P; h->n_ap_photons = 0;
-    g.em_ph_off = h->em_ph_off.as<i64>(); g.n_photons = P;
     const i64 TP = h->n_psets * d.n_tpc;        // primary tiles; afterpulse tiles follow
-    const bool ap_on = h->ap_active;
-    const i64 ap_cap = ap_on ? P / 8 + 65536 : 0;
     TRY(ensure(h, h->tile_count, (size_t)T * 4)); TRY(ensure(h, h->tile_cursor, (size_t)T * 4));
     HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (size_t)T * 4, h->stream)); HIPCHK(hipMemsetAsync(h->tile_cursor.p, 0, (size_t)T * 4, h->stream));
     TRY(fill32(h, h->tile_tmin, T, 0x7fffffff)); TRY(fill32(h, h->tile_tmax, T, (i32)0x80000000));
-    TRY(ensure(h, h->ph, (size_t)(P + ap_cap) * 8));
     TRY(ensure(h, h->tile_off, (size_t)(T + 1) * 8));
+    if (h->fuse_on) {
+        // surviving electrons compacted per instruction, tile buffers sized from their time range, photons per tile (Poisson)
+        { Timer t(h, "k_fuse_electrons"); hipLaunchKernelGGL(k_fuse_electrons, dim3((unsigned)N), dim3(256), 0, h->stream, d, f); }
+        TRY(scan(h, h->ins_bcap_all.as<i32>(), N, h->ins_boff, 23));
+        TRY(ensure(h, h->ftiles, (size_t)TP * sizeof(FTile)));
+        f.ins_boff = h->ins_boff.as<i64>(); f.tile_count = h->tile_count.as<i32>(); f.tiles = h->ftiles.as<FTile>();
+        { Timer t(h, "k_tile_counts"); hipLaunchKernelGGL(k_tile_counts, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, f); }
+    }
+    TRY(scan(h, h->em_nph.as<i32>(), E, h->em_ph_off, 6));
+    TRY(read_scal(h));
+    const i64 P = h->h_scal[6];                 // photons of the block generator; the tiles' own photons come on top
+    if (h->fuse_on) { h->p_fused = h->h_scal[24]; h->n_fused_tiles = h->h_scal[25]; }
+    h->n_photons = P + h->p_fused; h->n_ap_photons = 0;
+    g.em_ph_off = h->em_ph_off.as<i64>(); g.n_photons = P;
+    const bool ap_on = h->ap_active;
+    const i64 ap_cap = ap_on ? P / 8 + 65536 : 0;
+    TRY(ensure(h, h->ph, (size_t)(P + h->p_fused + ap_cap) * 8));
     g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
     g.tile_tmax = h->tile_tmax.as<i32>(); g.ph = h->ph.as<PhotonRec>();
     g.tile_off = h->tile_off.as<i64>();
@@ -1215,6 +1255,21 @@ static int run_generation(wfs_handle *h)
     } else {
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
     }
+    if (h->fuse_on && h->n_fused_tiles > 0) {
+        // the tiles' photons and pulses (before the geometry: the tile time ranges come out of this kernel)
+        TRY(ensure(h, h->tbuf, (size_t)h->h_scal[23] * 4));
+        TRY(ensure(h, h->tile_truth, (size_t)T * 8 * 8));
+        f.tile_off = h->tile_off.as<i64>(); f.tile_tmin = h->tile_tmin.as<i32>(); f.tile_tmax = h->tile_tmax.as<i32>(); f.tile_truth = h->tile_truth.as<double>();
+        f.tbuf = h->tbuf.as<i32>(); f.ph = h->ph.as<PhotonRec>(); f.keep_ph = (h->keep_currents & 16) ? 1 : 0;
+        TemplateArg tp;
+        for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
+        size_t lds = (size_t)(256 + d.tlen - 1) * d.dt * 8 + 4 * 4 * 4 + 64;
+        lds = (lds + 15) / 16 * 16;
+        Timer t(h, "k_s2_tile");
+        if (h->fuse_full) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<true>), dim3((unsigned)h->n_fused_tiles), dim3(256), lds, h->stream, d, f, tp);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<false>), dim3((unsigned)h->n_fused_tiles), dim3(256), lds, h->stream, d, f, tp);
+    }
+    h->fuse_args = f;
     if (ap_on) {
         // afterpulse photons: count per tile of the afterpulse sets, offsets behind the primary photons, place
         { Timer t(h, "k_ap_count"); hipLaunchKernelGGL(k_ap_count, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
@@ -1270,6 +1325,13 @@ try {
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
     ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.sparse_tiles = h->sparse_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.wave_tiles = h->wave_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
     ga.noise_override = h->n_noise_override ? h->noise_override.as<i64>() : nullptr; ga.n_noise_override = h->n_noise_override;
+    const bool tiles_done = !h->injected && !h->optical && h->fuse_full && h->n_fused_tiles > 0;      // pulses made by k_s2_tile (wfs_tilegen.h)
+    if (tiles_done) {
+        TRY(ensure(h, h->row_cnt, (size_t)CG * d.n_tpc * 4)); TRY(ensure(h, h->row_tile, (size_t)CG * d.n_tpc * 4));
+        HIPCHK(hipMemsetAsync(h->row_cnt.p, 0, (size_t)CG * d.n_tpc * 4, h->stream));
+        ga.tile_done_ins = h->ins_fused.as<i32>(); ga.row_cnt = h->row_cnt.as<i32>(); ga.row_tile = h->row_tile.as<i32>();
+        ga.ins_bcap = h->ins_bcap.as<i32>(); ga.ins_boff = h->ins_boff.as<i64>();
+    }
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 1024)), dim3(1024), 0, h->stream, d, ga); }
     { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(GROUPS_TPB), 0, h->stream, d, ga); }
     { Timer t(h, "k_tile_rows"); hipLaunchKernelGGL(k_tile_rows, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga); }
@@ -1292,6 +1354,7 @@ try {
     if (h->n_wave_tiles > 0)
         HIPCHK(hipMemcpyAsync(h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles + h->n_dense_tiles, h->wave_tiles.p, (size_t)h->n_wave_tiles * 4, hipMemcpyDeviceToDevice, h->stream));
     h->s_raw = h->h_scal[8]; h->n_itv_slots = h->h_scal[9];
+    h->s_raw_direct = tiles_done ? h->h_scal[26] : 0;      // samples of the rows that are read from a tile buffer in place
     // deterministic processing order of the work lists (they were appended with atomics)
     // (results do not depend on it; sorting keeps profiles and debug dumps reproducible)
 
@@ -1393,6 +1456,12 @@ try {
         }
     }
 
+    if (tiles_done) {   // tiles of k_s2_tile that share their row with other pulses: added into the row's accumulators
+        TileAddArgs ta{h->set_cluster.as<i32>(), h->cl_group.as<i32>(), h->row_lo.as<i64>(), h->acc_off.as<i64>(), h->row_cnt.as<i32>(), h->raw.as<i32>()};
+        Timer t(h, "k_tile_add");
+        hipLaunchKernelGGL(k_tile_add, dim3((unsigned)h->n_fused_tiles), dim3(256), 0, h->stream, d, h->fuse_args, ta);
+    }
+
     {   // truth accumulators of every pulse set from the per-tile partial sums
         TruthArgs ta{S, h->tile_count.as<i32>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_t0.as<i64>(), h->tile_truth.as<double>(),
                      h->truth.as<double>(), h->tminmax.as<i64>()};
@@ -1410,6 +1479,7 @@ try {
     za.acc_off = h->acc_off.as<i64>(); za.raw = h->raw.as<i32>(); za.grp_left = h->grp_left.as<i64>(); za.grp_ixrand = h->grp_ixrand.as<i64>();
     za.itv_off = h->itv_off.as<i64>(); za.itv_left = h->itv_left.as<i64>(); za.itv_right = h->itv_right.as<i64>();
     za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = 110;
+    if (tiles_done) { za.tile_done_ins = ga.tile_done_ins; za.row_cnt = ga.row_cnt; za.row_tile = ga.row_tile; za.ins_bcap = ga.ins_bcap; za.ins_boff = ga.ins_boff; za.tbuf = h->tbuf.as<i32>(); }
     h->row_dbg_total = 0;
     if ((h->keep_currents & 1) && h->n_active_rows > 0) {
         std::vector<i32> ar((size_t)h->n_active_rows);
@@ -1474,7 +1544,9 @@ try {
     if (!h->ran) return h->fail(WFS_E_STATE, "wfs_run has not completed");
     wfs_counts c{};
     c.n_instructions = h->n_ins; c.n_pulse_sets = h->n_sets; c.n_emitters = h->n_emitters; c.n_photons = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0);
-    c.n_tiles = h->n_active_tiles; c.n_groups = h->n_groups; c.n_rows = h->n_active_rows; c.n_raw_samples = h->s_raw;
+    const bool tiles_done = !h->injected && !h->optical && h->fuse_full && h->n_fused_tiles > 0;
+    c.n_tiles = h->n_active_tiles + (tiles_done ? h->n_fused_tiles : 0); c.n_groups = h->n_groups; c.n_rows = h->n_active_rows;
+    c.n_raw_samples = h->s_raw + (tiles_done ? h->s_raw_direct : 0);
     c.n_records = h->n_records;
     c.n_intervals = h->h_scal[20]; c.n_pe = h->h_scal[21];          // reduced on the device at the end of wfs_run (k_counts)
     *out = c; h->counts = c;
@@ -1669,6 +1741,8 @@ try {
 int wfs_copy_photons(wfs_handle *h, int64_t *set_off, int64_t *t, int16_t *ch, double *gain, uint8_t *dpe, int64_t cap)
 try {
     if (!h || !h->ran) return WFS_E_STATE;
+    if (!h->injected && !h->optical && h->fuse_full && h->n_fused_tiles > 0 && !(h->keep_currents & 16))
+        return h->fail(WFS_E_STATE, "the photons of tile-generated instructions were not kept: wfs_set_debug bit 4 before wfs_run");
     const WfsDev &d = h->dev;
     const i64 P = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0), T = h->n_tiles;
     if (cap < P) return h->fail(WFS_E_CAPACITY, "photon buffer too small");
@@ -1700,6 +1774,7 @@ try {
 int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t cap)
 try {
     if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
+    if (h->fuse_on && h->n_fused_tiles > 0) return h->fail(WFS_E_STATE, "photons in generation order do not exist with tile-local generation (wfs_config.tile_gen = 0 for the electron-afterpulse pre-pass)");
     const i64 N = h->n_ins;
     if (cap < N + 1) return h->fail(WFS_E_CAPACITY, "offset buffer too small");
     std::vector<i64> emo((size_t)N + 1), epo((size_t)h->n_emitters + 1);

@@ -127,6 +127,9 @@ struct GeomArgs {
     i32 *sparse_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
     i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
     i32 *wave_tiles;     // medium tiles (at most 64 photons, any width: wave per tile); scal[17] = their number
+    const i32 *tile_done_ins;   // [n_ins] 1: the tiles of this instruction (= pulse set) were simulated by k_s2_tile: on no work list (or nullptr)
+    i32 *row_cnt, *row_tile;    // [groups * n_tpc] tiles in the row; one of them
+    const i32 *ins_bcap; const i64 *ins_boff;      // tile sample buffers (wfs_tilegen.h)
     i32 force_dense;     // debug: send every tile to the dense kernel
     i32 init_has; i64 init_runmax;      // last_pulse_end_time carried in from earlier batches
     const i64 *noise_override; i64 n_noise_override;
@@ -165,6 +168,7 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
         cnt = a.tile_count[tile];
         if (!a.force_dense) cls = (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1
                                   : ((cnt <= WAVE_MAX_PHOTONS && nb <= WAVE_MAX_BINS) ? 3 : 2));
+        if (a.tile_done_ins && set < a.n_sets && a.tile_done_ins[set]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
     }
     {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
         const u64 ml = __ballot(live);
@@ -183,7 +187,8 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; s_mx[3] = 0; }
     __syncthreads();
     i32 rk = 0;
-    if (live) {
+    const bool listed = live && cls >= 0;
+    if (listed) {
         rk = atomicAdd(&s_n[cls], 1);
         if (cls == 1) { atomicMax(&s_mx[0], nb); atomicMax(&s_mx[1], (i64)cnt); } else if (cls == 2) { atomicMax(&s_mx[2], nb); atomicMax(&s_mx[3], (i64)cnt); }
     }
@@ -199,7 +204,7 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
         if (s_mx[3]) atomicMax(&a.scal[15], s_mx[3]);
     }
     __syncthreads();
-    if (live) (cls == 0 ? a.active_tiles : (cls == 1 ? a.sparse_tiles : (cls == 2 ? a.dense_tiles : a.wave_tiles)))[s_b[cls] + rk] = (i32)tile;
+    if (listed) (cls == 0 ? a.active_tiles : (cls == 1 ? a.sparse_tiles : (cls == 2 ? a.dense_tiles : a.wave_tiles)))[s_b[cls] + rk] = (i32)tile;
 }
 
 // Digitise groups.  The cache is digitised before cluster k when min(instruction key of k) - last_pulse_end_time > rext
@@ -272,6 +277,7 @@ __global__ void k_tile_rows(WfsDev d, GeomArgs a)
         tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
         g = a.cl_group[a.set_cluster[set]];
         atomicMin(&a.row_lo[g * d.n_tpc + ch], left); atomicMax(&a.row_hi[g * d.n_tpc + ch], right);
+        if (a.row_cnt) { atomicAdd(&a.row_cnt[g * d.n_tpc + ch], 1); a.row_tile[g * d.n_tpc + ch] = (i32)tile; }      // (row_tile: only read when the row has ONE tile)
     }
     // the group's range: the 494 tiles of a pulse set all aim at one address -- reduce inside the wave first when its
     // live lanes share the group (the usual case), one atomic pair per wave instead of 64
@@ -310,12 +316,17 @@ __global__ void k_group_final(WfsDev d, GeomArgs a)
     a.grp_ixrand[g] = ix;
 }
 
+__device__ __forceinline__ bool row_is_direct(const i32 *done_ins, const i32 *row_cnt, const i32 *row_tile, i64 ridx, int nch)
+{
+    return done_ins && row_cnt[ridx] == 1 && done_ins[row_tile[ridx] / nch] != 0;
+}
+
 // per (group, row slot): accumulator length and reserved ZLE interval slots; list of rows with data
 // (appended with one global atomic per workgroup)
 __global__ void k_row_len(WfsDev d, GeomArgs a)
 {
-    __shared__ i32 s_n; __shared__ i64 s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ i32 s_n, s_direct; __shared__ i64 s_base;
+    if (threadIdx.x == 0) { s_n = 0; s_direct = 0; }
     __syncthreads();
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 n = a.scal[0] * d.row_slots;
@@ -328,12 +339,15 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
             const i64 len = a.row_hi[g * d.n_tpc + ch] - lo + 1 + 2 * (i64)d.tw;
             i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
             cap = (i32)((len + hold) / (hold + 1));
-            if (slot < d.n_tpc) a.acc_len[g * d.n_tpc + ch] = (i32)len;
+            // a row made by ONE tile whose samples exist already (k_s2_tile) is read from the tile's buffer: no accumulators
+            const bool direct = row_is_direct(a.tile_done_ins, a.row_cnt, a.row_tile, g * d.n_tpc + ch, d.n_tpc);
+            if (slot < d.n_tpc) { a.acc_len[g * d.n_tpc + ch] = direct ? 0 : (i32)len; if (direct) atomicAdd(&s_direct, (i32)len); }
             rk = atomicAdd(&s_n, 1);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_n) s_base = (i64)atomicAdd((u64 *)&a.scal[2], (u64)s_n);
+    if (threadIdx.x == 0 && s_direct) atomicAdd((u64 *)&a.scal[26], (u64)s_direct);      // samples of the rows read in place
     __syncthreads();
     if (rk >= 0) a.active_rows[s_base + rk] = (i32)idx;
     if (idx < a.n_gslots * d.row_slots) a.itv_cap[idx] = cap;
@@ -398,6 +412,30 @@ __global__ void k_tile_desc(WfsDev d, DescArgs a)
     t.n = a.tile_count[tile]; t.nb = (i32)nb; t.L = (i32)(right - left + 1); t.tile = (i32)tile;
     t.ch = ch; t.mode = a.set_mode[set]; t.pad0 = 0; t.pad1 = 0;
     a.desc[i] = t;
+}
+
+// The gather of one sample (pulse.py:303-318 in the H-table form): thread `tid` owns the sample whose start bins are the H rows
+// tid (tap k = 21) .. tid + 21 (tap k = 0); it adds its tlen x dt possible contributions in ascending time, separate multiply and
+// add.  The tap loop is outermost so that only the dt taps of one k are live in SGPRs.
+__device__ __forceinline__ double tap_gather(const double *H, const TemplateArg &tp, int tid)
+{
+    constexpr int dt = WFS_DT, tlen = 22;
+    const double *Hs = H + (tid + (tlen - 1)) * dt;
+    double c = 0.0;
+#pragma unroll 1
+    for (int k = tlen - 1; k >= 0; k--) {
+        const double *Tk = tp.t + k * dt;          // the dt taps of one k are contiguous: two wide scalar loads
+        const double T0 = Tk[0], T1 = Tk[1], T2 = Tk[2], T3 = Tk[3], T4 = Tk[4], T5 = Tk[5], T6 = Tk[6], T7 = Tk[7], T8 = Tk[8], T9 = Tk[9];
+        const double2 *hp = (const double2 *)(Hs - k * dt);
+        const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
+        double prod;
+        prod = T0 * h0.x; c = c + prod;  prod = T1 * h0.y; c = c + prod;
+        prod = T2 * h1.x; c = c + prod;  prod = T3 * h1.y; c = c + prod;
+        prod = T4 * h2.x; c = c + prod;  prod = T5 * h2.y; c = c + prod;
+        prod = T6 * h3.x; c = c + prod;  prod = T7 * h3.y; c = c + prod;
+        prod = T8 * h4.x; c = c + prod;  prod = T9 * h4.y; c = c + prod;
+    }
+    return c;
 }
 
 template <int TPB, bool RESIDENT>
@@ -650,21 +688,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         // k are live in SGPRs.
         const bool act = c0 + tid < n_live;
         if (__any(act)) {                                  // wave-uniform
-            const double *Hs = H + (tid + (tlen - 1)) * dt;
-            double c = 0.0;
-#pragma unroll 1
-            for (int k = tlen - 1; k >= 0; k--) {
-                const double *Tk = tp.t + k * dt;          // the dt taps of one k are contiguous: two wide scalar loads
-                const double T0 = Tk[0], T1 = Tk[1], T2 = Tk[2], T3 = Tk[3], T4 = Tk[4], T5 = Tk[5], T6 = Tk[6], T7 = Tk[7], T8 = Tk[8], T9 = Tk[9];
-                const double2 *hp = (const double2 *)(Hs - k * dt);
-                const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
-                double prod;
-                prod = T0 * h0.x; c = c + prod;  prod = T1 * h0.y; c = c + prod;
-                prod = T2 * h1.x; c = c + prod;  prod = T3 * h1.y; c = c + prod;
-                prod = T4 * h2.x; c = c + prod;  prod = T5 * h2.y; c = c + prod;
-                prod = T6 * h3.x; c = c + prod;  prod = T7 * h3.y; c = c + prod;
-                prod = T8 * h4.x; c = c + prod;  prod = T9 * h4.y; c = c + prod;
-            }
+            const double c = tap_gather(H, tp, tid);
             if (act) {
                 const i64 sx = lead + c0 + tid;            // sample of the tile
                 if (a.currents) a.currents[a.cur_off[tidx] + sx] = c;
@@ -1112,6 +1136,7 @@ struct ZleArgs {
     struct RowDesc *desc;        // [n_active_rows] everything a row's wave needs, prepared by k_row_desc
     const u32 *rec_dest;         // record order by (time, channel): slot of record r in the output (nullptr: row order)
     u64 *rec_key; u32 *rec_val; i64 *key_base;     // k_rec_keys: sort key (sample - *key_base) << 12 | channel, and the record index; *key_base = first sample of the batch (k_row_desc)
+    const i32 *tile_done_ins, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf;      // rows read from a tile buffer in place (wfs_tilegen.h)
 };
 
 // One 64-byte descriptor per active row (thread per row: the divisions and the five dependent look-ups of a row are
@@ -1123,7 +1148,7 @@ struct __attribute__((aligned(64))) RowDesc {
     i64 itv_base;                // first interval slot of the row
     i64 thr;                     // ZLE threshold of the channel
     i64 idx;                     // row slot (group * row_slots + slot): index of itv_n / row_nrec / rec_off
-    i32 len, channel, he, pad;
+    i32 len, channel, he, src;   // src 1: acc_off points into the tile buffers (a row made by one k_s2_tile tile)
 };
 
 __global__ void k_row_desc(WfsDev d, ZleArgs a)
@@ -1136,8 +1161,13 @@ __global__ void k_row_desc(WfsDev d, ZleArgs a)
     const i64 ridx = g * d.n_tpc + acc_ch;
     RowDesc q;
     q.acc_off = a.acc_off[ridx]; q.row_abs = a.row_lo[ridx] - d.tw; q.ixr = a.grp_ixrand[g]; q.itv_base = a.itv_off[idx];
+    q.src = 0;
+    if (row_is_direct(a.tile_done_ins, a.row_cnt, a.row_tile, ridx, d.n_tpc)) {
+        const i32 tile = a.row_tile[ridx]; const i32 ins = tile / d.n_tpc;
+        q.acc_off = a.ins_boff[ins] + (i64)(tile - ins * d.n_tpc) * a.ins_bcap[ins]; q.src = 1;
+    }
     q.thr = d.thr_zle[channel]; q.idx = idx; q.len = (i32)(a.row_hi[ridx] - a.row_lo[ridx] + 1 + 2 * (i64)d.tw);
-    q.channel = channel; q.he = he ? 1 : 0; q.pad = 0;
+    q.channel = channel; q.he = he ? 1 : 0;
     a.desc[r] = q;
     if (a.key_base) atomicMin(a.key_base, q.row_abs);
 }
@@ -1198,7 +1228,7 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     const RowDesc q = a.desc[r];
     const i64 idx = q.idx; const i32 channel = q.channel; const bool he = q.he != 0;
     const i64 len = q.len;
-    const i32 *acc = a.raw + q.acc_off;
+    const i32 *acc = (q.src ? a.tbuf : a.raw) + q.acc_off;
     const i64 thr = q.thr;
     const i64 ixr = q.ixr;
     i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
@@ -1303,7 +1333,7 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const i32 count = a.itv_n[idx];
     if (count == 0) return;
     const i32 channel = q.channel; const bool he = q.he != 0;
-    const i32 *acc = a.raw + q.acc_off;
+    const i32 *acc = (q.src ? a.tbuf : a.raw) + q.acc_off;
     const i64 row_abs = q.row_abs;
     const i64 ixr = q.ixr;
     const i64 base = q.itv_base;
@@ -1386,6 +1416,7 @@ struct GenArgs {
     unsigned short *blk_cnt;      // [n_blocks][n_tpc] the block's photons per channel (count pass, single-instruction blocks)
     i32 *blk_ins;                 // [n_blocks] instruction of a single-instruction block, -1 otherwise (k_block_emitters)
     struct BlockDesc *blk_desc;   // [n_blocks] everything a generator workgroup needs to know about its block
+    const i32 *ins_fused;         // [n_ins] 1: the instruction's photons are generated tile by tile (wfs_tilegen.h), or nullptr
     i64 *ins_ph0;                 // [n_ins + 1] first photon (generation order) of every instruction: em_ph_off[em_off[i]]
     double *el_stat;              // [n_ins][4] electrons: n, sum t, sum t^2 ; el_minmax [n_ins][2]
     i64 *el_minmax;
@@ -1559,7 +1590,8 @@ __global__ __launch_bounds__(256) void k_s2_electrons(WfsDev d, GenArgs a)
             i64 et = a.ins_time[i] + (i64)timing;                         // s2.py:282
             a.em_time[e] = et;
             const i32 pk = a.pois_kmin[i];
-            if (pk == -1) a.em_zg[e] = z_gain;                             // gain above POIS_LAM_MAX: k_s2_photons (PTRS)
+            if (a.ins_fused && a.ins_fused[i]) a.em_nph[e] = 0;                // its photons are made tile by tile (wfs_tilegen.h)
+            else if (pk == -1) a.em_zg[e] = z_gain;                             // gain above POIS_LAM_MAX: k_s2_photons (PTRS)
             else {
                 i64 nph = pk >= 0 ? poisson_table_draw(d, a.pois_cdf + i * POIS_W, pk, j, gid) : 0;
                 nph += (i64)(0.0 + d.gain_spread * z_gain);               // s2.py:309

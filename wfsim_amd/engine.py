@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('WFSIM_AMD_LIB') or os.path.join(HERE, 'libwfsim_amd.s
 
 _I32 = ['dt', 'samples_before', 'samples_after', 'store_before', 'store_after', 'tlen', 'trigger_window', 'baseline',
         'n_rows', 'n_tpc', 'n_top', 'he_first', 'he_factor', 'sum_channel', 'last_bottom', 'detector_nt', 'enable_noise',
-        's1_simple', 's2_time_model', 'enable_pmt_ap']
+        's1_simple', 's2_time_model', 'enable_pmt_ap', 'tile_gen', 'reserved0']
 _F64 = ['c2a', 'tts_mean', 'tts_sigma', 'p_dpe', 's1_decay_time', 's1_decay_spread', 'sf_gas', 't1_gas', 't3_gas',
         's2_time_spread', 'trap_time', 'gain_spread', 'pmt_ap_modifier', 'pmt_ap_t_modifier', 'rext', 'drift_velocity']
 
@@ -153,8 +153,11 @@ def _arr(a, dtype):
 class Engine:
     """One GPU, one stream, one fax configuration."""
 
-    def __init__(self, config, resource, device=0, seed=None):
+    def __init__(self, config, resource, device=0, seed=None, keep_photons=False):
+        """keep_photons: the photons of tile-generated S2 instructions (wfs_config.tile_gen) are also written to the photon
+        array, for ``photons()`` -- by default they only exist in the registers of the pulse workgroup (tests: True)"""
         self.lib = load_library()
+        self.keep_photons = bool(keep_photons)
         self.config = config
         params = kernel_params(config)
         if seed is not None:
@@ -189,8 +192,8 @@ class Engine:
                     self._h, C.c_int32(e), C.c_int32(dc.shape[1]), C.c_int32(ac.shape[-1]), C.c_int32(ac.ndim == 2),
                     C.c_int32('Uniform' in name), C.c_double(d['delaytime_bin_size']), C.c_double(d['amplitude_bin_size']), _p(dc), _p(ac)))
 
-        if os.environ.get('WFS_CHECK_LAUNCHES', '0') not in ('', '0'):
-            self.set_debug(False)          # every launch checked from the first run on
+        if self.keep_photons or os.environ.get('WFS_CHECK_LAUNCHES', '0') not in ('', '0'):
+            self.set_debug(False)          # (every launch checked from the first run on)
         # HE records exist only when the HE rows can differ from a flat baseline (wfs_engine.hip refresh_dev): a non-zero
         if t['noise'] is not None and np.asarray(resource.noise_data).dtype.kind == 'f' \
                 and not np.array_equal(np.asarray(resource.noise_data), np.trunc(resource.noise_data)):
@@ -386,7 +389,7 @@ class Engine:
         if check_launches is None:
             check_launches = os.environ.get('WFS_CHECK_LAUNCHES', '0') not in ('', '0')
         self._check(self.lib.wfs_set_debug(self._h, C.c_int32(int(bool(on)) | (2 if force_dense else 0) | (4 if generate_only else 0)
-                                                              | (8 if check_launches else 0))))
+                                                              | (8 if check_launches else 0) | (16 if self.keep_photons else 0))))
 
     def generate(self):
         """photon generation only (no pulses / records): the pre-pass of the electron afterpulses"""
