@@ -108,6 +108,47 @@ __device__ __forceinline__ u32 gain_code(u32 w, u64 thr_dpe, double dpe_inv)
     return g1 | (g2 << 16);
 }
 
+// Wave-wide reductions on the DPP path (quad permutes, half-row and row mirrors: VALU moves, no LDS crossbar round trips as with
+// the shuffles; readlane joins the four 16-lane rows).  Every lane -- and the scalar result -- ends up with the value of all 64.
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = dpp_mov<CTRL>((int)(u32)b), hi = dpp_mov<CTRL>((int)(u32)((u64)b >> 32));
+    return __longlong_as_double((long long)(((u64)(u32)hi << 32) | (u32)lo));
+}
+// (every DPP move is made ONCE, by all lanes, before its value is used: inside a divergent region a DPP read of a switched-off
+// lane returns the old value instead)
+#define WFS_DPP_STEPS(T, COMBINE) \
+    { const T o = dpp_mov<0xB1>(v); v = COMBINE; } { const T o = dpp_mov<0x4E>(v); v = COMBINE; } \
+    { const T o = dpp_mov<0x141>(v); v = COMBINE; } { const T o = dpp_mov<0x140>(v); v = COMBINE; }
+__device__ __forceinline__ int wave_sum(int v)
+{
+    WFS_DPP_STEPS(int, v + o)
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+__device__ __forceinline__ int wave_min(int v)
+{
+    WFS_DPP_STEPS(int, min(v, o))
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max(int v)
+{
+    WFS_DPP_STEPS(int, max(v, o))
+    return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// (a fixed order of additions: the result does not depend on anything but the 64 values)
+__device__ __forceinline__ double wave_sum(double v)
+{
+    WFS_DPP_STEPS(double, v + o)
+    const long long b = __double_as_longlong(v);
+    const int lo = (int)(u32)b, hi = (int)(u32)((u64)b >> 32);
+    double r[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane(hi, 16 * q) << 32) | (u32)__builtin_amdgcn_readlane(lo, 16 * q)));
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
+
 // In-kernel phase stamps (diagnostic builds, -DWFS_STAMPS; MI355X_MICROARCH.md "In-kernel stamps"): thread 0 of every
 // workgroup adds the shader cycles since its previous stamp to slot i.  Production builds compile them away.
 #ifdef WFS_STAMPS

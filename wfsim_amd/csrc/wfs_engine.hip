@@ -98,6 +98,7 @@ struct wfs_handle {
     DevBuf ins_fused, ins_nsurv, ins_bcap, ins_bcap_all, ins_boff, et32, ftiles, tbuf, row_cnt, row_tile;
     bool fuse_on = false, fuse_full = false, run_sets_given = false, any_s2 = false;
     i64 n_fused_tiles = 0, p_fused = 0, s_raw_direct = 0;
+    int tap_sparse_max = 48;     // tap_block: occupied cells up to which a wave of the dense pulse kernels walks them (WFS_TAP_SPARSE_MAX)
     FuseArgs fuse_args{};
 
     std::string launch_err;      // first failed launch of the current call (wfs_set_debug bit 3: every launch is checked)
@@ -408,6 +409,7 @@ try {
     h->stamps.cap = 4096 * 64 * 8; hipMemset(h->stamps.p, 0, 4096 * 64 * 8); h->dev.stamps = h->stamps.as<unsigned long long>();
 #endif
     refresh_dev(h);
+    if (const char *e = getenv("WFS_TAP_SPARSE_MAX")) h->tap_sparse_max = std::min(atoi(e), TAP_LIST_LEN - 1);      // tuning knob of tap_block (results do not depend on it)
     if (build_time_tables(h) != WFS_OK) { delete h; return WFS_E_HIP; }
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
     hipFuncSetAttribute((const void *)k_pulse<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -431,6 +433,7 @@ try {
     if (!h) return WFS_OK;
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
+
 #ifdef WFS_STAMPS
     {   // diagnostic build: average cycles per workgroup and phase
         std::vector<unsigned long long> all((size_t)4096 * 64); unsigned long long v[64] = {0};
@@ -1263,8 +1266,9 @@ static int run_generation(wfs_handle *h)
         f.tbuf = h->tbuf.as<i32>(); f.ph = h->ph.as<PhotonRec>(); f.keep_ph = (h->keep_currents & 16) ? 1 : 0;
         TemplateArg tp;
         for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
-        size_t lds = (size_t)(256 + d.tlen - 1) * d.dt * 8 + 4 * 4 * 4 + 64;
+        size_t lds = (size_t)(256 + d.tlen - 1) * d.dt * 8 + 4 * 4 * 4 + TAP_LDS_BYTES(256) + 64;
         lds = (lds + 15) / 16 * 16;
+        f.sparse_max = h->tap_sparse_max;
         Timer t(h, "k_s2_tile");
         if (h->fuse_full) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<true>), dim3((unsigned)h->n_fused_tiles), dim3(256), lds, h->stream, d, f, tp);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<false>), dim3((unsigned)h->n_fused_tiles), dim3(256), lds, h->stream, d, f, tp);
@@ -1342,6 +1346,7 @@ try {
     TRY(read_scal(h));
     if (h->h_scal[1] == 1) return h->fail(WFS_E_CAPACITY, "Pulse cache too long (digitise window of 10^6 samples or more, rawdata.py:219)");
     if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
+    if (h->h_scal[1] == 3) return h->fail(WFS_E_STATE, "internal: a tile of k_s2_tile did not fit its sample buffer");
     h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5]; h->max_tile_dense = h->h_scal[15];
     h->n_dense_tiles = h->h_scal[11]; h->max_nb_dense = h->h_scal[12]; h->n_tiny_tiles = h->h_scal[16];
     h->n_wave_tiles = h->h_scal[17];
@@ -1442,8 +1447,9 @@ try {
         pd.W = tpb;
         TemplateArg tp;
         for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
-        size_t lds = (size_t)(tpb + d.tlen - 1) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64;
+        size_t lds = (size_t)(tpb + d.tlen - 1) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64 + TAP_LDS_BYTES(256) + 16;
         lds = (lds + 15) / 16 * 16;
+        pd.sparse_max = (h->keep_currents & 2) ? -1 : h->tap_sparse_max;      // (force_dense: every wave takes the dense gather)
         pd.spe_lds = ((size_t)(tpb + d.tlen - 1) * d.dt >= 2001) ? 1 : 0;
         const unsigned grid = (unsigned)(h->n_dense_tiles * pd.n_win);
         Timer t(h, "k_pulse_dense");
@@ -1456,7 +1462,7 @@ try {
         }
     }
 
-    if (tiles_done) {   // tiles of k_s2_tile that share their row with other pulses: added into the row's accumulators
+    if (tiles_done && h->h_scal[27] > 0) {   // tiles of k_s2_tile that share their row with other pulses: added into the row's accumulators
         TileAddArgs ta{h->set_cluster.as<i32>(), h->cl_group.as<i32>(), h->row_lo.as<i64>(), h->acc_off.as<i64>(), h->row_cnt.as<i32>(), h->raw.as<i32>()};
         Timer t(h, "k_tile_add");
         hipLaunchKernelGGL(k_tile_add, dim3((unsigned)h->n_fused_tiles), dim3(256), 0, h->stream, d, h->fuse_args, ta);

@@ -325,8 +325,8 @@ __device__ __forceinline__ bool row_is_direct(const i32 *done_ins, const i32 *ro
 // (appended with one global atomic per workgroup)
 __global__ void k_row_len(WfsDev d, GeomArgs a)
 {
-    __shared__ i32 s_n, s_direct; __shared__ i64 s_base;
-    if (threadIdx.x == 0) { s_n = 0; s_direct = 0; }
+    __shared__ i32 s_n, s_direct, s_shared; __shared__ i64 s_base;
+    if (threadIdx.x == 0) { s_n = 0; s_direct = 0; s_shared = 0; }
     __syncthreads();
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 n = a.scal[0] * d.row_slots;
@@ -342,12 +342,14 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
             // a row made by ONE tile whose samples exist already (k_s2_tile) is read from the tile's buffer: no accumulators
             const bool direct = row_is_direct(a.tile_done_ins, a.row_cnt, a.row_tile, g * d.n_tpc + ch, d.n_tpc);
             if (slot < d.n_tpc) { a.acc_len[g * d.n_tpc + ch] = direct ? 0 : (i32)len; if (direct) atomicAdd(&s_direct, (i32)len); }
+            if (slot < d.n_tpc && a.row_cnt && a.row_cnt[g * d.n_tpc + ch] > 1) atomicAdd(&s_shared, 1);
             rk = atomicAdd(&s_n, 1);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_n) s_base = (i64)atomicAdd((u64 *)&a.scal[2], (u64)s_n);
     if (threadIdx.x == 0 && s_direct) atomicAdd((u64 *)&a.scal[26], (u64)s_direct);      // samples of the rows read in place
+    if (threadIdx.x == 0 && s_shared) atomicAdd((u64 *)&a.scal[27], (u64)s_shared);      // rows made by several tiles (k_tile_add is needed)
     __syncthreads();
     if (rk >= 0) a.active_rows[s_base + rk] = (i32)idx;
     if (idx < a.n_gslots * d.row_slots) a.itv_cap[idx] = cap;
@@ -388,6 +390,7 @@ struct PulseArgs {
     i32 NP;               // photon capacity of the sparse kernel's LDS list
     i32 n_win;            // dense kernel: workgroups per tile (each takes every n_win-th chunk of TPB samples)
     i32 spe_lds;          // dense resident kernel: the H table has room for the channel's SPE row (2001 doubles), staged there before the gains are looked up
+    i32 sparse_max;       // dense kernel: a wave whose samples see at most this many occupied cells walks them instead of gathering all 220 per sample (tap_block)
 };
 
 #define DENSE_PPT 8        // photons per thread per batch held in registers
@@ -438,6 +441,80 @@ __device__ __forceinline__ double tap_gather(const double *H, const TemplateArg 
     return c;
 }
 
+// The same sample from the OCCUPIED cells alone, for waves whose 64 samples see few photons (the tails of an S2 tile, where most of
+// the 220 cells a sample gathers are empty: the dense gather spends 8 f64 issue cycles on every one of them).  The wave scans the
+// 850 cells its samples can reach (H rows 64 w .. 64 w + 84) with ballots -- two rounds in the middle first: a wave in the
+// bulk of the tile is recognised there and leaves for the dense gather.  With at most `sparse_max` (<= TAP_LIST_LEN) occupied cells
+// it lists them in ascending time (LDS, 2 bytes each), lane i takes entry i (cell, merged gain) into registers, and the entries
+// are then broadcast one by one with readlane: every lane looks up ITS tap W2[(10 (lane + 21) + 9) - cell] (the zero tap W2[220]
+// outside the reach of its sample) and adds the product with a separate multiply and add -- the additions of the dense gather in
+// the same order minus the additions of +0.0, hence the same bits (pulse.py:303-318).  W2[k * dt + (dt - 1 - r)] = templates[r][k].
+// A cell counts as occupied when the high word of its merged gain is non-zero (any gain of at least 2^-1022).
+#define TAP_W2_LEN (22 * WFS_DT + 2)
+#define TAP_LIST_LEN 64                // entries of a wave's list (unsigned short): one per lane
+#define TAP_LDS_BYTES(tpb) (TAP_W2_LEN * 8 + ((tpb) / 64) * TAP_LIST_LEN * 2)
+__device__ __forceinline__ void tap_w2_fill(double *W2, const double *templates, int tid, int tpb)
+{
+    constexpr int dt = WFS_DT, tlen = 22;
+    for (int i = tid; i < TAP_W2_LEN; i += tpb) W2[i] = i < tlen * dt ? templates[(dt - 1 - i % dt) * tlen + i / dt] : 0.0;
+}
+// W2 is followed by the waves' lists: [TAP_W2_LEN doubles][tpb / 64][TAP_LIST_LEN] unsigned short
+// n_cells: the cells of H that hold data (the caller may have cleared only the rows its live samples can see)
+__device__ __forceinline__ double tap_block(const double *H, double *W2, const TemplateArg &tp, int tid, int sparse_max, int n_cells)
+{
+    constexpr int dt = WFS_DT, tlen = 22, REACH = (64 + tlen - 1) * dt, NR = (REACH + 63) / 64;
+    const int lane = tid & 63;
+    if (sparse_max < 0) return tap_gather(H, tp, tid);
+    const double *Hw = H + (tid & ~63) * dt;            // first cell of the wave's reach
+    const u32 *Hhi = (const u32 *)Hw + 1;               // high words
+    unsigned short *list = (unsigned short *)(W2 + TAP_W2_LEN) + (tid >> 6) * TAP_LIST_LEN;
+    const u64 below = (1ull << lane) - 1ull;
+    const int c_end = min(REACH, n_cells - (tid & ~63) * dt);      // cells of the reach that hold data
+    {   // rounds 6 and 7 (the middle of the reach) first
+        const u32 a = 6 * 64 + lane < c_end ? Hhi[2 * (6 * 64 + lane)] : 0u, b = 7 * 64 + lane < c_end ? Hhi[2 * (7 * 64 + lane)] : 0u;
+        if (__popcll(__ballot(a != 0u)) + __popcll(__ballot(b != 0u)) > (sparse_max >> 2)) return tap_gather(H, tp, tid);      // wave-uniform
+    }
+    int m = 0;
+#pragma unroll 1
+    for (int r0 = 0; r0 < NR; r0 += 4) {                 // (four loads in flight at a time)
+        u32 hw[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int c = (r0 + u) * 64 + lane; hw[u] = c < c_end ? Hhi[2 * c] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u64 mk = __ballot(hw[u] != 0u);
+            if (mk) {                                    // wave-uniform
+                const int pos = m + __popcll(mk & below);
+                if (hw[u] != 0u && pos < TAP_LIST_LEN) list[pos] = (unsigned short)((r0 + u) * 64 + lane);
+                m += __popcll(mk);
+            }
+        }
+    }
+    if (m > sparse_max) return tap_gather(H, tp, tid);   // wave-uniform
+    if (m == 0) return 0.0;
+    // lane i <- entry i (behind the last entry: a cell no sample reaches)
+    const int ci = lane < m ? (int)list[lane] : 0x7fff;
+    const double gi = Hw[lane < m ? ci : 0];
+    const int g_lo = (int)(u32)__double_as_longlong(gi), g_hi = (int)(u32)((u64)__double_as_longlong(gi) >> 32);
+    const u32 A = (u32)((lane + tlen - 1) * dt + (dt - 1));
+    double acc = 0.0;
+    for (int i0 = 0; i0 < m; i0 += 4) {                  // four entries in flight (one LDS round trip per four)
+        double w[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = (i0 + u) & 63;                 // (entries behind the last one carry the cell 0x7fff: the zero tap for every lane)
+            const int c = __builtin_amdgcn_readlane(ci, i);
+            g[u] = __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane(g_hi, i) << 32) | (u32)__builtin_amdgcn_readlane(g_lo, i)));
+            u32 idx = A - (u32)c;
+            idx = idx < (u32)(tlen * dt) ? idx : (u32)(tlen * dt);
+            w[u] = W2[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const double prod = w[u] * g[u]; acc = acc + prod; }
+    }
+    return acc;
+}
+
 template <int TPB, bool RESIDENT>
 __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateArg tp)
 {
@@ -448,11 +525,13 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     constexpr int HROWS = TPB + tlen - 1;
     double *H = (double *)smem;                           // [HROWS][dt]: merged gain per (start bin, ns remainder)
     double *red = H + (size_t)HROWS * dt;                 // [TPB / 64][8]
-    u32 *wsum = (u32 *)(red + 8 * (TPB / 64));
+    u32 *wsum = (u32 *)(red + 8 * (TPB / 64));            // [16]
+    double *W2 = (double *)(wsum + 16);                   // [TAP_W2_LEN] taps by time difference + the waves' records (tap_block)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     // pulse.py:32 current_max, indexed per photon: from LDS (indexing the kernarg copy per lane becomes a global load)
     __shared__ double s_cmax[WFS_DT];
     if (tid < WFS_DT) s_cmax[tid] = d.current_max[tid];
+    tap_w2_fill(W2, d.templates, tid, TPB);
 
     // grid = tiles x a.n_win: workgroup `win` of a tile takes the chunks win, win + n_win, ... (n_win = 1: the resident form)
     const i64 tidx = blockIdx.x / a.n_win;
@@ -688,7 +767,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         // k are live in SGPRs.
         const bool act = c0 + tid < n_live;
         if (__any(act)) {                                  // wave-uniform
-            const double c = tap_gather(H, tp, tid);
+            const double c = tap_block(H, W2, tp, tid, a.sparse_max, HROWS * dt);
             if (act) {
                 const i64 sx = lead + c0 + tid;            // sample of the tile
                 if (a.currents) a.currents[a.cur_off[tidx] + sx] = c;

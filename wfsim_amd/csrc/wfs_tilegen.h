@@ -50,6 +50,7 @@ struct FuseArgs {
     FTile *tiles;         // work list of the tiles with photons
     i32 *tbuf;            // tile sample buffers
     PhotonRec *ph; i32 keep_ph;      // debug: the photons are also stored, tile by tile, in generation order
+    i32 sparse_max;       // occupied cells up to which a wave walks them instead of the dense gather (tap_block)
     i64 *scal;            // [1] error flag, [23] ints of all tile buffers, [24] photons of all tiles, [25] listed tiles
 };
 
@@ -179,16 +180,18 @@ __global__ __launch_bounds__(256) void k_tile_counts(WfsDev d, FuseArgs f)
 // 256 samples, per-pulse rounding), written to the tile's own sample buffer.  !FULL: generation only (debug modes: the
 // photons go to the photon array and the ordinary pulse kernels take the tile from there).
 template <bool FULL>
-__global__ __launch_bounds__(256) void k_s2_tile(WfsDev d, FuseArgs f, TemplateArg tp)
+__global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, TemplateArg tp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TPB = 256, dt = WFS_DT, tlen = 22, HROWS = TPB + tlen - 1, NPH = 8, NW = TPB / 64;
     double *H = (double *)smem;                           // [HROWS][dt]; before the chunks: the channel's SPE row, then the truth partial sums
     u32 *wsum = (u32 *)(H + (size_t)HROWS * dt);          // [4 * NW]
+    double *W2 = (double *)(wsum + 4 * NW);               // [TAP_W2_LEN] taps by time difference (tap_block)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     __shared__ double s_cmax[WFS_DT];
     __shared__ i32 s_mm[2 * NW];
     if (tid < WFS_DT) s_cmax[tid] = d.current_max[tid];
+    if (FULL) tap_w2_fill(W2, d.templates, tid, TPB);
     const FTile ft = f.tiles[blockIdx.x];                 // block-uniform: scalar loads
     const i32 n = ft.n;
     const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? ft.ch : 0) * 2001;
@@ -236,10 +239,7 @@ __global__ __launch_bounds__(256) void k_s2_tile(WfsDev d, FuseArgs f, TemplateA
         if (v) { tmin = t < tmin ? t : tmin; tmax = t > tmax ? t : tmax; ndpe += (code[k] >> 16) != 0; }
         else code[k] = 0;
     }
-    for (int o = 32; o > 0; o >>= 1) {
-        const i32 a = __shfl_xor(tmin, o, 64), b = __shfl_xor(tmax, o, 64);
-        tmin = a < tmin ? a : tmin; tmax = b > tmax ? b : tmax; ndpe += __shfl_xor(ndpe, o, 64);
-    }
+    tmin = wave_min(tmin); tmax = wave_max(tmax); ndpe = wave_sum(ndpe);
     if (lane == 0) { s_mm[2 * wid] = tmin; s_mm[2 * wid + 1] = tmax; wsum[wid] = (u32)ndpe; }
     if (FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the SPE row has landed in LDS
     __syncthreads();
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_s2_tile(WfsDev d, FuseArgs f, TemplateA
     const int lead = d.store_before + d.samples_before;
     const i64 L = nb + lead + d.store_after + d.samples_after;
     const i64 n_live = nb + (tlen - 1);
-    if (L + 2 * (i64)d.tw > (i64)ft.cap) { if (tid == 0) atomicMax(&f.scal[1], (i64)3); return; }      // (cannot happen: the buffer was sized from the bounds)
+    if (nb <= 0 || L + 2 * (i64)d.tw > (i64)ft.cap) { if (tid == 0) atomicMax(&f.scal[1], (i64)3); return; }      // (cannot happen: the buffer was sized from the bounds)
     i32 *tb = f.tbuf + ft.boff;                           // [tw zeros][L samples][tw zeros]
     const double G = ft.G, thr = ft.thr;
     i32 r_ns[NPH]; double r_gain[NPH];
@@ -304,17 +304,12 @@ __global__ __launch_bounds__(256) void k_s2_tile(WfsDev d, FuseArgs f, TemplateA
             }
         }
         if (f.tile_truth) {
-            double *S = H;                                 // [4][TPB]
-            S[0 * TPB + tid] = sg; S[1 * TPB + tid] = sgt; S[2 * TPB + tid] = st; S[3 * TPB + tid] = st2;
-            if (lane == 0) { wsum[NW + wid * 2] = c_trig; wsum[NW + wid * 2 + 1] = c_trig_dpe; }
+            // wave sums on the DPP path, then the four waves in a fixed order
+            sg = wave_sum(sg); sgt = wave_sum(sgt); st = wave_sum(st); st2 = wave_sum(st2);
+            double *S = H;                                 // [NW][4]
+            if (lane == 0) { S[wid * 4 + 0] = sg; S[wid * 4 + 1] = sgt; S[wid * 4 + 2] = st; S[wid * 4 + 3] = st2; wsum[NW + wid * 2] = c_trig; wsum[NW + wid * 2 + 1] = c_trig_dpe; }
             __syncthreads();
-            for (int q = wid; q < 4; q += NW) {
-                double x = 0;
-#pragma unroll
-                for (int j = 0; j < NW; j++) x += S[q * TPB + j * 64 + lane];
-                for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-                if (lane == 0) f.tile_truth[(i64)ft.tile * 8 + 4 + q] = x;
-            }
+            if (tid < 4) f.tile_truth[(i64)ft.tile * 8 + 4 + tid] = (S[0 * 4 + tid] + S[1 * 4 + tid]) + (S[2 * 4 + tid] + S[3 * 4 + tid]);
             if (tid == 0) {
                 u32 t2 = 0, t3 = 0;
                 for (int w = 0; w < NW; w++) { t2 += wsum[NW + w * 2]; t3 += wsum[NW + w * 2 + 1]; }
@@ -333,7 +328,10 @@ __global__ __launch_bounds__(256) void k_s2_tile(WfsDev d, FuseArgs f, TemplateA
     for (i64 c0 = 0; c0 < n_live; c0 += TPB) {
         const i64 b_lo = c0 - (tlen - 1);                  // start bin of H row 0
         __syncthreads();
-        for (int i = tid; i < HROWS * dt; i += TPB) H[i] = 0.0;
+        // (the rows this chunk's live samples can see: nothing behind them is read, tap_block is told)
+        const i64 rows = n_live - c0 + (tlen - 1);
+        const int ncell = (int)(rows < HROWS ? rows : HROWS) * dt;
+        for (int i = tid; i < ncell; i += TPB) H[i] = 0.0;
         __syncthreads();
         STAMP(d, 19);
         const i32 ns_lo = (i32)b_lo * dt, ns_hi = ns_lo + HROWS * dt;
@@ -346,7 +344,7 @@ __global__ __launch_bounds__(256) void k_s2_tile(WfsDev d, FuseArgs f, TemplateA
         STAMP(d, 20);
         const bool act = c0 + tid < n_live;
         if (__any(act)) {                                  // wave-uniform
-            const double c = tap_gather(H, tp, tid);
+            const double c = tap_block(H, W2, tp, tid, f.sparse_max, ncell);
             if (act) tb[d.tw + lead + c0 + tid] = (i32)(-(i64)rint(c * d.c2a));        // rawdata.py:236, np.around = round half to even
         }
         STAMP(d, 21);
