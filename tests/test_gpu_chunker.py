@@ -51,9 +51,8 @@ def _assert_same(a, b):
                 continue
             assert len(c0[k]) == len(c1[k])
             for f in c0[k].dtype.names:         # raw_area sums f64 contributions with atomics: last-bit differences between two runs
-                if 'n_pe_trigger' in f:         # depends on the photon order inside a channel (pulse.py:255): not reproducible run to run
-                    assert np.allclose(c0[k][f], c1[k][f], rtol=0.05, atol=5), f
-                elif c0[k][f].dtype.kind == 'f':
+                # (n_pe_trigger depends on the photon order inside a channel, pulse.py:255: generation order on the device, so equal)
+                if c0[k][f].dtype.kind == 'f' and 'n_pe_trigger' not in f:
                     assert np.allclose(c0[k][f], c1[k][f], rtol=1e-12, atol=0, equal_nan=True), f
                 else:
                     assert np.array_equal(c0[k][f], c1[k][f]), f

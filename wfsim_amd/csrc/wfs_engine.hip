@@ -49,7 +49,7 @@ struct wfs_handle {
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0, blk_desc;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles, wave_tiles;
-    DevBuf ph, ph_gain;
+    DevBuf ph, ph_gain, ph_idx, ap_key, order_list, ins_sbase;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off;
@@ -420,6 +420,7 @@ try {
     hipFuncSetAttribute((const void *)k_photon_fill<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_tile_order_big, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_s2_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_s2_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -452,7 +453,7 @@ try {
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal,
-        &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
+        &h->ph_idx, &h->ap_key, &h->order_list, &h->ins_sbase, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft, &h->ins_sigr, &h->ins_siga, &h->diff_row_ins, &h->diff_row_id, &h->diff_pre}) if (b->p) hipFree(b->p);
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
@@ -1209,6 +1210,7 @@ static int run_generation(wfs_handle *h)
     const bool ap_on = h->ap_active;
     const i64 ap_cap = ap_on ? P / 8 + 65536 : 0;
     TRY(ensure(h, h->ph, (size_t)(P + h->p_fused + ap_cap) * 8));
+    TRY(ensure(h, h->ph_idx, (size_t)(P + h->p_fused + ap_cap) * 4)); g.ph_idx = h->ph_idx.as<u32>();
     g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
     g.tile_tmax = h->tile_tmax.as<i32>(); g.ph = h->ph.as<PhotonRec>();
     g.tile_off = h->tile_off.as<i64>();
@@ -1221,12 +1223,15 @@ static int run_generation(wfs_handle *h)
                                  s.delay_sorted, s.amp_sorted};
         }
         TRY(ensure(h, h->ap_ins, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_ch, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_t, (size_t)ap_cap * 4));
-        TRY(ensure(h, h->ap_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ph_gain, (size_t)ap_cap * 8));
+        TRY(ensure(h, h->ap_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ph_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ap_key, (size_t)ap_cap * 4));
+        ap.ap_key = h->ap_key.as<u32>();
         ap.cap = ap_cap; ap.ap_ins = h->ap_ins.as<i32>(); ap.ap_ch = h->ap_ch.as<i32>(); ap.ap_t = h->ap_t.as<i32>(); ap.ap_gain = h->ap_gain.as<double>();
         ap.count = h->scal.as<i64>() + 13;
     }
     TRY(ensure(h, h->ins_ph0, (size_t)(N + 1) * 8)); g.ins_ph0 = h->ins_ph0.as<i64>();
     { Timer t(h, "k_ins_ph0"); hipLaunchKernelGGL(k_ins_ph0, dim3(nblocks(N + 1, 256)), dim3(256), 0, h->stream, g); }
+    TRY(ensure(h, h->ins_sbase, (size_t)N * 4)); g.ins_sbase = h->ins_sbase.as<u32>();
+    { Timer t(h, "k_set_bases"); hipLaunchKernelGGL(k_set_bases, dim3(nblocks(h->n_psets, 256)), dim3(256), 0, h->stream, g); }
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
         g.n_blocks = nb;
@@ -1282,6 +1287,20 @@ static int run_generation(wfs_handle *h)
         TRY(read_scal(h));
         if (h->h_scal[13] > ap_cap) return h->fail(WFS_E_CAPACITY, "more PMT afterpulse photons than 1/8 of the primary photons: afterpulse probability unreasonably high");
         h->n_ap_photons = h->h_scal[13];
+    }
+    if (P > 0 || ap_on) {
+        // every tile of the block generator into generation order (k_tile_order): the order the reference's Pulse call sees
+        TRY(ensure(h, h->order_list, (size_t)T * 4));
+        OrderArgs oa{T, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->ph.as<PhotonRec>(), h->ph_idx.as<u32>(),
+                     ap_on ? h->ph_gain.as<double>() : nullptr, P + h->p_fused, h->order_list.as<i32>(), h->scal.as<i64>(),
+                     (h->fuse_on && h->n_fused_tiles > 0) ? h->ins_fused.as<i32>() : nullptr, d.n_tpc};
+        { Timer t(h, "k_tile_order"); hipLaunchKernelGGL(k_tile_order, dim3(nblocks(T, 4)), dim3(256), 0, h->stream, oa); }
+        TRY(read_scal(h));
+        const i64 n_big = h->h_scal[28];
+        if (n_big > 0) {
+            Timer t(h, "k_tile_order_big");
+            hipLaunchKernelGGL(k_tile_order_big, dim3((unsigned)n_big), dim3(256), (size_t)TILE_ORDER_MAX * 24, h->stream, oa);
+        }
     }
     h->gen_args = g;
     return WFS_OK;

@@ -1467,7 +1467,8 @@ struct __attribute__((aligned(64))) BlockDesc {
     i32 set, row;         // pulse set, channel CDF row
     u32 gid, eb, jbase;   // Philox coordinates: instruction id, emitter base, emitter id of e_lo
     i32 is_s2;
-    i32 pad[2];
+    u32 sbase;            // photons of the instructions in front of this one in its pulse set (order keys count through the set)
+    i32 pad;
 };
 
 struct GenArgs {
@@ -1487,6 +1488,9 @@ struct GenArgs {
     const double *pois_cdf; const i32 *pois_kmin;     // [n_ins][POIS_W] cumulative Poisson table of the instruction's secondary gain, first k (-1: PTRS, -2: gain <= 0)
     i32 *tile_count; const i64 *tile_off; i32 *tile_cursor; i32 *tile_tmin, *tile_tmax;
     PhotonRec *ph;
+    u32 *ph_idx;                  // [photons] order key of every stored photon: its index among its pulse set's photons, instruction by
+                                  // instruction (afterpulses: element << 29 | key of the parent) -- k_tile_order sorts every tile by it
+    u32 *ins_sbase;               // [n_ins] photons of the instructions in front of this one in its pulse set (k_set_bases)
     i64 n_blocks;
     i64 xcd_chunk;                // XCD x (workgroup id % 8) walks the photon blocks [x * xcd_chunk, (x + 1) * xcd_chunk) in order
     i32 *eblk_ins;                // [ceil(n_emitters / 256) + 1] instruction of the first emitter of every block of k_s2_electrons
@@ -1760,9 +1764,10 @@ struct ApArgs {
     ApElemDev el[WFS_MAX_AP];
     i64 cap;                        // capacity of the staging list
     i32 *ap_ins; i32 *ap_ch; i32 *ap_t; double *ap_gain;     // [cap] instruction, channel, ns relative to the instruction, gain
+    u32 *ap_key;                    // [cap] order key: element << 29 | index of the parent photon among its instruction's photons
     i64 *count;                     // number of staged afterpulse photons (device scalar)
 };
-#define AP_STAGE 384               // afterpulse photons a block stages in LDS before it reserves space in the global list
+#define AP_STAGE 384               // afterpulse photons a block stages in LDS before it reserves space in the global list (24 bytes each)
 
 // first and last emitter of every photon block: one bisection per thread, all in flight together (a block doing
 // its own two bisections serially costs ~20 us of dependent HBM latency before its 2048 photons can start)
@@ -1788,7 +1793,7 @@ __global__ void k_block_emitters(GenArgs a)
     if (single) {
         bd.ins = i0; bd.e_lo = e_lo; bd.nwin = (i32)(e_hi - e_lo + 2); bd.set = a.ins_set[i0]; bd.itime = a.set_t0[bd.set];
         bd.R0 = p0 - a.ins_ph0[i0]; bd.row = a.ins_cdfrow[i0]; bd.gid = a.ins_gid[i0]; bd.eb = a.ins_embase[i0];
-        bd.jbase = (u32)(e_lo - a.em_off[i0]) + bd.eb; bd.is_s2 = a.ins_type[i0] != 1;
+        bd.jbase = (u32)(e_lo - a.em_off[i0]) + bd.eb; bd.is_s2 = a.ins_type[i0] != 1; bd.sbase = a.ins_sbase[i0];
     }
     a.blk_desc[b] = bd;
 }
@@ -1798,12 +1803,26 @@ __global__ void k_ins_ph0(GenArgs a)
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i <= a.n_ins) a.ins_ph0[i] = a.em_ph_off[a.em_off[i]];
 }
+// order keys run through a pulse set instruction by instruction (the reference appends the photons of a Pulse call's instructions
+// in that order, s1.py:95-103 / s2.py:107-136): photons in front of every instruction inside its set
+__global__ void k_set_bases(GenArgs a)
+{
+    const i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.n_psets) return;
+    i64 run = 0;
+    for (i64 q = a.set_ins_off[s]; q < a.set_ins_off[s + 1]; q++) {
+        const i32 i = a.set_ins_list[q];
+        if (run > 0xffffffffLL) atomicMax(&a.scal[1], (i64)2);
+        a.ins_sbase[i] = (u32)run;
+        run += a.em_ph_off[a.em_off[i + 1]] - a.em_ph_off[a.em_off[i]];
+    }
+}
 
 // PMT afterpulses of one photon (afterpulse.py:172-249): one uniform pair per element; generated photons are staged in
 // LDS (aps_*) and, past AP_STAGE, appended to the global list directly.
-struct ApStage { i32 *n; double *gain; i32 *ins, *ch, *t; };
+struct ApStage { i32 *n; double *gain; i32 *ins, *ch, *t; u32 *key; };
 __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st,
-                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t)
+                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P)
 {
     for (int e = 0; e < ap.n; e++) {
         const ApElemDev &el = ap.el[e];
@@ -1830,11 +1849,12 @@ __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, c
         i64 tap = (i64)tf - itime;
         if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
         const double gap = d.gains[ch] * amp;
+        const u32 key = ((u32)e << 29) | (P & 0x1fffffffu);        // the reference walks element by element, parent by parent (afterpulse.py:189-207)
         const i32 k = atomicAdd(st.n, 1);
-        if (k < AP_STAGE) { st.ins[k] = ins; st.ch[k] = ch; st.t[k] = (i32)tap; st.gain[k] = gap; }
+        if (k < AP_STAGE) { st.ins[k] = ins; st.ch[k] = ch; st.t[k] = (i32)tap; st.gain[k] = gap; st.key[k] = key; }
         else {
             const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull);
-            if (gk < ap.cap) { ap.ap_ins[gk] = ins; ap.ap_ch[gk] = ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = gap; }
+            if (gk < ap.cap) { ap.ap_ins[gk] = ins; ap.ap_ch[gk] = ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = gap; ap.ap_key[gk] = key; }
         }
     }
 }
@@ -2365,7 +2385,7 @@ __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
 
 // LDS layout of the fill pass (byte offsets; plain integer offsets: a pointer that went through an integer cast loses its
 // LDS address space)
-struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, stage, ap, total; };
+struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, pidx, stage, ap, total; };
 __host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap)
 {
     const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
@@ -2378,9 +2398,10 @@ __host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap
     o.hmax = o.hmin + nch * 4;
     o.hoff = o.hmax + nch * 4;                                // i32[nch]: slot of bucket position 0 of every channel, relative to the set's first photon
     o.chmap = o.hoff + nch * 4;                               // u16[GEN_BLOCK]: channel of every bucket position
-    o.stage = (o.chmap + GEN_BLOCK * 2 + 7) & ~7;             // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
+    o.pidx = o.chmap + GEN_BLOCK * 2;                         // u16[GEN_BLOCK]: block-relative photon index of every bucket position
+    o.stage = (o.pidx + GEN_BLOCK * 2 + 7) & ~7;              // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
     o.ap = o.stage + GEN_BLOCK * 8;                           // afterpulse staging
-    o.total = o.ap + (with_ap ? AP_STAGE * 20 : 0) + 16;
+    o.total = o.ap + (with_ap ? AP_STAGE * 24 : 0) + 16;
     return o;
 }
 
@@ -2397,11 +2418,11 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
     uint2 *T = (uint2 *)(smem + o.T);                        // alias cells of the block's channel row
     i32 *hist = (i32 *)(smem + o.hist), *cur = (i32 *)(smem + o.cur), *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
     i32 *hoff = (i32 *)(smem + o.hoff);
-    unsigned short *chmap = (unsigned short *)(smem + o.chmap);
+    unsigned short *chmap = (unsigned short *)(smem + o.chmap), *pidx = (unsigned short *)(smem + o.pidx);
     PhotonRec *stage = (PhotonRec *)(smem + o.stage);
     __shared__ i32 s_wtmp[TPB / 64];
     ApStage aps;
-    aps.gain = (double *)(smem + o.ap); aps.ins = (i32 *)(smem + o.ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE;
+    aps.gain = (double *)(smem + o.ap); aps.ins = (i32 *)(smem + o.ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE; aps.key = (u32 *)(aps.t + AP_STAGE);
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
     aps.n = &s_apn;
     if (AP && tid == 0) s_apn = 0;
@@ -2499,17 +2520,18 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                     t += (i32)(i64)s1_propagation(a, c >= d.n_top, pzi, pzf, X.x);
                 }
                 if (EXT && gg_lo >= 0) t += (i32)(i64)(gg_time(a, gg_lo, gg_w, word_of(LW, k)) - gg_m);      // s2.py:447-450, the cast of :532
-                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t);
+                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t, bd.sbase + (u32)(bd.R0 + pr));
                 atomicMin(&hmin[c], t); atomicMax(&hmax[c], t);
                 const int pos = hist[c] + atomicAdd(&cur[c], 1);
-                stage[pos] = PhotonRec{t, code}; chmap[pos] = (unsigned short)c;
+                stage[pos] = PhotonRec{t, code}; chmap[pos] = (unsigned short)c; pidx[pos] = (unsigned short)pr;
             }
         }
         STAMP(d, 2);
         __syncthreads();
         STAMP(d, 3);
         // ---- bucket order: neighbouring lanes store photons of the same tile to consecutive addresses
-        for (int i = tid; i < np; i += TPB) out[hoff[chmap[i]] + i] = stage[i];
+        u32 *out_idx = a.ph_idx + set_ph0;
+        for (int i = tid; i < np; i += TPB) { const int at = hoff[chmap[i]] + i; out[at] = stage[i]; out_idx[at] = bd.sbase + (u32)(bd.R0 + pidx[i]); }
         STAMP(d, 4);
         for (int c = tid; c < nch; c += TPB)
             if (hist[c + 1] > hist[c]) { atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]); }
@@ -2535,10 +2557,11 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
             }
             if (EXT && a.gg_inv && a.ins_gg[ins] >= 0) t += (i64)(gg_time(a, a.ins_gg[ins], a.ins_ggw[ins], photon_word(d, id, SITE_LUM)) - gg_mean(a, ins));
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-            if (AP) ap_generate(d, a, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t);
+            if (AP) ap_generate(d, a, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t, a.ins_sbase[ins] + id.P);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
             // photons of multi-instruction blocks take the first slots of their tile (k_block_ranges starts behind them)
-            a.ph[a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1)] = PhotonRec{(i32)t, code};
+            const i64 at = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
+            a.ph[at] = PhotonRec{(i32)t, code}; a.ph_idx[at] = a.ins_sbase[ins] + id.P;
         }
     }
     if (AP) {
@@ -2548,7 +2571,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
         __syncthreads();
         for (int k = tid; k < nst; k += TPB) {
             const i64 gk = s_apbase + k;
-            if (gk < ap.cap) { ap.ap_ins[gk] = aps.ins[k]; ap.ap_ch[gk] = aps.ch[k]; ap.ap_t[gk] = aps.t[k]; ap.ap_gain[gk] = aps.gain[k]; }
+            if (gk < ap.cap) { ap.ap_ins[gk] = aps.ins[k]; ap.ap_ch[gk] = aps.ch[k]; ap.ap_t[gk] = aps.t[k]; ap.ap_gain[gk] = aps.gain[k]; ap.ap_key[gk] = aps.key[k]; }
         }
     }
 }
@@ -2569,8 +2592,83 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
     if (i >= n) return;
     const i64 tile = ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i];
     const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
-    a.ph[pos] = PhotonRec{ap.ap_t[i], 0u}; ph_gain_base[pos] = ap.ap_gain[i];
+    a.ph[pos] = PhotonRec{ap.ap_t[i], 0u}; ph_gain_base[pos] = ap.ap_gain[i]; a.ph_idx[pos] = ap.ap_key[i];
     atomicMin(&a.tile_tmin[tile], ap.ap_t[i]); atomicMax(&a.tile_tmax[tile], ap.ap_t[i]);
+}
+
+// Generation order inside every tile.  The bucketing above leaves the photons of a tile in the order the atomics happened to
+// hand out slots; the reference's Pulse call sees them in channel-sorted GENERATION order (a stable argsort would; the oracle
+// does), and two things depend on that order: the truth quirk that counts the triggered photons among the FIRST n_dpe of the
+// channel slice (pulse.py:255) and the order in which three or more photons of one ns are merged.  Every stored photon carries
+// its order key (ph_idx); this pass sorts each tile by it -- one wave per tile up to 64 photons (bitonic network on key << 6 |
+// lane in registers), tiles up to TILE_ORDER_MAX go to a list and are sorted by a workgroup in LDS; larger ones keep the
+// order they have (documented: n_pe_trigger is then only statistically right).  Explicit gains (afterpulses) move along.
+#define TILE_ORDER_MAX 4096
+struct OrderArgs { i64 n_tiles; const i32 *tile_count; const i64 *tile_off; PhotonRec *ph; u32 *ph_idx; double *ph_gain; i64 gain_first;
+                   i32 *big_list; i64 *scal;         // ph_gain[p - gain_first] for photons p >= gain_first (afterpulses), or nullptr; scal[28] = listed tiles
+                   const i32 *skip_ins; i32 nch; };  // [n_ins] 1: the tiles of this instruction (tile / nch) come from k_s2_tile, already in order (or nullptr)
+__global__ __launch_bounds__(256) void k_tile_order(OrderArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const i64 tile = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= a.n_tiles) return;
+    const i32 n = a.tile_count[tile];
+    if (n < 2) return;                                       // wave-uniform
+    if (a.skip_ins && a.skip_ins[tile / a.nch]) return;
+    if (n > 64) { if (lane == 0 && n <= TILE_ORDER_MAX) a.big_list[atomicAdd((u64 *)&a.scal[28], 1ull)] = (i32)tile; return; }
+    const i64 off = a.tile_off[tile];
+    const bool v = lane < n;
+    const u32 k0 = v ? a.ph_idx[off + lane] : 0xffffffffu;
+    // already in order (the usual case for a handful of photons)?
+    const u32 prev = (u32)__shfl_up((int)k0, 1, 64);
+    if (!__any(v && lane > 0 && prev > k0)) return;
+    const PhotonRec r0 = a.ph[off + (v ? lane : 0)];
+    const bool has_gain = a.ph_gain && off >= a.gain_first;
+    const double g0 = has_gain ? a.ph_gain[off - a.gain_first + (v ? lane : 0)] : 0.0;
+    // rank = number of photons with a smaller key (keys of a tile are distinct)
+    int rank = 0;
+    for (int j = 0; j < n; j++) rank += (u32)__builtin_amdgcn_readlane((int)k0, j) < k0;
+    if (v) {
+        a.ph[off + rank] = r0; a.ph_idx[off + rank] = k0;
+        if (has_gain) a.ph_gain[off - a.gain_first + rank] = g0;
+    }
+}
+// tiles of 65 .. TILE_ORDER_MAX photons: (key, position) pairs sorted in LDS (bitonic), then the records move
+__global__ __launch_bounds__(256) void k_tile_order_big(OrderArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u64 *key = (u64 *)smem;                                  // [npow2] key << 32 | position
+    const i64 tile = a.big_list[blockIdx.x];
+    const i32 n = a.tile_count[tile]; const i64 off = a.tile_off[tile];
+    int np2 = 128; while (np2 < n) np2 <<= 1;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < np2; i += 256) key[i] = i < n ? ((u64)a.ph_idx[off + i] << 32) | (u32)i : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < np2; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const u64 x = key[i], y = key[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { key[i] = y; key[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    // gather through registers in rounds of 256 (source positions are arbitrary: all loads of a round first, then a barrier, then the stores)
+    const bool has_gain = a.ph_gain && off >= a.gain_first;
+    PhotonRec *ph = a.ph + off; u32 *idx = a.ph_idx + off; double *pg = has_gain ? a.ph_gain + (off - a.gain_first) : nullptr;
+    // (in place: every record is read before any is written -- two passes over LDS-held copies would need 12 bytes per photon more)
+    PhotonRec *cr = (PhotonRec *)(key + np2);                 // [n] copies
+    double *cg = (double *)(cr + np2);
+    for (int i = tid; i < n; i += 256) { cr[i] = ph[i]; if (has_gain) cg[i] = pg[i]; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int src = (int)(u32)key[i];
+        ph[i] = cr[src]; idx[i] = (u32)(key[i] >> 32);
+        if (has_gain) pg[i] = cg[src];
+    }
 }
 
 // Arrival times of chosen photons, addressed by their index in GENERATION order (emitter by emitter, the order of
