@@ -79,7 +79,7 @@ typedef struct orc_session_s {
     const int16_t *noise;        /* [noise_len][noise_channels] */
     const double *noise_f;       /* float noise (orc_set_noise_float): the truncated sum is stored, rawdata.py:436 */
     orc_ap_element ap[8];
-    double current_max[10];
+    double current_max[16];      /* per ns remainder: sample_duration <= 16 ns */
 
     /* pulse cache (rawdata.py:180-190) */
     vec_i32 pl_ch, pl_runset; vec_i64 pl_left, pl_right, pl_cur_off, pl_nph; vec_f64 cur;

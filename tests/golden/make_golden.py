@@ -457,6 +457,26 @@ def fixture_chain_params(ref):
         json.dump({k: (v.tolist() if isinstance(v, np.ndarray) else v) for k, v in ov.items()}, f)
 
 
+def geometry_overrides():
+    """chain I: a digitiser with another sample duration and pulse template length (pulse.py:146-187 builds the templates for
+    whatever the config says): 5 ns samples, 3 + 37 template samples, other stored / trigger windows"""
+    return dict(sample_duration=5, samples_before_pulse_center=3, samples_after_pulse_center=37,
+                samples_to_store_before=30, samples_to_store_after=40, trigger_window=40)
+
+
+def fixture_chain_geometry(ref):
+    pat = dict(s1=SyntheticPatternMap(14e-5, 30.0, 18.0, 0.15), s2=SyntheticPatternMap(30e-5, 9.0, 25.0, 0.02))
+    MS = 1_000_000
+    ov = geometry_overrides()
+    rows = [dict(type=1, time=MS, x=0, y=0, z=-40, amp=3000), dict(type=2, time=MS, x=4, y=-3, z=-40, amp=200),
+            dict(type=1, time=3 * MS, x=20, y=0, z=-5, amp=9000), dict(type=1, time=3 * MS + 300, x=-5, y=5, z=-15, amp=700),
+            dict(type=2, time=4 * MS, x=-12, y=30, z=-80, amp=50)]
+    ref.load_resource._cached_configs.clear()
+    np.savez_compressed(HERE + '/chain_geometry.npz', **run_chain(ref, base_config(**ov), make_instructions(rows), 707, pat, store_currents=True))
+    with open(HERE + '/chain_geometry_config.json', 'w') as f:
+        json.dump(ov, f)
+
+
 def fixture_chain_runsets(ref):
     """chain G: save_full_truth=False -- S1s within 100 ns and S2s within int(0.2 / v) ns of each other share one
     Pulse call and one truth row (rawdata.py:106-127, 364-372)"""
@@ -1059,6 +1079,8 @@ if __name__ == '__main__':
         fixture_chains(ref)
     if 'chains' in which or 'params' in which:
         fixture_chain_params(ref)
+    if 'chains' in which or 'geometry' in which:
+        fixture_chain_geometry(ref)
     if 'chains' in which or 'runsets' in which:
         fixture_chain_runsets(ref)
     if 'chains' in which or 'ele_ap' in which:

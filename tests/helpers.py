@@ -26,6 +26,12 @@ def params_chain_config():
     return xenonnt_test_config(**ov)
 
 
+def geometry_chain_config():
+    """the config of golden chain I (make_golden.py: geometry_overrides): 5 ns samples, 3 + 37 template samples"""
+    import json
+    return xenonnt_test_config(**json.load(open(os.path.join(GOLDEN, 'chain_geometry_config.json'))))
+
+
 def host_tables(config, resource=None):
     resource = resource or Resource(config)
     thr_truth, thr_zle = T.thresholds(config, N_ROWS)

@@ -81,10 +81,11 @@ def _check_chain(name, config, force_dense=False, noise_offsets=False):
     n_expected = np.ceil((d['zle_right'] - d['zle_left'] + 1) / 110).astype(int)
     assert len(rec) == n_expected.sum()
     first = np.concatenate([[0], np.cumsum(n_expected)[:-1]])
-    assert np.array_equal(rec['time'][first], 10 * d['zle_left'])
+    dt = int(config.get('sample_duration', 10))
+    assert np.array_equal(rec['time'][first], dt * d['zle_left'])
     assert np.array_equal(rec['channel'][first], d['zle_ch'])
     assert np.array_equal(rec['pulse_length'][first], d['zle_right'] - d['zle_left'] + 1)
-    assert np.all(rec['dt'] == 10) and np.all(rec['baseline'] == 0)
+    assert np.all(rec['dt'] == dt) and np.all(rec['baseline'] == 0)
     return d, eng
 
 
@@ -115,6 +116,22 @@ def test_chain_nondefault_parameters(force_dense):
     """chain F: non-default trigger window / stored samples / thresholds / baseline / rext, non-uniform gains, dead PMTs"""
     from tests.helpers import params_chain_config
     _check_chain('chain_params.npz', params_chain_config(), force_dense=force_dense)
+
+
+def test_chain_other_digitiser_geometry():
+    """chain I (made by the reference with sample_duration 5 ns and 3 + 37 template samples): every tile goes through
+    k_pulse_generic; currents bit-exact, windows, rows, ZLE, records exact; the records equal the oracle's bytes; and the
+    photon generators (block generator, generic geometry) agree with the oracle photon by photon"""
+    from tests.helpers import geometry_chain_config
+    cfg = geometry_chain_config()
+    d, eng = _check_chain('chain_geometry.npz', cfg)
+    orc = make_oracle(cfg)
+    replay_chain_on_oracle(orc, d)
+    assert eng.records().tobytes() == orc.pack_records().tobytes()
+    from tests.test_gpu_generation import _instructions, _run_both, _compare, MS
+    rows = [dict(type=1, time=MS * (i + 1), x=3, y=-2, z=-30, amp=2500) for i in range(3)]
+    rows += [dict(type=2, time=MS * (i + 1), x=3, y=-2, z=-30, amp=120) for i in range(3)]
+    _compare(*_run_both(cfg, _instructions(rows)))
 
 
 def test_chain_run_sets_and_electron_afterpulses():

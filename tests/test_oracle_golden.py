@@ -97,6 +97,19 @@ def test_chain_nondefault_parameters():
         assert np.array_equal(r['zl_' + k], d['zle_' + k]), k
 
 
+def test_chain_other_digitiser_geometry():
+    """chain I: sample_duration 5 ns, templates of 3 + 37 samples (pulse.py:146-187), other stored / trigger windows: currents
+    bit-exact, rows and ZLE exact"""
+    from tests.helpers import geometry_chain_config
+    cfg = geometry_chain_config()
+    from wfsim_amd.config import kernel_params
+    assert (kernel_params(cfg)['dt'], kernel_params(cfg)['tlen']) == (5, 40)
+    d, r, orc = _check_chain('chain_geometry.npz', cfg)
+    assert np.array_equal(r['row_data'], d['row_data'])
+    for k in ['ch', 'left', 'right', 'data']:
+        assert np.array_equal(r['zl_' + k], d['zle_' + k]), k
+
+
 def test_chain_pmt_afterpulse_pulses():
     # afterpulse photons are injected with their pre-assigned gains (Pulse.__call__ branch pulse.py:105-107)
     d, r, orc = _check_chain('chain_pmt_ap.npz', xenonnt_test_config())

@@ -64,13 +64,16 @@ def tile_local_generation(config):
     config['tile_local_generation'], default on).  Off wherever something needs the photons of an instruction in generation order
     or electron by electron: the electron-afterpulse pre-pass (photon counts and picked photon times per parent S2), Pulse calls
     that cover several instructions (save_full_truth=False) and the transverse-diffusion field maps (the pattern of an instruction
-    is then known only after its electrons).  The per-instruction conditions (s2_gain_spread == 0, PMT afterpulses off, default
+    is then known only after its electrons) and any digitiser geometry other than 10 ns samples / 22-sample templates (the fused
+    kernel is specialised for it).  The per-instruction conditions (s2_gain_spread == 0, PMT afterpulses off, default
     delay table, tile size) are checked where the instructions are: wfs_tilegen.h fuse_eligible and the oracle's twin."""
     sw = afterpulse_switches(config)
     transverse_maps = (config.get('diffusion_constant_transverse', 0) > 0
                        and config.get('enable_field_dependencies', {}).get('diffusion_transverse_map', False))
+    tpc_digitiser = (int(config.get('sample_duration', 10)) == 10
+                     and int(config.get('samples_before_pulse_center', 2)) + int(config.get('samples_after_pulse_center', 20)) == 22)
     return bool(config.get('tile_local_generation', True) and not sw['electron'] and not sw['gate']
-                and config.get('save_full_truth', True) and not transverse_maps)
+                and config.get('save_full_truth', True) and not transverse_maps and tpc_digitiser)
 
 
 def kernel_params(config):

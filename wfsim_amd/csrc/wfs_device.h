@@ -177,7 +177,7 @@ struct WfsDev {
     unsigned long long *stamps;                // -DWFS_STAMPS builds only: per-phase cycle sums of the instrumented kernels (nullptr otherwise)
     u64 thr_dpe;                               // Bernoulli threshold on a 32-bit word: floor(p * 2^32)
     double dpe_inv;                            // 2000 / thr_dpe
-    double current_max[10];
+    double current_max[16];                    // pulse.py:32, per ns remainder (sample_duration <= 16 ns)
     AliasTab tab_tts, tab_s1, tab_s2;          // alias tables of integer delays: transit time alone, all terms of an S1 / S2 photon
     // tables
     const double *templates, *spe, *gains, *thr_truth, *lum_x, *lum_t;

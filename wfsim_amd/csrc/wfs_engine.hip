@@ -1,6 +1,7 @@
 // wfs_engine.hip -- host side of libwfsim_amd.so: the C ABI of include/wfsim_amd.h, device memory arenas,
 // stage orchestration on one HIP stream.  gfx950 (MI355X) only.
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include "wfs_kernels.h"
 #include "wfs_tilegen.h"
 #include "../../include/wfsim_amd.h"
@@ -68,7 +69,8 @@ struct wfs_handle {
     i64 n_active_tiles = 0, n_tiny_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, n_wave_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
-    double h_templates[WFS_DT * 22] = {0};
+    std::vector<double> h_templates;      // [dt][tlen]
+    bool generic_geom = false;            // sample_duration / template length other than 10 ns / 22 samples: k_pulse_generic for every tile
     std::vector<double> h_gains;
     i64 zero64 = 0;
     DevBuf tt_alias[6];
@@ -389,13 +391,16 @@ int wfs_device_count(int *n) try { return hipGetDeviceCount(n) == hipSuccess ? W
 int wfs_create(const wfs_config *cfg, int device, wfs_handle **out)
 try {
     if (!cfg || !out) return WFS_E_INVALID;
-    if (cfg->n_tpc <= 0 || cfg->n_tpc > WFS_MAX_CH || cfg->dt != WFS_DT || cfg->tlen != 22) return WFS_E_INVALID;   // kernels are specialised for 10 ns samples and 22-tap templates
+    // (the fast kernels are specialised for 10 ns samples and 22-tap templates; any other geometry runs through k_pulse_generic)
+    if (cfg->n_tpc <= 0 || cfg->n_tpc > WFS_MAX_CH || cfg->dt < 1 || cfg->dt > WFS_MAX_DT || cfg->tlen < 1 || cfg->tlen > WFS_MAX_TLEN
+        || cfg->samples_before + cfg->samples_after != cfg->tlen) return WFS_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return WFS_E_HIP;      // fail loudly: no CPU fallback
     if (device < 0 || device >= ndev) return WFS_E_INVALID;
     if (hipSetDevice(device) != hipSuccess) return WFS_E_HIP;
     wfs_handle *h = new wfs_handle();
     h->cfg = *cfg; h->device = device;
+    h->generic_geom = cfg->dt != WFS_DT || cfg->tlen != 22;
     { hipDeviceProp_t prop; h->n_cus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256; }
     memset(&h->dev, 0, sizeof(h->dev));
     if (hipStreamCreate(&h->stream) != hipSuccess) { delete h; return WFS_E_HIP; }
@@ -421,6 +426,7 @@ try {
     hipFuncSetAttribute((const void *)k_photon_fill<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_tile_order_big, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_pulse_generic<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipFuncSetAttribute((const void *)k_s2_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_s2_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
@@ -549,7 +555,7 @@ try {
     }
     d.templates = h->t_templates.as<double>(); d.spe = h->t_spe.as<double>(); d.n_spe = n_spe; d.gains = h->t_gains.as<double>();
     d.thr_truth = h->t_thr_truth.as<double>(); d.thr_zle = h->t_thr_zle.as<i64>(); d.lum_x = h->t_lumx.as<double>(); d.lum_t = h->t_lumt.as<double>();
-    memcpy(h->h_templates, templates, sizeof(h->h_templates));
+    h->h_templates.assign(templates, templates + (size_t)c.dt * c.tlen);
     h->h_gains.assign(gains, gains + c.n_tpc);
     for (int r = 0; r < c.dt; r++) {                       // pulse.py:32 current_max
         double m = templates[r * c.tlen];
@@ -1145,7 +1151,7 @@ static int run_generation(wfs_handle *h)
     // tile-local generation (wfs_tilegen.h): which instructions take it is decided before the electrons are drawn -- theirs get no
     // photon numbers.  Debug modes that need the per-photon arrays (currents, generation only) run the generation half alone.
     const bool ap_cfg = h->ap_active;
-    h->fuse_on = h->cfg.tile_gen && h->any_s2 && !ext && !ap_cfg && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
+    h->fuse_on = h->cfg.tile_gen && !h->generic_geom && h->any_s2 && !ext && !ap_cfg && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
     h->fuse_full = h->fuse_on && !(h->keep_currents & 5);
     h->n_fused_tiles = 0; h->p_fused = 0;
     FuseArgs f{};
@@ -1346,7 +1352,7 @@ try {
     ga.cl_end = h->cl_end.as<i64>(); ga.cl_group = h->cl_group.as<i32>(); ga.grp_lo = h->grp_lo.as<i64>(); ga.grp_hi = h->grp_hi.as<i64>();
     ga.grp_left = h->grp_left.as<i64>(); ga.grp_right = h->grp_right.as<i64>(); ga.grp_ixrand = h->grp_ixrand.as<i64>(); ga.grp_gid = h->grp_gid.as<u32>();
     ga.row_lo = h->row_lo.as<i64>(); ga.row_hi = h->row_hi.as<i64>(); ga.acc_len = h->acc_len.as<i32>(); ga.itv_cap = h->itv_cap.as<i32>();
-    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.sparse_tiles = h->sparse_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.wave_tiles = h->wave_tiles.as<i32>(); ga.force_dense = (h->keep_currents & 2) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
+    ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.sparse_tiles = h->sparse_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.wave_tiles = h->wave_tiles.as<i32>(); ga.force_dense = ((h->keep_currents & 2) || h->generic_geom) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
     ga.noise_override = h->n_noise_override ? h->noise_override.as<i64>() : nullptr; ga.n_noise_override = h->n_noise_override;
     const bool tiles_done = !h->injected && !h->optical && h->fuse_full && h->n_fused_tiles > 0;      // pulses made by k_s2_tile (wfs_tilegen.h)
     if (tiles_done) {
@@ -1450,7 +1456,16 @@ try {
         if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_sparse<64>), dim3((unsigned)h->n_sparse_tiles), dim3(64), lds, h->stream, d, ps);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_sparse<256>), dim3((unsigned)h->n_sparse_tiles), dim3(256), lds, h->stream, d, ps);
     }
-    if (h->n_dense_tiles > 0) {
+    if (h->n_dense_tiles > 0 && h->generic_geom) {        // any digitiser geometry: one kernel for every tile
+        PulseArgs pd = pa;
+        pd.desc = h->tile_desc.as<TileDesc>() + h->n_tiny_tiles + h->n_sparse_tiles;
+        if (pd.cur_off) pd.cur_off += h->n_tiny_tiles + h->n_sparse_tiles;
+        size_t lds = (size_t)(256 + d.tlen - 1) * d.dt * 8 + (size_t)d.dt * d.tlen * 8 + 4 * 8 * 8 + 64;
+        lds = (lds + 15) / 16 * 16;
+        if (lds > 128 * 1024) return h->fail(WFS_E_CAPACITY, "sample_duration x template length too large for the LDS tables of k_pulse_generic");
+        Timer t(h, "k_pulse_generic");
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_generic<256>), dim3((unsigned)h->n_dense_tiles), dim3(256), lds, h->stream, d, pd);
+    } else if (h->n_dense_tiles > 0) {
         PulseArgs pd = pa;
         pd.active_tiles = h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles;
         pd.desc = h->tile_desc.as<TileDesc>() + h->n_tiny_tiles + h->n_sparse_tiles;
@@ -1465,7 +1480,7 @@ try {
         pd.n_win = (h->max_tile_dense <= (i64)tpb * DENSE_PPT) ? 1 : (int)std::min<i64>(NWIN_MAX, std::max<i64>(1, (n_live_max + tpb - 1) / tpb));
         pd.W = tpb;
         TemplateArg tp;
-        for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
+        for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[(size_t)r * 22 + k];
         size_t lds = (size_t)(tpb + d.tlen - 1) * d.dt * 8 + (size_t)8 * (tpb / 64) * 8 + 64 + TAP_LDS_BYTES(256) + 16;
         lds = (lds + 15) / 16 * 16;
         pd.sparse_max = (h->keep_currents & 2) ? -1 : h->tap_sparse_max;      // (force_dense: every wave takes the dense gather)
@@ -1524,7 +1539,11 @@ try {
         za.row_dbg = h->row_dbg.as<i32>(); za.row_dbg_off = h->row_dbg_off.as<i64>();
     }
     TRY(ensure(h, h->row_desc, (size_t)h->n_active_rows * sizeof(RowDesc))); za.desc = h->row_desc.as<RowDesc>();
-    if (h->sort_records) { za.key_base = h->scal.as<i64>() + 22; hipLaunchKernelGGL(k_fill_i64, dim3(1), dim3(64), 0, h->stream, za.key_base, (i64)1, I64_MAX); }
+    if (h->sort_records) {      // scal[22] / scal[29]: first sample / end of the last row of the batch (k_row_desc): origin and span of the sort keys
+        za.key_base = h->scal.as<i64>() + 22;
+        hipLaunchKernelGGL(k_fill_i64, dim3(1), dim3(64), 0, h->stream, za.key_base, (i64)1, I64_MAX);
+        hipLaunchKernelGGL(k_fill_i64, dim3(1), dim3(64), 0, h->stream, h->scal.as<i64>() + 29, (i64)1, I64_MIN);
+    }
     if (h->n_active_rows > 0) { Timer t(h, "k_row_desc"); hipLaunchKernelGGL(k_row_desc, dim3(nblocks(h->n_active_rows, 256)), dim3(256), 0, h->stream, d, za); }
     if (h->n_active_rows > 0) { Timer t(h, "k_zle"); hipLaunchKernelGGL(k_zle, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
     TRY(scan(h, h->row_nrec.as<i32>(), RS, h->rec_off, 10));
@@ -1543,10 +1562,13 @@ try {
         TRY(ensure(h, h->rec_val, (size_t)NR * 4)); TRY(ensure(h, h->rec_val2, (size_t)NR * 4)); TRY(ensure(h, h->rec_dest, (size_t)NR * 4));
         za.rec_key = h->rec_key.as<u64>(); za.rec_val = h->rec_val.as<u32>();
         { Timer t(h, "k_rec_keys"); hipLaunchKernelGGL(k_rec_keys, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
+        // rocPRIM's radix sort, over the key bits that are in use only: (samples the batch spans) << 12 | channel
+        unsigned end_bit = 13;
+        { const u64 span = (u64)std::max<i64>(h->h_scal[29] - h->h_scal[22], 1); while (end_bit < 64 && ((span << 12) >> end_bit) != 0) end_bit++; }
         size_t bytes = 0;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, h->rec_key.as<u64>(), h->rec_key2.as<u64>(), h->rec_val.as<u32>(), h->rec_val2.as<u32>(), (int)NR, 0, 64, h->stream));
+        HIPCHK(rocprim::radix_sort_pairs(nullptr, bytes, h->rec_key.as<u64>(), h->rec_key2.as<u64>(), h->rec_val.as<u32>(), h->rec_val2.as<u32>(), (size_t)NR, 0u, end_bit, h->stream));
         TRY(ensure(h, h->sort_tmp, bytes));
-        { Timer t(h, "record_sort"); HIPCHK(hipcub::DeviceRadixSort::SortPairs(h->sort_tmp.p, bytes, h->rec_key.as<u64>(), h->rec_key2.as<u64>(), h->rec_val.as<u32>(), h->rec_val2.as<u32>(), (int)NR, 0, 64, h->stream)); }
+        { Timer t(h, "record_sort"); HIPCHK(rocprim::radix_sort_pairs(h->sort_tmp.p, bytes, h->rec_key.as<u64>(), h->rec_key2.as<u64>(), h->rec_val.as<u32>(), h->rec_val2.as<u32>(), (size_t)NR, 0u, end_bit, h->stream)); }
         { Timer t(h, "k_invert_perm"); hipLaunchKernelGGL(k_invert_perm, dim3(nblocks(NR, 256)), dim3(256), 0, h->stream, h->rec_val2.as<u32>(), h->rec_dest.as<u32>(), NR); }
         za.rec_dest = h->rec_dest.as<u32>();
     }

@@ -788,6 +788,99 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
     }
 }
 
+// Any digitiser geometry (sample_duration dt <= WFS_MAX_DT ns, template length tlen <= WFS_MAX_TLEN samples; pulse.py:146-187 builds the
+// templates for whatever the config says): the same H-table scheme with the geometry taken from the config at run time -- merged
+// gains H[start bin][ns remainder] in LDS, every sample gathers its tlen x dt possible contributions in ascending time with a
+// separate multiply and add, templates read from LDS.  One workgroup per tile, chunks of TPB samples, the tile's photons re-read per
+// chunk; none of the specialisations of the 10 ns / 22 tap kernels (they keep the taps in SGPRs and unroll over dt): this is the
+// path of every tile when the configuration differs from the XENONnT TPC digitiser.  Same bits as the reference (add_current).
+#define WFS_MAX_DT 16
+#define WFS_MAX_TLEN 256
+template <int TPB>
+__global__ __launch_bounds__(TPB) void k_pulse_generic(WfsDev d, PulseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dt = d.dt, tlen = d.tlen;
+    const int HROWS = TPB + tlen - 1;
+    double *H = (double *)smem;                           // [HROWS][dt]
+    double *T = H + (size_t)HROWS * dt;                   // [dt][tlen] templates
+    double *red = T + (size_t)dt * tlen;                  // [TPB / 64][8]
+    __shared__ double s_cmax[WFS_MAX_DT];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < dt * tlen; i += TPB) T[i] = d.templates[i];
+    if (tid < dt) s_cmax[tid] = d.current_max[tid];
+    const TileDesc td = a.desc[blockIdx.x];
+    const i64 tile = td.tile; const i32 n = td.n; const i64 off = td.off;
+    const i64 nb = td.nb;
+    const int lead = d.store_before + d.samples_before;
+    i32 *dst = a.raw + td.dst;
+    const double G = td.G, thr = td.thr;
+    const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? td.ch : 0) * 2001;
+    const i64 rel0 = td.rel0;
+    const i64 n_live = nb + (tlen - 1);
+    // number of DPE photons of the tile (truth quirk pulse.py:255)
+    __shared__ i32 s_ndpe;
+    if (tid == 0) s_ndpe = 0;
+    __syncthreads();
+    {
+        i32 c = 0;
+        for (i32 p = tid; p < n; p += TPB) c += (a.ph[off + p].code >> 16) != 0;
+        c = wave_sum(c);
+        if (lane == 0 && c) atomicAdd(&s_ndpe, c);
+    }
+    __syncthreads();
+    const i32 n_dpe_tile = s_ndpe;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // n, n_dpe, n_trig, n_trig_dpe, sum g, sum g trig, sum t, sum t^2
+    if (a.currents) for (i64 sz = tid; sz < td.L; sz += TPB) if (sz < lead || sz >= lead + n_live) a.currents[a.cur_off[blockIdx.x] + sz] = 0.0;
+    for (i64 c0 = 0; c0 < n_live; c0 += TPB) {
+        const bool first = c0 == 0;
+        const i64 b_lo = c0 - (tlen - 1);
+        __syncthreads();
+        for (int i = tid; i < HROWS * dt; i += TPB) H[i] = 0.0;
+        __syncthreads();
+        for (i32 p = tid; p < n; p += TPB) {
+            const PhotonRec rec = a.ph[off + p];
+            const i32 ns = (i32)(rec.t - rel0);
+            const int bin = ns / dt, r = ns - bin * dt;
+            const i64 jw = bin - b_lo;
+            const bool mine = jw >= 0 && jw < HROWS;
+            if (!first && !mine) continue;
+            double gain;
+            if (td.mode != 0) gain = a.ph_gain[off + p];
+            else { gain = G * spe_row[rec.code & 0xffffu]; if (rec.code >> 16) gain += G * spe_row[rec.code >> 16]; }      // pulse.py:97-103
+            if (mine) atomicAdd(&H[(int)jw * dt + r], gain);
+            if (first) {
+                const bool above = gain * s_cmax[r] * d.c2a > thr;
+                acc[0] += 1; acc[1] += (rec.code >> 16) != 0; acc[4] += gain;
+                if (above) { acc[2] += 1; acc[5] += gain; if (p < n_dpe_tile) acc[3] += 1; }
+                const double tr = (double)(ns + rel0);
+                acc[6] += tr; acc[7] += tr * tr;
+            }
+        }
+        __syncthreads();
+        if (c0 + tid < n_live) {
+            // sample c0 + tid sees the start bins (rows) tid (tap tlen - 1) .. tid + tlen - 1 (tap 0), ascending time (pulse.py:303-318)
+            double c = 0.0;
+            for (int k = tlen - 1; k >= 0; k--) {
+                const double *hp = H + (size_t)(tid + (tlen - 1) - k) * dt;
+                for (int r = 0; r < dt; r++) { const double prod = T[r * tlen + k] * hp[r]; c = c + prod; }
+            }
+            const i64 sx = lead + c0 + tid;
+            if (a.currents) a.currents[a.cur_off[blockIdx.x] + sx] = c;
+            const i64 adc = -(i64)rint(c * d.c2a);         // rawdata.py:236
+            if (adc != 0) atomicAdd(&dst[sx], (i32)adc);
+        }
+    }
+    if (a.tile_truth) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) acc[q] = wave_sum(acc[q]);
+        __syncthreads();
+        if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
+        __syncthreads();
+        if (tid < 8) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + tid]; a.tile_truth[tile * 8 + tid] = sum; }
+    }
+}
+
 // Tiny tiles (a few photons in a few start bins: almost every tile of an S1): one THREAD per tile.  The photons are
 // sorted by time in registers, equal-ns photons merged (first of the run carries the summed gain), and every sample in
 // reach of a photon adds templates[r][k] * gain in ascending time with a separate multiply and add: the arithmetic of
@@ -1248,7 +1341,7 @@ __global__ void k_row_desc(WfsDev d, ZleArgs a)
     q.thr = d.thr_zle[channel]; q.idx = idx; q.len = (i32)(a.row_hi[ridx] - a.row_lo[ridx] + 1 + 2 * (i64)d.tw);
     q.channel = channel; q.he = he ? 1 : 0;
     a.desc[r] = q;
-    if (a.key_base) atomicMin(a.key_base, q.row_abs);
+    if (a.key_base) { atomicMin(a.key_base, q.row_abs); atomicMax(a.key_base + 7, q.row_abs + (i64)q.len); }      // (scal[22], scal[29])
 }
 
 // finished sample of a row: accumulated ADC + noise + baseline, clamped at 0
