@@ -299,16 +299,16 @@ def main():
     dom_ms, dom_launches = ktimes[dom]
     b_alg = algorithmic_bytes(counts)
     # HBM bytes per launch of the dominant kernel and what limits it, from the committed PMC profiles of this command
-    # (tools/profile_round.sh + tools/make_profiles.py -> profiles/r2_traffic.json, r2_counters.json); only for the profiled workload
+    # (tools/profile_round.sh + tools/make_profiles.py -> profiles/r3_traffic.json, r3_counters.json); only for the profiled workload
     traffic, limiter, valu_util = None, None, None
     if args.workload == 's2' and M == 1000:
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r2_traffic.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r3_traffic.json')) as f:
                 traffic = json.load(f)['kernels'][dom]['hbm_bytes']
         except (OSError, KeyError):
             pass
         try:
-            with open(os.path.join(ROOT, 'profiles', 'r2_counters.json')) as f:
+            with open(os.path.join(ROOT, 'profiles', 'r3_counters.json')) as f:
                 kc = json.load(f)['kernels'][dom]
                 limiter, valu_util = kc.get('limited_by'), kc.get('valu_busy')
         except (OSError, KeyError):
@@ -317,7 +317,9 @@ def main():
     # the dominant kernel's OWN algorithmic bytes (the pulse kernel reads every photon record once and adds into the raw
     # accumulators once; the generator writes every photon record once): what "achieved" would be without crediting one
     # kernel with the whole pipeline's bytes
-    own = {'k_pulse_dense': 8 * counts['n_photons'] + 4 * counts['n_raw_samples'], 'k_photon_fill': 8 * counts['n_photons']}.get(dom)
+    # (k_s2_tile makes its photons in registers: what it moves are the tile buffers' samples, written once)
+    own = {'k_pulse_dense': 8 * counts['n_photons'] + 4 * counts['n_raw_samples'], 'k_photon_fill': 8 * counts['n_photons'],
+           'k_s2_tile': 4 * counts['n_raw_samples']}.get(dom)
     out = dict(
         metric='photoelectrons/sec + raw_records MB/s, 10^6-PE S2 batch', value=total_pe * args.steps / elapsed,
         unit='photoelectrons/s', n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,

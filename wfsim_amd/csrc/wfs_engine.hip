@@ -97,7 +97,7 @@ struct wfs_handle {
     DevBuf map_row_ins[2], map_row_id[2], map_x, map_y, map_z, map_nb_idx[2], map_nb_w[2];
 
     // tile-local generation (wfs_tilegen.h): S2 instructions whose photons are made inside the pulse workgroup
-    DevBuf ins_fused, ins_nsurv, ins_bcap, ins_bcap_all, ins_boff, et32, ftiles, tbuf, row_cnt, row_tile;
+    DevBuf row_pmax, ins_fused, ins_nsurv, ins_bcap, ins_bcap_all, ins_boff, et32, ftiles, tbuf, row_cnt, row_tile;
     bool fuse_on = false, fuse_full = false, run_sets_given = false, any_s2 = false;
     i64 n_fused_tiles = 0, p_fused = 0, s_raw_direct = 0;
     int tap_sparse_max = 48;     // tap_block: occupied cells up to which a wave of the dense pulse kernels walks them (WFS_TAP_SPARSE_MAX)
@@ -459,7 +459,7 @@ try {
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal,
-        &h->ph_idx, &h->ap_key, &h->order_list, &h->ins_sbase, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
+        &h->ph_idx, &h->ap_key, &h->order_list, &h->ins_sbase, &h->row_pmax, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft, &h->ins_sigr, &h->ins_siga, &h->diff_row_ins, &h->diff_row_id, &h->diff_pre}) if (b->p) hipFree(b->p);
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
@@ -1164,7 +1164,13 @@ static int run_generation(wfs_handle *h)
         HIPCHK(hipMemsetAsync(h->ins_bcap.p, 0, (size_t)N * 4, h->stream)); HIPCHK(hipMemsetAsync(h->ins_bcap_all.p, 0, (size_t)N * 4, h->stream));
         f.ins_fused = h->ins_fused.as<i32>(); f.ins_nsurv = h->ins_nsurv.as<i32>(); f.ins_bcap = h->ins_bcap.as<i32>(); f.ins_bcap_all = h->ins_bcap_all.as<i32>();
         f.et32 = h->et32.as<i32>();
-        { Timer t(h, "k_fuse_decide"); hipLaunchKernelGGL(k_fuse_decide, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, f); }
+        {
+            const i64 n_rows = h->n_host_rows + (i64)h->dev_row_ins.size();
+            TRY(ensure(h, h->row_pmax, (size_t)n_rows * 8)); f.row_pmax = h->row_pmax.as<double>();
+            Timer t(h, "k_fuse_decide");
+            hipLaunchKernelGGL(k_row_pmax, dim3(nblocks(n_rows, 4)), dim3(256), 0, h->stream, f.cdf_table, d.n_tpc, n_rows, h->row_pmax.as<double>());
+            hipLaunchKernelGGL(k_fuse_decide, dim3(nblocks(N, 256)), dim3(256), 0, h->stream, f);
+        }
         g.ins_fused = f.ins_fused;
     }
     { Timer t(h, "k_s1_hits"); hipLaunchKernelGGL(k_s1_hits, dim3(nblocks(N, 4)), dim3(256), 0, h->stream, d, g); }
@@ -1576,7 +1582,7 @@ try {
     {   // totals of wfs_get_counts: afterpulse sets carry no truth (rawdata.py:322-323)
         const i64 n_prim = (!h->injected && h->ap_active) ? h->n_psets : h->n_sets;
         const i64 work = std::max<i64>(RS, n_prim);
-        hipLaunchKernelGGL(k_counts, dim3((unsigned)std::min<i64>(nblocks(work, 256), 2048)), dim3(256), 0, h->stream, h->itv_n.as<i32>(), RS, h->truth.as<double>(), n_prim, h->scal.as<i64>());
+        hipLaunchKernelGGL(k_counts, dim3((unsigned)std::min<i64>(nblocks(work, 256), 128)), dim3(256), 0, h->stream, h->itv_n.as<i32>(), RS, h->truth.as<double>(), n_prim, h->scal.as<i64>());
     }
     TRY(read_scal(h));
     HIPCHK(hipGetLastError());

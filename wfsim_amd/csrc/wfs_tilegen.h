@@ -39,7 +39,7 @@ struct __attribute__((aligned(16))) FTile {
 struct FuseArgs {
     i64 n_ins; i32 nch; i32 table_span;      // cells of the S2 delay table (bound of its support)
     const int8_t *ins_type; const i32 *ins_amp; const double *ins_sc; const u32 *ins_embase, *ins_gid; const i32 *ins_cdfrow;
-    const double *cdf_table; const i64 *ins_time; const i64 *em_off; const i64 *em_time; const i64 *el_minmax;
+    const double *cdf_table; const double *row_pmax; const i64 *ins_time; const i64 *em_off; const i64 *em_time; const i64 *el_minmax;
     i32 *ins_fused;       // [n_ins] 1: the instruction's photons are generated tile by tile
     i32 *ins_nsurv;       // [n_ins] surviving electrons
     i32 *ins_bcap;        // [n_ins] samples reserved per tile buffer
@@ -54,21 +54,33 @@ struct FuseArgs {
     i64 *scal;            // [1] error flag, [23] ints of all tile buffers, [24] photons of all tiles, [25] listed tiles
 };
 
-// Both sides of the parity tests evaluate this rule (oracle/wfsim_oracle.c: fuse_eligible): the same IEEE operations in the same order.
-__device__ __forceinline__ bool fuse_eligible(int type, u32 em_base, i32 amp, double sc, const double *row, int nch)
+// Both sides of the parity tests evaluate this rule (oracle/wfsim_oracle.c: fuse_eligible): the same IEEE operations (a maximum does
+// not depend on the order it is taken in).
+__device__ __forceinline__ bool fuse_eligible(int type, u32 em_base, i32 amp, double sc, double pmax)
 {
     if (type != 2 || em_base != 0u || amp <= 0 || !(sc > 0)) return false;
-    double pmax = 0.0;
-    for (int c = 0; c < nch; c++) { const double p = row[c] - (c ? row[c - 1] : 0.0); pmax = p > pmax ? p : pmax; }
     const double lam = (double)amp * sc * pmax;
     return lam + 8.0 * sqrt(lam) + 8.0 <= (double)TILE_MAX_PHOTONS;
+}
+
+// largest channel probability of every pattern row: one wave per row (a thread walking a row alone pays one load latency per channel)
+__global__ __launch_bounds__(256) void k_row_pmax(const double *cdf_table, int nch, i64 n_rows, double *row_pmax)
+{
+    const i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= n_rows) return;
+    const double *row = cdf_table + r * nch;
+    double pmax = 0.0;
+    for (int c = lane; c < nch; c += 64) { const double p = row[c] - (c ? row[c - 1] : 0.0); pmax = p > pmax ? p : pmax; }
+    for (int o = 32; o > 0; o >>= 1) { const double x = __shfl_xor(pmax, o, 64); pmax = x > pmax ? x : pmax; }
+    if (lane == 0) row_pmax[r] = pmax;
 }
 
 __global__ void k_fuse_decide(FuseArgs f)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= f.n_ins) return;
-    f.ins_fused[i] = fuse_eligible(f.ins_type[i], f.ins_embase[i], f.ins_amp[i], f.ins_sc[i], f.cdf_table + (i64)f.ins_cdfrow[i] * f.nch, f.nch) ? 1 : 0;
+    f.ins_fused[i] = fuse_eligible(f.ins_type[i], f.ins_embase[i], f.ins_amp[i], f.ins_sc[i], f.row_pmax[f.ins_cdfrow[i]]) ? 1 : 0;
 }
 
 // Surviving electrons of a tile-generated instruction, compacted in candidate order: arrival times relative to the set origin
