@@ -50,7 +50,7 @@ struct wfs_handle {
     DevBuf set_cluster, set_t0, set_mode, cl_tmin, cl_gid, cl_end, cl_group;
     DevBuf em_time, em_nph, em_ins, em_ph_off, el_stat, el_minmax, blk_e, blk_base, blk_cnt, blk_ins, eblk_ins, ins_ph0, blk_desc;
     DevBuf tile_count, tile_off, tile_cursor, tile_tmin, tile_tmax, active_tiles, sparse_tiles, dense_tiles, wave_tiles;
-    DevBuf ph, ph_gain, ph_idx, ap_key, order_list, ins_sbase;
+    DevBuf ph, ph_gain, ph_idx, ap_key, order_list, order_list2, ins_sbase, tile_tail, tile_tailbase, ins_fullsort;
     DevBuf grp_lo, grp_hi, grp_left, grp_right, grp_ixrand, grp_gid;
     DevBuf row_lo, row_hi, acc_len, acc_off, itv_cap, itv_off, active_rows, raw;
     DevBuf itv_left, itv_right, itv_n, row_nrec, rec_off;
@@ -459,7 +459,7 @@ try {
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal,
-        &h->ph_idx, &h->ap_key, &h->order_list, &h->ins_sbase, &h->row_pmax, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
+        &h->ph_idx, &h->ap_key, &h->order_list, &h->order_list2, &h->ins_sbase, &h->tile_tail, &h->tile_tailbase, &h->ins_fullsort, &h->row_pmax, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft, &h->ins_sigr, &h->ins_siga, &h->diff_row_ins, &h->diff_row_id, &h->diff_pre}) if (b->p) hipFree(b->p);
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
@@ -1243,6 +1243,10 @@ static int run_generation(wfs_handle *h)
     TRY(ensure(h, h->ins_ph0, (size_t)(N + 1) * 8)); g.ins_ph0 = h->ins_ph0.as<i64>();
     { Timer t(h, "k_ins_ph0"); hipLaunchKernelGGL(k_ins_ph0, dim3(nblocks(N + 1, 256)), dim3(256), 0, h->stream, g); }
     TRY(ensure(h, h->ins_sbase, (size_t)N * 4)); g.ins_sbase = h->ins_sbase.as<u32>();
+    TRY(ensure(h, h->ins_fullsort, (size_t)N * 4)); g.ins_fullsort = h->ins_fullsort.as<i32>();
+    TRY(ensure(h, h->tile_tail, (size_t)TP * 4)); TRY(ensure(h, h->tile_tailbase, (size_t)TP * 4));
+    HIPCHK(hipMemsetAsync(h->tile_tail.p, 0, (size_t)TP * 4, h->stream)); HIPCHK(hipMemsetAsync(h->tile_tailbase.p, 0, (size_t)TP * 4, h->stream));
+    g.tile_tail = h->tile_tail.as<i32>(); g.tile_tailbase = h->tile_tailbase.as<i32>();
     { Timer t(h, "k_set_bases"); hipLaunchKernelGGL(k_set_bases, dim3(nblocks(h->n_psets, 256)), dim3(256), 0, h->stream, g); }
     if (P > 0) {
         const unsigned nb = (unsigned)((P + GEN_BLOCK - 1) / GEN_BLOCK);
@@ -1302,13 +1306,15 @@ static int run_generation(wfs_handle *h)
     }
     if (P > 0 || ap_on) {
         // every tile of the block generator into generation order (k_tile_order): the order the reference's Pulse call sees
-        TRY(ensure(h, h->order_list, (size_t)T * 4));
-        OrderArgs oa{T, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->ph.as<PhotonRec>(), h->ph_idx.as<u32>(),
-                     ap_on ? h->ph_gain.as<double>() : nullptr, P + h->p_fused, h->order_list.as<i32>(), h->scal.as<i64>(),
-                     (h->fuse_on && h->n_fused_tiles > 0) ? h->ins_fused.as<i32>() : nullptr, d.n_tpc};
-        { Timer t(h, "k_tile_order"); hipLaunchKernelGGL(k_tile_order, dim3(nblocks(T, 4)), dim3(256), 0, h->stream, oa); }
+        TRY(ensure(h, h->order_list, (size_t)T * 2 * sizeof(OrderRange))); TRY(ensure(h, h->order_list2, (size_t)T * 2 * sizeof(OrderRange)));
+        OrderArgs oa{T, TP, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->ph.as<PhotonRec>(), h->ph_idx.as<u32>(),
+                     ap_on ? h->ph_gain.as<double>() : nullptr, P + h->p_fused, h->order_list.as<OrderRange>(), h->order_list2.as<OrderRange>(), h->scal.as<i64>(),
+                     (h->fuse_on && h->n_fused_tiles > 0) ? h->ins_fused.as<i32>() : nullptr, d.n_tpc,
+                     h->tile_cursor.as<i32>(), h->tile_tailbase.as<i32>(), h->ins_fullsort.as<i32>(), h->set_ins_off.as<i64>(), h->set_ins_list.as<i32>()};
+        { Timer t(h, "k_tile_order_scan"); hipLaunchKernelGGL(k_tile_order_scan, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, oa); }
         TRY(read_scal(h));
-        const i64 n_big = h->h_scal[28];
+        const i64 n_wave = h->h_scal[30], n_big = h->h_scal[31];
+        if (n_wave > 0) { Timer t(h, "k_tile_order"); hipLaunchKernelGGL(k_tile_order, dim3(nblocks(n_wave, 4)), dim3(256), 0, h->stream, oa, n_wave); }
         if (n_big > 0) {
             Timer t(h, "k_tile_order_big");
             hipLaunchKernelGGL(k_tile_order_big, dim3((unsigned)n_big), dim3(256), (size_t)TILE_ORDER_MAX * 24, h->stream, oa);

@@ -1561,7 +1561,7 @@ struct __attribute__((aligned(64))) BlockDesc {
     u32 gid, eb, jbase;   // Philox coordinates: instruction id, emitter base, emitter id of e_lo
     i32 is_s2;
     u32 sbase;            // photons of the instructions in front of this one in its pulse set (order keys count through the set)
-    i32 pad;
+    i32 multi;            // the pulse set holds several instructions: order keys are written for every photon (the tile is sorted as a whole)
 };
 
 struct GenArgs {
@@ -1584,6 +1584,11 @@ struct GenArgs {
     u32 *ph_idx;                  // [photons] order key of every stored photon: its index among its pulse set's photons, instruction by
                                   // instruction (afterpulses: element << 29 | key of the parent) -- k_tile_order sorts every tile by it
     u32 *ins_sbase;               // [n_ins] photons of the instructions in front of this one in its pulse set (k_set_bases)
+    i32 *tile_tail;               // [primary tiles] photons that the generic path puts BEHIND the tile's block ranges: those of an instruction that
+                                  // began in an earlier block (count pass; the fill pass uses it as their cursor)
+    i32 *tile_tailbase;           // [primary tiles] first slot of those photons inside the tile (k_block_ranges)
+    i32 *ins_fullsort;            // [n_ins] 1: the tiles of this instruction are sorted as a whole (several instructions in its pulse set, or a block
+                                  // in the MIDDLE of the instruction that takes the generic path: more emitters than the LDS window holds)
     i64 n_blocks;
     i64 xcd_chunk;                // XCD x (workgroup id % 8) walks the photon blocks [x * xcd_chunk, (x + 1) * xcd_chunk) in order
     i32 *eblk_ins;                // [ceil(n_emitters / 256) + 1] instruction of the first emitter of every block of k_s2_electrons
@@ -1881,12 +1886,14 @@ __global__ void k_block_emitters(GenArgs a)
     const i32 i0 = a.em_ins[e_lo];
     const bool single = e_hi - e_lo + 2 <= GEN_WIN && i0 == a.em_ins[e_hi];
     a.blk_ins[b] = single ? i0 : -1;
+    if (!single && i0 == a.em_ins[e_hi] && a.ins_ph0[i0] < p0 && a.ins_ph0[i0 + 1] > p1) a.ins_fullsort[i0] = 1;      // generic block inside one instruction
     BlockDesc bd{};
     bd.ins = -1;
     if (single) {
         bd.ins = i0; bd.e_lo = e_lo; bd.nwin = (i32)(e_hi - e_lo + 2); bd.set = a.ins_set[i0]; bd.itime = a.set_t0[bd.set];
         bd.R0 = p0 - a.ins_ph0[i0]; bd.row = a.ins_cdfrow[i0]; bd.gid = a.ins_gid[i0]; bd.eb = a.ins_embase[i0];
         bd.jbase = (u32)(e_lo - a.em_off[i0]) + bd.eb; bd.is_s2 = a.ins_type[i0] != 1; bd.sbase = a.ins_sbase[i0];
+        bd.multi = 0;      // (whether the tile is sorted as a whole is only known when every block has been looked at: ins_fullsort, read by the fill pass)
     }
     a.blk_desc[b] = bd;
 }
@@ -1907,6 +1914,7 @@ __global__ void k_set_bases(GenArgs a)
         const i32 i = a.set_ins_list[q];
         if (run > 0xffffffffLL) atomicMax(&a.scal[1], (i64)2);
         a.ins_sbase[i] = (u32)run;
+        a.ins_fullsort[i] = a.set_ins_off[s + 1] - a.set_ins_off[s] > 1;       // (k_block_emitters adds the instructions with a generic block in their middle)
         run += a.em_ph_off[a.em_off[i + 1]] - a.em_ph_off[a.em_off[i]];
     }
 }
@@ -2315,6 +2323,8 @@ __global__ void k_block_ranges(WfsDev d, GenArgs a)
             for (int k = 0; k < NB; k++) if (mine[k]) { a.blk_base[(b0 + k) * nch + c] = run; run += cnt[k]; }
         }
     }
+    a.tile_tailbase[idx] = (i32)run;                             // the last photons of the instruction (generic path) go behind the block ranges
+    run += (u32)a.tile_tail[idx]; a.tile_tail[idx] = 0;         // (the fill pass counts them again as it places them)
     a.tile_count[idx] = (i32)run;
 }
 
@@ -2400,6 +2410,14 @@ __device__ __forceinline__ int photon_channel_global(const WfsDev &d, const GenA
     return channel_lookup(a.chan_alias + ((size_t)a.ins_cdfrow[id.ins] << a.ch_lg), a.ch_lg, photon_word(d, id, SITE_CH));
 }
 
+// A block that spans instructions (generic path) holds the LAST photons of the instruction it starts in and the FIRST photons of the
+// ones that begin in it.  The tile of a single-instruction pulse set is laid out [first photons (generic) | block ranges in block
+// order | last photons (generic)]: photon order up to the order inside the two small generic groups, which k_tile_order_scan repairs.
+__device__ __forceinline__ bool generic_is_tail(const GenArgs &a, const PhotonId &id, i64 p0)
+{
+    return a.ins_ph0[id.ins] < p0 && !a.ins_fullsort[id.ins];
+}
+
 #define COUNT_TPB (GEN_BLOCK / 8)
 #define FILL_TPB (GEN_BLOCK / 4)   // one quad of photons per thread: many waves per workgroup keep enough table gathers in flight
 
@@ -2471,7 +2489,8 @@ __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
         for (int pr = tid; pr < np; pr += COUNT_TPB) {
             const PhotonId id = photon_id(a, p0 + pr, a.blk_e[2 * vb], a.blk_e[2 * vb + 1] + 1);      // (23 dependent loads over all emitters otherwise)
             const int ch = photon_channel_global(d, a, id);
-            atomicAdd(&a.tile_count[(i64)a.ins_set[id.ins] * nch + ch], 1);
+            const i64 tile = (i64)a.ins_set[id.ins] * nch + ch;
+            atomicAdd(generic_is_tail(a, id, p0) ? &a.tile_tail[tile] : &a.tile_count[tile], 1);
         }
     }
 }
@@ -2621,10 +2640,24 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
         }
         STAMP(d, 2);
         __syncthreads();
+        // the few photons of every (block, channel) segment into photon order (an insertion sort per channel): with consecutive
+        // blocks owning consecutive ranges the tile is then in generation order as it is written, k_tile_order finds nothing to do
+        for (int c = tid; c < nch; c += TPB) {
+            const int s0 = hist[c], s1 = hist[c + 1];
+            if (s1 - s0 < 2 || s1 - s0 > 64) continue;       // (longer segments: left to k_tile_order)
+            for (int i = s0 + 1; i < s1; i++) {
+                const unsigned short key = pidx[i]; const PhotonRec r = stage[i];
+                int j = i - 1;
+                while (j >= s0 && pidx[j] > key) { pidx[j + 1] = pidx[j]; stage[j + 1] = stage[j]; j--; }
+                pidx[j + 1] = key; stage[j + 1] = r;
+            }
+        }
+        __syncthreads();
         STAMP(d, 3);
         // ---- bucket order: neighbouring lanes store photons of the same tile to consecutive addresses
-        u32 *out_idx = a.ph_idx + set_ph0;
-        for (int i = tid; i < np; i += TPB) { const int at = hoff[chmap[i]] + i; out[at] = stage[i]; out_idx[at] = bd.sbase + (u32)(bd.R0 + pidx[i]); }
+        // (order keys only where the tile is sorted as a whole: the block ranges of a single-instruction set are in order as written)
+        if (a.ins_fullsort[bd.ins]) { u32 *out_idx = a.ph_idx + set_ph0; for (int i = tid; i < np; i += TPB) { const int at = hoff[chmap[i]] + i; out[at] = stage[i]; out_idx[at] = bd.sbase + (u32)(bd.R0 + pidx[i]); } }
+        else for (int i = tid; i < np; i += TPB) out[hoff[chmap[i]] + i] = stage[i];
         STAMP(d, 4);
         for (int c = tid; c < nch; c += TPB)
             if (hist[c + 1] > hist[c]) { atomicMin(&a.tile_tmin[tbase + c], hmin[c]); atomicMax(&a.tile_tmax[tbase + c], hmax[c]); }
@@ -2653,7 +2686,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
             if (AP) ap_generate(d, a, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t, a.ins_sbase[ins] + id.P);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
             // photons of multi-instruction blocks take the first slots of their tile (k_block_ranges starts behind them)
-            const i64 at = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
+            const i64 at = a.tile_off[tile] + (generic_is_tail(a, id, p0) ? a.tile_tailbase[tile] + atomicAdd(&a.tile_tail[tile], 1) : atomicAdd(&a.tile_cursor[tile], 1));
             a.ph[at] = PhotonRec{(i32)t, code}; a.ph_idx[at] = a.ins_sbase[ins] + id.P;
         }
     }
@@ -2693,32 +2726,83 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
 // hand out slots; the reference's Pulse call sees them in channel-sorted GENERATION order (a stable argsort would; the oracle
 // does), and two things depend on that order: the truth quirk that counts the triggered photons among the FIRST n_dpe of the
 // channel slice (pulse.py:255) and the order in which three or more photons of one ns are merged.  Every stored photon carries
-// its order key (ph_idx); this pass sorts each tile by it -- one wave per tile up to 64 photons (bitonic network on key << 6 |
-// lane in registers), tiles up to TILE_ORDER_MAX go to a list and are sorted by a workgroup in LDS; larger ones keep the
-// order they have (documented: n_pe_trigger is then only statistically right).  Explicit gains (afterpulses) move along.
+// its order key (ph_idx); tiles whose keys are out of order are listed (one thread per tile) and sorted: by a wave up to 64
+// photons (rank by counting smaller keys), by a workgroup in LDS up to TILE_ORDER_MAX; larger ones keep the order they have
+// (documented: n_pe_trigger is then only statistically right).  Explicit gains (afterpulses) move along.
 #define TILE_ORDER_MAX 4096
-struct OrderArgs { i64 n_tiles; const i32 *tile_count; const i64 *tile_off; PhotonRec *ph; u32 *ph_idx; double *ph_gain; i64 gain_first;
-                   i32 *big_list; i64 *scal;         // ph_gain[p - gain_first] for photons p >= gain_first (afterpulses), or nullptr; scal[28] = listed tiles
-                   const i32 *skip_ins; i32 nch; };  // [n_ins] 1: the tiles of this instruction (tile / nch) come from k_s2_tile, already in order (or nullptr)
-__global__ __launch_bounds__(256) void k_tile_order(OrderArgs a)
+#define TILE_ORDER_INLINE 12        // ranges up to this many photons are sorted by the scanning thread itself
+struct OrderRange { i64 start; i32 n, pad; };          // photons [start, start + n) of the photon array
+struct OrderArgs { i64 n_tiles, n_ptiles; const i32 *tile_count; const i64 *tile_off; PhotonRec *ph; u32 *ph_idx; double *ph_gain; i64 gain_first;
+                   OrderRange *wave_list, *big_list; i64 *scal;      // ph_gain[p - gain_first] for photons p >= gain_first (afterpulses), or nullptr;
+                                                                     // scal[30] / scal[31]: ranges on the wave list / the workgroup list
+                   const i32 *skip_ins; i32 nch;                     // [n_ins] 1: the tiles of this instruction (tile / nch) come from k_s2_tile, already in order (or nullptr)
+                   const i32 *tile_cursor, *tile_tailbase; const i32 *ins_fullsort; const i64 *set_ins_off; const i32 *set_ins_list; };
+                   // primary tiles of a set whose (first) instruction is not flagged ins_fullsort: head = [0, cursor), tail = [tailbase, n)
+// pass 1, one THREAD per tile.  A primary tile of a single-instruction pulse set is [first photons | block ranges | last photons]
+// with the block ranges in order as written: only the two small generic groups are looked at.  Every other tile (afterpulse sets,
+// sets of several instructions) is looked at as a whole.  A range that is out of order is sorted on the spot when it is tiny,
+// listed for a wave (<= 64) or a workgroup (<= TILE_ORDER_MAX) otherwise.
+__device__ __forceinline__ void order_range(const OrderArgs &a, i64 start, i32 n, int &cls)
+{
+    cls = -1;
+    if (n < 2) return;
+    const u32 *k = a.ph_idx + start;
+    bool sorted = true;
+    u32 prev = k[0];
+    for (i32 q = 1; q < n; q++) { const u32 x = k[q]; if (x < prev) { sorted = false; break; } prev = x; }
+    if (sorted) return;
+    if (n > TILE_ORDER_INLINE) { cls = n <= 64 ? 0 : (n <= TILE_ORDER_MAX ? 1 : -1); return; }
+    const bool has_gain = a.ph_gain && start >= a.gain_first;
+    for (i32 i = 1; i < n; i++) {                            // insertion sort of a handful of records
+        const u32 key = a.ph_idx[start + i]; const PhotonRec r = a.ph[start + i];
+        const double g = has_gain ? a.ph_gain[start - a.gain_first + i] : 0.0;
+        i32 jj = i - 1;
+        while (jj >= 0 && a.ph_idx[start + jj] > key) {
+            a.ph_idx[start + jj + 1] = a.ph_idx[start + jj]; a.ph[start + jj + 1] = a.ph[start + jj];
+            if (has_gain) a.ph_gain[start - a.gain_first + jj + 1] = a.ph_gain[start - a.gain_first + jj];
+            jj--;
+        }
+        a.ph_idx[start + jj + 1] = key; a.ph[start + jj + 1] = r;
+        if (has_gain) a.ph_gain[start - a.gain_first + jj + 1] = g;
+    }
+}
+__global__ __launch_bounds__(256) void k_tile_order_scan(OrderArgs a)
+{
+    __shared__ i32 s_n[2]; __shared__ i64 s_base[2];
+    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    __syncthreads();
+    const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    OrderRange rg[2] = {{0, 0, 0}, {0, 0, 0}}; int cls[2] = {-1, -1}, rk[2] = {0, 0};
+    if (tile < a.n_tiles) {
+        const i32 n = a.tile_count[tile];
+        const i64 set = tile / a.nch;
+        if (n >= 2 && !(a.skip_ins && tile < a.n_ptiles && a.skip_ins[set])) {
+            const i64 off = a.tile_off[tile];
+            if (tile < a.n_ptiles && !a.ins_fullsort[a.set_ins_list[a.set_ins_off[set]]]) {
+                rg[0] = OrderRange{off, a.tile_cursor[tile], 0};
+                rg[1] = OrderRange{off + a.tile_tailbase[tile], n - a.tile_tailbase[tile], 0};
+            } else rg[0] = OrderRange{off, n, 0};
+            for (int q = 0; q < 2; q++) { order_range(a, rg[q].start, rg[q].n, cls[q]); if (cls[q] >= 0) rk[q] = atomicAdd(&s_n[cls[q]], 1); }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 && s_n[threadIdx.x]) s_base[threadIdx.x] = (i64)atomicAdd((u64 *)&a.scal[30 + threadIdx.x], (u64)s_n[threadIdx.x]);
+    __syncthreads();
+    for (int q = 0; q < 2; q++) if (cls[q] >= 0) (cls[q] == 0 ? a.wave_list : a.big_list)[s_base[cls[q]] + rk[q]] = rg[q];
+}
+// pass 2, one wave per listed range of at most 64 photons: rank = number of smaller keys (the keys of a range are distinct)
+__global__ __launch_bounds__(256) void k_tile_order(OrderArgs a, i64 n_list)
 {
     const int lane = threadIdx.x & 63;
-    const i64 tile = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tile >= a.n_tiles) return;
-    const i32 n = a.tile_count[tile];
-    if (n < 2) return;                                       // wave-uniform
-    if (a.skip_ins && a.skip_ins[tile / a.nch]) return;
-    if (n > 64) { if (lane == 0 && n <= TILE_ORDER_MAX) a.big_list[atomicAdd((u64 *)&a.scal[28], 1ull)] = (i32)tile; return; }
-    const i64 off = a.tile_off[tile];
+    const i64 li = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (li >= n_list) return;
+    const OrderRange rg = a.wave_list[li];
+    const i32 n = rg.n; const i64 off = rg.start;
     const bool v = lane < n;
     const u32 k0 = v ? a.ph_idx[off + lane] : 0xffffffffu;
-    // already in order (the usual case for a handful of photons)?
-    const u32 prev = (u32)__shfl_up((int)k0, 1, 64);
-    if (!__any(v && lane > 0 && prev > k0)) return;
     const PhotonRec r0 = a.ph[off + (v ? lane : 0)];
     const bool has_gain = a.ph_gain && off >= a.gain_first;
     const double g0 = has_gain ? a.ph_gain[off - a.gain_first + (v ? lane : 0)] : 0.0;
-    // rank = number of photons with a smaller key (keys of a tile are distinct)
     int rank = 0;
     for (int j = 0; j < n; j++) rank += (u32)__builtin_amdgcn_readlane((int)k0, j) < k0;
     if (v) {
@@ -2726,13 +2810,13 @@ __global__ __launch_bounds__(256) void k_tile_order(OrderArgs a)
         if (has_gain) a.ph_gain[off - a.gain_first + rank] = g0;
     }
 }
-// tiles of 65 .. TILE_ORDER_MAX photons: (key, position) pairs sorted in LDS (bitonic), then the records move
+// ranges of 65 .. TILE_ORDER_MAX photons: (key, position) pairs sorted in LDS (bitonic), then the records move
 __global__ __launch_bounds__(256) void k_tile_order_big(OrderArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u64 *key = (u64 *)smem;                                  // [npow2] key << 32 | position
-    const i64 tile = a.big_list[blockIdx.x];
-    const i32 n = a.tile_count[tile]; const i64 off = a.tile_off[tile];
+    const OrderRange rg = a.big_list[blockIdx.x];
+    const i32 n = rg.n; const i64 off = rg.start;
     int np2 = 128; while (np2 < n) np2 <<= 1;
     const int tid = threadIdx.x;
     for (int i = tid; i < np2; i += 256) key[i] = i < n ? ((u64)a.ph_idx[off + i] << 32) | (u32)i : ~0ull;
@@ -2749,11 +2833,9 @@ __global__ __launch_bounds__(256) void k_tile_order_big(OrderArgs a)
             }
             __syncthreads();
         }
-    // gather through registers in rounds of 256 (source positions are arbitrary: all loads of a round first, then a barrier, then the stores)
     const bool has_gain = a.ph_gain && off >= a.gain_first;
     PhotonRec *ph = a.ph + off; u32 *idx = a.ph_idx + off; double *pg = has_gain ? a.ph_gain + (off - a.gain_first) : nullptr;
-    // (in place: every record is read before any is written -- two passes over LDS-held copies would need 12 bytes per photon more)
-    PhotonRec *cr = (PhotonRec *)(key + np2);                 // [n] copies
+    PhotonRec *cr = (PhotonRec *)(key + np2);                 // [n] copies: every record is read before any is written
     double *cg = (double *)(cr + np2);
     for (int i = tid; i < n; i += 256) { cr[i] = ph[i]; if (has_gain) cg[i] = pg[i]; }
     __syncthreads();
