@@ -62,7 +62,8 @@ typedef struct wfs_config {
                                   RNG spec v9): Poisson(n_e g p_ch) photons per (instruction, channel), a uniform surviving
                                   electron per photon -- the distribution of s2.py:308 + :673 when s2_gain_spread == 0.  0: every
                                   photon comes from the per-electron generator (needed by the electron-afterpulse pre-pass)   */
-    int32_t reserved0;         /* keeps the doubles 8-byte aligned                                   */
+    int32_t tile_gen_min;      /* ... and only where amp * gain * max(p_ch) reaches this many photons: below it a workgroup per tile
+                                  costs more than the block generator (crossover measured at ~60 photons per tile)        */
     double c2a;                /* current_2_adc                                     pulse.py:33-35   */
     double tts_mean, tts_sigma;/* pmt_transit_time_mean, spread/2.35482             pulse.py:53-56   */
     double p_dpe;              /* p_double_pe_emision                               pulse.py:76      */

@@ -36,6 +36,7 @@ typedef struct {
     /* models */
     i32 s1_simple, s2_time_model /*0 zero_delay, 1 spread around zero*/, n_lum, enable_pmt_ap, n_ap_elements;
     i32 tile_gen;                                   /* tile-local generation of eligible S2s (RNG spec v9): see gen_s2 */
+    i32 tile_gen_min, pad1;                         /* ... from this many photons per tile (amp * gain * max p_ch) on */
     double c2a;                                     /* current_2_adc, pulse.py:33-35 */
     double tts_mean, tts_sigma, p_dpe;
     double s1_decay_time, s1_decay_spread;
@@ -971,7 +972,7 @@ static int fuse_eligible(const orc_session *s, int type, u32 em_base, i64 amp, d
     double pmax = 0.0;
     for (int ch = 0; ch < c->n_tpc; ch++) { const double p = cdf[ch] - (ch ? cdf[ch - 1] : 0.0); pmax = p > pmax ? p : pmax; }
     const double lam = (double)amp * sc_gain * pmax;
-    return lam + 8.0 * sqrt(lam) + 8.0 <= (double)TILE_MAX_PHOTONS;
+    return lam >= (double)c->tile_gen_min && lam + 8.0 * sqrt(lam) + 8.0 <= (double)TILE_MAX_PHOTONS;
 }
 static i64 gen_s2(orc_session *s, call_ctx *x, int type, u32 gid, u32 em_base, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
                   double sc_gain, const double *cdf)

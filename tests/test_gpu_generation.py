@@ -30,6 +30,8 @@ def _instructions(rows):
 
 
 def _run_both(cfg, ins, seed=7, ap=None):
+    cfg = dict(cfg)
+    cfg.setdefault('tile_local_min_photons', 0)          # every eligible S2 through the tile-local generator, also the small ones
     if ap is not None:
         cfg = dict(cfg, enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap)
     res = Resource(cfg)
@@ -88,6 +90,17 @@ def _compare(orc, o, eng, counts, s_ins):
     assert np.array_equal(g['right'][keep], o['dg_right'])
     assert eng.records().tobytes() == orc.pack_records().tobytes()
     assert counts['n_pe'] == orc.n_pe
+
+
+def test_s2_sizes_around_the_tile_thresholds():
+    """default thresholds (wfs_config.tile_gen_min = 64 photons on the brightest channel, 2048 photon registers): S2s below, inside
+    and above the band in one batch -- block generator, tile-local generator, block generator -- equal the oracle photon by photon"""
+    cfg = xenonnt_test_config(s2_secondary_sc_gain=100.0, tile_local_min_photons=64)
+    rows = [dict(type=2, time=MS * (i + 1), x=1.0 * i, y=-2.0, z=-8.0 - 3 * i, amp=a) for i, a in enumerate([150, 380, 420, 2000, 9000, 11200, 13000])]
+    rows += [dict(type=1, time=MS * 9, x=0, y=0, z=-40, amp=3000)]
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows), seed=23)
+    _compare(orc, o, eng, counts, s_ins)
+    assert counts['n_photons'] > 2_000_000
 
 
 def test_s1_batch():

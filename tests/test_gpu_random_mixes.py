@@ -18,6 +18,7 @@ pytestmark = pytest.mark.gpu
 def _random_case(seed):
     rng = np.random.default_rng(seed)
     kw = dict(s2_secondary_sc_gain=float(rng.choice([1.5, 4.0, 21.3, 100.0])), seed=int(rng.integers(1, 10 ** 6)))
+    kw['tile_local_min_photons'] = int(rng.choice([0, 0, 64]))       # (the tile-local generator also for S2s too small to pay for it)
     if rng.random() < 0.4:
         kw['save_full_truth'] = False
     if rng.random() < 0.3:

@@ -19,6 +19,7 @@ MS = 1_000_000
 
 
 def _s2(n, amp, z=-10.0, **cfg_kw):
+    cfg_kw.setdefault('tile_local_min_photons', 0)       # (every S2 size through the tile path: by default only tiles worth a workgroup take it)
     cfg = xenonnt_test_config(**cfg_kw)
     ins = np.zeros(n, dtype=instruction_dtype)
     ins['type'], ins['amp'], ins['z'], ins['recoil'] = 2, amp, z, 7
@@ -45,6 +46,11 @@ def test_switch_and_eligibility_rule():
     cfg, ins = _s2(3, 300, seed=3)
     a, b = _simulate(cfg, ins), _simulate(dict(cfg, tile_local_generation=False), ins)
     assert len(a['ph_t']) != len(b['ph_t']) or not np.array_equal(a['ph_t'], b['ph_t'])
+    # small tiles keep the per-electron generator by default (wfs_config.tile_gen_min: a workgroup per tile does not pay below ~60 photons)
+    small = dict(cfg); small.pop('tile_local_min_photons')
+    assert kernel_params(small)['tile_gen_min'] == 64
+    e, f = _simulate(small, ins), _simulate(dict(small, tile_local_generation=False), ins)
+    assert np.array_equal(e['ph_t'], f['ph_t'])
     # a gain spread needs the per-electron generator
     c = _simulate(dict(cfg, s2_gain_spread=2.0), ins)
     d = _simulate(dict(cfg, s2_gain_spread=2.0, tile_local_generation=False), ins)

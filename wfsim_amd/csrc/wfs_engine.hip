@@ -1156,7 +1156,7 @@ static int run_generation(wfs_handle *h)
     h->n_fused_tiles = 0; h->p_fused = 0;
     FuseArgs f{};
     if (h->fuse_on) {
-        f.n_ins = N; f.nch = d.n_tpc; f.table_span = (i32)(1u << (32 - d.tab_s2.shift));
+        f.lam_min = h->cfg.tile_gen_min; f.n_ins = N; f.nch = d.n_tpc; f.table_span = (i32)(1u << (32 - d.tab_s2.shift));
         f.ins_type = g.ins_type; f.ins_amp = g.ins_amp; f.ins_sc = g.ins_sc; f.ins_embase = g.ins_embase; f.ins_gid = g.ins_gid; f.ins_cdfrow = g.ins_cdfrow;
         f.cdf_table = g.cdf_table; f.ins_time = g.ins_time; f.em_off = g.em_off; f.em_time = g.em_time; f.el_minmax = g.el_minmax; f.scal = g.scal;
         TRY(ensure(h, h->ins_fused, (size_t)N * 4)); TRY(ensure(h, h->ins_nsurv, (size_t)N * 4)); TRY(ensure(h, h->ins_bcap, (size_t)N * 4));

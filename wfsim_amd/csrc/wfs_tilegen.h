@@ -20,7 +20,8 @@
 //
 // Which instructions take this path is a rule both the device and the CPU oracle evaluate (fuse_eligible): type 2, no
 // emitter offset (not an electron afterpulse), s2_gain_spread == 0, PMT afterpulses off, default delay table, and a tile that
-// fits the 2048 photon registers of a workgroup with eight standard deviations to spare.
+// fits the 2048 photon registers of a workgroup with eight standard deviations to spare -- and is worth a workgroup: at least
+// wfs_config.tile_gen_min photons expected on the brightest channel (below ~60 per tile the block generator is faster).
 #pragma once
 
 #define TILE_MAX_PHOTONS 2048      // photons a pulse workgroup holds in registers (256 threads x 8)
@@ -38,6 +39,7 @@ struct __attribute__((aligned(16))) FTile {
 
 struct FuseArgs {
     i64 n_ins; i32 nch; i32 table_span;      // cells of the S2 delay table (bound of its support)
+    i32 lam_min, pad0;    // wfs_config.tile_gen_min
     const int8_t *ins_type; const i32 *ins_amp; const double *ins_sc; const u32 *ins_embase, *ins_gid; const i32 *ins_cdfrow;
     const double *cdf_table; const double *row_pmax; const i64 *ins_time; const i64 *em_off; const i64 *em_time; const i64 *el_minmax;
     i32 *ins_fused;       // [n_ins] 1: the instruction's photons are generated tile by tile
@@ -56,11 +58,11 @@ struct FuseArgs {
 
 // Both sides of the parity tests evaluate this rule (oracle/wfsim_oracle.c: fuse_eligible): the same IEEE operations (a maximum does
 // not depend on the order it is taken in).
-__device__ __forceinline__ bool fuse_eligible(int type, u32 em_base, i32 amp, double sc, double pmax)
+__device__ __forceinline__ bool fuse_eligible(int type, u32 em_base, i32 amp, double sc, double pmax, i32 lam_min)
 {
     if (type != 2 || em_base != 0u || amp <= 0 || !(sc > 0)) return false;
     const double lam = (double)amp * sc * pmax;
-    return lam + 8.0 * sqrt(lam) + 8.0 <= (double)TILE_MAX_PHOTONS;
+    return lam >= (double)lam_min && lam + 8.0 * sqrt(lam) + 8.0 <= (double)TILE_MAX_PHOTONS;
 }
 
 // largest channel probability of every pattern row: one wave per row (a thread walking a row alone pays one load latency per channel)
@@ -80,7 +82,7 @@ __global__ void k_fuse_decide(FuseArgs f)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= f.n_ins) return;
-    f.ins_fused[i] = fuse_eligible(f.ins_type[i], f.ins_embase[i], f.ins_amp[i], f.ins_sc[i], f.row_pmax[f.ins_cdfrow[i]]) ? 1 : 0;
+    f.ins_fused[i] = fuse_eligible(f.ins_type[i], f.ins_embase[i], f.ins_amp[i], f.ins_sc[i], f.row_pmax[f.ins_cdfrow[i]], f.lam_min) ? 1 : 0;
 }
 
 // Surviving electrons of a tile-generated instruction, compacted in candidate order: arrival times relative to the set origin
