@@ -108,6 +108,11 @@ __device__ __forceinline__ u32 gain_code(u32 w, u64 thr_dpe, double dpe_inv)
     return g1 | (g2 << 16);
 }
 
+// Index of the wave inside its workgroup as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes but the compiler cannot know, and
+// everything computed from it (row descriptors, base pointers, loop bounds of the wave-per-row kernels) would sit in vector
+// registers and be recomputed by the vector unit; through readfirstlane it becomes SGPR work and scalar loads.
+__device__ __forceinline__ int wave_in_block() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // Wave-wide reductions on the DPP path (quad permutes, half-row and row mirrors: VALU moves, no LDS crossbar round trips as with
 // the shuffles; readlane joins the four 16-lane rows).  Every lane -- and the scalar result -- ends up with the value of all 64.
 template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false); }

@@ -1557,7 +1557,13 @@ try {
         hipLaunchKernelGGL(k_fill_i64, dim3(1), dim3(64), 0, h->stream, h->scal.as<i64>() + 29, (i64)1, I64_MIN);
     }
     if (h->n_active_rows > 0) { Timer t(h, "k_row_desc"); hipLaunchKernelGGL(k_row_desc, dim3(nblocks(h->n_active_rows, 256)), dim3(256), 0, h->stream, d, za); }
-    if (h->n_active_rows > 0) { Timer t(h, "k_zle"); hipLaunchKernelGGL(k_zle, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
+    const int noise_kind = !d.enable_noise ? 0 : (d.noise_f ? 2 : 1);      // (a template parameter of the two row kernels: no branch between their loads)
+    if (h->n_active_rows > 0) {
+        Timer t(h, "k_zle"); const dim3 grid(nblocks(h->n_active_rows, 4));
+        if (noise_kind == 0) hipLaunchKernelGGL(k_zle<0>, grid, dim3(256), 0, h->stream, d, za);
+        else if (noise_kind == 1) hipLaunchKernelGGL(k_zle<1>, grid, dim3(256), 0, h->stream, d, za);
+        else hipLaunchKernelGGL(k_zle<2>, grid, dim3(256), 0, h->stream, d, za);
+    }
     TRY(scan(h, h->row_nrec.as<i32>(), RS, h->rec_off, 10));
     TRY(read_scal(h));
     h->n_records = h->h_scal[10];
@@ -1584,7 +1590,12 @@ try {
         { Timer t(h, "k_invert_perm"); hipLaunchKernelGGL(k_invert_perm, dim3(nblocks(NR, 256)), dim3(256), 0, h->stream, h->rec_val2.as<u32>(), h->rec_dest.as<u32>(), NR); }
         za.rec_dest = h->rec_dest.as<u32>();
     }
-    if (h->n_active_rows > 0 && h->n_records > 0) { Timer t(h, "k_pack"); hipLaunchKernelGGL(k_pack, dim3(nblocks(h->n_active_rows, 4)), dim3(256), 0, h->stream, d, za); }
+    if (h->n_active_rows > 0 && h->n_records > 0) {
+        Timer t(h, "k_pack"); const dim3 grid(nblocks(h->n_active_rows, 4));
+        if (noise_kind == 0) hipLaunchKernelGGL(k_pack<0>, grid, dim3(256), 0, h->stream, d, za);
+        else if (noise_kind == 1) hipLaunchKernelGGL(k_pack<1>, grid, dim3(256), 0, h->stream, d, za);
+        else hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, h->stream, d, za);
+    }
     {   // totals of wfs_get_counts: afterpulse sets carry no truth (rawdata.py:322-323)
         const i64 n_prim = (!h->injected && h->ap_active) ? h->n_psets : h->n_sets;
         const i64 work = std::max<i64>(RS, n_prim);

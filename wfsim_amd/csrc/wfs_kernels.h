@@ -1370,32 +1370,42 @@ __device__ __forceinline__ void row_of_slot(const WfsDev &d, i64 idx, i64 &g, i3
 // The same in two steps, for loops that want ALL their loads in flight before the first use: with the load inside finish_sample
 // the compiler waits for every load right behind it (a branch follows), and a wave spends one memory round trip per load.
 // A row no longer than the noise array wraps at most once (ix_rand < noise_len, i < len <= noise_len): no loop on the load path.
-struct RawSample { i32 acc; i32 nz; double nzf; };
-__device__ __forceinline__ RawSample load_sample(const WfsDev &d, const i32 *acc, i64 i, i64 noise_row, bool noisy, i64 ix_rand)
+// NK, the noise table of the batch, is a template parameter (0: none, 1: int16, 2: float64) and a row outside the table
+// (noisy false, wave-uniform) reads row 0 and drops the value: NO branch sits between two loads -- with a branch around the
+// noise load the compiler drained the memory counter after every one of them.
+template <int NK> struct RawSample;
+template <> struct RawSample<0> { i32 acc; };
+template <> struct RawSample<1> { i32 acc; i32 nz; };
+template <> struct RawSample<2> { i32 acc; double nzf; };
+template <int NK>
+__device__ __forceinline__ RawSample<NK> load_sample(const WfsDev &d, const i32 *acc, i32 i, i64 noise_row, i64 ix_rand, i32 nmask)
 {
-    RawSample s; s.acc = acc[i]; s.nz = 0; s.nzf = 0.0;
-    if (noisy) {                                                // (wave-uniform)
-        i64 in = ix_rand + i;
+    RawSample<NK> s; s.acc = acc[i];
+    if constexpr (NK != 0) {
+        i64 in = ix_rand + (i & nmask);                         // (nmask 0: a row outside the noise table reads the table's first sample)
         in = in >= d.noise_len ? in - d.noise_len : in;
-        if (d.noise_f) s.nzf = d.noise_f[noise_row + in]; else s.nz = d.noise[noise_row + in];
+        if constexpr (NK == 2) s.nzf = d.noise_f[noise_row + in]; else s.nz = d.noise[noise_row + in];
     }
     return s;
 }
-__device__ __forceinline__ i32 finish_loaded(const WfsDev &d, const RawSample &s, bool he, bool noisy)
+template <int NK>
+__device__ __forceinline__ i32 finish_loaded(const WfsDev &d, const RawSample<NK> &s, bool he, bool noisy)
 {
     i64 v = s.acc;
     if (he) v *= d.he_factor;
-    if (noisy) { if (d.noise_f) v = (i64)((double)v + s.nzf); else v += s.nz; }
+    if constexpr (NK == 1) v += noisy ? s.nz : 0;
+    if constexpr (NK == 2) { const i64 w = (i64)((double)v + s.nzf); v = noisy ? w : v; }
     v += d.baseline;
     return v < 0 ? 0 : (i32)v;
 }
 
 // one wave per row: find_intervals_below_threshold (utils.py:13-58) in its parallel form: consecutive
 // hit samples a < b belong to one interval iff b - a <= max(holdoff, 1); then the window of rawdata.py:302-308.
+template <int NK>
 __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
 {
     const int lane = threadIdx.x & 63;
-    i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 r = (i64)blockIdx.x * 4 + wave_in_block();         // (an SGPR: the descriptor and everything derived from it stay scalar)
     if (r >= a.n_active_rows) return;
     const RowDesc q = a.desc[r];
     const i64 idx = q.idx; const i32 channel = q.channel; const bool he = q.he != 0;
@@ -1418,18 +1428,58 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     };
     i32 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;      // (a row is shorter than 10^6 samples: 32-bit indices)
     const i32 len32 = (i32)len, hold32 = (i32)hold;
-    const bool noisy = d.enable_noise && channel < d.noise_channels;
+    const bool noisy = NK != 0 && channel < d.noise_channels;
     const bool fast_loads = len32 >= 1 && (!noisy || len32 <= d.noise_len);
-    const i64 noise_row = (i64)channel * d.noise_len;
+    const i64 noise_row = noisy ? (i64)channel * d.noise_len : 0, nixr = noisy ? ixr : 0; const i32 nmask = noisy ? -1 : 0;
+    if (hold32 >= 63 && fast_loads) {
+        // The usual geometry (hold-off of at least a chunk): two hits of one chunk are never more than the hold-off apart, so only
+        // the FIRST hit of a chunk can open an interval -- the whole interval bookkeeping is scalar work on the ballot mask, and
+        // the vector unit is left with load, finish and compare.  Four chunks of loads in flight per wave.
+        constexpr int G = 4;
+        i32 s_last = -1, s_left = -1, s_count = 0, s_nrec = 0;
+        auto close_scalar = [&](i32 k, i32 rawl, i32 rawr) -> i32 {
+            i32 l = rawl - d.tw, rr = rawr + d.tw;
+            l = l < 0 ? 0 : (l > len32 - 1 ? len32 - 1 : l); rr = rr < 0 ? 0 : (rr > len32 - 1 ? len32 - 1 : rr);
+            l = (l + 1) / 2 * 2; rr = rr / 2 * 2;
+            if (lane == 0) { a.itv_left[base + k] = row_abs + l; a.itv_right[base + k] = row_abs + rr; }
+            const i32 plen = rr - l + 1;
+            return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
+        };
+        for (i32 g0 = 0; g0 < len32; g0 += 64 * G) {
+            RawSample<NK> rs[G];
+#pragma unroll
+            for (int u = 0; u < G; u++) { const i32 i = g0 + 64 * u + lane; rs[u] = load_sample<NK>(d, acc, i < len32 ? i : len32 - 1, noise_row, nixr, nmask); }
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const i32 c0 = g0 + 64 * u;
+                if (c0 >= len32) break;                         // wave-uniform
+                const i32 i = c0 + lane;
+                const i32 v = finish_loaded(d, rs[u], he, noisy);
+                if (a.row_dbg && i < len32) a.row_dbg[a.row_dbg_off[r] + i] = v;
+                const u64 mask = __ballot(i < len32 && (i64)v < thr);
+                if (mask) {
+                    const i32 first = c0 + (i32)__builtin_ctzll(mask);
+                    if (s_last < 0 || first - s_last > hold32) {
+                        if (s_count > 0) s_nrec += close_scalar(s_count - 1, s_left, s_last);
+                        s_left = first; s_count++;
+                    }
+                    s_last = c0 + 63 - (i32)__builtin_clzll(mask);
+                }
+            }
+        }
+        if (s_count > 0) s_nrec += close_scalar(s_count - 1, s_left, s_last);
+        if (lane == 0) { a.itv_n[idx] = s_count; a.row_nrec[idx] = s_nrec; }
+        return;
+    }
     // chunks of 64 samples; the loads of ZLE_GROUP chunks are issued together (one dependent load per chunk leaves the wave
     // waiting a memory round trip per 64 samples)
     constexpr int ZLE_GROUP = 2;
     for (i32 g0 = 0; g0 < len32; g0 += 64 * ZLE_GROUP) {
         i32 vv[ZLE_GROUP];
         if (fast_loads) {                                       // (wave-uniform) every load of the group first, then the arithmetic
-            RawSample rs[ZLE_GROUP];
+            RawSample<NK> rs[ZLE_GROUP];
 #pragma unroll
-            for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; rs[u] = load_sample(d, acc, i < len32 ? i : len32 - 1, noise_row, noisy, ixr); }
+            for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; rs[u] = load_sample<NK>(d, acc, i < len32 ? i : len32 - 1, noise_row, nixr, nmask); }
 #pragma unroll
             for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; vv[u] = i < len32 ? finish_loaded(d, rs[u], he, noisy) : 0x7fffffff; }
         } else {
@@ -1473,7 +1523,7 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
 __global__ __launch_bounds__(256) void k_rec_keys(WfsDev d, ZleArgs a)
 {
     const int lane = threadIdx.x & 63;
-    i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 r = (i64)blockIdx.x * 4 + wave_in_block();
     if (r >= a.n_active_rows) return;
     const RowDesc q = a.desc[r];
     const i32 count = a.itv_n[q.idx];
@@ -1494,11 +1544,14 @@ __global__ __launch_bounds__(256) void k_rec_keys(WfsDev d, ZleArgs a)
 }
 __global__ void k_invert_perm(const u32 *val, u32 *dest, i64 n) { const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (p < n) dest[val[p]] = (u32)p; }
 
-// one wave per row: write its intervals as strax raw_records (strax_interface.py:425-435); a record is 61 dwords
+// one wave per row: write its intervals as strax raw_records (strax_interface.py:425-435).  A record is 24 bytes of header and
+// samples_per_record int16: lane q writes dword q of the record (61 dwords with 110 samples: three idle lanes, no division by the
+// record length anywhere), PACK_U records in flight so that the loads of one do not wait behind the stores of the one before.
+template <int NK>
 __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
 {
     const int lane = threadIdx.x & 63;
-    i64 r = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 r = (i64)blockIdx.x * 4 + wave_in_block();
     if (r >= a.n_active_rows) return;
     const RowDesc q = a.desc[r];
     const i64 idx = q.idx;
@@ -1509,39 +1562,63 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const i64 row_abs = q.row_abs;
     const i64 ixr = q.ixr;
     const i64 base = q.itv_base;
+    const i32 len32 = q.len;
     const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
+    const i64 rec_bytes = 24 + 2 * (i64)spr;
+    const bool noisy = NK != 0 && channel < d.noise_channels;
+    const bool fast_loads = !noisy || len32 <= d.noise_len;        // the noise index wraps at most once inside the row
+    const i64 noise_row = noisy ? (i64)channel * d.noise_len : 0, nixr = noisy ? ixr : 0; const i32 nmask = noisy ? -1 : 0;
+    const u32 w3 = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
+    constexpr int PACK_U = 4;
     i64 rec = a.rec_off[idx];
     for (i32 k = 0; k < count; k++) {
         const i64 left = a.itv_left[base + k]; const i32 plen = (i32)(a.itv_right[base + k] - left + 1);
         if (plen <= 0) continue;
         const i32 need = (plen + spr - 1) / spr;
-        // all dwords of the interval's records as one index space (record f, dword q of 61), four per lane in flight
-        const i32 n_dw = need * rec_dwords;
-        for (i32 t0 = lane; t0 < n_dw; t0 += 64 * 4) {
+        const i32 off = (i32)(left - row_abs);                     // first sample of the interval inside the row
+        for (int q0 = 0; q0 < rec_dwords; q0 += 64) {              // (one pass unless a record is longer than 64 dwords)
+            const int qd = q0 + lane;
+            const int s0 = (qd - 6) * 2;                            // first of the lane's two samples (lanes of the header: negative)
+            for (i32 f0 = 0; f0 < need; f0 += PACK_U) {
+                RawSample<NK> lo[PACK_U], hi[PACK_U];
+                if (fast_loads) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const i32 t = t0 + 64 * u;
-                if (t >= n_dw) break;
-                const i32 f = t / rec_dwords, qd = t - f * rec_dwords;
-                if (rec + f >= a.rec_capacity) continue;
-                u32 *out = (u32 *)(a.records + (a.rec_dest ? (i64)a.rec_dest[rec + f] : rec + f) * (24 + 2 * (i64)spr));
-                const i64 time = (i64)d.dt * (left + spr * f);
-                const i32 length = (i32)((plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f);
-                u32 w;
-                if (qd == 0) w = (u32)(u64)time;
-                else if (qd == 1) w = (u32)((u64)time >> 32);
-                else if (qd == 2) w = (u32)length;
-                else if (qd == 3) w = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
-                else if (qd == 4) w = (u32)plen;
-                else if (qd == 5) w = (u32)(uint16_t)f;           // record_i, baseline = 0
-                else {
-                    const int s0 = (qd - 6) * 2;
-                    const i64 i0 = (left - row_abs) + spr * f + s0;
-                    const u32 lo = s0 < length ? (u32)(uint16_t)finish_sample(d, acc, i0, channel, he, ixr) : 0u;
-                    const u32 hi = s0 + 1 < length ? (u32)(uint16_t)finish_sample(d, acc, i0 + 1, channel, he, ixr) : 0u;
-                    w = lo | (hi << 16);
+                    for (int u = 0; u < PACK_U; u++) {
+                        const i32 f = f0 + u;
+                        if (f >= need) break;                       // wave-uniform
+                        i32 i0 = off + spr * f + (s0 < 0 ? 0 : s0);
+                        i0 = i0 > len32 - 1 ? len32 - 1 : i0;       // (lanes past the record's samples read a valid sample and drop it)
+                        const i32 i1 = i0 + 1 > len32 - 1 ? len32 - 1 : i0 + 1;
+                        lo[u] = load_sample<NK>(d, acc, i0, noise_row, nixr, nmask); hi[u] = load_sample<NK>(d, acc, i1, noise_row, nixr, nmask);
+                    }
                 }
-                out[qd] = w;
+#pragma unroll
+                for (int u = 0; u < PACK_U; u++) {
+                    const i32 f = f0 + u;
+                    if (f >= need) break;
+                    if (rec + f >= a.rec_capacity) break;
+                    u32 *out = (u32 *)(a.records + (a.rec_dest ? (i64)a.rec_dest[rec + f] : rec + f) * rec_bytes);
+                    const i64 time = (i64)d.dt * (left + spr * f);
+                    const i32 length = (plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f;
+                    u32 w;
+                    if (qd >= 6) {
+                        u32 vlo, vhi;
+                        if (fast_loads) { vlo = (u32)(uint16_t)finish_loaded(d, lo[u], he, noisy); vhi = (u32)(uint16_t)finish_loaded(d, hi[u], he, noisy); }
+                        else {
+                            const i64 i0 = (i64)off + spr * f + s0;
+                            vlo = s0 < length ? (u32)(uint16_t)finish_sample(d, acc, i0, channel, he, ixr) : 0u;
+                            vhi = s0 + 1 < length ? (u32)(uint16_t)finish_sample(d, acc, i0 + 1, channel, he, ixr) : 0u;
+                        }
+                        w = (s0 < length ? vlo : 0u) | ((s0 + 1 < length ? vhi : 0u) << 16);
+                    }
+                    else if (qd == 0) w = (u32)(u64)time;
+                    else if (qd == 1) w = (u32)((u64)time >> 32);
+                    else if (qd == 2) w = (u32)length;
+                    else if (qd == 3) w = w3;
+                    else if (qd == 4) w = (u32)plen;
+                    else w = (u32)(uint16_t)f;                        // record_i, baseline = 0
+                    if (qd < rec_dwords) out[qd] = w;
+                }
             }
         }
         rec += need;
