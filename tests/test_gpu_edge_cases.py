@@ -65,6 +65,18 @@ def test_window_longer_than_1e6_samples_is_an_error():
     assert len(list(rd(ins[:20]))) > 0
 
 
+def test_rows_with_more_than_64_intervals():
+    # 100 S1s 90 us apart share one window (right_raw_extension is 100 us): every channel's row is ~900k samples with an
+    # interval per S1 that reached it -- k_zle keeps closed intervals in lanes and flushes them 64 at a time
+    cfg = xenonnt_test_config(seed=47)
+    ins = _instructions([dict(type=1, time=MS + 90_000 * i, x=0, y=0, z=-10, amp=20000) for i in range(100)])
+    orc, o, eng, counts, s_ins = _run_both(cfg, ins)
+    z = eng.intervals()
+    per_row = np.unique(z['channel'], return_counts=True)[1]
+    assert per_row.max() > 64 and (per_row > 64).sum() > 10
+    _compare(orc, o, eng, counts, s_ins)
+
+
 def test_float_noise_array():
     """a noise array of floats with non-integral values (rawdata.py:436 stores the truncated sum into the int64 row):
     device == oracle, and different from the same array truncated on upload"""

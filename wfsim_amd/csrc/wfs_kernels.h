@@ -1378,13 +1378,14 @@ template <> struct RawSample<0> { i32 acc; };
 template <> struct RawSample<1> { i32 acc; i32 nz; };
 template <> struct RawSample<2> { i32 acc; double nzf; };
 template <int NK>
-__device__ __forceinline__ RawSample<NK> load_sample(const WfsDev &d, const i32 *acc, i32 i, i64 noise_row, i64 ix_rand, i32 nmask)
+__device__ __forceinline__ RawSample<NK> load_sample(const WfsDev &d, const i32 *acc, i32 i, const void *noise_row, u32 ix_rand, i32 nmask)
 {
-    RawSample<NK> s; s.acc = acc[i];
+    // (32-bit offsets from wave-uniform row pointers: the address arithmetic is one add per load, the bases stay in SGPRs)
+    RawSample<NK> s; s.acc = acc[(u32)i];
     if constexpr (NK != 0) {
-        i64 in = ix_rand + (i & nmask);                         // (nmask 0: a row outside the noise table reads the table's first sample)
-        in = in >= d.noise_len ? in - d.noise_len : in;
-        if constexpr (NK == 2) s.nzf = d.noise_f[noise_row + in]; else s.nz = d.noise[noise_row + in];
+        u32 in = ix_rand + (u32)(i & nmask);                    // (nmask 0: a row outside the noise table reads the table's first sample)
+        in = in >= (u32)d.noise_len ? in - (u32)d.noise_len : in;
+        if constexpr (NK == 2) s.nzf = ((const double *)noise_row)[in]; else s.nz = ((const int16_t *)noise_row)[in];
     }
     return s;
 }
@@ -1430,32 +1431,47 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     const i32 len32 = (i32)len, hold32 = (i32)hold;
     const bool noisy = NK != 0 && channel < d.noise_channels;
     const bool fast_loads = len32 >= 1 && (!noisy || len32 <= d.noise_len);
-    const i64 noise_row = noisy ? (i64)channel * d.noise_len : 0, nixr = noisy ? ixr : 0; const i32 nmask = noisy ? -1 : 0;
-    if (hold32 >= 63 && fast_loads) {
+    const i64 noise_off = noisy ? (i64)channel * d.noise_len : 0; const u32 nixr = noisy ? (u32)ixr : 0u; const i32 nmask = noisy ? -1 : 0;
+    const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
+    if (hold32 >= 63 && fast_loads && !a.row_dbg) {
         // The usual geometry (hold-off of at least a chunk): two hits of one chunk are never more than the hold-off apart, so only
         // the FIRST hit of a chunk can open an interval -- the whole interval bookkeeping is scalar work on the ballot mask, and
-        // the vector unit is left with load, finish and compare.  Four chunks of loads in flight per wave.
+        // the vector unit is left with load, finish and compare.  The loads of the next four chunks are issued before the four in
+        // hand are looked at (a row is a chain of memory round trips otherwise: ~800 samples of a row with afterpulses = 4 trips).
         constexpr int G = 4;
         i32 s_last = -1, s_left = -1, s_count = 0, s_nrec = 0;
+        // Closed intervals wait in lane (k mod 64) and leave in one store behind the loop.  A store inside the loop -- even one that is
+        // almost never executed -- may be outstanding together with loads, the two kinds retire out of order, and the compiler then
+        // waits for EVERYTHING at the top of the loop; the flush of a row with more than 64 intervals drains the counter itself.
+        i32 my_l = 0, my_r = 0;
         auto close_scalar = [&](i32 k, i32 rawl, i32 rawr) -> i32 {
             i32 l = rawl - d.tw, rr = rawr + d.tw;
             l = l < 0 ? 0 : (l > len32 - 1 ? len32 - 1 : l); rr = rr < 0 ? 0 : (rr > len32 - 1 ? len32 - 1 : rr);
             l = (l + 1) / 2 * 2; rr = rr / 2 * 2;
-            if (lane == 0) { a.itv_left[base + k] = row_abs + l; a.itv_right[base + k] = row_abs + rr; }
+            const int slot = k & 63;
+            if (lane == slot) { my_l = l; my_r = rr; }
+            if (slot == 63) {
+                a.itv_left[base + (k - 63) + lane] = row_abs + my_l; a.itv_right[base + (k - 63) + lane] = row_abs + my_r;
+                __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+            }
             const i32 plen = rr - l + 1;
             return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
         };
-        for (i32 g0 = 0; g0 < len32; g0 += 64 * G) {
-            RawSample<NK> rs[G];
+        // Two register sets, A and B, alternately filled and looked at -- and never copied: a move out of a load's destination is a
+        // wait for that load.  Loads are unconditional (past the end of the row every lane reads the row's last sample): behind a
+        // branch the compiler drains the memory counter instead of counting.
+        RawSample<NK> A[G], B[G];
+        auto fetch = [&](RawSample<NK> *buf, i32 g0) {
 #pragma unroll
-            for (int u = 0; u < G; u++) { const i32 i = g0 + 64 * u + lane; rs[u] = load_sample<NK>(d, acc, i < len32 ? i : len32 - 1, noise_row, nixr, nmask); }
+            for (int u = 0; u < G; u++) { const i32 i = g0 + 64 * u + lane; buf[u] = load_sample<NK>(d, acc, i < len32 ? i : len32 - 1, noise_row, nixr, nmask); }
+        };
+        auto look = [&](const RawSample<NK> *buf, i32 g0) {
 #pragma unroll
             for (int u = 0; u < G; u++) {
                 const i32 c0 = g0 + 64 * u;
                 if (c0 >= len32) break;                         // wave-uniform
                 const i32 i = c0 + lane;
-                const i32 v = finish_loaded(d, rs[u], he, noisy);
-                if (a.row_dbg && i < len32) a.row_dbg[a.row_dbg_off[r] + i] = v;
+                const i32 v = finish_loaded(d, buf[u], he, noisy);
                 const u64 mask = __ballot(i < len32 && (i64)v < thr);
                 if (mask) {
                     const i32 first = c0 + (i32)__builtin_ctzll(mask);
@@ -1466,8 +1482,15 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
                     s_last = c0 + 63 - (i32)__builtin_clzll(mask);
                 }
             }
+        };
+        fetch(A, 0);
+        for (i32 g0 = 0; g0 < len32; g0 += 128 * G) {
+            fetch(B, g0 + 64 * G); look(A, g0);
+            if (g0 + 64 * G >= len32) break;
+            fetch(A, g0 + 128 * G); look(B, g0 + 64 * G);
         }
         if (s_count > 0) s_nrec += close_scalar(s_count - 1, s_left, s_last);
+        if (lane < (s_count & 63)) { const i64 k0 = base + (s_count & ~63); a.itv_left[k0 + lane] = row_abs + my_l; a.itv_right[k0 + lane] = row_abs + my_r; }
         if (lane == 0) { a.itv_n[idx] = s_count; a.row_nrec[idx] = s_nrec; }
         return;
     }
@@ -1567,7 +1590,8 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const i64 rec_bytes = 24 + 2 * (i64)spr;
     const bool noisy = NK != 0 && channel < d.noise_channels;
     const bool fast_loads = !noisy || len32 <= d.noise_len;        // the noise index wraps at most once inside the row
-    const i64 noise_row = noisy ? (i64)channel * d.noise_len : 0, nixr = noisy ? ixr : 0; const i32 nmask = noisy ? -1 : 0;
+    const i64 noise_off = noisy ? (i64)channel * d.noise_len : 0; const u32 nixr = noisy ? (u32)ixr : 0u; const i32 nmask = noisy ? -1 : 0;
+    const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
     const u32 w3 = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
     constexpr int PACK_U = 4;
     i64 rec = a.rec_off[idx];
