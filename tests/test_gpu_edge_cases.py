@@ -109,6 +109,23 @@ def test_float_noise_array():
     assert out['float'] != out['truncated']
 
 
+@pytest.mark.parametrize('noise_len,as_float', [(100, False), (511, True), (512, False), (700, True), (3000, False)])
+def test_rows_longer_than_the_noise_table(noise_len, as_float):
+    """the noise index of a row wraps modulo the table length (rawdata.py:433-434) as often as the row is long: tables shorter
+    than a block of samples take the general path of k_zle / k_pack, longer ones the scalar-start path; S1 + S2 pairs with PMT
+    afterpulses give rows of several thousand samples"""
+    from tests.helpers import golden, ap_tables_from_golden
+    nz = golden('noise.npz')['noise'][:noise_len]
+    if as_float: nz = nz.astype(np.float64) + np.random.default_rng(5).uniform(-0.9, 0.9, nz.shape)
+    cfg = xenonnt_test_config(seed=70 + noise_len, enable_noise=True, noise_data=nz)
+    rows = []
+    for i in range(6):
+        rows += [dict(type=1, time=MS * (i + 1), x=2, y=1, z=-40, amp=4000), dict(type=2, time=MS * (i + 1), x=2, y=1, z=-40, amp=300)]
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows), ap=ap_tables_from_golden())
+    assert (eng.intervals()['right'] - eng.intervals()['left']).max() > 0 and counts['n_records'] > 1000
+    _compare(orc, o, eng, counts, s_ins)
+
+
 def small_array_config(n, **kw):
     """a detector of n PMTs (upper half = top array): fewer channels than a wave has lanes"""
     c = xenonnt_test_config(**kw)

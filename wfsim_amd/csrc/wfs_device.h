@@ -170,12 +170,18 @@ __device__ __forceinline__ double wave_sum(double v)
 __host__ __device__ __forceinline__ i64 floordiv(i64 a, i64 b) { i64 q = a / b; return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q; }
 __host__ __device__ __forceinline__ i64 floormod(i64 a, i64 b) { i64 m = a % b; return (m != 0 && ((m < 0) != (b < 0))) ? m + b : m; }
 
+// A lane of k_zle reads 4 consecutive noise samples from any start below noise_len: every channel row of the device copy is
+// followed by its own first NOISE_PAD samples, so the read never meets the wrap (rawdata.py:433-434 indexes modulo noise_len).
+constexpr int NOISE_PAD = 4;
+constexpr int NOISE_MIN_FAST = 512;            // shortest noise table of the fast row kernels (a block of 256 samples wraps at most once)
+
 // Everything a kernel needs, passed by value (fits the kernarg segment).
 struct WfsDev {
     // scalars (wfs_config)
     i32 dt, samples_before, samples_after, store_before, store_after, tlen, tw, baseline, n_rows;
     i32 n_tpc, n_top, he_first, he_factor, last_bottom, detector_nt, enable_noise, s1_simple, s2_time_model, enable_pmt_ap;
     i32 n_spe, n_lum, noise_len, noise_channels, n_ap, he_rows /* HE rows materialised */, row_slots /* per group */;
+    i32 noise_stride;                          // samples between the noise rows of two channels: noise_len + NOISE_PAD, the pad repeats the row's start
     double c2a, tts_mean, tts_sigma, p_dpe, s1_decay_time, s1_decay_spread, sf_gas, t1_gas, t3_gas, s2_time_spread;
     double trap_time, gain_spread, pmt_ap_modifier, pmt_ap_t_modifier, rext;
     u32 k0, k1;

@@ -493,12 +493,13 @@ try {
     if (!h->tables_set) return h->fail(WFS_E_STATE, "wfs_set_tables must be called first");
     if (!noise || noise_len <= 0 || noise_channels <= 0) return h->fail(WFS_E_INVALID, "wfs_set_noise_float: empty noise array");
     HIPCHK(hipSetDevice(h->device));
-    std::vector<double> nt((size_t)noise_len * noise_channels);
-    for (int64_t i = 0; i < noise_len; i++) for (int c = 0; c < noise_channels; c++) nt[(size_t)c * noise_len + i] = noise[(size_t)i * noise_channels + c];
+    const size_t stride = (size_t)noise_len + NOISE_PAD;        // (every row followed by its own first samples: wfs_device.h NOISE_PAD)
+    std::vector<double> nt(stride * noise_channels);
+    for (int64_t i = 0; i < (int64_t)stride; i++) for (int c = 0; c < noise_channels; c++) nt[(size_t)c * stride + i] = noise[(size_t)(i % noise_len) * noise_channels + c];
     TRY(upload(h, h->t_noise_f, nt.data(), sizeof(double) * nt.size()));
     HIPCHK(hipStreamSynchronize(h->stream));
     WfsDev &d = h->dev;
-    d.noise_f = h->t_noise_f.as<double>(); d.noise = (const int16_t *)d.noise_f; d.noise_len = noise_len; d.noise_channels = noise_channels;
+    d.noise_f = h->t_noise_f.as<double>(); d.noise = (const int16_t *)d.noise_f; d.noise_len = noise_len; d.noise_channels = noise_channels; d.noise_stride = (i32)stride;
     refresh_dev(h);
     return WFS_OK;
 } WFS_CATCH(h)
@@ -543,15 +544,17 @@ try {
         d.n_lum = n_lum; h->h_lum_x.assign(lum_x, lum_x + n_lum); h->h_lum_t.assign(lum_t, lum_t + n_lum);
     }
     TRY(build_time_tables(h));         // the S2 delay table contains the luminescence term
-    d.noise = nullptr; d.noise_f = nullptr; d.noise_len = 0; d.noise_channels = 0;
+    d.noise = nullptr; d.noise_f = nullptr; d.noise_len = 0; d.noise_channels = 0; d.noise_stride = 0;
     if (noise && noise_len > 0 && noise_channels > 0) {
         // channel-major on the device ([channel][sample]; the reference's array is [sample][channel], rawdata.py:429): a row reads
         // consecutive samples of ONE channel -- time-major that is one cache line per sample
-        std::vector<int16_t> nt((size_t)noise_len * noise_channels);
-        for (int64_t i = 0; i < noise_len; i++) for (int c = 0; c < noise_channels; c++) nt[(size_t)c * noise_len + i] = noise[(size_t)i * noise_channels + c];
+        // (and every row followed by its own first samples: wfs_device.h NOISE_PAD)
+        const size_t stride = (size_t)noise_len + NOISE_PAD;
+        std::vector<int16_t> nt(stride * noise_channels);
+        for (int64_t i = 0; i < (int64_t)stride; i++) for (int c = 0; c < noise_channels; c++) nt[(size_t)c * stride + i] = noise[(size_t)(i % noise_len) * noise_channels + c];
         TRY(upload(h, h->t_noise, nt.data(), sizeof(int16_t) * nt.size()));
         HIPCHK(hipStreamSynchronize(h->stream));
-        d.noise = h->t_noise.as<int16_t>(); d.noise_len = noise_len; d.noise_channels = noise_channels;
+        d.noise = h->t_noise.as<int16_t>(); d.noise_len = noise_len; d.noise_channels = noise_channels; d.noise_stride = (i32)stride;
     }
     d.templates = h->t_templates.as<double>(); d.spe = h->t_spe.as<double>(); d.n_spe = n_spe; d.gains = h->t_gains.as<double>();
     d.thr_truth = h->t_thr_truth.as<double>(); d.thr_zle = h->t_thr_zle.as<i64>(); d.lum_x = h->t_lumx.as<double>(); d.lum_t = h->t_lumt.as<double>();
@@ -1281,7 +1284,7 @@ static int run_generation(wfs_handle *h)
     }
     if (h->fuse_on && h->n_fused_tiles > 0) {
         // the tiles' photons and pulses (before the geometry: the tile time ranges come out of this kernel)
-        TRY(ensure(h, h->tbuf, (size_t)h->h_scal[23] * 4));
+        TRY(ensure(h, h->tbuf, (size_t)h->h_scal[23] * 4 + 64));
         TRY(ensure(h, h->tile_truth, (size_t)T * 8 * 8));
         f.tile_off = h->tile_off.as<i64>(); f.tile_tmin = h->tile_tmin.as<i32>(); f.tile_tmax = h->tile_tmax.as<i32>(); f.tile_truth = h->tile_truth.as<double>();
         f.tbuf = h->tbuf.as<i32>(); f.ph = h->ph.as<PhotonRec>(); f.keep_ph = (h->keep_currents & 16) ? 1 : 0;
@@ -1401,7 +1404,7 @@ try {
     // (results do not depend on it; sorting keeps profiles and debug dumps reproducible)
 
     // ---- pulses
-    TRY(ensure(h, h->raw, (size_t)h->s_raw * 4)); HIPCHK(hipMemsetAsync(h->raw.p, 0, (size_t)h->s_raw * 4, h->stream));
+    TRY(ensure(h, h->raw, (size_t)h->s_raw * 4 + 64)); HIPCHK(hipMemsetAsync(h->raw.p, 0, (size_t)h->s_raw * 4, h->stream));       // (+64: a lane of k_zle reads 4 samples from its first valid one)
     TRY(ensure(h, h->truth, (size_t)S * 16 * 8)); HIPCHK(hipMemsetAsync(h->truth.p, 0, (size_t)S * 16 * 8, h->stream));
     TRY(ensure(h, h->tminmax, (size_t)S * 16)); TRY(ensure(h, h->tile_truth, (size_t)T * 8 * 8));
     PulseArgs pa{};

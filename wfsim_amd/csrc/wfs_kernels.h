@@ -1351,11 +1351,10 @@ __device__ __forceinline__ i32 finish_sample(const WfsDev &d, const i32 *acc, i6
     i64 v = acc[i];
     if (he) v *= d.he_factor;                                   // rawdata.py:242-246
     if (d.enable_noise && slot_ch < d.noise_channels) {
-        i64 in = ix_rand + i;
-        while (in >= d.noise_len) in -= d.noise_len;            // (= in mod noise_len, rawdata.py:433-434; a 64-bit division here costs more than the row)
+        const u32 in = ((u32)ix_rand + (u32)i) % (u32)d.noise_len;      // rawdata.py:433-434 (ix_rand < noise_len <= 2^31, i < 2^20: 32 bits hold the sum)
         // channel-major copy (wfs_set_tables): consecutive samples, consecutive addresses
-        if (d.noise_f) v = (i64)((double)v + d.noise_f[(i64)slot_ch * d.noise_len + in]);     // numba: int64 += float64 stores the truncated sum
-        else v += d.noise[(i64)slot_ch * d.noise_len + in];
+        if (d.noise_f) v = (i64)((double)v + d.noise_f[(i64)slot_ch * d.noise_stride + in]);     // numba: int64 += float64 stores the truncated sum
+        else v += d.noise[(i64)slot_ch * d.noise_stride + in];
     }
     v += d.baseline;
     return v < 0 ? 0 : (i32)v;
@@ -1378,12 +1377,13 @@ template <> struct RawSample<0> { i32 acc; };
 template <> struct RawSample<1> { i32 acc; i32 nz; };
 template <> struct RawSample<2> { i32 acc; double nzf; };
 template <int NK>
-__device__ __forceinline__ RawSample<NK> load_sample(const WfsDev &d, const i32 *acc, i32 i, const void *noise_row, u32 ix_rand, i32 nmask)
+__device__ __forceinline__ RawSample<NK> load_sample(const WfsDev &d, const i32 *acc, i32 i, const void *noise_row, u32 nstart, u32 noff)
 {
     // (32-bit offsets from wave-uniform row pointers: the address arithmetic is one add per load, the bases stay in SGPRs)
+    // noise sample nstart + noff of the row, nstart < noise_len a scalar, noff < noise_len: one conditional subtraction wraps it
     RawSample<NK> s; s.acc = acc[(u32)i];
     if constexpr (NK != 0) {
-        u32 in = ix_rand + (u32)(i & nmask);                    // (nmask 0: a row outside the noise table reads the table's first sample)
+        u32 in = nstart + noff;
         in = in >= (u32)d.noise_len ? in - (u32)d.noise_len : in;
         if constexpr (NK == 2) s.nzf = ((const double *)noise_row)[in]; else s.nz = ((const int16_t *)noise_row)[in];
     }
@@ -1396,6 +1396,34 @@ __device__ __forceinline__ i32 finish_loaded(const WfsDev &d, const RawSample<NK
     if (he) v *= d.he_factor;
     if constexpr (NK == 1) v += noisy ? s.nz : 0;
     if constexpr (NK == 2) { const i64 w = (i64)((double)v + s.nzf); v = noisy ? w : v; }
+    v += d.baseline;
+    return v < 0 ? 0 : (i32)v;
+}
+
+// Four consecutive samples of a row per lane (k_zle): 16 bytes of the row at a 4-byte aligned address, 8 (32) bytes of the noise at a
+// 2 (8)-byte aligned one -- the hardware takes both as single loads; NOISE_PAD keeps the noise read off the wrap.
+template <int NK> struct Raw4;
+template <> struct Raw4<0> { i32 acc[4]; };
+template <> struct Raw4<1> { i32 acc[4]; int16_t nz[4]; };
+template <> struct Raw4<2> { i32 acc[4]; double nzf[4]; };
+template <int NK>
+__device__ __forceinline__ Raw4<NK> load_four(const WfsDev &d, const i32 *acc, i32 i, const void *noise_row, u32 nstart, u32 noff)
+{
+    Raw4<NK> s; __builtin_memcpy(s.acc, acc + (u32)i, 16);
+    if constexpr (NK != 0) {
+        u32 in = nstart + noff;
+        in = in >= (u32)d.noise_len ? in - (u32)d.noise_len : in;
+        if constexpr (NK == 2) __builtin_memcpy(s.nzf, (const double *)noise_row + in, 32); else __builtin_memcpy(s.nz, (const int16_t *)noise_row + in, 8);
+    }
+    return s;
+}
+template <int NK>
+__device__ __forceinline__ i32 finish_four(const WfsDev &d, const Raw4<NK> &s, int j, bool he, bool noisy)
+{
+    i64 v = s.acc[j];
+    if (he) v *= d.he_factor;
+    if constexpr (NK == 1) v += noisy ? (i32)s.nz[j] : 0;
+    if constexpr (NK == 2) { const i64 w = (i64)((double)v + s.nzf[j]); v = noisy ? w : v; }
     v += d.baseline;
     return v < 0 ? 0 : (i32)v;
 }
@@ -1430,14 +1458,16 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     i32 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;      // (a row is shorter than 10^6 samples: 32-bit indices)
     const i32 len32 = (i32)len, hold32 = (i32)hold;
     const bool noisy = NK != 0 && channel < d.noise_channels;
-    const bool fast_loads = len32 >= 1 && (!noisy || len32 <= d.noise_len);
-    const i64 noise_off = noisy ? (i64)channel * d.noise_len : 0; const u32 nixr = noisy ? (u32)ixr : 0u; const i32 nmask = noisy ? -1 : 0;
+    // the noise index of a row's sample i is (ix + i) mod noise_len (rawdata.py:433-434): a scalar start per block of samples that
+    // steps with the block and wraps, plus the lane's offset inside the block -- rows may be any number of noise lengths long.
+    // (A table shorter than NOISE_MIN_FAST samples would wrap more than once inside a block: the general path below.)
+    const bool fast_loads = len32 >= 1 && (NK == 0 || d.noise_len >= NOISE_MIN_FAST);
+    const i64 noise_off = noisy ? (i64)channel * d.noise_stride : 0; const u32 nixr = noisy ? (u32)ixr : 0u;
     const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
     if (hold32 >= 63 && fast_loads && !a.row_dbg) {
         // The usual geometry (hold-off of at least a chunk): two hits of one chunk are never more than the hold-off apart, so only
         // the FIRST hit of a chunk can open an interval -- the whole interval bookkeeping is scalar work on the ballot mask, and
-        // the vector unit is left with load, finish and compare.  The loads of the next four chunks are issued before the four in
-        // hand are looked at (a row is a chain of memory round trips otherwise: ~800 samples of a row with afterpulses = 4 trips).
+        // the vector unit is left with load, finish and compare.
         constexpr int G = 4;
         i32 s_last = -1, s_left = -1, s_count = 0, s_nrec = 0;
         // Closed intervals wait in lane (k mod 64) and leave in one store behind the loop.  A store inside the loop -- even one that is
@@ -1457,38 +1487,50 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
             const i32 plen = rr - l + 1;
             return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
         };
-        // Two register sets, A and B, alternately filled and looked at -- and never copied: a move out of a load's destination is a
-        // wait for that load.  Loads are unconditional (past the end of the row every lane reads the row's last sample): behind a
-        // branch the compiler drains the memory counter instead of counting.
-        RawSample<NK> A[G], B[G];
-        auto fetch = [&](RawSample<NK> *buf, i32 g0) {
-#pragma unroll
-            for (int u = 0; u < G; u++) { const i32 i = g0 + 64 * u + lane; buf[u] = load_sample<NK>(d, acc, i < len32 ? i : len32 - 1, noise_row, nixr, nmask); }
-        };
-        auto look = [&](const RawSample<NK> *buf, i32 g0) {
+        // A lane takes FOUR consecutive samples (one 16-byte load of the row, one 8-byte load of the noise): a wave instruction moves
+        // 1 KB of the row, and the hits of a lane are a nibble.  16 lanes are a chunk of 64 samples; its first and last hit come from
+        // the ballot of the non-empty nibbles and two readlanes.
+        // G such loads per trip: 1024 samples, most rows in one trip (6 KB in flight per wave; a second register set filled ahead
+        // bought nothing -- the register allocator reuses the first set's registers for addresses and waits for its loads anyway).
+        // Loads are unconditional (lanes past the end of the row read its first samples): behind a branch the compiler drains the
+        // memory counter instead of counting.
+        Raw4<NK> A[G];
+        u32 nrun = nixr;                                        // noise index of the next block's first sample (a scalar)
+        auto fetch = [&](Raw4<NK> *buf, i32 g0) {
 #pragma unroll
             for (int u = 0; u < G; u++) {
-                const i32 c0 = g0 + 64 * u;
-                if (c0 >= len32) break;                         // wave-uniform
-                const i32 i = c0 + lane;
-                const i32 v = finish_loaded(d, buf[u], he, noisy);
-                const u64 mask = __ballot(i < len32 && (i64)v < thr);
-                if (mask) {
-                    const i32 first = c0 + (i32)__builtin_ctzll(mask);
+                const i32 i = g0 + 256 * u + 4 * lane;
+                buf[u] = load_four<NK>(d, acc, i < len32 ? i : 0, noise_row, nrun, 4u * (u32)lane);
+                if constexpr (NK != 0) { nrun += 256u; nrun = nrun >= (u32)d.noise_len ? nrun - (u32)d.noise_len : nrun; }
+            }
+        };
+        auto look = [&](const Raw4<NK> *buf, i32 g0) {
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const i32 b0 = g0 + 256 * u;
+                if (b0 >= len32) break;                         // wave-uniform
+                const i32 i = b0 + 4 * lane;
+                u32 nib = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const i32 v = finish_four<NK>(d, buf[u], j, he, noisy); nib |= (i + j < len32 && (i64)v < thr) ? (1u << j) : 0u; }
+                const u64 mask = __ballot(nib != 0);
+                if (mask == 0) continue;                        // wave-uniform
+                const i32 fpos = i + (i32)__builtin_ctz(nib | 16u), lpos = i + 31 - (i32)__builtin_clz(nib | 1u);      // first / last hit of the lane
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const u32 m = (u32)(mask >> (16 * c)) & 0xffffu;
+                    if (m == 0) continue;
+                    const i32 first = __builtin_amdgcn_readlane(fpos, 16 * c + (i32)__builtin_ctz(m));
+                    const i32 last = __builtin_amdgcn_readlane(lpos, 16 * c + 31 - (i32)__builtin_clz(m));
                     if (s_last < 0 || first - s_last > hold32) {
                         if (s_count > 0) s_nrec += close_scalar(s_count - 1, s_left, s_last);
                         s_left = first; s_count++;
                     }
-                    s_last = c0 + 63 - (i32)__builtin_clzll(mask);
+                    s_last = last;
                 }
             }
         };
-        fetch(A, 0);
-        for (i32 g0 = 0; g0 < len32; g0 += 128 * G) {
-            fetch(B, g0 + 64 * G); look(A, g0);
-            if (g0 + 64 * G >= len32) break;
-            fetch(A, g0 + 128 * G); look(B, g0 + 64 * G);
-        }
+        for (i32 g0 = 0; g0 < len32; g0 += 256 * G) { fetch(A, g0); look(A, g0); }
         if (s_count > 0) s_nrec += close_scalar(s_count - 1, s_left, s_last);
         if (lane < (s_count & 63)) { const i64 k0 = base + (s_count & ~63); a.itv_left[k0 + lane] = row_abs + my_l; a.itv_right[k0 + lane] = row_abs + my_r; }
         if (lane == 0) { a.itv_n[idx] = s_count; a.row_nrec[idx] = s_nrec; }
@@ -1497,12 +1539,17 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     // chunks of 64 samples; the loads of ZLE_GROUP chunks are issued together (one dependent load per chunk leaves the wave
     // waiting a memory round trip per 64 samples)
     constexpr int ZLE_GROUP = 2;
+    u32 nrun1 = nixr;
     for (i32 g0 = 0; g0 < len32; g0 += 64 * ZLE_GROUP) {
         i32 vv[ZLE_GROUP];
         if (fast_loads) {                                       // (wave-uniform) every load of the group first, then the arithmetic
             RawSample<NK> rs[ZLE_GROUP];
 #pragma unroll
-            for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; rs[u] = load_sample<NK>(d, acc, i < len32 ? i : len32 - 1, noise_row, nixr, nmask); }
+            for (int u = 0; u < ZLE_GROUP; u++) {
+                const i32 i = g0 + 64 * u + lane;
+                rs[u] = load_sample<NK>(d, acc, i < len32 ? i : len32 - 1, noise_row, nrun1, (u32)lane);
+                if constexpr (NK != 0) { nrun1 += 64u; nrun1 = nrun1 >= (u32)d.noise_len ? nrun1 - (u32)d.noise_len : nrun1; }
+            }
 #pragma unroll
             for (int u = 0; u < ZLE_GROUP; u++) { const i32 i = g0 + 64 * u + lane; vv[u] = i < len32 ? finish_loaded(d, rs[u], he, noisy) : 0x7fffffff; }
         } else {
@@ -1589,8 +1636,8 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
     const i64 rec_bytes = 24 + 2 * (i64)spr;
     const bool noisy = NK != 0 && channel < d.noise_channels;
-    const bool fast_loads = !noisy || len32 <= d.noise_len;        // the noise index wraps at most once inside the row
-    const i64 noise_off = noisy ? (i64)channel * d.noise_len : 0; const u32 nixr = noisy ? (u32)ixr : 0u; const i32 nmask = noisy ? -1 : 0;
+    const bool fast_loads = NK == 0 || (d.noise_len >= NOISE_MIN_FAST && spr <= NOISE_MIN_FAST / 2);       // (as in k_zle: a scalar noise start per record)
+    const i64 noise_off = noisy ? (i64)channel * d.noise_stride : 0; const u32 nixr = noisy ? (u32)ixr : 0u;
     const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
     const u32 w3 = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
     constexpr int PACK_U = 4;
@@ -1603,6 +1650,9 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
         for (int q0 = 0; q0 < rec_dwords; q0 += 64) {              // (one pass unless a record is longer than 64 dwords)
             const int qd = q0 + lane;
             const int s0 = (qd - 6) * 2;                            // first of the lane's two samples (lanes of the header: negative)
+            u32 nrun = 0;                                           // noise index of the next record's first sample (a scalar)
+            if constexpr (NK != 0) { if (fast_loads) nrun = (nixr + (u32)off) % (u32)d.noise_len; }
+            const u32 noff = (u32)(s0 < 0 ? 0 : s0);
             for (i32 f0 = 0; f0 < need; f0 += PACK_U) {
                 RawSample<NK> lo[PACK_U], hi[PACK_U];
                 if (fast_loads) {
@@ -1610,10 +1660,11 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
                     for (int u = 0; u < PACK_U; u++) {
                         const i32 f = f0 + u;
                         if (f >= need) break;                       // wave-uniform
-                        i32 i0 = off + spr * f + (s0 < 0 ? 0 : s0);
+                        i32 i0 = off + spr * f + (i32)noff;
                         i0 = i0 > len32 - 1 ? len32 - 1 : i0;       // (lanes past the record's samples read a valid sample and drop it)
                         const i32 i1 = i0 + 1 > len32 - 1 ? len32 - 1 : i0 + 1;
-                        lo[u] = load_sample<NK>(d, acc, i0, noise_row, nixr, nmask); hi[u] = load_sample<NK>(d, acc, i1, noise_row, nixr, nmask);
+                        lo[u] = load_sample<NK>(d, acc, i0, noise_row, nrun, noff); hi[u] = load_sample<NK>(d, acc, i1, noise_row, nrun, noff + 1u);
+                        if constexpr (NK != 0) { nrun += (u32)spr; nrun = nrun >= (u32)d.noise_len ? nrun - (u32)d.noise_len : nrun; }
                     }
                 }
 #pragma unroll
