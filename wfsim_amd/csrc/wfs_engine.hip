@@ -1448,7 +1448,7 @@ try {
         PulseArgs pt = pa;
         pt.desc = h->tile_desc.as<TileDesc>();
         Timer t(h, "k_pulse_tiny");
-        hipLaunchKernelGGL(k_pulse_tiny, dim3(nblocks(h->n_tiny_tiles, 256)), dim3(256), 0, h->stream, d, pt, h->n_tiny_tiles);
+        hipLaunchKernelGGL(k_pulse_tiny, dim3(nblocks(h->n_tiny_tiles * TINY_LANES, 256)), dim3(256), 0, h->stream, d, pt, h->n_tiny_tiles);
     }
     if (h->n_wave_tiles > 0) {          // work list order: tiny | sparse | dense | wave
         PulseArgs pw = pa;
@@ -1526,7 +1526,7 @@ try {
 
     // ---- ZLE + records
     const i64 RS = CG * d.row_slots;
-    TRY(ensure(h, h->itv_left, (size_t)h->n_itv_slots * 8)); TRY(ensure(h, h->itv_right, (size_t)h->n_itv_slots * 8));
+    TRY(ensure(h, h->itv_left, (size_t)h->n_itv_slots * 8 + 16)); TRY(ensure(h, h->itv_right, (size_t)h->n_itv_slots * 8 + 16));      // (+16: k_pack reads the first two slots of a row whatever its capacity)
     TRY(ensure(h, h->itv_n, (size_t)RS * 4)); TRY(ensure(h, h->row_nrec, (size_t)RS * 4));
     HIPCHK(hipMemsetAsync(h->itv_n.p, 0, (size_t)RS * 4, h->stream)); HIPCHK(hipMemsetAsync(h->row_nrec.p, 0, (size_t)RS * 4, h->stream));
     ZleArgs za{};

@@ -139,6 +139,7 @@ struct GeomArgs {
 #define SPARSE_MAX_BINS 64
 #define TINY_MAX_PHOTONS 4         // tiles of a few photons in a few start bins (the bulk of an S1): one THREAD per tile
 #define TINY_MAX_BINS 32
+#define TINY_LANES 16              // lanes that share the samples of one tiny tile (k_pulse_tiny)
 #define WAVE_MAX_PHOTONS 64        // medium tiles: photons fit the lanes of one wave (any width): k_pulse_wave
 #define WAVE_MAX_BINS 16384
 
@@ -893,7 +894,11 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
     for (int i = threadIdx.x; i < dt * tlen; i += blockDim.x) sT[i] = d.templates[i];
     if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
     __syncthreads();
-    const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    // TINY_LANES lanes per tile: all of them load, sort and merge the tile's (at most 4) photons -- the same registers in each, no
+    // exchange -- and share the tile's samples, lane j taking s_first + j, + TINY_LANES, ...: the adds of a tile land in runs of 64
+    // bytes instead of 64 rows per instruction, and a wave's loop is as long as its longest tile divided by TINY_LANES.
+    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 idx = gtid / TINY_LANES; const int sub = (int)(gtid % TINY_LANES);
     if (idx >= n_tiny) return;
     const TileDesc td = a.desc[idx];
     const int n = td.n, L = td.L;
@@ -913,7 +918,7 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
             else { g[k] = G * spe_row[code[k] & 0xffffu]; if (code[k] >> 16) g[k] += G * spe_row[code[k] >> 16]; }      // pulse.py:97-103
         }
     }
-    if (a.tile_truth) {        // pulse.py:229-271, photons in their order in the channel slice
+    if (a.tile_truth && sub == 0) {        // pulse.py:229-271, photons in their order in the channel slice
         i32 n_dpe = 0;
 #pragma unroll
         for (int k = 0; k < NP; k++) n_dpe += (code[k] >> 16) != 0;
@@ -957,7 +962,7 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
 #pragma unroll
     for (int k = 0; k < NP; k++) if (k < n) jmax = jb[k] > jmax ? jb[k] : jmax;
     const int s_last = a.currents ? L - 1 : (jmax + lead + tlen - 1 < L - 1 ? jmax + lead + tlen - 1 : L - 1);
-    for (int s = s_first; s <= s_last; s++) {
+    for (int s = s_first + sub; s <= s_last; s += TINY_LANES) {
         double cur = 0.0;
 #pragma unroll
         for (int k = 0; k < NP; k++) {
@@ -988,7 +993,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const i64 idx = (i64)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const i64 idx = (i64)blockIdx.x * 4 + wave_in_block();       // (an SGPR: the tile descriptor stays scalar)
     if (idx >= n_wave) return;                            // wave-uniform
     const TileDesc td = a.desc[idx];
     const int n = td.n, L = td.L;
@@ -1013,8 +1018,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
         const bool above = v && (g * s_cmax[v ? ns0 % dt : 0] * d.c2a > td.thr);
         const i32 n_trig = __popcll(__ballot(above)), n_trig_dpe = __popcll(__ballot(above && lane < n_dpe));
         const double tr = v ? (double)(ns0 + td.rel0) : 0.0;
-        double sg = g, sgt = above ? g : 0.0, st = tr, st2 = tr * tr;
-        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_down(sg, o, 64); sgt += __shfl_down(sgt, o, 64); st += __shfl_down(st, o, 64); st2 += __shfl_down(st2, o, 64); }
+        const double sg = wave_sum(g), sgt = wave_sum(above ? g : 0.0), st = wave_sum(tr), st2 = wave_sum(tr * tr);     // (DPP: no LDS crossbar trips)
         if (lane == 0) {
             double *o = a.tile_truth + (i64)td.tile * 8;
             o[0] = (double)n; o[1] = (double)n_dpe; o[2] = (double)n_trig; o[3] = (double)n_trig_dpe; o[4] = sg; o[5] = sgt; o[6] = st; o[7] = st2;
@@ -1050,6 +1054,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     }
     const i32 bin = lane < n ? ns / dt : 0x3fffffff, r = lane < n ? ns - (ns / dt) * dt : 0;
     const u32 g_lo = (u32)__double_as_longlong(g), g_hi = (u32)((u64)__double_as_longlong(g) >> 32);
+    const i32 binr = lane < n ? (bin << 4) | r : 0;       // one broadcast for both (a tile has fewer than 2^20 start bins, r < 10)
     // ---- lane = sample.  Live samples: s' = 0 .. nb + 20 (sample lead + s' of the tile sees the start bins s' - 21 .. s')
     i32 *dst = a.raw + td.dst;
     const int n_live = td.nb + tlen - 1;
@@ -1060,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
         const int sp = s0 + lane;
         double c = 0.0;
         for (int q = q_lo; q < q_hi; q++) {
-            const int bq = __builtin_amdgcn_readlane(bin, q), rq = __builtin_amdgcn_readlane(r, q);
+            const int brq = __builtin_amdgcn_readlane(binr, q); const int bq = brq >> 4, rq = brq & 15;
             const double gq = __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane((int)g_hi, q) << 32) | (u32)__builtin_amdgcn_readlane((int)g_lo, q)));
             const int kk = sp - bq;
             if (kk >= 0 && kk < tlen) { const double prod = sT[rq * tlen + kk] * gq; c = c + prod; }
