@@ -22,7 +22,7 @@ struct DevBuf {
 };
 struct Pmf { std::vector<double> p; long vmin = 0; };      // probability mass function of an integer delay term
 
-struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf;
+struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf, prob;
                 int delay_sorted = 0, amp_sorted = 0; };
 
 struct KernelTime { std::string name; hipEvent_t a, b; };
@@ -465,7 +465,7 @@ try {
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
     for (auto &b : h->x_alias) if (b.p) hipFree(b.p);
-    for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); }
+    for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); if (a.prob.p) hipFree(a.prob.p); }
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
@@ -579,6 +579,10 @@ try {
     a.n_bins_delay = n_bins_delay; a.n_bins_amp = n_bins_amp; a.amp_2d = amp_2d; a.is_uniform = is_uniform; a.delay_bin = delay_bin; a.amp_bin = amp_bin;
     TRY(upload(h, a.delay_cdf, delay_cdf, sizeof(double) * (size_t)h->cfg.n_tpc * n_bins_delay));
     TRY(upload(h, a.amp_cdf, amp_cdf, sizeof(double) * (size_t)(amp_2d ? h->cfg.n_tpc : 1) * n_bins_amp));
+    // the probability column on its own (last entry of every channel's delay row): the generator keeps it in LDS
+    std::vector<double> prob((size_t)h->cfg.n_tpc);
+    for (int c = 0; c < h->cfg.n_tpc; c++) prob[c] = delay_cdf[(size_t)c * n_bins_delay + n_bins_delay - 1];
+    TRY(upload(h, a.prob, prob.data(), sizeof(double) * prob.size()));
     // non-decreasing rows (every cumulative distribution is): np.argmin(|cdf - u|) by bisection on the device
     auto rows_sorted = [](const double *c, size_t rows, int n) {
         for (size_t r = 0; r < rows; r++) for (int k = 1; k < n; k++) if (!(c[r * n + k] >= c[r * n + k - 1])) return 0;
@@ -1236,6 +1240,7 @@ static int run_generation(wfs_handle *h)
             const ApElem &s = h->ap[e];
             ap.el[e] = ApElemDev{s.n_bins_delay, s.n_bins_amp, s.amp_2d, s.is_uniform, s.delay_bin, s.amp_bin, s.delay_cdf.as<double>(), s.amp_cdf.as<double>(),
                                  s.delay_sorted, s.amp_sorted};
+            ap.prob[e] = s.prob.as<double>();
         }
         TRY(ensure(h, h->ap_ins, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_ch, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_t, (size_t)ap_cap * 4));
         TRY(ensure(h, h->ap_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ph_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ap_key, (size_t)ap_cap * 4));
@@ -1273,7 +1278,7 @@ static int run_generation(wfs_handle *h)
         { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(COUNT_TPB), GEN_COUNT_LDS(d.n_tpc, g.ch_lg), h->stream, d, g); }
         { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
-        const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, g.ch_lg, ap_on).total;
+        const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, g.ch_lg, ap_on, ap_on ? d.n_ap : 0).total;
         { Timer t(h, "k_photon_fill");
           if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);
           else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);

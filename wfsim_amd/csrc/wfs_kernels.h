@@ -2017,12 +2017,13 @@ __device__ __forceinline__ int argmin_abs_diff(const double *c, int n, double u,
 struct ApArgs {
     i32 n; i32 pad;
     ApElemDev el[WFS_MAX_AP];
+    const double *prob[WFS_MAX_AP]; // [n_tpc] per element: afterpulse probability of every channel (last entry of its delay CDF row), contiguous
     i64 cap;                        // capacity of the staging list
     i32 *ap_ins; i32 *ap_ch; i32 *ap_t; double *ap_gain;     // [cap] instruction, channel, ns relative to the instruction, gain
     u32 *ap_key;                    // [cap] order key: element << 29 | index of the parent photon among its instruction's photons
     i64 *count;                     // number of staged afterpulse photons (device scalar)
 };
-#define AP_STAGE 384               // afterpulse photons a block stages in LDS before it reserves space in the global list (24 bytes each)
+#define AP_STAGE 256               // afterpulse candidates a block parks in LDS (56 bytes each; a block of 2048 photons has ~60)
 
 // first and last emitter of every photon block: one bisection per thread, all in flight together (a block doing
 // its own two bisections serially costs ~20 us of dependent HBM latency before its 2048 photons can start)
@@ -2076,44 +2077,51 @@ __global__ void k_set_bases(GenArgs a)
     }
 }
 
-// PMT afterpulses of one photon (afterpulse.py:172-249): one uniform pair per element; generated photons are staged in
-// LDS (aps_*) and, past AP_STAGE, appended to the global list directly.
-struct ApStage { i32 *n; double *gain; i32 *ins, *ch, *t; u32 *key; };
+// PMT afterpulses of one photon (afterpulse.py:172-249): one uniform pair per element.  Two steps.  ap_generate, inside the photon
+// loop, only SCREENS: Philox, the two uniforms, the comparison with the channel's probability -- and parks the rare candidate in LDS.
+// ap_finish turns a candidate into an afterpulse photon (two bisections of cumulative rows in global memory, ~20 dependent loads)
+// and runs behind the loop, one candidate per thread: inside the loop a wave paid that chain whenever ONE of its 64 lanes had a
+// candidate, which with p ~ 1 % per element is most of the time (3.7 of the fill pass's 5 ms on the mixed batch).
+// A block with more than AP_STAGE candidates finishes the excess inline.
+struct ApCand { double u0, u1; i64 itime; i32 ins, ch, t; u32 key, j, m, gid; i32 e; };     // (56 bytes)
+struct ApStage { i32 *n; ApCand *cand; };
+__device__ __forceinline__ void ap_finish(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApCand &q, i64 gk)
+{
+    const ApElemDev &el = ap.el[q.e];
+    const double *dc = el.delay_cdf + (size_t)q.ch * el.n_bins_delay;
+    double delay, amp;
+    if (el.is_uniform) {
+        const u32x4 x = philox4x32_10(q.j, q.gid, q.m, SITE_AP_X + (u32)q.e, d.k0, d.k1);
+        delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
+    } else {
+        const int best = argmin_abs_diff(dc, el.n_bins_delay, q.u0, el.delay_sorted != 0);      // np.argmin(|cdf - u|): first minimum
+        delay = best * el.delay_bin - d.pmt_ap_t_modifier;
+        const double *ac = el.amp_2d ? el.amp_cdf + (size_t)q.ch * el.n_bins_amp : el.amp_cdf;
+        const int ba = argmin_abs_diff(ac, el.n_bins_amp, q.u1, el.amp_sorted != 0);
+        amp = ba * el.amp_bin;
+    }
+    const double tf = (double)(q.itime + q.t) + delay;          // afterpulse.py:235, int64 + float
+    i64 tap = (i64)tf - q.itime;
+    if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
+    if (gk < ap.cap) { ap.ap_ins[gk] = q.ins; ap.ap_ch[gk] = q.ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = d.gains[q.ch] * amp; ap.ap_key[gk] = q.key; }
+}
 __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st,
-                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P)
+                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P, const double *prob_lds = nullptr)
 {
     for (int e = 0; e < ap.n; e++) {
-        const ApElemDev &el = ap.el[e];
         const u32x4 w = philox4x32_10(j, gid, m, SITE_AP + (u32)e, d.k0, d.k1);
         double rU0 = 1.0 - u53(w.x, w.y);
-        const double rU1 = 1.0 - u53(w.z, w.w);
-        const double *dc = el.delay_cdf + (size_t)ch * el.n_bins_delay;
-        const double prob = dc[el.n_bins_delay - 1];
+        // the channel's afterpulse probability = last entry of its delay CDF row (from the block's LDS copy where there is one)
+        const double prob = prob_lds ? prob_lds[e * d.n_tpc + ch] : ap.prob[e][ch];
         rU0 /= d.pmt_ap_modifier;
         if (is_dpe) rU0 /= 2;
         if (!(rU0 <= prob)) continue;
-        double delay, amp;
-        if (el.is_uniform) {
-            const u32x4 x = philox4x32_10(j, gid, m, SITE_AP_X + (u32)e, d.k0, d.k1);
-            delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
-        } else {
-            const int best = argmin_abs_diff(dc, el.n_bins_delay, rU0, el.delay_sorted != 0);      // np.argmin(|cdf - u|): first minimum
-            delay = best * el.delay_bin - d.pmt_ap_t_modifier;
-            const double *ac = el.amp_2d ? el.amp_cdf + (size_t)ch * el.n_bins_amp : el.amp_cdf;
-            const int ba = argmin_abs_diff(ac, el.n_bins_amp, rU1, el.amp_sorted != 0);
-            amp = ba * el.amp_bin;
-        }
-        const double tf = (double)(itime + t) + delay;              // afterpulse.py:235, int64 + float
-        i64 tap = (i64)tf - itime;
-        if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
-        const double gap = d.gains[ch] * amp;
-        const u32 key = ((u32)e << 29) | (P & 0x1fffffffu);        // the reference walks element by element, parent by parent (afterpulse.py:189-207)
+        ApCand q;
+        q.u0 = rU0; q.u1 = 1.0 - u53(w.z, w.w); q.itime = itime; q.ins = ins; q.ch = ch; q.t = (i32)t; q.j = j; q.m = m; q.gid = gid; q.e = e;
+        q.key = ((u32)e << 29) | (P & 0x1fffffffu);                 // the reference walks element by element, parent by parent (afterpulse.py:189-207)
         const i32 k = atomicAdd(st.n, 1);
-        if (k < AP_STAGE) { st.ins[k] = ins; st.ch[k] = ch; st.t[k] = (i32)tap; st.gain[k] = gap; st.key[k] = key; }
-        else {
-            const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull);
-            if (gk < ap.cap) { ap.ap_ins[gk] = ins; ap.ap_ch[gk] = ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = gap; ap.ap_key[gk] = key; }
-        }
+        if (k < AP_STAGE) st.cand[k] = q;
+        else ap_finish(d, a, ap, q, (i64)atomicAdd((u64 *)ap.count, 1ull));
     }
 }
 
@@ -2654,8 +2662,8 @@ __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
 
 // LDS layout of the fill pass (byte offsets; plain integer offsets: a pointer that went through an integer cast loses its
 // LDS address space)
-struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, pidx, stage, ap, total; };
-__host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap)
+struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, pidx, stage, ap, approb, total; };
+__host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap, int n_ap = 0)
 {
     const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
     GenFillLds o;
@@ -2670,7 +2678,8 @@ __host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap
     o.pidx = o.chmap + GEN_BLOCK * 2;                         // u16[GEN_BLOCK]: block-relative photon index of every bucket position
     o.stage = (o.pidx + GEN_BLOCK * 2 + 7) & ~7;              // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
     o.ap = o.stage + GEN_BLOCK * 8;                           // afterpulse staging
-    o.total = o.ap + (with_ap ? AP_STAGE * 24 : 0) + 16;
+    o.approb = (o.ap + (with_ap ? AP_STAGE * (int)sizeof(ApCand) : 0) + 7) & ~7;       // double[n_ap][nch]: afterpulse probability of every (element, channel)
+    o.total = o.approb + (with_ap ? n_ap * nch * 8 : 0) + 16;
     return o;
 }
 
@@ -2682,7 +2691,8 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
     constexpr int TPB = FILL_TPB, CPT = (WFS_MAX_CH + TPB - 1) / TPB;      // channels per thread
     const int nch = d.n_tpc, tid = threadIdx.x;
     const int lg = a.ch_lg;
-    const GenFillLds o = gen_fill_lds(nch, lg, AP);
+    const GenFillLds o = gen_fill_lds(nch, lg, AP, AP ? ap.n : 0);
+    double *ap_prob = (double *)(smem + o.approb);
     i32 *win = (i32 *)smem, *wtime = (i32 *)(smem + o.wtime);
     uint2 *T = (uint2 *)(smem + o.T);                        // alias cells of the block's channel row
     i32 *hist = (i32 *)(smem + o.hist), *cur = (i32 *)(smem + o.cur), *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
@@ -2691,7 +2701,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
     PhotonRec *stage = (PhotonRec *)(smem + o.stage);
     __shared__ i32 s_wtmp[TPB / 64];
     ApStage aps;
-    aps.gain = (double *)(smem + o.ap); aps.ins = (i32 *)(smem + o.ap + AP_STAGE * 8); aps.ch = aps.ins + AP_STAGE; aps.t = aps.ch + AP_STAGE; aps.key = (u32 *)(aps.t + AP_STAGE);
+    aps.cand = (ApCand *)(smem + o.ap);
     __shared__ i32 s_apn; __shared__ i64 s_apbase;
     aps.n = &s_apn;
     if (AP && tid == 0) s_apn = 0;
@@ -2732,6 +2742,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
             }
         }
         for (int c = tid; c < (1 << lg); c += TPB) T[c] = a.chan_alias[((size_t)bd.row << lg) + c];
+        if (AP) for (int i = tid; i < ap.n * nch; i += TPB) { const int e = i / nch, c = i - e * nch; ap_prob[i] = ap.prob[e][c]; }
         for (int k = tid; k < nwin; k += TPB) {
             win[k] = (i32)(a.em_ph_off[bd.e_lo + k] - p0);
             // the block's own emitters only (slot nwin - 1 is the sentinel behind them); I64_MIN: an electron that did not survive (no photons)
@@ -2789,7 +2800,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                     t += (i32)(i64)s1_propagation(a, c >= d.n_top, pzi, pzf, X.x);
                 }
                 if (EXT && gg_lo >= 0) t += (i32)(i64)(gg_time(a, gg_lo, gg_w, word_of(LW, k)) - gg_m);      // s2.py:447-450, the cast of :532
-                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t, bd.sbase + (u32)(bd.R0 + pr));
+                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t, bd.sbase + (u32)(bd.R0 + pr), ap_prob);
                 atomicMin(&hmin[c], t); atomicMax(&hmax[c], t);
                 const int pos = hist[c] + atomicAdd(&cur[c], 1);
                 stage[pos] = PhotonRec{t, code}; chmap[pos] = (unsigned short)c; pidx[pos] = (unsigned short)pr;
@@ -2852,10 +2863,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
         const int nst = s_apn < AP_STAGE ? s_apn : AP_STAGE;
         if (tid == 0 && nst > 0) s_apbase = (i64)atomicAdd((u64 *)ap.count, (u64)nst);
         __syncthreads();
-        for (int k = tid; k < nst; k += TPB) {
-            const i64 gk = s_apbase + k;
-            if (gk < ap.cap) { ap.ap_ins[gk] = aps.ins[k]; ap.ap_ch[gk] = aps.ch[k]; ap.ap_t[gk] = aps.t[k]; ap.ap_gain[gk] = aps.gain[k]; ap.ap_key[gk] = aps.key[k]; }
-        }
+        for (int k = tid; k < nst; k += TPB) ap_finish(d, a, ap, aps.cand[k], s_apbase + k);        // one candidate per thread, all chains together
     }
 }
 
