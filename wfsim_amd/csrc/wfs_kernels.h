@@ -987,13 +987,17 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
 __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n_wave)
 {
     constexpr int dt = WFS_DT, tlen = 22;
-    __shared__ double sT[dt * tlen];                      // templates[r][k]
+    __shared__ double sTz[dt * (tlen + 2)];               // templates[r][k] with a zero tap in front of and behind every row
     __shared__ double s_cmax[dt];
-    for (int i = threadIdx.x; i < dt * tlen; i += blockDim.x) sT[i] = d.templates[i];
+    struct __attribute__((aligned(16))) WavePhoton { i32 bin, row; double g; };       // start bin, first tap of its template row in sTz, merged gain
+    constexpr int PW_U = 2;
+    __shared__ WavePhoton s_ph[4][64 + PW_U];             // the sorted, merged photons of each wave's tile, pad entries that reach nothing behind them
+    for (int i = threadIdx.x; i < dt * (tlen + 2); i += blockDim.x) { const int r = i / (tlen + 2), k = i - r * (tlen + 2) - 1; sTz[i] = (k >= 0 && k < tlen) ? d.templates[r * tlen + k] : 0.0; }
     if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const i64 idx = (i64)blockIdx.x * 4 + wave_in_block();       // (an SGPR: the tile descriptor stays scalar)
+    WavePhoton *wph = s_ph[wave_in_block()];
     if (idx >= n_wave) return;                            // wave-uniform
     const TileDesc td = a.desc[idx];
     const int n = td.n, L = td.L;
@@ -1053,28 +1057,44 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
         }
     }
     const i32 bin = lane < n ? ns / dt : 0x3fffffff, r = lane < n ? ns - (ns / dt) * dt : 0;
-    const u32 g_lo = (u32)__double_as_longlong(g), g_hi = (u32)((u64)__double_as_longlong(g) >> 32);
-    const i32 binr = lane < n ? (bin << 4) | r : 0;       // one broadcast for both (a tile has fewer than 2^20 start bins, r < 10)
-    // ---- lane = sample.  Live samples: s' = 0 .. nb + 20 (sample lead + s' of the tile sees the start bins s' - 21 .. s')
+    if (lane < PW_U) wph[64 + lane] = WavePhoton{0x3fffffff, 1, 0.0};
+    wph[lane] = WavePhoton{bin, r * (tlen + 2) + 1, g};    // (read back by every lane of this wave: one 16-byte LDS broadcast per photon
+                                                          //  instead of three readlanes and their scalar unpacking on the vector unit)
+    // ---- lane = sample.  Live samples: s' = 0 .. nb + 20 (sample lead + s' of the tile sees the start bins s' - 21 .. s').
+    // Blocks of 64 samples start where something lands: behind a block the next one begins at the first start bin that can still
+    // reach a sample not yet written (a photon of the thin tail of an S2 is alone in its 22 samples; whole blocks between the
+    // photons are skipped).  Inside a block every sample walks the photons in reach, in ascending time; sTz has a zero tap on
+    // either side of every template row, so a photon out of a sample's reach adds +0.0, which changes nothing (no exec masking).
     i32 *dst = a.raw + td.dst;
     const int n_live = td.nb + tlen - 1;
-    if (a.currents) for (int s = lane; s < L; s += 64) if (s < lead || s >= lead + n_live) a.currents[a.cur_off[idx] + s] = 0.0;
-    for (int s0 = 0; s0 < n_live; s0 += 64) {
+    if (a.currents) for (int s = lane; s < L; s += 64) a.currents[a.cur_off[idx] + s] = 0.0;
+    int s0 = 0;
+    while (s0 < n_live) {
         // sorted photons with a start bin in [s0 - 21, s0 + 63]: a contiguous range [q_lo, q_hi) of lanes
         const int q_lo = __popcll(__ballot(bin < s0 - (tlen - 1))), q_hi = __popcll(__ballot(bin <= s0 + 63));
+        if (q_lo >= n) break;                                 // nothing reaches s0 or anything behind it
+        if (q_hi == q_lo) { s0 = __builtin_amdgcn_readlane(bin, q_lo); continue; }      // (bin[q_lo] > s0 + 63: the next block starts at that photon)
         const int sp = s0 + lane;
         double c = 0.0;
-        for (int q = q_lo; q < q_hi; q++) {
-            const int brq = __builtin_amdgcn_readlane(binr, q); const int bq = brq >> 4, rq = brq & 15;
-            const double gq = __longlong_as_double((long long)(((u64)(u32)__builtin_amdgcn_readlane((int)g_hi, q) << 32) | (u32)__builtin_amdgcn_readlane((int)g_lo, q)));
-            const int kk = sp - bq;
-            if (kk >= 0 && kk < tlen) { const double prod = sT[rq * tlen + kk] * gq; c = c + prod; }
+        // (PW_U photons per trip, their LDS reads in flight together; a photon past q_hi is out of reach of this block -- or one of
+        // the pad entries behind the list -- and adds +0.0)
+        for (int q = q_lo; q < q_hi; q += PW_U) {
+            WavePhoton w[PW_U]; double tap[PW_U];
+#pragma unroll
+            for (int u = 0; u < PW_U; u++) w[u] = wph[q + u];
+#pragma unroll
+            for (int u = 0; u < PW_U; u++) { int kk = sp - w[u].bin; kk = kk < -1 ? -1 : (kk > tlen ? tlen : kk); tap[u] = sTz[w[u].row + kk]; }
+#pragma unroll
+            for (int u = 0; u < PW_U; u++) { const double prod = tap[u] * w[u].g; c = c + prod; }
         }
         if (sp < n_live) {
             if (a.currents) a.currents[a.cur_off[idx] + lead + sp] = c;
-            const i64 adc = -(i64)rint(c * d.c2a);             // rawdata.py:236
-            if (adc != 0) atomicAdd(&dst[lead + sp], (i32)adc);
+            const double x = rint(c * d.c2a);                  // rawdata.py:236
+            // (|x| < 2^31 unless a current is absurd: the one-instruction conversion; the general one otherwise, same value)
+            const i32 adc = fabs(x) < 2147483648.0 ? -(i32)x : (i32)(-(i64)x);
+            if (adc != 0) atomicAdd(&dst[lead + sp], adc);
         }
+        s0 += 64;
     }
 }
 
