@@ -137,7 +137,7 @@ enum { SITE_S1_HIT = 1, SITE_S2_SURVIVE = 2, SITE_EL_A = 3, SITE_EL_B = 4, SITE_
        /* tile-local generation (spec v9): counter (em_base + channel, gid, item, site) */
        SITE_TILE_N = 24 /* photons of the tile: Poisson, item = iteration */, SITE_TILE_E = 25 /* item = P >> 2, word P & 3 -> surviving electron */,
        SITE_TILE_DELAY = 26, SITE_TILE_GAIN = 27,
-       SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64 };
+       SITE_AP = 32, SITE_AP_SCREEN = 40, SITE_AP_X = 48, SITE_NOISE = 64 };
 
 static inline void draw(const orc_session *s, u32 emitter, u32 gid, u32 item, u32 site, u32 w[4])
 {
@@ -899,8 +899,11 @@ static void pmt_afterpulse_call(orc_session *s, int runset, const u32 *gid_of, i
         const orc_ap_element *ap = &s->ap[e];
         for (i64 i = a; i < b; i++) {
             int ch = s->ph_ch.p[i]; u32 w[4];
+            /* RNG spec v10: the top 32 bits of the first uniform of elements 4k .. 4k + 3 are the words of ONE call (the device screens
+             * four elements with it); the low bits and the second uniform come from the element's own call */
+            u32 sw[4]; draw(s, emitter_of[i - a], gid_of[i - a], item_of[i - a], SITE_AP_SCREEN + (u32)(e >> 2), sw);
             draw(s, emitter_of[i - a], gid_of[i - a], item_of[i - a], SITE_AP + (u32)e, w);
-            double rU0 = 1.0 - u53(w[0], w[1]), rU1 = 1.0 - u53(w[2], w[3]);
+            double rU0 = 1.0 - u53(sw[e & 3], w[1]), rU1 = 1.0 - u53(w[2], w[3]);
             const double *dc = ap->delay_cdf + (i64)ch * ap->n_bins_delay;
             double prob = dc[ap->n_bins_delay - 1];
             rU0 /= c->pmt_ap_modifier;

@@ -33,7 +33,7 @@ enum WfsSite : u32 {
     SITE_TILE_E = 25,    // item = P >> 2 (P: photon of the tile), word P & 3 -> surviving electron
     SITE_TILE_DELAY = 26,    // -> summed delay (alias table)
     SITE_TILE_GAIN = 27,     // -> SPE indices and double-PE flag
-    SITE_AP = 32, SITE_AP_X = 48, SITE_NOISE = 64
+    SITE_AP = 32, SITE_AP_SCREEN = 40, SITE_AP_X = 48, SITE_NOISE = 64
 };
 
 struct u32x4 { u32 x, y, z, w; };

@@ -22,7 +22,8 @@ struct DevBuf {
 };
 struct Pmf { std::vector<double> p; long vmin = 0; };      // probability mass function of an integer delay term
 
-struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf, prob;
+struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf, prob, thr;
+                std::vector<double> prob_h; double thr_mod = -1.0;      // host copy of the probability column; modifier the thresholds were built for
                 int delay_sorted = 0, amp_sorted = 0; };
 
 struct KernelTime { std::string name; hipEvent_t a, b; };
@@ -76,7 +77,7 @@ struct wfs_handle {
     DevBuf tt_alias[6];
     std::vector<i64> h_rs_off; std::vector<i32> h_rs_list;        // run set -> instructions (host copy)
     std::vector<double> h_lum_x, h_lum_t;          // luminescence table (host copy, enters the S2 delay table)
-    DevBuf ap_ins, ap_ch, ap_t, ap_gain; i64 n_ap_photons = 0; bool ap_active = false;
+    DevBuf ap_ins, ap_ch, ap_t, ap_gain, ap_cand; i64 n_ap_photons = 0; bool ap_active = false;
     // model variants of the photon delays
     std::vector<DevBuf> x_alias; std::vector<AliasTab> h_tabs; DevBuf d_tabs; i32 n_user_tabs = 0;
     std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
@@ -111,6 +112,19 @@ namespace {
 
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     return h->fail(WFS_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+
+// Screening threshold of the afterpulse generator for one (element, channel, single / double PE parent): the uniform of the
+// acceptance test is rU0 = 1 - u53(x, y) (afterpulse.py:196), accepted when rU0 / modifier [/ 2] <= prob.  With a = x >> 5 (the top
+// 27 bits of u53) rU0 > 1 - (a + 1) 2^-27, so a < floor((1 - prob * modifier * k * (1 + 1e-9)) 2^27) - 2 cannot be accepted whatever
+// the low bits and the two roundings of the divisions are.  Everything else is a candidate and gets the reference's comparison.
+static u32 ap_threshold(double prob, double modifier, bool dpe)
+{
+    if (!(modifier > 0.0) || !(prob == prob)) return 0u;           // (nothing screened: the exact comparison decides)
+    const double pm = prob * modifier * (dpe ? 2.0 : 1.0) * (1.0 + 1e-9);
+    if (!(pm < 1.0)) return 0u;
+    const double a = std::floor((1.0 - pm) * 134217728.0) - 2.0;
+    return a <= 0.0 ? 0u : (a >= 134217728.0 ? 134217728u : (u32)a);
+}
 
 int ensure(wfs_handle *h, DevBuf &b, size_t bytes)
 {
@@ -451,7 +465,7 @@ try {
         hipFree(h->stamps.p);
     }
 #endif
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->ap_cand, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->chan_alias, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->em_zg, &h->pois_cdf, &h->pois_kmin, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -465,7 +479,7 @@ try {
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
     for (auto &b : h->x_alias) if (b.p) hipFree(b.p);
-    for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); if (a.prob.p) hipFree(a.prob.p); }
+    for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); if (a.prob.p) hipFree(a.prob.p); if (a.thr.p) hipFree(a.thr.p); }
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
@@ -583,6 +597,7 @@ try {
     std::vector<double> prob((size_t)h->cfg.n_tpc);
     for (int c = 0; c < h->cfg.n_tpc; c++) prob[c] = delay_cdf[(size_t)c * n_bins_delay + n_bins_delay - 1];
     TRY(upload(h, a.prob, prob.data(), sizeof(double) * prob.size()));
+    a.prob_h = prob; a.thr_mod = -1.0;
     // non-decreasing rows (every cumulative distribution is): np.argmin(|cdf - u|) by bisection on the device
     auto rows_sorted = [](const double *c, size_t rows, int n) {
         for (size_t r = 0; r < rows; r++) for (int k = 1; k < n; k++) if (!(c[r * n + k] >= c[r * n + k - 1])) return 0;
@@ -1241,12 +1256,22 @@ static int run_generation(wfs_handle *h)
             ap.el[e] = ApElemDev{s.n_bins_delay, s.n_bins_amp, s.amp_2d, s.is_uniform, s.delay_bin, s.amp_bin, s.delay_cdf.as<double>(), s.amp_cdf.as<double>(),
                                  s.delay_sorted, s.amp_sorted};
             ap.prob[e] = s.prob.as<double>();
+            ApElem &sm = h->ap[e];
+            if (sm.thr_mod != d.pmt_ap_modifier || !sm.thr.p) {           // screening thresholds of the generator (ap_threshold), once per modifier
+                std::vector<u32> th(sm.prob_h.size() * 2);
+                for (size_t c = 0; c < sm.prob_h.size(); c++) for (int dpe = 0; dpe < 2; dpe++) th[2 * c + dpe] = ap_threshold(sm.prob_h[c], d.pmt_ap_modifier, dpe != 0);
+                TRY(upload(h, sm.thr, th.data(), th.size() * 4));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                sm.thr_mod = d.pmt_ap_modifier;
+            }
+            ap.thr[e] = sm.thr.as<u32>();
         }
         TRY(ensure(h, h->ap_ins, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_ch, (size_t)ap_cap * 4)); TRY(ensure(h, h->ap_t, (size_t)ap_cap * 4));
         TRY(ensure(h, h->ap_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ph_gain, (size_t)ap_cap * 8)); TRY(ensure(h, h->ap_key, (size_t)ap_cap * 4));
         ap.ap_key = h->ap_key.as<u32>();
         ap.cap = ap_cap; ap.ap_ins = h->ap_ins.as<i32>(); ap.ap_ch = h->ap_ch.as<i32>(); ap.ap_t = h->ap_t.as<i32>(); ap.ap_gain = h->ap_gain.as<double>();
         ap.count = h->scal.as<i64>() + 13;
+        TRY(ensure(h, h->ap_cand, (size_t)ap_cap * sizeof(ApCand))); ap.cand = h->ap_cand.as<ApCand>();
     }
     TRY(ensure(h, h->ins_ph0, (size_t)(N + 1) * 8)); g.ins_ph0 = h->ins_ph0.as<i64>();
     { Timer t(h, "k_ins_ph0"); hipLaunchKernelGGL(k_ins_ph0, dim3(nblocks(N + 1, 256)), dim3(256), 0, h->stream, g); }
@@ -1305,12 +1330,13 @@ static int run_generation(wfs_handle *h)
     h->fuse_args = f;
     if (ap_on) {
         // afterpulse photons: count per tile of the afterpulse sets, offsets behind the primary photons, place
+        { Timer t(h, "k_ap_finish"); hipLaunchKernelGGL(k_ap_finish, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
         { Timer t(h, "k_ap_count"); hipLaunchKernelGGL(k_ap_count, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
         TRY(scan_into(h, h->tile_count.as<i32>() + TP, TP, h->tile_off.as<i64>() + TP, 14, P));
         { Timer t(h, "k_ap_place"); hipLaunchKernelGGL(k_ap_place, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - P); }
         TRY(read_scal(h));
         if (h->h_scal[13] > ap_cap) return h->fail(WFS_E_CAPACITY, "more PMT afterpulse photons than 1/8 of the primary photons: afterpulse probability unreasonably high");
-        h->n_ap_photons = h->h_scal[13];
+        h->n_ap_photons = h->h_scal[28];                             // (the accepted candidates, k_ap_finish)
     }
     if (P > 0 || ap_on) {
         // every tile of the block generator into generation order (k_tile_order): the order the reference's Pulse call sees

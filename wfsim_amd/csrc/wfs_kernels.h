@@ -2030,6 +2030,7 @@ __device__ __forceinline__ int argmin_abs_diff(const double *c, int n, double u,
     if (lo == n) best = n - 1;
     else if (lo > 0 && !(fabs(c[lo] - u) < fabs(c[lo - 1] - u))) best = lo - 1;
     const double v = c[best];
+    if (best == 0 || c[best - 1] < v) return best;       // (no plateau in front of it: the usual case, one load instead of a second bisection)
     int a = 0, b = best;                                 // first k with c[k] == v: first k with c[k] >= v
     while (a < b) { const int mid = (a + b) >> 1; if (c[mid] >= v) b = mid; else a = mid + 1; }
     return a;
@@ -2038,12 +2039,14 @@ struct ApArgs {
     i32 n; i32 pad;
     ApElemDev el[WFS_MAX_AP];
     const double *prob[WFS_MAX_AP]; // [n_tpc] per element: afterpulse probability of every channel (last entry of its delay CDF row), contiguous
+    const u32 *thr[WFS_MAX_AP];     // [n_tpc][2] per element: screening thresholds (single / double photoelectron parent), ap_threshold
     i64 cap;                        // capacity of the staging list
     i32 *ap_ins; i32 *ap_ch; i32 *ap_t; double *ap_gain;     // [cap] instruction, channel, ns relative to the instruction, gain
     u32 *ap_key;                    // [cap] order key: element << 29 | index of the parent photon among its instruction's photons
-    i64 *count;                     // number of staged afterpulse photons (device scalar)
+    i64 *count;                     // number of afterpulse candidates in the list (device scalar, scal[13]); k_ap_finish adds the accepted ones to count[15] (scal[28])
+    struct ApCand *cand;            // [cap] candidates of the generator (k_ap_finish turns entry i into afterpulse photon i, or a hole: ap_ch[i] = -1)
 };
-#define AP_STAGE 256               // afterpulse candidates a block parks in LDS (56 bytes each; a block of 2048 photons has ~60)
+#define AP_STAGE 128               // afterpulse candidates a block parks in LDS (48 bytes each; a block of 2048 photons has ~60)
 
 // first and last emitter of every photon block: one bisection per thread, all in flight together (a block doing
 // its own two bisections serially costs ~20 us of dependent HBM latency before its 2048 photons can start)
@@ -2097,27 +2100,45 @@ __global__ void k_set_bases(GenArgs a)
     }
 }
 
-// PMT afterpulses of one photon (afterpulse.py:172-249): one uniform pair per element.  Two steps.  ap_generate, inside the photon
-// loop, only SCREENS: Philox, the two uniforms, the comparison with the channel's probability -- and parks the rare candidate in LDS.
-// ap_finish turns a candidate into an afterpulse photon (two bisections of cumulative rows in global memory, ~20 dependent loads)
-// and runs behind the loop, one candidate per thread: inside the loop a wave paid that chain whenever ONE of its 64 lanes had a
-// candidate, which with p ~ 1 % per element is most of the time (3.7 of the fill pass's 5 ms on the mixed batch).
-// A block with more than AP_STAGE candidates finishes the excess inline.
-struct ApCand { double u0, u1; i64 itime; i32 ins, ch, t; u32 key, j, m, gid; i32 e; };     // (56 bytes)
+__device__ __forceinline__ u32 word_of(const u32x4 &W, int k) { return k == 0 ? W.x : (k == 1 ? W.y : (k == 2 ? W.z : W.w)); }
+
+// PMT afterpulses of one photon (afterpulse.py:172-249): one uniform pair per element.  RNG spec v10: the top 32 bits of the FIRST
+// uniform of elements 4k .. 4k + 3 are the four words of one call (site SITE_AP_SCREEN + k); its low bits and the second uniform come
+// from the element's own call (SITE_AP + e: words y, z, w), which only a candidate ever makes.  The generator only SCREENS
+// (ap_generate, inside the photon loop): one Philox call per four elements and an integer comparison of the screen word with a
+// threshold of the (element, channel) that no accepted uniform can miss (ap_threshold in wfs_engine.hip); the rare candidate is
+// parked in LDS and leaves with the block's other candidates for the global list.  k_ap_finish, one thread per candidate, makes
+// the reference's own floating-point comparison and turns the accepted ones into afterpulse photons (two bisections of cumulative
+// rows in global memory, ~20 dependent loads).  Inside the photon loop a wave paid that chain whenever ONE of its 64 lanes had a
+// candidate, which with p ~ 1 % per element is most of the time; behind the loop, once per block, it still kept the block's LDS
+// and its eight mostly idle waves on the CU for tens of microseconds (fill pass 5.1 -> 2.7 ms -> see DESIGN.md for the last step).
+struct __attribute__((aligned(8))) ApCand { i64 itime; u32 x; i32 ins, ch, t; u32 key, j, m, gid; i32 e_dpe, pad; };     // (48 bytes)
 struct ApStage { i32 *n; ApCand *cand; };
+// the uniform of the acceptance test, exactly as the reference forms and scales it (afterpulse.py:196-204); w: the element's own call
+__device__ __forceinline__ double ap_uniform(const WfsDev &d, const ApCand &q, const u32x4 &w)
+{
+    double rU0 = 1.0 - u53(q.x, w.y);
+    rU0 /= d.pmt_ap_modifier;
+    if (q.e_dpe >> 8) rU0 /= 2;
+    return rU0;
+}
+__device__ __forceinline__ u32x4 ap_call(const WfsDev &d, const ApCand &q) { return philox4x32_10(q.j, q.gid, q.m, SITE_AP + (u32)(q.e_dpe & 0xff), d.k0, d.k1); }
+__device__ __forceinline__ bool ap_accept(const WfsDev &d, const ApArgs &ap, const ApCand &q) { return ap_uniform(d, q, ap_call(d, q)) <= ap.prob[q.e_dpe & 0xff][q.ch]; }
 __device__ __forceinline__ void ap_finish(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApCand &q, i64 gk)
 {
-    const ApElemDev &el = ap.el[q.e];
+    const int e = q.e_dpe & 0xff;
+    const ApElemDev &el = ap.el[e];
     const double *dc = el.delay_cdf + (size_t)q.ch * el.n_bins_delay;
     double delay, amp;
     if (el.is_uniform) {
-        const u32x4 x = philox4x32_10(q.j, q.gid, q.m, SITE_AP_X + (u32)q.e, d.k0, d.k1);
+        const u32x4 x = philox4x32_10(q.j, q.gid, q.m, SITE_AP_X + (u32)e, d.k0, d.k1);
         delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
     } else {
-        const int best = argmin_abs_diff(dc, el.n_bins_delay, q.u0, el.delay_sorted != 0);      // np.argmin(|cdf - u|): first minimum
+        const u32x4 w = ap_call(d, q);
+        const int best = argmin_abs_diff(dc, el.n_bins_delay, ap_uniform(d, q, w), el.delay_sorted != 0);      // np.argmin(|cdf - u|): first minimum
         delay = best * el.delay_bin - d.pmt_ap_t_modifier;
         const double *ac = el.amp_2d ? el.amp_cdf + (size_t)q.ch * el.n_bins_amp : el.amp_cdf;
-        const int ba = argmin_abs_diff(ac, el.n_bins_amp, q.u1, el.amp_sorted != 0);
+        const int ba = argmin_abs_diff(ac, el.n_bins_amp, 1.0 - u53(w.z, w.w), el.amp_sorted != 0);
         amp = ba * el.amp_bin;
     }
     const double tf = (double)(q.itime + q.t) + delay;          // afterpulse.py:235, int64 + float
@@ -2125,23 +2146,31 @@ __device__ __forceinline__ void ap_finish(const WfsDev &d, const GenArgs &a, con
     if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
     if (gk < ap.cap) { ap.ap_ins[gk] = q.ins; ap.ap_ch[gk] = q.ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = d.gains[q.ch] * amp; ap.ap_key[gk] = q.key; }
 }
-__device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st,
-                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P, const double *prob_lds = nullptr)
+// a candidate into the block's LDS list (or, past AP_STAGE, straight to the end)
+__device__ __forceinline__ void ap_park(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st, u32 x, i32 e_dpe, u32 j, u32 gid, u32 m,
+                                     i32 ins, i32 ch, i64 itime, i32 t, u32 key)
 {
-    for (int e = 0; e < ap.n; e++) {
-        const u32x4 w = philox4x32_10(j, gid, m, SITE_AP + (u32)e, d.k0, d.k1);
-        double rU0 = 1.0 - u53(w.x, w.y);
-        // the channel's afterpulse probability = last entry of its delay CDF row (from the block's LDS copy where there is one)
-        const double prob = prob_lds ? prob_lds[e * d.n_tpc + ch] : ap.prob[e][ch];
-        rU0 /= d.pmt_ap_modifier;
-        if (is_dpe) rU0 /= 2;
-        if (!(rU0 <= prob)) continue;
-        ApCand q;
-        q.u0 = rU0; q.u1 = 1.0 - u53(w.z, w.w); q.itime = itime; q.ins = ins; q.ch = ch; q.t = (i32)t; q.j = j; q.m = m; q.gid = gid; q.e = e;
-        q.key = ((u32)e << 29) | (P & 0x1fffffffu);                 // the reference walks element by element, parent by parent (afterpulse.py:189-207)
-        const i32 k = atomicAdd(st.n, 1);
-        if (k < AP_STAGE) st.cand[k] = q;
-        else ap_finish(d, a, ap, q, (i64)atomicAdd((u64 *)ap.count, 1ull));
+    ApCand q;
+    q.x = x; q.itime = itime; q.ins = ins; q.ch = ch; q.t = t; q.j = j; q.m = m; q.gid = gid; q.e_dpe = e_dpe; q.pad = 0;
+    q.key = key;                                                    // element << 29 | parent: the reference walks element by element, parent by parent (afterpulse.py:189-207)
+    const i32 kq = atomicAdd(st.n, 1);
+    if (kq < AP_STAGE) st.cand[kq] = q;
+    else { const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull); if (gk < ap.cap) ap.cand[gk] = q; }      // (a block with more candidates than the stage holds)
+}
+__device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st,
+                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P, const u32 *thr_lds = nullptr)
+{
+    for (int e0 = 0; e0 < ap.n; e0 += 4) {
+        const u32x4 S = philox4x32_10(j, gid, m, SITE_AP_SCREEN + (u32)(e0 >> 2), d.k0, d.k1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = e0 + k;
+            if (e >= ap.n) break;
+            const u32 x = word_of(S, k);
+            const u32 thr = thr_lds ? thr_lds[(e * d.n_tpc + ch) * 2 + (is_dpe ? 1 : 0)] : ap.thr[e][ch * 2 + (is_dpe ? 1 : 0)];
+            if ((x >> 5) < thr) continue;                           // surely rejected (ap_threshold)
+            ap_park(d, a, ap, st, x, e | (is_dpe ? 256 : 0), j, gid, m, ins, ch, itime, (i32)t, ((u32)e << 29) | (P & 0x1fffffffu));
+        }
     }
 }
 
@@ -2574,7 +2603,6 @@ __global__ __launch_bounds__(64) void k_chan_alias(const double *cdf_table, int 
     __syncthreads();
     for (int i = threadIdx.x; i < K; i += 64) out[r * K + i] = cell[i];
 }
-__device__ __forceinline__ u32 word_of(const u32x4 &W, int k) { return k == 0 ? W.x : (k == 1 ? W.y : (k == 2 ? W.z : W.w)); }
 
 // photon p (generation order) -> emitter, instruction, Philox coordinates; generic path and k_photon_times
 struct PhotonId { i64 em; i32 ins; u32 gid, eb, j, m, P; };
@@ -2698,8 +2726,8 @@ __host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap
     o.pidx = o.chmap + GEN_BLOCK * 2;                         // u16[GEN_BLOCK]: block-relative photon index of every bucket position
     o.stage = (o.pidx + GEN_BLOCK * 2 + 7) & ~7;              // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
     o.ap = o.stage + GEN_BLOCK * 8;                           // afterpulse staging
-    o.approb = (o.ap + (with_ap ? AP_STAGE * (int)sizeof(ApCand) : 0) + 7) & ~7;       // double[n_ap][nch]: afterpulse probability of every (element, channel)
-    o.total = o.approb + (with_ap ? n_ap * nch * 8 : 0) + 16;
+    o.approb = (o.ap + (with_ap ? AP_STAGE * (int)sizeof(ApCand) : 0) + 7) & ~7;       // u32[n_ap][nch][2]: screening thresholds of every (element, channel)
+    o.total = o.approb + 16;
     return o;
 }
 
@@ -2712,7 +2740,6 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
     const int nch = d.n_tpc, tid = threadIdx.x;
     const int lg = a.ch_lg;
     const GenFillLds o = gen_fill_lds(nch, lg, AP, AP ? ap.n : 0);
-    double *ap_prob = (double *)(smem + o.approb);
     i32 *win = (i32 *)smem, *wtime = (i32 *)(smem + o.wtime);
     uint2 *T = (uint2 *)(smem + o.T);                        // alias cells of the block's channel row
     i32 *hist = (i32 *)(smem + o.hist), *cur = (i32 *)(smem + o.cur), *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
@@ -2762,7 +2789,6 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
             }
         }
         for (int c = tid; c < (1 << lg); c += TPB) T[c] = a.chan_alias[((size_t)bd.row << lg) + c];
-        if (AP) for (int i = tid; i < ap.n * nch; i += TPB) { const int e = i / nch, c = i - e * nch; ap_prob[i] = ap.prob[e][c]; }
         for (int k = tid; k < nwin; k += TPB) {
             win[k] = (i32)(a.em_ph_off[bd.e_lo + k] - p0);
             // the block's own emitters only (slot nwin - 1 is the sentinel behind them); I64_MIN: an electron that did not survive (no photons)
@@ -2820,7 +2846,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                     t += (i32)(i64)s1_propagation(a, c >= d.n_top, pzi, pzf, X.x);
                 }
                 if (EXT && gg_lo >= 0) t += (i32)(i64)(gg_time(a, gg_lo, gg_w, word_of(LW, k)) - gg_m);      // s2.py:447-450, the cast of :532
-                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t, bd.sbase + (u32)(bd.R0 + pr), ap_prob);
+                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t, bd.sbase + (u32)(bd.R0 + pr));
                 atomicMin(&hmin[c], t); atomicMax(&hmax[c], t);
                 const int pos = hist[c] + atomicAdd(&cur[c], 1);
                 stage[pos] = PhotonRec{t, code}; chmap[pos] = (unsigned short)c; pidx[pos] = (unsigned short)pr;
@@ -2883,8 +2909,22 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
         const int nst = s_apn < AP_STAGE ? s_apn : AP_STAGE;
         if (tid == 0 && nst > 0) s_apbase = (i64)atomicAdd((u64 *)ap.count, (u64)nst);
         __syncthreads();
-        for (int k = tid; k < nst; k += TPB) ap_finish(d, a, ap, aps.cand[k], s_apbase + k);        // one candidate per thread, all chains together
+        for (int k = tid; k < nst; k += TPB) { const i64 gk = s_apbase + k; if (gk < ap.cap) ap.cand[gk] = aps.cand[k]; }
     }
+}
+
+// one thread per candidate: the reference's acceptance comparison, then delay and amplitude of the accepted ones (ap_finish); a rejected
+// candidate leaves a hole that k_ap_count / k_ap_place skip
+__global__ void k_ap_finish(WfsDev d, GenArgs a, ApArgs ap)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
+    if (i >= n) return;
+    const ApCand q = ap.cand[i];
+    const bool ok = ap_accept(d, ap, q);
+    if (ok) ap_finish(d, a, ap, q, i); else ap.ap_ch[i] = -1;
+    const int n_ok = __popcll(__ballot(ok));
+    if ((threadIdx.x & 63) == 0 && n_ok) atomicAdd((u64 *)(ap.count + 15), (u64)n_ok);
 }
 
 // afterpulse photons -> tiles of the afterpulse pulse set of their primary set (set n_psets + set): count, then place
@@ -2892,7 +2932,7 @@ __global__ void k_ap_count(WfsDev d, GenArgs a, ApArgs ap)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
-    if (i >= n) return;
+    if (i >= n || ap.ap_ch[i] < 0) return;
     atomicAdd(&a.tile_count[((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i]], 1);
 }
 
@@ -2900,7 +2940,7 @@ __global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
-    if (i >= n) return;
+    if (i >= n || ap.ap_ch[i] < 0) return;
     const i64 tile = ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i];
     const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
     a.ph[pos] = PhotonRec{ap.ap_t[i], 0u}; ph_gain_base[pos] = ap.ap_gain[i]; a.ph_idx[pos] = ap.ap_key[i];
