@@ -153,7 +153,7 @@ def main():
     ap.add_argument('--instructions', type=int, default=None, help='instructions per GPU per step (default: 1000 S2 / 10000 mixed / 200000 nveto)')
     ap.add_argument('--workload', choices=['s2', 'mixed', 'nveto'], default='s2',
                     help='s2: the headline batch (BASELINE configs[2]); mixed: configs[3]; nveto: configs[4]')
-    ap.add_argument('--cpu-sample', type=int, default=60, help="S2 instructions timed on the CPU oracle, ~15 s (0: skip)")
+    ap.add_argument('--cpu-sample', type=int, default=120, help="S2 instructions timed on the CPU oracle, ~13 s on one thread + ~4 s on all cores (0: skip)")
     ap.add_argument('--no-gather', action='store_true', help='skip the RCCL gather of records (N > 1)')
     ap.add_argument('--sync-gather', action='store_true', help='do not overlap the gather with the next batch')
     args = ap.parse_args()

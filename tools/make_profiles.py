@@ -41,8 +41,8 @@ json.dump(bench, open(os.path.join(dst, f'{tag}_bench.json'), 'w'), indent=1)
 stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
 if stats:
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f'{tag}_kernel_stats.csv'))
-fetch, _ = per_launch('fetch')
-write, _ = per_launch('write')
+fetch, n_fetch = per_launch('fetch')
+write, n_write = per_launch('write')
 out = dict(note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 0 (the full headline batch), '
                 'per launch averages; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950: FETCH_SIZE counts half the bytes of coalesced '
                 'streaming reads, MI355X_MICROARCH.md HBM section; narrower accesses are uncalibrated)',
@@ -54,6 +54,15 @@ kms = bench.get('roofline', {}).get('kernels_ms', {})
 tot = sum(v['hbm_bytes'] for k, v in out['kernels'].items() if k in kms)
 out['pipeline'] = dict(hbm_bytes_all_timed_kernels=tot, algorithmic_bytes=bench.get('roofline', {}).get('algorithmic_bytes_per_launch'),
                        ratio=(tot / bench['roofline']['algorithmic_bytes_per_launch']) if bench.get('roofline', {}).get('algorithmic_bytes_per_launch') else None)
+# every dispatch of one batch, runtime fills and copies (memsets of the accumulators!) included: per-launch mean x launches per batch, the
+# number of batches in the profiled process taken from a kernel that runs once per batch
+runs = max(1, n_fetch.get('k_counts', n_fetch.get('k_row_len', 1)))
+every = sum((2 * fetch.get(k, {}).get('FETCH_SIZE', 0.0) * n_fetch.get(k, 0) + write.get(k, {}).get('WRITE_SIZE', 0.0) * n_write.get(k, 0)) * 1024
+            for k in set(fetch) | set(write)) / runs
+out['pipeline']['hbm_bytes_every_dispatch_per_batch'] = every
+out['pipeline']['batches_in_profiled_process'] = runs
+if out['pipeline']['algorithmic_bytes']:
+    out['pipeline']['ratio_every_dispatch'] = every / out['pipeline']['algorithmic_bytes']
 json.dump(out, open(os.path.join(dst, f'{tag}_traffic.json'), 'w'), indent=1)
 
 # ---- SQ counters
