@@ -154,7 +154,10 @@ def main():
     ap.add_argument('--workload', choices=['s2', 'mixed', 'nveto'], default='s2',
                     help='s2: the headline batch (BASELINE configs[2]); mixed: configs[3]; nveto: configs[4]')
     ap.add_argument('--cpu-sample', type=int, default=120, help="S2 instructions timed on the CPU oracle, ~13 s on one thread + ~4 s on all cores (0: skip)")
-    ap.add_argument('--no-gather', action='store_true', help='skip the RCCL gather of records (N > 1)')
+    ap.add_argument('--no-copy-ceiling', action='store_true', help='skip the 1 GiB device-copy measurement (counter passes: it is not part of the batch)')
+    ap.add_argument('--gather', action='store_true', help='N > 1: also gather every rank\'s records on rank 0 over RCCL inside the timed region (the reference\'s single feeding '
+                    'process; default: every rank keeps its records in its own HBM, as the one-GPU run does -- the path has no exchange step)')
+    ap.add_argument('--no-gather', action='store_true', help='(default since round 3; kept for old command lines)')
     ap.add_argument('--sync-gather', action='store_true', help='do not overlap the gather with the next batch')
     args = ap.parse_args()
 
@@ -216,7 +219,7 @@ def main():
         nonlocal pending
         eng.set_profiling(profile)
         counts = eng.run()
-        if world > 1 and not args.no_gather:
+        if world > 1 and args.gather:
             if pending is not None:
                 wait_gather(pending[1])
             mine = torch.empty(counts['n_records'] * 244, dtype=torch.uint8, device='cuda')
@@ -284,16 +287,18 @@ def main():
             dist.destroy_process_group()
         return
     # measured ceiling next to the spec peak: a plain device-to-device copy of 1 GiB (bytes read + written per second)
-    src_buf = torch.empty(1 << 30, dtype=torch.uint8, device='cuda'); dst_buf = torch.empty_like(src_buf)
-    for _ in range(2):
-        dst_buf.copy_(src_buf)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10):
-        dst_buf.copy_(src_buf)
-    e1.record(); torch.cuda.synchronize()
-    copy_gbs = 2 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del src_buf, dst_buf
+    copy_gbs = None
+    if not args.no_copy_ceiling:
+        src_buf = torch.empty(1 << 30, dtype=torch.uint8, device='cuda'); dst_buf = torch.empty_like(src_buf)
+        for _ in range(2):
+            dst_buf.copy_(src_buf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst_buf.copy_(src_buf)
+        e1.record(); torch.cuda.synchronize()
+        copy_gbs = 2 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src_buf, dst_buf
     ms_per_step = 1e3 * elapsed / args.steps
     dom = max(ktimes, key=lambda k: ktimes[k][0])
     dom_ms, dom_launches = ktimes[dom]
@@ -332,7 +337,7 @@ def main():
                               'nveto': f'{M} optical nVeto instructions per GPU at 1 MHz, ~10 photons each, 120 channels '
                                        f'(BASELINE configs[4])'}[args.workload],
                     instructions_per_gpu=M, instructions_per_s=M * world * args.steps / elapsed, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
-                    gather='none' if (world == 1 or args.no_gather) else (('rccl' if backend == 'nccl' else backend) + ' send/recv to rank 0' + ('' if args.sync_gather else ', overlapped with the next batch')),
+                    gather='none' if (world == 1 or not args.gather) else (('rccl' if backend == 'nccl' else backend) + ' send/recv to rank 0' + ('' if args.sync_gather else ', overlapped with the next batch')),
                     ms_per_step_incl_d2h_of_records=pcie_ms, d2h='pinned host buffers, copy of batch k overlapped with batch k + 1' if pinned else 'pageable host buffers'),
         # bound: the roofline these numbers are priced on (HBM bytes: there is no dense contraction for MFMA).  What actually
         # limits the dominant kernel is in `limited_by` (SQ counters: f64 VALU issue + exposed latency, not HBM).
@@ -341,7 +346,7 @@ def main():
                       limited_by=limiter, valu_busy=valu_util,
                       kernel_own_bytes=own, kernel_own_frac=(own / (dom_ms / dom_launches * 1e-3) / 1e9 / HBM_PEAK_GBS) if own else None,
                       pipeline_frac=b_alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      measured_copy_GBs=copy_gbs, frac_of_measured_copy=achieved / copy_gbs,
+                      measured_copy_GBs=copy_gbs, frac_of_measured_copy=(achieved / copy_gbs) if copy_gbs else None,
                       kernels_ms={k: round(v[0], 4) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}),
     )
     if cpu is not None:

@@ -102,9 +102,10 @@ def test_bench_launches_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     env['WFS_BENCH_BACKEND'] = 'gloo'
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--instructions', '12', '--steps', '2', '--warmup', '1',
-                        '--cpu-sample', '0'], capture_output=True, text=True, cwd=root, env=env, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
-    assert line['config']['instructions_per_gpu'] == 12 and 'gloo' in line['config']['gather']
+    for extra, gather in (([], 'none'), (['--gather'], 'gloo')):       # default: every rank keeps its records (no exchange step on this path)
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--instructions', '12', '--steps', '2', '--warmup', '1',
+                            '--cpu-sample', '0'] + extra, capture_output=True, text=True, cwd=root, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+        assert line['config']['instructions_per_gpu'] == 12 and gather in line['config']['gather']

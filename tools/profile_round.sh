@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --cpu-sample 0 $*"
+B="python3 $R/bench.py --cpu-sample 0 --no-copy-ceiling $*"
 python3 $R/bench.py --steps 5 --warmup 2 $* > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.log 2>&1; echo "trace rc=$?"
 run() { n=$1; shift; timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -- $B --steps 1 --warmup 0 > $OUT/$n.log 2>&1; echo "$n rc=$?"; }

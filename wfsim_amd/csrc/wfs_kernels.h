@@ -1030,14 +1030,18 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     }
     // ---- ascending time: bitonic sort of the keys ns << 6 | lane (unique: a deterministic order), then the gains follow
     u32 key = ((u32)ns0 << 6) | (u32)lane;
+    // (the photons sit in lanes 0 .. n - 1 and every other lane holds a larger key: with n <= 32 (16) the merges of 64 (32) lanes have
+    // nothing to do -- the lower half is sorted ascending after the stages before them, which is all that is read)
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1)
+    for (int k = 2; k <= 64; k <<= 1) {
+        if ((k >> 1) >= n && k > 16) break;                  // wave-uniform
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
             const u32 other = (u32)__shfl_xor((int)key, j, 64);
             const bool up = (lane & k) == 0, low = (lane & j) == 0;
             key = (low == up) ? (key < other ? key : other) : (key > other ? key : other);
         }
+    }
     const int src = (int)(key & 63u);
     i32 ns = (i32)(key >> 6);
     g = __shfl(g, src, 64);
