@@ -209,6 +209,30 @@ def test_pmt_afterpulses_generated_on_device():
     _compare(orc, o, eng, counts, s_ins)
 
 
+@pytest.mark.parametrize('scale,scale_uniform,modifier', [(1.0, 1.0, 1.0), (12.0, 12.0, 0.37), (4.0, 4.0, 2.5), (2.0, 60.0, 2.5), (0.0, 0.0, 1.0)])
+def test_pmt_afterpulse_screen_never_loses_an_afterpulse(scale, scale_uniform, modifier):
+    """The generator screens afterpulse candidates with an integer threshold per (element, channel, single / double PE parent)
+    (RNG spec v10, ap_threshold in wfs_engine.hip) and only candidates get the reference's floating-point comparison
+    (afterpulse.py:196-204); the oracle makes that comparison for every photon and element.  Probabilities from 0 to beyond 1
+    after the modifier (the 'Uniform' element of the fourth case fires for every photon), ~3 x 10^4 parent photons: every
+    afterpulse the oracle makes must be there, photon by photon."""
+    from tests.helpers import ap_tables_from_golden
+    ap = ap_tables_from_golden()
+    for name in ap:                                      # the last column of the delay CDF is the channel's afterpulse probability
+        k = scale_uniform if name == 'Uniform' else scale
+        ap[name] = dict(ap[name], delaytime_cdf=ap[name]['delaytime_cdf'] * k)
+    rows = [dict(type=1, time=MS * (i + 1), x=i, y=-i, z=-20, amp=10000) for i in range(6)]
+    rows += [dict(type=2, time=MS * (i + 10), x=i, y=i, z=-10, amp=150) for i in range(6)]
+    orc, o, eng, counts, s_ins = _run_both(xenonnt_test_config(pmt_ap_modifier=modifier), _instructions(rows), seed=23, ap=ap)
+    n_ap = sum(o['call_ph_off'][k + 1] - o['call_ph_off'][k] for k in range(len(o['call_kind'])) if o['call_kind'][k] == 3)
+    n_par = counts['n_photons'] - n_ap
+    assert n_par > 15000
+    if scale == 0.0: assert n_ap == 0
+    elif scale_uniform == 60.0: assert n_ap >= n_par     # P(Uniform) * modifier = 0.48 * 2.5 > 1: one for every parent, and the others
+    else: assert n_ap > 500
+    _compare(orc, o, eng, counts, s_ins)
+
+
 def test_noise_on_generated_path():
     from tests.helpers import golden
     noise = golden('noise.npz')['noise']
