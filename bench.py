@@ -68,8 +68,11 @@ def mixed_config(seed):
                                enable_noise=True, noise_data=golden('noise.npz')['noise'])
 
 
-def bench_config(seed):
+def bench_config(seed, pmt_afterpulses=False):
     # E[PE] = 10^4 e- * survival * sc_gain 100 = ~10^6 PE per instruction
+    if pmt_afterpulses:         # side measurement (--pmt-afterpulses): the headline batch with PMT afterpulses on (synthetic tables)
+        from tests.helpers import ap_tables_from_golden
+        return xenonnt_test_config(s2_secondary_sc_gain=100.0, seed=seed, enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap_tables_from_golden())
     return xenonnt_test_config(s2_secondary_sc_gain=100.0, seed=seed)
 
 
@@ -154,6 +157,7 @@ def main():
     ap.add_argument('--workload', choices=['s2', 'mixed', 'nveto'], default='s2',
                     help='s2: the headline batch (BASELINE configs[2]); mixed: configs[3]; nveto: configs[4]')
     ap.add_argument('--cpu-sample', type=int, default=120, help="S2 instructions timed on the CPU oracle, ~13 s on one thread + ~4 s on all cores (0: skip)")
+    ap.add_argument('--pmt-afterpulses', action='store_true', help='s2 workload with PMT afterpulses on (synthetic tables): a side measurement, not the headline')
     ap.add_argument('--no-copy-ceiling', action='store_true', help='skip the 1 GiB device-copy measurement (counter passes: it is not part of the batch)')
     ap.add_argument('--gather', action='store_true', help='N > 1: also gather every rank\'s records on rank 0 over RCCL inside the timed region (the reference\'s single feeding '
                     'process; default: every rank keeps its records in its own HBM, as the one-GPU run does -- the path has no exchange step)')
@@ -201,7 +205,7 @@ def main():
         eng = Engine(cfg, res, device=local_rank)
         eng.load_optical(ins[order], (rank * M + order).astype(np.uint32), cluster, key, channels, timings, int(1e6))
     else:
-        cfg = bench_config(seed=3) if args.workload == 's2' else mixed_config(seed=3)
+        cfg = bench_config(seed=3, pmt_afterpulses=args.pmt_afterpulses) if args.workload == 's2' else mixed_config(seed=3)
         res = Resource(cfg)
         ins = s2_batch(M, first_gid=rank * M) if args.workload == 's2' else mixed_batch(M, first_gid=rank * M)
         M = len(ins)
@@ -335,7 +339,7 @@ def main():
                               'mixed': f'{M} instructions per GPU: S1 (3000 quanta) + S2 (1500 e-) pairs over the TPC, PMT afterpulses and '
                                        f'noise on (synthetic tables), 494 PMTs (BASELINE configs[3])',
                               'nveto': f'{M} optical nVeto instructions per GPU at 1 MHz, ~10 photons each, 120 channels '
-                                       f'(BASELINE configs[4])'}[args.workload],
+                                       f'(BASELINE configs[4])'}[args.workload] + (' -- SIDE MEASUREMENT: PMT afterpulses ON (synthetic tables)' if (args.workload == 's2' and args.pmt_afterpulses) else ''),
                     instructions_per_gpu=M, instructions_per_s=M * world * args.steps / elapsed, pe_per_step=total_pe, photons_per_step=total_ph, records_per_step=total_rec,
                     gather='none' if (world == 1 or not args.gather) else (('rccl' if backend == 'nccl' else backend) + ' send/recv to rank 0' + ('' if args.sync_gather else ', overlapped with the next batch')),
                     ms_per_step_incl_d2h_of_records=pcie_ms, d2h='pinned host buffers, copy of batch k overlapped with batch k + 1' if pinned else 'pageable host buffers'),

@@ -970,7 +970,7 @@ static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, doubl
 static int fuse_eligible(const orc_session *s, int type, u32 em_base, i64 amp, double sc_gain, const double *cdf)
 {
     const orc_config *c = &s->c;
-    if (!c->tile_gen || c->gain_spread != 0.0 || c->enable_pmt_ap || s->n_ins_models > 0 || !s->save_full_truth) return 0;
+    if (!c->tile_gen || c->gain_spread != 0.0 || s->n_ins_models > 0 || !s->save_full_truth) return 0;
     if (type != 2 || em_base != 0u || amp <= 0 || !(sc_gain > 0)) return 0;
     double pmax = 0.0;
     for (int ch = 0; ch < c->n_tpc; ch++) { const double p = cdf[ch] - (ch ? cdf[ch - 1] : 0.0); pmax = p > pmax ? p : pmax; }
@@ -1027,7 +1027,7 @@ static i64 gen_s2(orc_session *s, call_ctx *x, int type, u32 gid, u32 em_base, i
                 int g1, g2; gain_code(s, G[q & 3], &g1, &g2);
                 double gain = s->gains[ch] * row[g1];
                 if (g2) gain += s->gains[ch] * row[g2];
-                ctx_push(x, t, ch, g2 != 0, gain, gid, 0, q);
+                ctx_push(x, t, ch, g2 != 0, gain, gid, (i64)c0, q);                   /* (c0, gid, q): the photon's coordinates for its PMT afterpulse draws */
             }
         }
         free(surv.p);

@@ -65,7 +65,7 @@ def tile_local_generation(config):
     or electron by electron: the electron-afterpulse pre-pass (photon counts and picked photon times per parent S2), Pulse calls
     that cover several instructions (save_full_truth=False) and the transverse-diffusion field maps (the pattern of an instruction
     is then known only after its electrons) and any digitiser geometry other than 10 ns samples / 22-sample templates (the fused
-    kernel is specialised for it).  The per-instruction conditions (s2_gain_spread == 0, PMT afterpulses off, default
+    kernel is specialised for it).  The per-instruction conditions (s2_gain_spread == 0, default
     delay table, tile size) are checked where the instructions are: wfs_tilegen.h fuse_eligible and the oracle's twin."""
     sw = afterpulse_switches(config)
     transverse_maps = (config.get('diffusion_constant_transverse', 0) > 0

@@ -77,7 +77,7 @@ struct wfs_handle {
     DevBuf tt_alias[6];
     std::vector<i64> h_rs_off; std::vector<i32> h_rs_list;        // run set -> instructions (host copy)
     std::vector<double> h_lum_x, h_lum_t;          // luminescence table (host copy, enters the S2 delay table)
-    DevBuf ap_ins, ap_ch, ap_t, ap_gain, ap_cand; i64 n_ap_photons = 0; bool ap_active = false;
+    DevBuf ap_ins, ap_ch, ap_t, ap_gain, ap_cand, ap_args_dev; i64 n_ap_photons = 0; bool ap_active = false;
     // model variants of the photon delays
     std::vector<DevBuf> x_alias; std::vector<AliasTab> h_tabs; DevBuf d_tabs; i32 n_user_tabs = 0;
     std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
@@ -441,8 +441,10 @@ try {
     hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_tile_order_big, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_generic<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipFuncSetAttribute((const void *)k_s2_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_s2_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_s2_tile<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_s2_tile<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_s2_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipFuncSetAttribute((const void *)k_s2_tile<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     *out = h;
@@ -465,7 +467,7 @@ try {
         hipFree(h->stamps.p);
     }
 #endif
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->ap_cand, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->ap_cand, &h->ap_args_dev, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->chan_alias, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->em_zg, &h->pois_cdf, &h->pois_kmin, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -1173,7 +1175,8 @@ static int run_generation(wfs_handle *h)
     // tile-local generation (wfs_tilegen.h): which instructions take it is decided before the electrons are drawn -- theirs get no
     // photon numbers.  Debug modes that need the per-photon arrays (currents, generation only) run the generation half alone.
     const bool ap_cfg = h->ap_active;
-    h->fuse_on = h->cfg.tile_gen && !h->generic_geom && h->any_s2 && !ext && !ap_cfg && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
+    h->fuse_on = h->cfg.tile_gen && !h->generic_geom && h->any_s2 && !ext && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
+    (void)ap_cfg;                                // (PMT afterpulses of tile-generated photons are screened inside k_s2_tile)
     h->fuse_full = h->fuse_on && !(h->keep_currents & 5);
     h->n_fused_tiles = 0; h->p_fused = 0;
     FuseArgs f{};
@@ -1242,7 +1245,7 @@ static int run_generation(wfs_handle *h)
     h->n_photons = P + h->p_fused; h->n_ap_photons = 0;
     g.em_ph_off = h->em_ph_off.as<i64>(); g.n_photons = P;
     const bool ap_on = h->ap_active;
-    const i64 ap_cap = ap_on ? P / 8 + 65536 : 0;
+    const i64 ap_cap = ap_on ? (P + h->p_fused) / 8 + 65536 : 0;
     TRY(ensure(h, h->ph, (size_t)(P + h->p_fused + ap_cap) * 8));
     TRY(ensure(h, h->ph_idx, (size_t)(P + h->p_fused + ap_cap) * 4)); g.ph_idx = h->ph_idx.as<u32>();
     g.tile_count = h->tile_count.as<i32>(); g.tile_cursor = h->tile_cursor.as<i32>(); g.tile_tmin = h->tile_tmin.as<i32>();
@@ -1322,18 +1325,27 @@ static int run_generation(wfs_handle *h)
         for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
         size_t lds = (size_t)(256 + d.tlen - 1) * d.dt * 8 + 4 * 4 * 4 + TAP_LDS_BYTES(256) + 64;
         lds = (lds + 15) / 16 * 16;
+        const int ap_lds_off = (int)lds;                         // afterpulse candidates of the tile (AP variants)
+        const ApArgs *app = nullptr;
+        if (ap_on) {
+            lds += (size_t)AP_STAGE * sizeof(ApCand);
+            TRY(upload(h, h->ap_args_dev, &ap, sizeof ap)); app = h->ap_args_dev.as<ApArgs>();      // (`ap` outlives the copy: read_scal below)
+        }
         f.sparse_max = h->tap_sparse_max;
         Timer t(h, "k_s2_tile");
-        if (h->fuse_full) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<true>), dim3((unsigned)h->n_fused_tiles), dim3(256), lds, h->stream, d, f, tp);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<false>), dim3((unsigned)h->n_fused_tiles), dim3(256), lds, h->stream, d, f, tp);
+        const dim3 grid((unsigned)h->n_fused_tiles);
+        if (h->fuse_full && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<true, true>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
+        else if (h->fuse_full) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<true, false>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
+        else if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<false, true>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<false, false>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
     }
     h->fuse_args = f;
     if (ap_on) {
         // afterpulse photons: count per tile of the afterpulse sets, offsets behind the primary photons, place
         { Timer t(h, "k_ap_finish"); hipLaunchKernelGGL(k_ap_finish, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
         { Timer t(h, "k_ap_count"); hipLaunchKernelGGL(k_ap_count, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
-        TRY(scan_into(h, h->tile_count.as<i32>() + TP, TP, h->tile_off.as<i64>() + TP, 14, P));
-        { Timer t(h, "k_ap_place"); hipLaunchKernelGGL(k_ap_place, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - P); }
+        TRY(scan_into(h, h->tile_count.as<i32>() + TP, TP, h->tile_off.as<i64>() + TP, 14, P + h->p_fused));      // (behind the slots of every primary tile, the tile-generated ones included)
+        { Timer t(h, "k_ap_place"); hipLaunchKernelGGL(k_ap_place, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - (P + h->p_fused)); }
         TRY(read_scal(h));
         if (h->h_scal[13] > ap_cap) return h->fail(WFS_E_CAPACITY, "more PMT afterpulse photons than 1/8 of the primary photons: afterpulse probability unreasonably high");
         h->n_ap_photons = h->h_scal[28];                             // (the accepted candidates, k_ap_finish)
@@ -1404,7 +1416,7 @@ try {
     if (tiles_done) {
         TRY(ensure(h, h->row_cnt, (size_t)CG * d.n_tpc * 4)); TRY(ensure(h, h->row_tile, (size_t)CG * d.n_tpc * 4));
         HIPCHK(hipMemsetAsync(h->row_cnt.p, 0, (size_t)CG * d.n_tpc * 4, h->stream));
-        ga.tile_done_ins = h->ins_fused.as<i32>(); ga.row_cnt = h->row_cnt.as<i32>(); ga.row_tile = h->row_tile.as<i32>();
+        ga.tile_done_ins = h->ins_fused.as<i32>(); ga.n_done = h->n_ins; ga.row_cnt = h->row_cnt.as<i32>(); ga.row_tile = h->row_tile.as<i32>();
         ga.ins_bcap = h->ins_bcap.as<i32>(); ga.ins_boff = h->ins_boff.as<i64>();
     }
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 1024)), dim3(1024), 0, h->stream, d, ga); }
@@ -1565,7 +1577,7 @@ try {
     za.acc_off = h->acc_off.as<i64>(); za.raw = h->raw.as<i32>(); za.grp_left = h->grp_left.as<i64>(); za.grp_ixrand = h->grp_ixrand.as<i64>();
     za.itv_off = h->itv_off.as<i64>(); za.itv_left = h->itv_left.as<i64>(); za.itv_right = h->itv_right.as<i64>();
     za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = 110;
-    if (tiles_done) { za.tile_done_ins = ga.tile_done_ins; za.row_cnt = ga.row_cnt; za.row_tile = ga.row_tile; za.ins_bcap = ga.ins_bcap; za.ins_boff = ga.ins_boff; za.tbuf = h->tbuf.as<i32>(); }
+    if (tiles_done) { za.tile_done_ins = ga.tile_done_ins; za.n_done = ga.n_done; za.row_cnt = ga.row_cnt; za.row_tile = ga.row_tile; za.ins_bcap = ga.ins_bcap; za.ins_boff = ga.ins_boff; za.tbuf = h->tbuf.as<i32>(); }
     h->row_dbg_total = 0;
     if ((h->keep_currents & 1) && h->n_active_rows > 0) {
         std::vector<i32> ar((size_t)h->n_active_rows);

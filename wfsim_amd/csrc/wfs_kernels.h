@@ -127,7 +127,8 @@ struct GeomArgs {
     i32 *sparse_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
     i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
     i32 *wave_tiles;     // medium tiles (at most 64 photons, any width: wave per tile); scal[17] = their number
-    const i32 *tile_done_ins;   // [n_ins] 1: the tiles of this instruction (= pulse set) were simulated by k_s2_tile: on no work list (or nullptr)
+    const i32 *tile_done_ins;   // [n_done] 1: the tiles of this instruction (= pulse set) were simulated by k_s2_tile: on no work list (or nullptr)
+    i64 n_done;                 // primary pulse sets (afterpulse sets, which follow them, are never done)
     i32 *row_cnt, *row_tile;    // [groups * n_tpc] tiles in the row; one of them
     const i32 *ins_bcap; const i64 *ins_boff;      // tile sample buffers (wfs_tilegen.h)
     i32 force_dense;     // debug: send every tile to the dense kernel
@@ -169,7 +170,7 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
         cnt = a.tile_count[tile];
         if (!a.force_dense) cls = (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1
                                   : ((cnt <= WAVE_MAX_PHOTONS && nb <= WAVE_MAX_BINS) ? 3 : 2));
-        if (a.tile_done_ins && set < a.n_sets && a.tile_done_ins[set]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
+        if (a.tile_done_ins && set < a.n_done && a.tile_done_ins[set]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
     }
     {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
         const u64 ml = __ballot(live);
@@ -317,9 +318,11 @@ __global__ void k_group_final(WfsDev d, GeomArgs a)
     a.grp_ixrand[g] = ix;
 }
 
-__device__ __forceinline__ bool row_is_direct(const i32 *done_ins, const i32 *row_cnt, const i32 *row_tile, i64 ridx, int nch)
+__device__ __forceinline__ bool row_is_direct(const i32 *done_ins, i64 n_done, const i32 *row_cnt, const i32 *row_tile, i64 ridx, int nch)
 {
-    return done_ins && row_cnt[ridx] == 1 && done_ins[row_tile[ridx] / nch] != 0;
+    if (!done_ins || row_cnt[ridx] != 1) return false;
+    const i64 set = row_tile[ridx] / nch;
+    return set < n_done && done_ins[set] != 0;
 }
 
 // per (group, row slot): accumulator length and reserved ZLE interval slots; list of rows with data
@@ -341,7 +344,7 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
             i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
             cap = (i32)((len + hold) / (hold + 1));
             // a row made by ONE tile whose samples exist already (k_s2_tile) is read from the tile's buffer: no accumulators
-            const bool direct = row_is_direct(a.tile_done_ins, a.row_cnt, a.row_tile, g * d.n_tpc + ch, d.n_tpc);
+            const bool direct = row_is_direct(a.tile_done_ins, a.n_done, a.row_cnt, a.row_tile, g * d.n_tpc + ch, d.n_tpc);
             if (slot < d.n_tpc) { a.acc_len[g * d.n_tpc + ch] = direct ? 0 : (i32)len; if (direct) atomicAdd(&s_direct, (i32)len); }
             if (slot < d.n_tpc && a.row_cnt && a.row_cnt[g * d.n_tpc + ch] > 1) atomicAdd(&s_shared, 1);
             rk = atomicAdd(&s_n, 1);
@@ -1337,7 +1340,7 @@ struct ZleArgs {
     struct RowDesc *desc;        // [n_active_rows] everything a row's wave needs, prepared by k_row_desc
     const u32 *rec_dest;         // record order by (time, channel): slot of record r in the output (nullptr: row order)
     u64 *rec_key; u32 *rec_val; i64 *key_base;     // k_rec_keys: sort key (sample - *key_base) << 12 | channel, and the record index; *key_base = first sample of the batch (k_row_desc)
-    const i32 *tile_done_ins, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf;      // rows read from a tile buffer in place (wfs_tilegen.h)
+    const i32 *tile_done_ins, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf; i64 n_done;      // rows read from a tile buffer in place (wfs_tilegen.h)
 };
 
 // One 64-byte descriptor per active row (thread per row: the divisions and the five dependent look-ups of a row are
@@ -1363,7 +1366,7 @@ __global__ void k_row_desc(WfsDev d, ZleArgs a)
     RowDesc q;
     q.acc_off = a.acc_off[ridx]; q.row_abs = a.row_lo[ridx] - d.tw; q.ixr = a.grp_ixrand[g]; q.itv_base = a.itv_off[idx];
     q.src = 0;
-    if (row_is_direct(a.tile_done_ins, a.row_cnt, a.row_tile, ridx, d.n_tpc)) {
+    if (row_is_direct(a.tile_done_ins, a.n_done, a.row_cnt, a.row_tile, ridx, d.n_tpc)) {
         const i32 tile = a.row_tile[ridx]; const i32 ins = tile / d.n_tpc;
         q.acc_off = a.ins_boff[ins] + (i64)(tile - ins * d.n_tpc) * a.ins_bcap[ins]; q.src = 1;
     }
@@ -2128,7 +2131,7 @@ __device__ __forceinline__ double ap_uniform(const WfsDev &d, const ApCand &q, c
 }
 __device__ __forceinline__ u32x4 ap_call(const WfsDev &d, const ApCand &q) { return philox4x32_10(q.j, q.gid, q.m, SITE_AP + (u32)(q.e_dpe & 0xff), d.k0, d.k1); }
 __device__ __forceinline__ bool ap_accept(const WfsDev &d, const ApArgs &ap, const ApCand &q) { return ap_uniform(d, q, ap_call(d, q)) <= ap.prob[q.e_dpe & 0xff][q.ch]; }
-__device__ __forceinline__ void ap_finish(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApCand &q, i64 gk)
+__device__ __forceinline__ void ap_finish(const WfsDev &d, i64 *scal, const ApArgs &ap, const ApCand &q, i64 gk)
 {
     const int e = q.e_dpe & 0xff;
     const ApElemDev &el = ap.el[e];
@@ -2147,11 +2150,11 @@ __device__ __forceinline__ void ap_finish(const WfsDev &d, const GenArgs &a, con
     }
     const double tf = (double)(q.itime + q.t) + delay;          // afterpulse.py:235, int64 + float
     i64 tap = (i64)tf - q.itime;
-    if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); tap = 0; }
+    if (tap > 0x7fffffffLL || tap < -0x7fffffffLL) { atomicMax(&scal[1], (i64)2); tap = 0; }
     if (gk < ap.cap) { ap.ap_ins[gk] = q.ins; ap.ap_ch[gk] = q.ch; ap.ap_t[gk] = (i32)tap; ap.ap_gain[gk] = d.gains[q.ch] * amp; ap.ap_key[gk] = q.key; }
 }
 // a candidate into the block's LDS list (or, past AP_STAGE, straight to the end)
-__device__ __forceinline__ void ap_park(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st, u32 x, i32 e_dpe, u32 j, u32 gid, u32 m,
+__device__ __forceinline__ void ap_park(const ApArgs &ap, const ApStage &st, u32 x, i32 e_dpe, u32 j, u32 gid, u32 m,
                                      i32 ins, i32 ch, i64 itime, i32 t, u32 key)
 {
     ApCand q;
@@ -2161,7 +2164,27 @@ __device__ __forceinline__ void ap_park(const WfsDev &d, const GenArgs &a, const
     if (kq < AP_STAGE) st.cand[kq] = q;
     else { const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull); if (gk < ap.cap) ap.cand[gk] = q; }      // (a block with more candidates than the stage holds)
 }
-__device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, const ApArgs &ap, const ApStage &st,
+// the screen alone: bit e set when element e of this photon is a candidate (k_s2_tile keeps eight photons in registers and parks the
+// rare candidates in a loop of its own); ap_screen_word recomputes a candidate's screen word
+__device__ __forceinline__ u32 ap_screen_mask(const WfsDev &d, const ApArgs &ap, u32 j, u32 gid, u32 m, int ch, bool is_dpe)
+{
+    u32 mask = 0;
+    for (int e0 = 0; e0 < ap.n; e0 += 4) {
+        const u32x4 S = philox4x32_10(j, gid, m, SITE_AP_SCREEN + (u32)(e0 >> 2), d.k0, d.k1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int e = e0 + k;
+            if (e >= ap.n) break;
+            if ((word_of(S, k) >> 5) >= ap.thr[e][ch * 2 + (is_dpe ? 1 : 0)]) mask |= 1u << e;
+        }
+    }
+    return mask;
+}
+__device__ __forceinline__ u32 ap_screen_word(const WfsDev &d, u32 j, u32 gid, u32 m, int e)
+{
+    return word_of(philox4x32_10(j, gid, m, SITE_AP_SCREEN + (u32)(e >> 2), d.k0, d.k1), e & 3);
+}
+__device__ __forceinline__ void ap_generate(const WfsDev &d, const ApArgs &ap, const ApStage &st,
                                             u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P, const u32 *thr_lds = nullptr)
 {
     for (int e0 = 0; e0 < ap.n; e0 += 4) {
@@ -2173,7 +2196,7 @@ __device__ __forceinline__ void ap_generate(const WfsDev &d, const GenArgs &a, c
             const u32 x = word_of(S, k);
             const u32 thr = thr_lds ? thr_lds[(e * d.n_tpc + ch) * 2 + (is_dpe ? 1 : 0)] : ap.thr[e][ch * 2 + (is_dpe ? 1 : 0)];
             if ((x >> 5) < thr) continue;                           // surely rejected (ap_threshold)
-            ap_park(d, a, ap, st, x, e | (is_dpe ? 256 : 0), j, gid, m, ins, ch, itime, (i32)t, ((u32)e << 29) | (P & 0x1fffffffu));
+            ap_park(ap, st, x, e | (is_dpe ? 256 : 0), j, gid, m, ins, ch, itime, (i32)t, ((u32)e << 29) | (P & 0x1fffffffu));
         }
     }
 }
@@ -2850,7 +2873,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
                     t += (i32)(i64)s1_propagation(a, c >= d.n_top, pzi, pzf, X.x);
                 }
                 if (EXT && gg_lo >= 0) t += (i32)(i64)(gg_time(a, gg_lo, gg_w, word_of(LW, k)) - gg_m);      // s2.py:447-450, the cast of :532
-                if (AP) ap_generate(d, a, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t, bd.sbase + (u32)(bd.R0 + pr));
+                if (AP) ap_generate(d, ap, aps, j, gid, m, set_lo, c, (code >> 16) != 0, itime, (i64)t, bd.sbase + (u32)(bd.R0 + pr));
                 atomicMin(&hmin[c], t); atomicMax(&hmax[c], t);
                 const int pos = hist[c] + atomicAdd(&cur[c], 1);
                 stage[pos] = PhotonRec{t, code}; chmap[pos] = (unsigned short)c; pidx[pos] = (unsigned short)pr;
@@ -2901,7 +2924,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
             }
             if (EXT && a.gg_inv && a.ins_gg[ins] >= 0) t += (i64)(gg_time(a, a.ins_gg[ins], a.ins_ggw[ins], photon_word(d, id, SITE_LUM)) - gg_mean(a, ins));
             if (t > 0x7fffffffLL || t < -0x7fffffffLL) { atomicMax(&a.scal[1], (i64)2); t = 0; }
-            if (AP) ap_generate(d, a, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t, a.ins_sbase[ins] + id.P);
+            if (AP) ap_generate(d, ap, aps, id.j, id.gid, id.m, set, ch, (code >> 16) != 0, itime, t, a.ins_sbase[ins] + id.P);
             atomicMin(&a.tile_tmin[tile], (i32)t); atomicMax(&a.tile_tmax[tile], (i32)t);
             // photons of multi-instruction blocks take the first slots of their tile (k_block_ranges starts behind them)
             const i64 at = a.tile_off[tile] + (generic_is_tail(a, id, p0) ? a.tile_tailbase[tile] + atomicAdd(&a.tile_tail[tile], 1) : atomicAdd(&a.tile_cursor[tile], 1));
@@ -2926,29 +2949,61 @@ __global__ void k_ap_finish(WfsDev d, GenArgs a, ApArgs ap)
     if (i >= n) return;
     const ApCand q = ap.cand[i];
     const bool ok = ap_accept(d, ap, q);
-    if (ok) ap_finish(d, a, ap, q, i); else ap.ap_ch[i] = -1;
+    if (ok) ap_finish(d, a.scal, ap, q, i); else ap.ap_ch[i] = -1;
     const int n_ok = __popcll(__ballot(ok));
     if ((threadIdx.x & 63) == 0 && n_ok) atomicAdd((u64 *)(ap.count + 15), (u64)n_ok);
 }
 
 // afterpulse photons -> tiles of the afterpulse pulse set of their primary set (set n_psets + set): count, then place
-__global__ void k_ap_count(WfsDev d, GenArgs a, ApArgs ap)
+// Runs of consecutive list entries that go to the same tile (the candidates of a k_s2_tile workgroup all do, in key order) share one
+// atomic: the first lane of a run reserves for the run, the others take their place behind it -- in list order, so a tile filled by
+// one run is in generation order as it is written.  (70 afterpulses per tile of a 10^6-PE S2: one atomic per photon on the tile's
+// cursor and two on its time range serialised the kernel, 8.3 ms for 3.5 x 10^7 afterpulses.)
+struct ApRun { int head, rank, len; };
+__device__ __forceinline__ ApRun ap_run(i64 tile, int lane)
+{
+    const i64 prev = __shfl_up(tile, 1, 64);
+    const u64 heads = __ballot(lane == 0 || tile != prev);
+    ApRun r;
+    r.head = 63 - __clzll(heads & ((2ull << lane) - 1ull));
+    const u64 behind = r.head == 63 ? 0ull : heads & ~((2ull << r.head) - 1ull);
+    r.len = (behind ? __builtin_ctzll(behind) : 64) - r.head;
+    r.rank = lane - r.head;
+    return r;
+}
+__global__ __launch_bounds__(256) void k_ap_count(WfsDev d, GenArgs a, ApArgs ap)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
-    if (i >= n || ap.ap_ch[i] < 0) return;
-    atomicAdd(&a.tile_count[((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i]], 1);
+    const bool v = i < n && ap.ap_ch[i] >= 0;
+    const i64 tile = v ? ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i] : -1 - lane;       // (a hole is a run of its own)
+    const ApRun r = ap_run(tile, lane);
+    if (v && r.rank == 0) atomicAdd(&a.tile_count[tile], r.len);
 }
 
-__global__ void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
+__global__ __launch_bounds__(256) void k_ap_place(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
 {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
-    if (i >= n || ap.ap_ch[i] < 0) return;
-    const i64 tile = ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i];
-    const i64 pos = a.tile_off[tile] + atomicAdd(&a.tile_cursor[tile], 1);
-    a.ph[pos] = PhotonRec{ap.ap_t[i], 0u}; ph_gain_base[pos] = ap.ap_gain[i]; a.ph_idx[pos] = ap.ap_key[i];
-    atomicMin(&a.tile_tmin[tile], ap.ap_t[i]); atomicMax(&a.tile_tmax[tile], ap.ap_t[i]);
+    const bool v = i < n && ap.ap_ch[i] >= 0;
+    const i64 tile = v ? ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i] : -1 - lane;
+    const ApRun r = ap_run(tile, lane);
+    const i32 t = v ? ap.ap_t[i] : 0;
+    i32 first = 0;
+    if (v && r.rank == 0) first = atomicAdd(&a.tile_cursor[tile], r.len);
+    first = __shfl(first, r.head, 64);
+    // earliest / latest photon of the run, reduced towards its first lane
+    i32 lo = t, hi = t;
+    for (int o = 1; o < 64; o <<= 1) {
+        const i32 l2 = __shfl_down(lo, o, 64), h2 = __shfl_down(hi, o, 64);
+        if (r.rank + o < r.len) { lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi; }
+    }
+    if (!v) return;
+    const i64 pos = a.tile_off[tile] + first + r.rank;
+    a.ph[pos] = PhotonRec{t, 0u}; ph_gain_base[pos] = ap.ap_gain[i]; a.ph_idx[pos] = ap.ap_key[i];
+    if (r.rank == 0) { atomicMin(&a.tile_tmin[tile], lo); atomicMax(&a.tile_tmax[tile], hi); }
 }
 
 // Generation order inside every tile.  The bucketing above leaves the photons of a tile in the order the atomics happened to

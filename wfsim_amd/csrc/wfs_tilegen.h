@@ -19,7 +19,7 @@
 // accumulators afterwards (k_tile_add).
 //
 // Which instructions take this path is a rule both the device and the CPU oracle evaluate (fuse_eligible): type 2, no
-// emitter offset (not an electron afterpulse), s2_gain_spread == 0, PMT afterpulses off, default delay table, and a tile that
+// emitter offset (not an electron afterpulse), s2_gain_spread == 0, default delay table, and a tile that
 // fits the 2048 photon registers of a workgroup with eight standard deviations to spare -- and is worth a workgroup: at least
 // wfs_config.tile_gen_min photons expected on the brightest channel (below ~60 per tile the block generator is faster).
 #pragma once
@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256) void k_tile_counts(WfsDev d, FuseArgs f)
 // range, and -- FULL -- everything k_pulse does for a resident tile (SPE gains, truth sums, the H-table gather in chunks of
 // 256 samples, per-pulse rounding), written to the tile's own sample buffer.  !FULL: generation only (debug modes: the
 // photons go to the photon array and the ordinary pulse kernels take the tile from there).
-template <bool FULL>
-__global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, TemplateArg tp)
+// AP: PMT afterpulses of the tile's photons (same channel, the afterpulse set of the instruction): screened here, photon by photon
+// (ap_screen_mask: counter (c0, gid, q) of the parent photon q of the tile), the candidates leave for the global list that
+// k_ap_finish works through (wfs_kernels.h); their photons become ordinary tiles of the afterpulse sets.
+template <bool FULL, bool AP>
+__global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, TemplateArg tp, const ApArgs *app, int ap_lds_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TPB = 256, dt = WFS_DT, tlen = 22, HROWS = TPB + tlen - 1, NPH = 8, NW = TPB / 64;
@@ -208,6 +211,8 @@ __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, Templa
     if (FULL) tap_w2_fill(W2, d.templates, tid, TPB);
     const FTile ft = f.tiles[blockIdx.x];                 // block-uniform: scalar loads
     const i32 n = ft.n;
+    __shared__ i32 s_apn; __shared__ i64 s_apbase;
+    if (AP) { if (tid == 0) s_apn = 0; __syncthreads(); }
     const double *spe_row = d.spe + (size_t)(d.n_spe > 1 ? ft.ch : 0) * 2001;
     STAMP_INIT;
     if (FULL) {                                           // the SPE row (16 KB) on its way to LDS under the generation (see k_pulse)
@@ -253,6 +258,26 @@ __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, Templa
         if (v) { tmin = t < tmin ? t : tmin; tmax = t > tmax ? t : tmax; ndpe += (code[k] >> 16) != 0; }
         else code[k] = 0;
     }
+    if constexpr (AP) {
+        const ApArgs &ap = *app;
+        ApStage aps; aps.n = &s_apn; aps.cand = (ApCand *)(smem + ap_lds_off);
+        const i32 set = ft.tile / f.nch;
+        u64 cm = 0;                                       // bit 8 k + e: element e of photon k is a candidate
+#pragma unroll
+        for (int k = 0; k < NPH; k++) {
+            const i32 P = 4 * (tid + (k >> 2) * TPB) + (k & 3);
+            if (P < n) cm |= (u64)ap_screen_mask(d, ap, ft.c0, ft.gid, (u32)P, ft.ch, (code[k] >> 16) != 0) << (8 * k);
+        }
+        while (cm) {                                      // (one photon in a hundred: the parking code once, not eight times)
+            const int b = __builtin_ctzll(cm); cm &= cm - 1;
+            const int k = b >> 3, e = b & 7;
+            i32 tk = r_t[0]; u32 ck = code[0];
+#pragma unroll
+            for (int q = 1; q < NPH; q++) { tk = k == q ? r_t[q] : tk; ck = k == q ? code[q] : ck; }
+            const u32 P = (u32)(4 * (tid + (k >> 2) * TPB) + (k & 3));
+            ap_park(ap, aps, ap_screen_word(d, ft.c0, ft.gid, P, e), e | ((ck >> 16) ? 256 : 0), ft.c0, ft.gid, P, set, ft.ch, ft.t0, tk, ((u32)e << 29) | (P & 0x1fffffffu));
+        }
+    }
     tmin = wave_min(tmin); tmax = wave_max(tmax); ndpe = wave_sum(ndpe);
     if (lane == 0) { s_mm[2 * wid] = tmin; s_mm[2 * wid + 1] = tmax; wsum[wid] = (u32)ndpe; }
     if (FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the SPE row has landed in LDS
@@ -261,6 +286,20 @@ __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, Templa
 #pragma unroll
     for (int w = 0; w < NW; w++) { tmin = s_mm[2 * w] < tmin ? s_mm[2 * w] : tmin; tmax = s_mm[2 * w + 1] > tmax ? s_mm[2 * w + 1] : tmax; n_dpe_tile += (i32)wsum[w]; }
     if (tid == 0) { f.tile_tmin[ft.tile] = tmin; f.tile_tmax[ft.tile] = tmax; }
+    if constexpr (AP) {                                   // the block's candidates to the global list (all parked: the barrier above)
+        const ApArgs &ap = *app;
+        const ApCand *cand = (const ApCand *)(smem + ap_lds_off);
+        const int nst = s_apn < AP_STAGE ? s_apn : AP_STAGE;
+        if (tid == 0 && nst > 0) s_apbase = (i64)atomicAdd((u64 *)ap.count, (u64)nst);
+        __syncthreads();
+        // in key order (element, parent photon): the tile's afterpulses then reach their tile in generation order (k_ap_place)
+        for (int k = tid; k < nst; k += TPB) {
+            const ApCand q = cand[k];
+            int rank = 0;
+            for (int j = 0; j < nst; j++) rank += cand[j].key < q.key;
+            const i64 gk = s_apbase + rank; if (gk < ap.cap) ap.cand[gk] = q;
+        }
+    }
     if (!FULL || f.keep_ph) {
         PhotonRec *out = f.ph + f.tile_off[ft.tile];
 #pragma unroll
