@@ -77,7 +77,7 @@ struct wfs_handle {
     DevBuf tt_alias[6];
     std::vector<i64> h_rs_off; std::vector<i32> h_rs_list;        // run set -> instructions (host copy)
     std::vector<double> h_lum_x, h_lum_t;          // luminescence table (host copy, enters the S2 delay table)
-    DevBuf ap_ins, ap_ch, ap_t, ap_gain, ap_cand, ap_args_dev; i64 n_ap_photons = 0; bool ap_active = false;
+    DevBuf ap_ins, ap_ch, ap_t, ap_gain, ap_cand, ap_args_dev, ap_seg; i64 n_ap_photons = 0; bool ap_active = false;
     // model variants of the photon delays
     std::vector<DevBuf> x_alias; std::vector<AliasTab> h_tabs; DevBuf d_tabs; i32 n_user_tabs = 0;
     std::vector<Pmf> base_pmf;           // transit time only, S1 terms, S2 terms, S2 terms without the 'simple' luminescence
@@ -467,7 +467,7 @@ try {
         hipFree(h->stamps.p);
     }
 #endif
-    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->ap_cand, &h->ap_args_dev, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
+    DevBuf *all[] = {&h->rec_key, &h->rec_key2, &h->rec_val, &h->rec_val2, &h->rec_dest, &h->sort_tmp, &h->row_desc, &h->pmap[0].values, &h->pmap[1].values, &h->map_row_ins[0], &h->map_row_ins[1], &h->map_row_id[0], &h->map_row_id[1], &h->map_x, &h->map_y, &h->map_z, &h->map_nb_idx[0], &h->map_nb_idx[1], &h->map_nb_w[0], &h->map_nb_w[1], &h->d_tabs, &h->gg_inv, &h->ins_gg, &h->ins_ggw, &h->ins_ggsum, &h->prop_top, &h->prop_bot, &h->ins_tab, &h->ins_tabb, &h->ins_pzi, &h->ins_pzf, &h->blk_e, &h->blk_base, &h->blk_cnt, &h->blk_ins, &h->eblk_ins, &h->ins_ph0, &h->blk_desc, &h->noise_override, &h->ap_ins, &h->ap_ch, &h->ap_t, &h->ap_gain, &h->ap_cand, &h->ap_args_dev, &h->ap_seg, &h->set_gid, &h->opt_t, &h->opt_item, &h->opt_first, &h->opt_last, &h->opt_ch, &h->opt_time, &h->t_templates, &h->t_spe, &h->t_gains, &h->t_thr_truth, &h->t_thr_zle, &h->t_lumx, &h->t_lumt, &h->t_noise, &h->t_noise_f,
         &h->ins_type, &h->ins_time, &h->ins_amp, &h->ins_gid, &h->ins_p, &h->ins_dm, &h->ins_ds, &h->ins_sc, &h->ins_cdfrow, &h->cdf_table, &h->cdf_guide, &h->chan_alias, &h->ins_embase, &h->ins_set, &h->set_ins_off, &h->set_ins_list,
         &h->em_off, &h->em_zg, &h->pois_cdf, &h->pois_kmin, &h->set_cluster, &h->set_t0, &h->set_mode, &h->cl_tmin, &h->cl_gid, &h->cl_end, &h->cl_group, &h->em_time, &h->em_nph,
         &h->em_ins, &h->em_ph_off, &h->el_stat, &h->el_minmax, &h->tile_count, &h->tile_off, &h->tile_cursor, &h->tile_tmin, &h->tile_tmax,
@@ -1329,6 +1329,8 @@ static int run_generation(wfs_handle *h)
         const ApArgs *app = nullptr;
         if (ap_on) {
             lds += (size_t)AP_STAGE * sizeof(ApCand);
+            TRY(ensure(h, h->ap_seg, (size_t)h->n_fused_tiles * sizeof(ApSeg))); ap.seg = h->ap_seg.as<ApSeg>(); ap.n_seg = h->n_fused_tiles;
+            f.n_ptiles = TP;
             TRY(upload(h, h->ap_args_dev, &ap, sizeof ap)); app = h->ap_args_dev.as<ApArgs>();      // (`ap` outlives the copy: read_scal below)
         }
         f.sparse_max = h->tap_sparse_max;
@@ -1343,9 +1345,11 @@ static int run_generation(wfs_handle *h)
     if (ap_on) {
         // afterpulse photons: count per tile of the afterpulse sets, offsets behind the primary photons, place
         { Timer t(h, "k_ap_finish"); hipLaunchKernelGGL(k_ap_finish, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
-        { Timer t(h, "k_ap_count"); hipLaunchKernelGGL(k_ap_count, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap); }
+        { Timer t(h, "k_ap_count"); hipLaunchKernelGGL(k_ap_count, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap);
+          if (ap.n_seg > 0) hipLaunchKernelGGL(k_ap_seg<false>, dim3(nblocks(ap.n_seg, 4)), dim3(256), 0, h->stream, d, g, ap, (double *)nullptr); }
         TRY(scan_into(h, h->tile_count.as<i32>() + TP, TP, h->tile_off.as<i64>() + TP, 14, P + h->p_fused));      // (behind the slots of every primary tile, the tile-generated ones included)
-        { Timer t(h, "k_ap_place"); hipLaunchKernelGGL(k_ap_place, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - (P + h->p_fused)); }
+        { Timer t(h, "k_ap_place"); hipLaunchKernelGGL(k_ap_place, dim3(nblocks(ap_cap, 256)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - (P + h->p_fused));
+          if (ap.n_seg > 0) hipLaunchKernelGGL(k_ap_seg<true>, dim3(nblocks(ap.n_seg, 4)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - (P + h->p_fused)); }
         TRY(read_scal(h));
         if (h->h_scal[13] > ap_cap) return h->fail(WFS_E_CAPACITY, "more PMT afterpulse photons than 1/8 of the primary photons: afterpulse probability unreasonably high");
         h->n_ap_photons = h->h_scal[28];                             // (the accepted candidates, k_ap_finish)

@@ -2051,6 +2051,7 @@ struct ApArgs {
     i32 *ap_ins; i32 *ap_ch; i32 *ap_t; double *ap_gain;     // [cap] instruction, channel, ns relative to the instruction, gain
     u32 *ap_key;                    // [cap] order key: element << 29 | index of the parent photon among its instruction's photons
     i64 *count;                     // number of afterpulse candidates in the list (device scalar, scal[13]); k_ap_finish adds the accepted ones to count[15] (scal[28])
+    struct ApSeg *seg; i64 n_seg;   // candidates of a k_s2_tile workgroup: one contiguous, key-ordered stretch of the list per tile (k_ap_seg)
     struct ApCand *cand;            // [cap] candidates of the generator (k_ap_finish turns entry i into afterpulse photon i, or a hole: ap_ch[i] = -1)
 };
 #define AP_STAGE 128               // afterpulse candidates a block parks in LDS (48 bytes each; a block of 2048 photons has ~60)
@@ -2121,6 +2122,8 @@ __device__ __forceinline__ u32 word_of(const u32x4 &W, int k) { return k == 0 ? 
 // and its eight mostly idle waves on the CU for tens of microseconds (fill pass 5.1 -> 2.7 ms -> see DESIGN.md for the last step).
 struct __attribute__((aligned(8))) ApCand { i64 itime; u32 x; i32 ins, ch, t; u32 key, j, m, gid; i32 e_dpe, pad; };     // (48 bytes)
 struct ApStage { i32 *n; ApCand *cand; };
+struct ApSeg { i64 base; i32 n, tile; };     // list entries [base, base + n) belong to afterpulse tile `tile`
+#define AP_SEG_MARK (1 << 30)                // in ApCand.ins / ap_ins: the entry belongs to a segment (k_ap_seg places it, k_ap_count / k_ap_place skip it)
 // the uniform of the acceptance test, exactly as the reference forms and scales it (afterpulse.py:196-204); w: the element's own call
 __device__ __forceinline__ double ap_uniform(const WfsDev &d, const ApCand &q, const u32x4 &w)
 {
@@ -2155,13 +2158,13 @@ __device__ __forceinline__ void ap_finish(const WfsDev &d, i64 *scal, const ApAr
 }
 // a candidate into the block's LDS list (or, past AP_STAGE, straight to the end)
 __device__ __forceinline__ void ap_park(const ApArgs &ap, const ApStage &st, u32 x, i32 e_dpe, u32 j, u32 gid, u32 m,
-                                     i32 ins, i32 ch, i64 itime, i32 t, u32 key)
+                                     i32 ins, i32 ch, i64 itime, i32 t, u32 key, bool seg = false)
 {
     ApCand q;
     q.x = x; q.itime = itime; q.ins = ins; q.ch = ch; q.t = t; q.j = j; q.m = m; q.gid = gid; q.e_dpe = e_dpe; q.pad = 0;
     q.key = key;                                                    // element << 29 | parent: the reference walks element by element, parent by parent (afterpulse.py:189-207)
     const i32 kq = atomicAdd(st.n, 1);
-    if (kq < AP_STAGE) st.cand[kq] = q;
+    if (kq < AP_STAGE) { if (seg) q.ins |= AP_SEG_MARK; st.cand[kq] = q; }
     else { const i64 gk = (i64)atomicAdd((u64 *)ap.count, 1ull); if (gk < ap.cap) ap.cand[gk] = q; }      // (a block with more candidates than the stage holds)
 }
 // the screen alone: bit e set when element e of this photon is a candidate (k_s2_tile keeps eight photons in registers and parks the
@@ -2976,7 +2979,7 @@ __global__ __launch_bounds__(256) void k_ap_count(WfsDev d, GenArgs a, ApArgs ap
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
-    const bool v = i < n && ap.ap_ch[i] >= 0;
+    const bool v = i < n && ap.ap_ch[i] >= 0 && !(ap.ap_ins[i] & AP_SEG_MARK);
     const i64 tile = v ? ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i] : -1 - lane;       // (a hole is a run of its own)
     const ApRun r = ap_run(tile, lane);
     if (v && r.rank == 0) atomicAdd(&a.tile_count[tile], r.len);
@@ -2987,7 +2990,7 @@ __global__ __launch_bounds__(256) void k_ap_place(WfsDev d, GenArgs a, ApArgs ap
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
-    const bool v = i < n && ap.ap_ch[i] >= 0;
+    const bool v = i < n && ap.ap_ch[i] >= 0 && !(ap.ap_ins[i] & AP_SEG_MARK);
     const i64 tile = v ? ((i64)a.n_psets + ap.ap_ins[i]) * d.n_tpc + ap.ap_ch[i] : -1 - lane;
     const ApRun r = ap_run(tile, lane);
     const i32 t = v ? ap.ap_t[i] : 0;
@@ -3004,6 +3007,45 @@ __global__ __launch_bounds__(256) void k_ap_place(WfsDev d, GenArgs a, ApArgs ap
     const i64 pos = a.tile_off[tile] + first + r.rank;
     a.ph[pos] = PhotonRec{t, 0u}; ph_gain_base[pos] = ap.ap_gain[i]; a.ph_idx[pos] = ap.ap_key[i];
     if (r.rank == 0) { atomicMin(&a.tile_tmin[tile], lo); atomicMax(&a.tile_tmax[tile], hi); }
+}
+
+// The afterpulses of a tile-generated tile: ONE wave per segment of the list (ApSeg).  PLACE false: the accepted entries are counted
+// into the afterpulse tile; PLACE true: they go to the tile in list order = key order -- the tile is in generation order as written,
+// whatever order the atomics of other workgroups happen in (k_tile_order finds nothing to do).
+template <bool PLACE>
+__global__ __launch_bounds__(256) void k_ap_seg(WfsDev d, GenArgs a, ApArgs ap, double *ph_gain_base)
+{
+    const int lane = threadIdx.x & 63;
+    const i64 w = (i64)blockIdx.x * 4 + wave_in_block();
+    if (w >= ap.n_seg) return;
+    const ApSeg sg = ap.seg[w];
+    if (sg.n <= 0) return;
+    i32 total = 0;
+    for (i32 c = 0; c < sg.n; c += 64) {
+        const i64 i = sg.base + c + lane;
+        total += __popcll(__ballot(c + lane < sg.n && i < ap.cap && ap.ap_ch[i] >= 0));
+    }
+    if (total == 0) return;
+    if (!PLACE) { if (lane == 0) atomicAdd(&a.tile_count[sg.tile], total); return; }
+    i32 first = 0;
+    if (lane == 0) first = atomicAdd(&a.tile_cursor[sg.tile], total);
+    first = __builtin_amdgcn_readfirstlane(first);
+    const i64 off = a.tile_off[sg.tile] + first;
+    i32 done = 0, lo = 0x7fffffff, hi = (i32)0x80000000;
+    for (i32 c = 0; c < sg.n; c += 64) {
+        const i64 i = sg.base + c + lane;
+        const bool v = c + lane < sg.n && i < ap.cap && ap.ap_ch[i] >= 0;
+        const u64 m = __ballot(v);
+        if (v) {
+            const i64 pos = off + done + __popcll(m & ((1ull << lane) - 1ull));
+            const i32 t = ap.ap_t[i];
+            a.ph[pos] = PhotonRec{t, 0u}; ph_gain_base[pos] = ap.ap_gain[i]; a.ph_idx[pos] = ap.ap_key[i];
+            lo = t < lo ? t : lo; hi = t > hi ? t : hi;
+        }
+        done += __popcll(m);
+    }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if (lane == 0) { atomicMin(&a.tile_tmin[sg.tile], lo); atomicMax(&a.tile_tmax[sg.tile], hi); }
 }
 
 // Generation order inside every tile.  The bucketing above leaves the photons of a tile in the order the atomics happened to

@@ -40,6 +40,7 @@ struct __attribute__((aligned(16))) FTile {
 struct FuseArgs {
     i64 n_ins; i32 nch; i32 table_span;      // cells of the S2 delay table (bound of its support)
     i32 lam_min, pad0;    // wfs_config.tile_gen_min
+    i64 n_ptiles;         // primary tiles: the afterpulse tile of tile t is t + n_ptiles
     const int8_t *ins_type; const i32 *ins_amp; const double *ins_sc; const u32 *ins_embase, *ins_gid; const i32 *ins_cdfrow;
     const double *cdf_table; const double *row_pmax; const i64 *ins_time; const i64 *em_off; const i64 *em_time; const i64 *el_minmax;
     i32 *ins_fused;       // [n_ins] 1: the instruction's photons are generated tile by tile
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, Templa
 #pragma unroll
             for (int q = 1; q < NPH; q++) { tk = k == q ? r_t[q] : tk; ck = k == q ? code[q] : ck; }
             const u32 P = (u32)(4 * (tid + (k >> 2) * TPB) + (k & 3));
-            ap_park(ap, aps, ap_screen_word(d, ft.c0, ft.gid, P, e), e | ((ck >> 16) ? 256 : 0), ft.c0, ft.gid, P, set, ft.ch, ft.t0, tk, ((u32)e << 29) | (P & 0x1fffffffu));
+            ap_park(ap, aps, ap_screen_word(d, ft.c0, ft.gid, P, e), e | ((ck >> 16) ? 256 : 0), ft.c0, ft.gid, P, set, ft.ch, ft.t0, tk, ((u32)e << 29) | (P & 0x1fffffffu), true);
         }
     }
     tmin = wave_min(tmin); tmax = wave_max(tmax); ndpe = wave_sum(ndpe);
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, Templa
         const int nst = s_apn < AP_STAGE ? s_apn : AP_STAGE;
         if (tid == 0 && nst > 0) s_apbase = (i64)atomicAdd((u64 *)ap.count, (u64)nst);
         __syncthreads();
+        if (tid == 0) ap.seg[blockIdx.x] = ApSeg{nst > 0 ? s_apbase : 0, nst, ft.tile + (i32)f.n_ptiles};     // the tile's stretch of the list (k_ap_seg)
         // in key order (element, parent photon): the tile's afterpulses then reach their tile in generation order (k_ap_place)
         for (int k = tid; k < nst; k += TPB) {
             const ApCand q = cand[k];
