@@ -233,6 +233,22 @@ def test_pmt_afterpulse_screen_never_loses_an_afterpulse(scale, scale_uniform, m
     _compare(orc, o, eng, counts, s_ins)
 
 
+def test_pmt_afterpulses_of_large_tile_generated_tiles():
+    """PMT afterpulses of tile-generated S2s (k_s2_tile<.., AP>): ~800 photons per tile, afterpulse probabilities x 4 so that about half
+    of the tiles have more candidates than the workgroup's LDS stage holds (AP_STAGE = 128: the excess goes to the list entry by
+    entry and is placed by the generic kernels, the rest as one key-ordered stretch per tile by k_ap_seg); one small S2 and an S1
+    through the block generator in the same batch.  Device == oracle photon by photon, afterpulse tiles in generation order."""
+    from tests.helpers import ap_tables_from_golden
+    ap = ap_tables_from_golden()
+    for name in ap: ap[name] = dict(ap[name], delaytime_cdf=ap[name]['delaytime_cdf'] * 4.0)
+    rows = [dict(type=2, time=MS * (i + 1), x=3 * i, y=-2 * i, z=-10 - i, amp=4000) for i in range(2)]
+    rows += [dict(type=2, time=MS * 5, x=1, y=1, z=-30, amp=40), dict(type=1, time=MS * 7, x=0, y=0, z=-50, amp=5000)]
+    orc, o, eng, counts, s_ins = _run_both(xenonnt_test_config(s2_secondary_sc_gain=100.0), _instructions(rows), seed=29, ap=ap)
+    n_ap = sum(o['call_ph_off'][k + 1] - o['call_ph_off'][k] for k in range(len(o['call_kind'])) if o['call_kind'][k] == 3)
+    assert n_ap > 60000 and counts['n_photons'] - n_ap > 500000
+    _compare(orc, o, eng, counts, s_ins)
+
+
 def test_noise_on_generated_path():
     from tests.helpers import golden
     noise = golden('noise.npz')['noise']

@@ -2133,8 +2133,8 @@ __device__ __forceinline__ double ap_uniform(const WfsDev &d, const ApCand &q, c
     return rU0;
 }
 __device__ __forceinline__ u32x4 ap_call(const WfsDev &d, const ApCand &q) { return philox4x32_10(q.j, q.gid, q.m, SITE_AP + (u32)(q.e_dpe & 0xff), d.k0, d.k1); }
-__device__ __forceinline__ bool ap_accept(const WfsDev &d, const ApArgs &ap, const ApCand &q) { return ap_uniform(d, q, ap_call(d, q)) <= ap.prob[q.e_dpe & 0xff][q.ch]; }
-__device__ __forceinline__ void ap_finish(const WfsDev &d, i64 *scal, const ApArgs &ap, const ApCand &q, i64 gk)
+__device__ __forceinline__ bool ap_accept(const WfsDev &d, const ApArgs &ap, const ApCand &q, const u32x4 &w) { return ap_uniform(d, q, w) <= ap.prob[q.e_dpe & 0xff][q.ch]; }
+__device__ __forceinline__ void ap_finish(const WfsDev &d, i64 *scal, const ApArgs &ap, const ApCand &q, const u32x4 &w, i64 gk)
 {
     const int e = q.e_dpe & 0xff;
     const ApElemDev &el = ap.el[e];
@@ -2144,7 +2144,6 @@ __device__ __forceinline__ void ap_finish(const WfsDev &d, i64 *scal, const ApAr
         const u32x4 x = philox4x32_10(q.j, q.gid, q.m, SITE_AP_X + (u32)e, d.k0, d.k1);
         delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
     } else {
-        const u32x4 w = ap_call(d, q);
         const int best = argmin_abs_diff(dc, el.n_bins_delay, ap_uniform(d, q, w), el.delay_sorted != 0);      // np.argmin(|cdf - u|): first minimum
         delay = best * el.delay_bin - d.pmt_ap_t_modifier;
         const double *ac = el.amp_2d ? el.amp_cdf + (size_t)q.ch * el.n_bins_amp : el.amp_cdf;
@@ -2951,8 +2950,9 @@ __global__ void k_ap_finish(WfsDev d, GenArgs a, ApArgs ap)
     const i64 n = *ap.count < ap.cap ? *ap.count : ap.cap;
     if (i >= n) return;
     const ApCand q = ap.cand[i];
-    const bool ok = ap_accept(d, ap, q);
-    if (ok) ap_finish(d, a.scal, ap, q, i); else ap.ap_ch[i] = -1;
+    const u32x4 w = ap_call(d, q);                          // the element's own call: low bits of the first uniform, the second uniform
+    const bool ok = ap_accept(d, ap, q, w);
+    if (ok) ap_finish(d, a.scal, ap, q, w, i); else ap.ap_ch[i] = -1;
     const int n_ok = __popcll(__ballot(ok));
     if ((threadIdx.x & 63) == 0 && n_ok) atomicAdd((u64 *)(ap.count + 15), (u64)n_ok);
 }
