@@ -126,6 +126,35 @@ def test_rows_longer_than_the_noise_table(noise_len, as_float):
     _compare(orc, o, eng, counts, s_ins)
 
 
+@pytest.mark.parametrize('tw', [0, 10, 31, 50, 200])
+def test_trigger_windows_on_both_sides_of_the_chunk_rule(tw):
+    """k_zle keeps its interval state on the scalar unit when the hold-off (2 * trigger_window + 1, rawdata.py:297-308) spans a chunk
+    of 64 samples, and in vector form otherwise: windows of 0, 10 (hold-off 21), 31 (63: the first scalar case), 50 (the default) and
+    200 samples, with noise, against the oracle -- with and without the debug copy of the rows (which takes the vector form too)."""
+    from tests.helpers import golden, make_engine, make_oracle
+    from wfsim_amd.physics import instruction_params
+    from wfsim_amd.resource import Resource
+    from wfsim_amd.scheduler import schedule
+    cfg = xenonnt_test_config(seed=90 + tw, trigger_window=tw, enable_noise=True, noise_data=golden('noise.npz')['noise'])
+    rows = [dict(type=1, time=MS * (i + 1), x=i, y=-i, z=-30, amp=3000 + 700 * i) for i in range(5)]
+    rows += [dict(type=2, time=MS * (i + 1), x=i, y=-i, z=-30, amp=200 + 60 * i) for i in range(5)]
+    ins = _instructions(rows)
+    res = Resource(cfg)
+    order, key, cluster = schedule(ins, cfg)
+    s_ins, gid = ins[order], order.astype(np.uint32)
+    ip = instruction_params(s_ins, cfg, res)
+    orc = make_oracle(cfg, resource=res)
+    orc.simulate(s_ins, gid, ip)
+    ref = orc.pack_records().tobytes()
+    assert len(ref) > 244 * 200
+    for debug in (False, True):
+        eng = make_engine(cfg, resource=res)
+        eng.set_debug(debug)
+        eng.load_instructions(s_ins, gid, cluster, key, ip)
+        eng.run()
+        assert eng.records().tobytes() == ref, (tw, debug)
+
+
 def small_array_config(n, **kw):
     """a detector of n PMTs (upper half = top array): fewer channels than a wave has lanes"""
     c = xenonnt_test_config(**kw)
