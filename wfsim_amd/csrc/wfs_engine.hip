@@ -22,7 +22,7 @@ struct DevBuf {
 };
 struct Pmf { std::vector<double> p; long vmin = 0; };      // probability mass function of an integer delay term
 
-struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf, prob, thr;
+struct ApElem { int n_bins_delay = 0, n_bins_amp = 0, amp_2d = 0, is_uniform = 0; double delay_bin = 0, amp_bin = 0; DevBuf delay_cdf, amp_cdf, prob, thr, delay_guide, amp_guide;
                 std::vector<double> prob_h; double thr_mod = -1.0;      // host copy of the probability column; modifier the thresholds were built for
                 int delay_sorted = 0, amp_sorted = 0; };
 
@@ -481,7 +481,7 @@ try {
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
     for (auto &b : h->x_alias) if (b.p) hipFree(b.p);
-    for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); if (a.prob.p) hipFree(a.prob.p); if (a.thr.p) hipFree(a.thr.p); }
+    for (auto &a : h->ap) { if (a.delay_cdf.p) hipFree(a.delay_cdf.p); if (a.amp_cdf.p) hipFree(a.amp_cdf.p); if (a.prob.p) hipFree(a.prob.p); if (a.thr.p) hipFree(a.thr.p); if (a.delay_guide.p) hipFree(a.delay_guide.p); if (a.amp_guide.p) hipFree(a.amp_guide.p); }
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     if (h->copy_stream) { hipStreamSynchronize(h->copy_stream); hipStreamDestroy(h->copy_stream); }
@@ -607,6 +607,31 @@ try {
     };
     a.delay_sorted = rows_sorted(delay_cdf, (size_t)h->cfg.n_tpc, n_bins_delay);
     a.amp_sorted = rows_sorted(amp_cdf, (size_t)(amp_2d ? h->cfg.n_tpc : 1), n_bins_amp);
+    // guides of the sorted rows (ApGuide): for every cell of u * scale a bracket of "first entry >= u" that holds for every u the
+    // device can put into the cell -- the cell's ends moved outwards by 2^-40 (the one rounding of u * scale is 2^-53)
+    auto build_guides = [&](DevBuf &buf, const double *c, size_t rows, int n) -> int {
+        if (buf.p) { hipFree(buf.p); buf.p = nullptr; buf.cap = 0; }
+        if (n < 1 || n > 65535) return WFS_OK;
+        std::vector<ApGuide> g(rows);
+        const double margin = 9.094947017729282e-13;            // 2^-40
+        for (size_t r = 0; r < rows; r++) {
+            const double *row = c + r * n;
+            auto first_ge = [&](double x) { return (int)(std::lower_bound(row, row + n, x) - row); };
+            const double top = row[n - 1];
+            g[r].scale = top > 0.0 ? (double)AP_GUIDE / top : 0.0;
+            for (int j = 0; j < AP_GUIDE; j++) {
+                if (!(g[r].scale > 0.0)) { g[r].lo[j] = 0; g[r].hi[j] = (unsigned short)n; continue; }
+                const double x_lo = (double)j / g[r].scale * (1.0 - margin), x_hi = (double)(j + 1) / g[r].scale * (1.0 + margin);
+                g[r].lo[j] = (unsigned short)first_ge(x_lo);
+                g[r].hi[j] = j == AP_GUIDE - 1 ? (unsigned short)n : (unsigned short)first_ge(x_hi);       // (the last cell also takes every u above the row)
+            }
+        }
+        int rc = upload(h, buf, g.data(), g.size() * sizeof(ApGuide)); if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(h->stream));
+        return WFS_OK;
+    };
+    if (a.delay_sorted) TRY(build_guides(a.delay_guide, delay_cdf, (size_t)h->cfg.n_tpc, n_bins_delay)); else if (a.delay_guide.p) { hipFree(a.delay_guide.p); a.delay_guide.p = nullptr; a.delay_guide.cap = 0; }
+    if (a.amp_sorted) TRY(build_guides(a.amp_guide, amp_cdf, (size_t)(amp_2d ? h->cfg.n_tpc : 1), n_bins_amp)); else if (a.amp_guide.p) { hipFree(a.amp_guide.p); a.amp_guide.p = nullptr; a.amp_guide.cap = 0; }
     h->dev.n_ap = std::max(h->dev.n_ap, e + 1);
     HIPCHK(hipStreamSynchronize(h->stream));
     return WFS_OK;
@@ -1257,7 +1282,7 @@ static int run_generation(wfs_handle *h)
         for (int e = 0; e < d.n_ap; e++) {
             const ApElem &s = h->ap[e];
             ap.el[e] = ApElemDev{s.n_bins_delay, s.n_bins_amp, s.amp_2d, s.is_uniform, s.delay_bin, s.amp_bin, s.delay_cdf.as<double>(), s.amp_cdf.as<double>(),
-                                 s.delay_sorted, s.amp_sorted};
+                                 s.delay_sorted, s.amp_sorted, s.delay_guide.as<ApGuide>(), s.amp_guide.as<ApGuide>()};
             ap.prob[e] = s.prob.as<double>();
             ApElem &sm = h->ap[e];
             if (sm.thr_mod != d.pmt_ap_modifier || !sm.thr.p) {           // screening thresholds of the generator (ap_threshold), once per modifier
@@ -1352,7 +1377,7 @@ static int run_generation(wfs_handle *h)
           if (ap.n_seg > 0) hipLaunchKernelGGL(k_ap_seg<true>, dim3(nblocks(ap.n_seg, 4)), dim3(256), 0, h->stream, d, g, ap, h->ph_gain.as<double>() - (P + h->p_fused)); }
         TRY(read_scal(h));
         if (h->h_scal[13] > ap_cap) return h->fail(WFS_E_CAPACITY, "more PMT afterpulse photons than 1/8 of the primary photons: afterpulse probability unreasonably high");
-        h->n_ap_photons = h->h_scal[28];                             // (the accepted candidates, k_ap_finish)
+        h->n_ap_photons = h->h_scal[14];                             // (the accepted candidates: total of the afterpulse tiles' counts, the scan above)
     }
     if (P > 0 || ap_on) {
         // every tile of the block generator into generation order (k_tile_order): the order the reference's Pulse call sees

@@ -2015,16 +2015,23 @@ __device__ __forceinline__ int channel_from_cdf(const double *cdf, int n, double
 #define GEN_WIN 512                // emitter offsets staged in LDS per block
 #define CDF_G 512                  // guide cells of the per-block channel search
 
+// Guide of a non-decreasing CDF row: cell j = int(u * scale), clamped to AP_GUIDE - 1, holds a bracket [lo, hi] of "the first entry >= u"
+// for every u of the cell (built on the host from the row itself with a margin on either side of the cell, wfs_set_ap_element): the
+// bisection of argmin_abs_diff starts from two entries instead of the row -- ~8 dependent, divergent loads per search fewer.
+#define AP_GUIDE 256
+struct ApGuide { double scale; unsigned short lo[AP_GUIDE], hi[AP_GUIDE]; };
+
 // PMT afterpulse element tables (afterpulse.py:181-186) and the staging list of generated afterpulse photons
 struct ApElemDev { i32 n_bins_delay, n_bins_amp, amp_2d, is_uniform; double delay_bin, amp_bin; const double *delay_cdf, *amp_cdf;
-                   i32 delay_sorted, amp_sorted; };     // the rows are non-decreasing (checked on the host): argmin by bisection
+                   i32 delay_sorted, amp_sorted;        // the rows are non-decreasing (checked on the host): argmin by bisection
+                   const ApGuide *delay_guide, *amp_guide; };     // per row of the two tables (or nullptr): where the bisection starts
 
 // np.argmin(|cdf - u|) (afterpulse.py:222, 229): the FIRST index of the smallest distance.  On a non-decreasing row the
 // distance falls up to the first entry >= u and rises behind it, so the answer is that entry or the one in front of it
 // (lower index on a tie), moved to the start of its plateau of equal values -- two bisections instead of a scan of the row
 // (a scan costs every wave that holds one accepted photon ~n_bins iterations: 20 of 23 ms of the fill pass with
 // afterpulses on).  Rows that are not sorted (never seen; the host checks) keep the scan.
-__device__ __forceinline__ int argmin_abs_diff(const double *c, int n, double u, bool sorted)
+__device__ __forceinline__ int argmin_abs_diff(const double *c, int n, double u, bool sorted, const ApGuide *guide = nullptr)
 {
     if (!sorted) {
         int best = 0; double bd = fabs(c[0] - u);
@@ -2032,6 +2039,11 @@ __device__ __forceinline__ int argmin_abs_diff(const double *c, int n, double u,
         return best;
     }
     int lo = 0, hi = n;                                  // first k with c[k] >= u (n: none)
+    if (guide && u >= 0.0) {
+        const double x = u * guide->scale;
+        const int j = x < (double)(AP_GUIDE - 1) ? (int)x : AP_GUIDE - 1;
+        lo = guide->lo[j]; hi = guide->hi[j];
+    }
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] >= u) hi = mid; else lo = mid + 1; }
     int best = lo;
     if (lo == n) best = n - 1;
@@ -2050,7 +2062,7 @@ struct ApArgs {
     i64 cap;                        // capacity of the staging list
     i32 *ap_ins; i32 *ap_ch; i32 *ap_t; double *ap_gain;     // [cap] instruction, channel, ns relative to the instruction, gain
     u32 *ap_key;                    // [cap] order key: element << 29 | index of the parent photon among its instruction's photons
-    i64 *count;                     // number of afterpulse candidates in the list (device scalar, scal[13]); k_ap_finish adds the accepted ones to count[15] (scal[28])
+    i64 *count;                     // number of afterpulse candidates in the list (device scalar, scal[13])
     struct ApSeg *seg; i64 n_seg;   // candidates of a k_s2_tile workgroup: one contiguous, key-ordered stretch of the list per tile (k_ap_seg)
     struct ApCand *cand;            // [cap] candidates of the generator (k_ap_finish turns entry i into afterpulse photon i, or a hole: ap_ch[i] = -1)
 };
@@ -2144,10 +2156,10 @@ __device__ __forceinline__ void ap_finish(const WfsDev &d, i64 *scal, const ApAr
         const u32x4 x = philox4x32_10(q.j, q.gid, q.m, SITE_AP_X + (u32)e, d.k0, d.k1);
         delay = (dc[0] + (dc[1] - dc[0]) * u53(x.x, x.y)) * el.delay_bin; amp = 1.0;
     } else {
-        const int best = argmin_abs_diff(dc, el.n_bins_delay, ap_uniform(d, q, w), el.delay_sorted != 0);      // np.argmin(|cdf - u|): first minimum
+        const int best = argmin_abs_diff(dc, el.n_bins_delay, ap_uniform(d, q, w), el.delay_sorted != 0, el.delay_guide ? el.delay_guide + q.ch : nullptr);      // np.argmin(|cdf - u|): first minimum
         delay = best * el.delay_bin - d.pmt_ap_t_modifier;
         const double *ac = el.amp_2d ? el.amp_cdf + (size_t)q.ch * el.n_bins_amp : el.amp_cdf;
-        const int ba = argmin_abs_diff(ac, el.n_bins_amp, 1.0 - u53(w.z, w.w), el.amp_sorted != 0);
+        const int ba = argmin_abs_diff(ac, el.n_bins_amp, 1.0 - u53(w.z, w.w), el.amp_sorted != 0, el.amp_guide ? el.amp_guide + (el.amp_2d ? q.ch : 0) : nullptr);
         amp = ba * el.amp_bin;
     }
     const double tf = (double)(q.itime + q.t) + delay;          // afterpulse.py:235, int64 + float
@@ -2953,8 +2965,8 @@ __global__ void k_ap_finish(WfsDev d, GenArgs a, ApArgs ap)
     const u32x4 w = ap_call(d, q);                          // the element's own call: low bits of the first uniform, the second uniform
     const bool ok = ap_accept(d, ap, q, w);
     if (ok) ap_finish(d, a.scal, ap, q, w, i); else ap.ap_ch[i] = -1;
-    const int n_ok = __popcll(__ballot(ok));
-    if ((threadIdx.x & 63) == 0 && n_ok) atomicAdd((u64 *)(ap.count + 15), (u64)n_ok);
+    // (no counter of the accepted ones here: one atomic per wave on one address was 5.5 of this kernel's 6.8 ms with 3.5 x 10^7
+    // candidates -- the scan over the afterpulse tiles' counts yields the total anyway)
 }
 
 // afterpulse photons -> tiles of the afterpulse pulse set of their primary set (set n_psets + set): count, then place
