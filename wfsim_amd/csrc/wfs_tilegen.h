@@ -263,11 +263,27 @@ __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, Templa
         const ApArgs &ap = *app;
         ApStage aps; aps.n = &s_apn; aps.cand = (ApCand *)(smem + ap_lds_off);
         const i32 set = ft.tile / f.nch;
+        // the tile's thresholds (one channel: two per element) once, in scalar registers: a dependent pair of global loads per photon and
+        // element otherwise, in the middle of every tile's chain
+        const int n_ap = ap.n;
+        u32 thr_s[WFS_MAX_AP], thr_d[WFS_MAX_AP];
+#pragma unroll
+        for (int e = 0; e < WFS_MAX_AP; e++) { thr_s[e] = 0xffffffffu; thr_d[e] = 0xffffffffu; if (e < n_ap) { thr_s[e] = ap.thr[e][ft.ch * 2]; thr_d[e] = ap.thr[e][ft.ch * 2 + 1]; } }
         u64 cm = 0;                                       // bit 8 k + e: element e of photon k is a candidate
 #pragma unroll
         for (int k = 0; k < NPH; k++) {
             const i32 P = 4 * (tid + (k >> 2) * TPB) + (k & 3);
-            if (P < n) cm |= (u64)ap_screen_mask(d, ap, ft.c0, ft.gid, (u32)P, ft.ch, (code[k] >> 16) != 0) << (8 * k);
+            if (P >= n) continue;
+            const bool dpe = (code[k] >> 16) != 0;
+            u32 m = 0;
+#pragma unroll
+            for (int e0 = 0; e0 < WFS_MAX_AP; e0 += 4) {
+                if (e0 >= n_ap) break;                     // block-uniform
+                const u32x4 S = philox4x32_10(ft.c0, ft.gid, (u32)P, SITE_AP_SCREEN + (u32)(e0 >> 2), d.k0, d.k1);
+#pragma unroll
+                for (int j = 0; j < 4; j++) if ((word_of(S, j) >> 5) >= (dpe ? thr_d[e0 + j] : thr_s[e0 + j])) m |= 1u << (e0 + j);      // (elements past n_ap: threshold 2^32 - 1, never met)
+            }
+            cm |= (u64)m << (8 * k);
         }
         while (cm) {                                      // (one photon in a hundred: the parking code once, not eight times)
             const int b = __builtin_ctzll(cm); cm &= cm - 1;
