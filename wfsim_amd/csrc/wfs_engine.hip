@@ -1331,7 +1331,7 @@ static int run_generation(wfs_handle *h)
         { Timer t(h, "k_photon_count"); hipLaunchKernelGGL(k_photon_count, dim3(nbx), dim3(COUNT_TPB), GEN_COUNT_LDS(d.n_tpc, g.ch_lg), h->stream, d, g); }
         { Timer t(h, "k_block_ranges"); hipLaunchKernelGGL(k_block_ranges, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, g); }
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
-        const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, g.ch_lg, ap_on, ap_on ? d.n_ap : 0).total;
+        const size_t gen_lds = (size_t)gen_fill_lds(d.n_tpc, g.ch_lg, ap_on).total;
         { Timer t(h, "k_photon_fill");
           if (ext && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<true, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);
           else if (ext) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_photon_fill<false, true>), dim3(nbx), dim3(FILL_TPB), gen_lds, h->stream, d, g, ap);

@@ -2199,7 +2199,7 @@ __device__ __forceinline__ u32 ap_screen_word(const WfsDev &d, u32 j, u32 gid, u
     return word_of(philox4x32_10(j, gid, m, SITE_AP_SCREEN + (u32)(e >> 2), d.k0, d.k1), e & 3);
 }
 __device__ __forceinline__ void ap_generate(const WfsDev &d, const ApArgs &ap, const ApStage &st,
-                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P, const u32 *thr_lds = nullptr)
+                                            u32 j, u32 gid, u32 m, i32 ins, int ch, bool is_dpe, i64 itime, i64 t, u32 P)
 {
     for (int e0 = 0; e0 < ap.n; e0 += 4) {
         const u32x4 S = philox4x32_10(j, gid, m, SITE_AP_SCREEN + (u32)(e0 >> 2), d.k0, d.k1);
@@ -2208,7 +2208,7 @@ __device__ __forceinline__ void ap_generate(const WfsDev &d, const ApArgs &ap, c
             const int e = e0 + k;
             if (e >= ap.n) break;
             const u32 x = word_of(S, k);
-            const u32 thr = thr_lds ? thr_lds[(e * d.n_tpc + ch) * 2 + (is_dpe ? 1 : 0)] : ap.thr[e][ch * 2 + (is_dpe ? 1 : 0)];
+            const u32 thr = ap.thr[e][ch * 2 + (is_dpe ? 1 : 0)];
             if ((x >> 5) < thr) continue;                           // surely rejected (ap_threshold)
             ap_park(ap, st, x, e | (is_dpe ? 256 : 0), j, gid, m, ins, ch, itime, (i32)t, ((u32)e << 29) | (P & 0x1fffffffu));
         }
@@ -2751,8 +2751,8 @@ __global__ __launch_bounds__(COUNT_TPB) void k_photon_count(WfsDev d, GenArgs a)
 
 // LDS layout of the fill pass (byte offsets; plain integer offsets: a pointer that went through an integer cast loses its
 // LDS address space)
-struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, pidx, stage, ap, approb, total; };
-__host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap, int n_ap = 0)
+struct GenFillLds { int wtime, T, hist, cur, hmin, hmax, hoff, chmap, pidx, stage, ap, total; };
+__host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap)
 {
     const int nch1 = nch + 1 + ((nch + 1) & 1);              // even: keeps what follows 8-byte aligned
     GenFillLds o;
@@ -2767,8 +2767,7 @@ __host__ __device__ inline GenFillLds gen_fill_lds(int nch, int lg, bool with_ap
     o.pidx = o.chmap + GEN_BLOCK * 2;                         // u16[GEN_BLOCK]: block-relative photon index of every bucket position
     o.stage = (o.pidx + GEN_BLOCK * 2 + 7) & ~7;              // PhotonRec[GEN_BLOCK]: the block's photons in bucket order
     o.ap = o.stage + GEN_BLOCK * 8;                           // afterpulse staging
-    o.approb = (o.ap + (with_ap ? AP_STAGE * (int)sizeof(ApCand) : 0) + 7) & ~7;       // u32[n_ap][nch][2]: screening thresholds of every (element, channel)
-    o.total = o.approb + 16;
+    o.total = ((o.ap + (with_ap ? AP_STAGE * (int)sizeof(ApCand) : 0) + 7) & ~7) + 16;
     return o;
 }
 
@@ -2780,7 +2779,7 @@ __global__ __launch_bounds__(FILL_TPB) void k_photon_fill(WfsDev d, GenArgs a, A
     constexpr int TPB = FILL_TPB, CPT = (WFS_MAX_CH + TPB - 1) / TPB;      // channels per thread
     const int nch = d.n_tpc, tid = threadIdx.x;
     const int lg = a.ch_lg;
-    const GenFillLds o = gen_fill_lds(nch, lg, AP, AP ? ap.n : 0);
+    const GenFillLds o = gen_fill_lds(nch, lg, AP);
     i32 *win = (i32 *)smem, *wtime = (i32 *)(smem + o.wtime);
     uint2 *T = (uint2 *)(smem + o.T);                        // alias cells of the block's channel row
     i32 *hist = (i32 *)(smem + o.hist), *cur = (i32 *)(smem + o.cur), *hmin = (i32 *)(smem + o.hmin), *hmax = (i32 *)(smem + o.hmax);
