@@ -61,6 +61,34 @@ def test_headline_batch_properties():
     assert orc.pack_records().tobytes() == rec3.tobytes()
 
 
+def test_headline_batch_with_pmt_afterpulses():
+    """The headline shape with PMT afterpulses on (300 instructions, ~3 x 10^8 PE): the afterpulses of tile-generated tiles are screened
+    inside the pulse workgroup and placed tile by tile (k_s2_tile<.., AP>, k_ap_seg).  Afterpulse fraction, determinism, batch
+    invariance, and three instructions against the oracle byte for byte."""
+    from tests.helpers import ap_tables_from_golden
+    cfg = bench_config(seed=3, pmt_afterpulses=True)
+    res = Resource(cfg)
+    eng = Engine(cfg, res)
+    ins = s2_batch(300, 0)
+    counts, rec, groups = _run(eng, cfg, res, ins)
+    plain = Engine(bench_config(seed=3), Resource(bench_config(seed=3)))
+    c0, rec0, _ = _run(plain, bench_config(seed=3), Resource(bench_config(seed=3)), ins)
+    # same primaries (the afterpulse draws have their own sites); He + Xe + Uniform: ~4 % of the photons make an afterpulse
+    n_ap = counts['n_photons'] - c0['n_photons']
+    assert 0.030 < n_ap / c0['n_photons'] < 0.055 and counts['n_groups'] == 300
+    first = np.append(groups['first_record'], len(rec))
+    digest = hashlib.sha1(rec.tobytes()).hexdigest()
+    _, rec2, _ = _run(eng, cfg, res, ins)
+    assert hashlib.sha1(rec2.tobytes()).hexdigest() == digest
+    sub = ins[150:153]
+    c3, rec3, g3 = _run(eng, cfg, res, sub, gid0=150)
+    assert rec3.tobytes() == rec[first[150]:first[153]].tobytes()
+    orc = make_oracle(cfg, ap_tables_from_golden())
+    order, key, cluster = schedule(sub, cfg)
+    orc.simulate(sub[order], (150 + order).astype(np.uint32), instruction_params(sub[order], cfg, res))
+    assert orc.pack_records().tobytes() == rec3.tobytes()
+
+
 def test_config1_s1_batch_properties():
     from wfsim_amd.config import xenonnt_test_config
     n = 10_000
