@@ -1287,8 +1287,8 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
 }
 
 // Truth accumulators of a pulse set (pulse.py:229-271 add_truth: totals, bottom-array totals; rawdata.py:330-345 photon
-// time moments) from the per-tile partial sums, one wave per set.  Channels are summed in a fixed order (lane, then a
-// shuffle tree), so the result does not depend on the order the tiles were processed in.
+// time moments) from the per-tile partial sums, one wave per set.  Channels are summed in a fixed order (lane, then the
+// DPP tree of wave_sum), so the result does not depend on the order the tiles were processed in.
 struct TruthArgs { i64 n_sets; const i32 *tile_count, *tile_tmin, *tile_tmax; const i64 *set_t0; const double *tile_truth;
                    double *truth; i64 *tminmax; };
 __global__ __launch_bounds__(256) void k_truth_reduce(WfsDev d, TruthArgs a)
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_truth_reduce(WfsDev d, TruthArgs a)
         tmin = lo < tmin ? lo : tmin; tmax = hi > tmax ? hi : tmax;
     }
 #pragma unroll
-    for (int q = 0; q < 15; q++) for (int o = 32; o > 0; o >>= 1) v[q] += __shfl_down(v[q], o, 64);
+    for (int q = 0; q < 15; q++) v[q] = wave_sum(v[q]);         // (DPP: a fixed order, no LDS crossbar trips -- 180 of them per set otherwise)
     for (int o = 32; o > 0; o >>= 1) {
         const i64 lo = __shfl_down(tmin, o, 64), hi = __shfl_down(tmax, o, 64);
         tmin = lo < tmin ? lo : tmin; tmax = hi > tmax ? hi : tmax;
