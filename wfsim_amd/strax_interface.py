@@ -93,7 +93,7 @@ class ChunkRawRecords(object):
         """Generator of chunks (strax_interface.py:368-440): dicts of record arrays + truth rows; ``chunk_time_pre`` / ``chunk_time``
         are the bounds of the chunk just yielded."""
         if not len(instructions):               # nothing to simulate: no chunk at all (:370-373)
-            self.rawdata.source_finished = True
+            setattr(self.rawdata, 'source_finished', True)
             return
         c = self.config
         self._dt, self._rext, self._cksz = c['sample_duration'], int(c['right_raw_extension']), int(c['chunk_size'] * 1e9)
@@ -112,7 +112,7 @@ class ChunkRawRecords(object):
         else:
             yield from self._run_pulses(instructions, **kwargs)
         # the last chunk ends behind the last digitised window, and is at least one sample long (:438-440)
-        self.last_digitized_right = self.current_digitized_right
+        self.last_digitized_right = int(self.current_digitized_right)
         end_of_data = (self.last_digitized_right + 1) * dt
         self.chunk_time = end_of_data if end_of_data > self.chunk_time_pre + dt else self.chunk_time_pre + dt
         yield from self.final_results()
@@ -222,7 +222,7 @@ class ChunkRawRecords(object):
                 if self.blevel + len(wrec) > L:
                     yield from self._buffer_full_flush()
                 if self.blevel + len(wrec) > L:
-                    log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
+                    log.warning('pulse longer than the record buffer has room for: skipped')
                     # the reference skips pulse by pulse in the order it yields them; here whole records in time order
                     wrec = wrec[:max(L - self.blevel, 0)]
                 buf = self.record_buffer
@@ -296,7 +296,7 @@ class ChunkRawRecords(object):
                     if self.blevel + e > capacity:
                         break
                     keep = e
-                log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
+                log.warning('pulse longer than the record buffer has room for: skipped')
                 rec = rec[:keep]
             self.record_buffer[self.blevel:self.blevel + len(rec)] = rec
             self.blevel += len(rec)
@@ -327,7 +327,7 @@ class ChunkRawRecords(object):
             if self.blevel + len(rec) > room:
                 yield from self._buffer_full_flush()
                 if self.blevel + len(rec) > room:           # longer than the whole buffer: dropped (:419-422)
-                    log.warning('Pulse length too large, insufficient record buffer, skipping pulse')
+                    log.warning('pulse longer than the record buffer has room for: skipped')
                     continue
             self.record_buffer[self.blevel:self.blevel + len(rec)] = rec
             self.blevel += len(rec)
@@ -369,7 +369,7 @@ class ChunkRawRecords(object):
             _truth[column] = leaving[column]
         seen = ~np.isnan(_truth['t_first_photon'])
         _truth['time'][seen] = _truth['t_first_photon'][seen].astype(int)
-        _truth.sort(order='time')
+        _truth.sort(order=('time',))
 
         det = self.config['detector']
         moved = False
@@ -441,7 +441,7 @@ class SimulatorPlugin(_Plugin):
         """strax_interface.py:566-608 without the CMT / straxen look-ups: gains must be in the config (or to_pe)."""
         c = self.config
         overrides = c.get('fax_config_override')
-        if overrides is not None:
+        if overrides:
             c.update(overrides)
         if 'field_distortion_on' in c and 'field_distortion_model' not in c:
             c['field_distortion_model'] = 'inverse_fdc' if c['field_distortion_on'] else 'none'
@@ -504,7 +504,7 @@ class RawRecordsFromFaxNT(SimulatorPlugin):
 
     def _setup(self):
         self.sim = ChunkRawRecords(self.config, device=self.device)
-        self.sim_iter = self.sim(self.instructions)
+        self.sim_iter = iter(self.sim(self.instructions))
 
     def get_instructions(self):
         if self.config.get('instructions') is not None:           # in-memory instructions (tests, benchmarks)
@@ -557,7 +557,7 @@ class RawRecordsFromFaxOpticalNT(RawRecordsFromFaxNT):
         self.sim = ChunkRawRecords(self.config, rawdata_generator=RawDataOptical, channels=self.channels,
                                    timings=self.timings, device=self.device)
         self.sim.truth_buffer = _optical_truth_buffer(self._truth_dtype)
-        self.sim_iter = self.sim(self.instructions)
+        self.sim_iter = iter(self.sim(self.instructions))
 
     def get_instructions(self):
         c = self.config
@@ -583,7 +583,7 @@ class RawRecordsFromFaxnVeto(RawRecordsFromFaxOpticalNT):
         self.config['detector'] = 'XENONnT_neutron_veto'
         c = self.config
         overrides = c.get('fax_config_override_nveto') or c.get('fax_config_override')
-        if overrides is not None:
+        if overrides:
             c.update(overrides)
         if 'gains' not in c:
             to_pe = np.asarray(c['to_pe_nveto'], dtype=np.float64)
@@ -649,9 +649,9 @@ class RawRecordsFromMcChain(SimulatorPlugin):
         self.config.setdefault('entry_stop', None)
         super().set_config()
         if 'nveto' in self.config['targets']:
-            from copy import deepcopy
+            import copy
             skip = ('instructions_epix', 'instructions_nveto', 'nveto_channels', 'nveto_timings')
-            cn = {k: (v if k in skip else deepcopy(v)) for k, v in self.config.items()}
+            cn = {k: (v if k in skip else copy.deepcopy(v)) for k, v in self.config.items()}
             cn.update(self.config.get('fax_config_nveto') or {})
             cn['detector'] = 'XENONnT_neutron_veto'
             cn['channel_map'] = dict(cn['channel_map'])
