@@ -160,8 +160,8 @@ __device__ i64 poisson_site(const WfsDev &d, u32 emitter, u32 gid, u32 site, dou
 // with photons go on the work list with everything their workgroup needs (one scalar load).
 __global__ __launch_bounds__(256) void k_tile_counts(WfsDev d, FuseArgs f)
 {
-    __shared__ i32 s_n; __shared__ i64 s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    __shared__ i32 s_n, s_tot; __shared__ i64 s_base;
+    if (threadIdx.x == 0) { s_n = 0; s_tot = 0; }
     __syncthreads();
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 i = idx / f.nch; const int c = (int)(idx - i * f.nch);
@@ -181,10 +181,10 @@ __global__ __launch_bounds__(256) void k_tile_counts(WfsDev d, FuseArgs f)
             ft.G = d.gains[c]; ft.thr = d.thr_truth[c]; ft.n = (i32)N; ft.n_surv = ns; ft.ch = c; ft.tile = (i32)idx; ft.gid = gid; ft.c0 = c0;
         }
     }
-    i64 tot = N;
-    for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
-    if ((threadIdx.x & 63) == 0 && tot) atomicAdd((u64 *)&f.scal[24], (u64)tot);
+    const int tot = wave_sum((int)N);                        // (a workgroup's 256 tiles hold at most 2^19 photons)
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(&s_tot, tot);
     __syncthreads();
+    if (threadIdx.x == 0 && s_tot) atomicAdd((u64 *)&f.scal[24], (u64)s_tot);      // one atomic per workgroup on each of the two counters
     if (threadIdx.x == 0 && s_n) s_base = (i64)atomicAdd((u64 *)&f.scal[25], (u64)s_n);
     __syncthreads();
     if (rk >= 0) f.tiles[s_base + rk] = ft;
