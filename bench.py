@@ -158,6 +158,8 @@ def main():
                     help='s2: the headline batch (BASELINE configs[2]); mixed: configs[3]; nveto: configs[4]')
     ap.add_argument('--cpu-sample', type=int, default=120, help="S2 instructions timed on the CPU oracle, ~13 s on one thread + ~4 s on all cores (0: skip)")
     ap.add_argument('--pmt-afterpulses', action='store_true', help='s2 workload with PMT afterpulses on (synthetic tables): a side measurement, not the headline')
+    ap.add_argument('--exact-currents', action='store_true', help="fused_multiply_add off: add_current with numpy's separately rounded product and sum "
+                    '(currents bit-exact with the reference; side measurement)')
     ap.add_argument('--no-copy-ceiling', action='store_true', help='skip the 1 GiB device-copy measurement (counter passes: it is not part of the batch)')
     ap.add_argument('--gather', action='store_true', help='N > 1: also gather every rank\'s records on rank 0 over RCCL inside the timed region (the reference\'s single feeding '
                     'process; default: every rank keeps its records in its own HBM, as the one-GPU run does -- the path has no exchange step)')
@@ -206,6 +208,8 @@ def main():
         eng.load_optical(ins[order], (rank * M + order).astype(np.uint32), cluster, key, channels, timings, int(1e6))
     else:
         cfg = bench_config(seed=3, pmt_afterpulses=args.pmt_afterpulses) if args.workload == 's2' else mixed_config(seed=3)
+        if args.exact_currents:
+            cfg['fused_multiply_add'] = False
         res = Resource(cfg)
         ins = s2_batch(M, first_gid=rank * M) if args.workload == 's2' else mixed_batch(M, first_gid=rank * M)
         M = len(ins)

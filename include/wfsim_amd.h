@@ -64,6 +64,13 @@ typedef struct wfs_config {
                                   photon comes from the per-electron generator (needed by the electron-afterpulse pre-pass)   */
     int32_t tile_gen_min;      /* ... and only where amp * gain * max(p_ch) reaches this many photons: below it a workgroup per tile
                                   costs more than the block generator (crossover measured at ~60 photons per tile)        */
+    int32_t fma;               /* 1 (config 'fused_multiply_add', the default): Pulse.add_current (pulse.py:303-318) accumulates
+                                  template * gain into the current with ONE rounding per term (v_fma_f64) instead of the separately
+                                  rounded product and sum of numpy: currents within 1 ulp of the tile maximum per term of the
+                                  reference's, ADC samples / ZLE / records equal unless a current lands within that distance of a
+                                  rounding tie (tolerance of the path: 1 ADC count).  0: the reference's two roundings, currents
+                                  bit-exact                                                                   */
+    int32_t pad0;              /* (keeps the doubles 8-byte aligned; must be 0)                                             */
     double c2a;                /* current_2_adc                                     pulse.py:33-35   */
     double tts_mean, tts_sigma;/* pmt_transit_time_mean, spread/2.35482             pulse.py:53-56   */
     double p_dpe;              /* p_double_pe_emision                               pulse.py:76      */

@@ -16,7 +16,7 @@ _I32_FIELDS = ['dt', 'samples_before', 'samples_after', 'store_before', 'store_a
                'trigger_window', 'baseline', 'n_rows',
                'n_tpc', 'n_top', 'he_first', 'he_factor', 'sum_channel', 'last_bottom', 'detector_nt',
                'n_spe_channels', 'noise_len', 'noise_channels', 'enable_noise',
-               's1_simple', 's2_time_model', 'n_lum', 'enable_pmt_ap', 'n_ap_elements', 'tile_gen', 'tile_gen_min', 'pad1']
+               's1_simple', 's2_time_model', 'n_lum', 'enable_pmt_ap', 'n_ap_elements', 'tile_gen', 'tile_gen_min', 'fma']
 _F64_FIELDS = ['c2a', 'tts_mean', 'tts_sigma', 'p_dpe', 's1_decay_time', 's1_decay_spread',
                'sf_gas', 't1_gas', 't3_gas', 's2_time_spread', 'trap_time', 'gain_spread',
                'pmt_ap_modifier', 'pmt_ap_t_modifier', 'rext', 'drift_velocity']
@@ -130,12 +130,12 @@ class Oracle:
 
     # ---- stages -------------------------------------------------------------------------------
     @staticmethod
-    def add_current(t, g, pulse_left, dt, templates, length):
+    def add_current(t, g, pulse_left, dt, templates, length, fma=False):
         t = _arr(t, np.int64)
         g = _arr(g, np.float64)
         T = _arr(templates, np.float64)
         cur = np.zeros(length, dtype=np.float64)
-        lib().orc_add_current(_p(t), _p(g), C.c_int64(len(t)), C.c_int64(pulse_left), C.c_int64(dt), _p(T),
+        (lib().orc_add_current_fma if fma else lib().orc_add_current)(_p(t), _p(g), C.c_int64(len(t)), C.c_int64(pulse_left), C.c_int64(dt), _p(T),
                               C.c_int64(T.shape[1]), _p(cur))
         return cur
 

@@ -36,7 +36,10 @@ typedef struct {
     /* models */
     i32 s1_simple, s2_time_model /*0 zero_delay, 1 spread around zero*/, n_lum, enable_pmt_ap, n_ap_elements;
     i32 tile_gen;                                   /* tile-local generation of eligible S2s (RNG spec v9): see gen_s2 */
-    i32 tile_gen_min, pad1;                         /* ... from this many photons per tile (amp * gain * max p_ch) on */
+    i32 tile_gen_min;                               /* ... from this many photons per tile (amp * gain * max p_ch) on */
+    i32 fma;                                        /* 1: add_current accumulates with fma(template, gain, current) -- one rounding per term instead
+                                                       of two; the switch of wfs_config.fma (north_star tolerance: 1 ADC count).  0: the reference's
+                                                       separately rounded product and sum (bit-exact currents) */
     double c2a;                                     /* current_2_adc, pulse.py:33-35 */
     double tts_mean, tts_sigma, p_dpe;
     double s1_decay_time, s1_decay_spread;
@@ -288,8 +291,8 @@ static int tkey_cmp(const void *a, const void *b)
  * (gains summed) and placed once: cur[start : start+tlen] += templates[t % dt] * gain_total, product and sum
  * rounded separately (numpy does not fuse them).  The reference's argsort is numpy's default introsort, whose
  * order among equal keys is unspecified; ties are taken here in input order. */
-void orc_add_current(const i64 *t, const double *g, i64 n, i64 pulse_left, i64 dt,
-                     const double *templates, i64 tlen, double *cur)
+static void add_current_impl(const i64 *t, const double *g, i64 n, i64 pulse_left, i64 dt,
+                             const double *templates, i64 tlen, double *cur, int fused)
 {
     if (n == 0) return;
     tkey *k = (tkey *)malloc((size_t)n * sizeof(tkey));
@@ -301,7 +304,8 @@ void orc_add_current(const i64 *t, const double *g, i64 n, i64 pulse_left, i64 d
         if (j == n || k[j].t > tmp) {
             i64 start = floordiv(tmp, dt) - pulse_left, rem = floormod(tmp, dt);
             const double *T = templates + rem * tlen;
-            for (i64 q = 0; q < tlen; q++) {
+            if (fused) for (i64 q = 0; q < tlen; q++) cur[start + q] = fma(T[q], gain_total, cur[start + q]);      /* one rounding per term */
+            else for (i64 q = 0; q < tlen; q++) {
                 volatile double prod = T[q] * gain_total;      /* separate rounding of product and sum */
                 cur[start + q] += prod;
             }
@@ -312,6 +316,17 @@ void orc_add_current(const i64 *t, const double *g, i64 n, i64 pulse_left, i64 d
         }
     }
     free(k);
+}
+void orc_add_current(const i64 *t, const double *g, i64 n, i64 pulse_left, i64 dt,
+                     const double *templates, i64 tlen, double *cur)
+{
+    add_current_impl(t, g, n, pulse_left, dt, templates, tlen, cur, 0);
+}
+/* the same walk with fused multiply-adds (wfs_config.fma): what the HIP kernels compute when the switch is on */
+void orc_add_current_fma(const i64 *t, const double *g, i64 n, i64 pulse_left, i64 dt,
+                         const double *templates, i64 tlen, double *cur)
+{
+    add_current_impl(t, g, n, pulse_left, dt, templates, tlen, cur, 1);
 }
 
 /* np.sum over a contiguous float64 array: numpy's pairwise summation (blocks of 128, 8 partial sums),
@@ -372,7 +387,7 @@ void orc_pulse_call(orc_session *s, int kind, int runset, i64 n, const i64 *t, c
         i64 len = right - left + 1;
         VEC_RESERVE(s->cur, double, len);
         double *cur = s->cur.p + s->cur.n; memset(cur, 0, (size_t)len * sizeof(double)); s->cur.n += len;
-        orc_add_current(t + a, gain + a, cnt, left, c->dt, s->templates, c->tlen, cur);
+        add_current_impl(t + a, gain + a, cnt, left, c->dt, s->templates, c->tlen, cur, c->fma);
         VEC_PUSH(s->pl_ch, i32, channel); VEC_PUSH(s->pl_runset, i32, runset); VEC_PUSH(s->pl_left, i64, left);
         VEC_PUSH(s->pl_right, i64, right); VEC_PUSH(s->pl_nph, i64, cnt); VEC_PUSH(s->pl_cur_off, i64, s->cur.n);
         i64 end = right * c->dt;                                 /* rawdata.py:188-190 */

@@ -12,6 +12,23 @@ from wfsim_amd.resource import Resource
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
+# Pulse.add_current with fused multiply-adds (config 'fused_multiply_add', the default of the HIP path; wfs_config.fma): every
+# term template * gain is added to the current with one rounding instead of numpy's two.  A sample sums at most tlen x (photons in
+# reach) terms; the two forms differ by at most half an ulp of the running sum per term, so by a few ulp of the tile maximum at the
+# end.  Tolerance of the golden comparisons in that mode (measured maximum on the golden chains: 2 ulp); everything downstream of the
+# per-pulse rounding (rows, ZLE intervals, records) is asserted EQUAL in both modes.
+FMA_CURRENT_TOL_ULP = 8
+
+
+def with_fma(config, on):
+    return dict(config, fused_multiply_add=bool(on))
+
+
+def assert_currents_close(cur, ref, what=''):
+    tol = FMA_CURRENT_TOL_ULP * np.spacing(np.abs(ref).max()) if len(ref) else 0.0
+    assert np.all(np.abs(cur - ref) <= tol), f'{what}: max diff {np.abs(cur - ref).max()} > {tol}'
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

@@ -3,15 +3,16 @@
 Everything here goes through the C ABI (wfsim_amd.engine -> libwfsim_amd.so).  Photons are injected at the
 stage boundary Pulse.__call__ so that all results are deterministic:
   * pulse bounds, photon counts: exact
-  * tile currents (f64): bit-exact (tolerance 4 ulp of the tile maximum only for tiles with >= 3 photons in one ns,
-    whose merge order the reference leaves to numpy's unstable argsort)
-  * digitised rows, ZLE intervals, records: exact (the north-star bar is 1 ADC count; we get 0)
+  * tile currents (f64): bit-exact with fused_multiply_add off (tolerance 4 ulp of the tile maximum only for tiles with >= 3
+    photons in one ns, whose merge order the reference leaves to numpy's unstable argsort); with the switch on (the default: one
+    rounding per template * gain term instead of two) within FMA_CURRENT_TOL_ULP of the tile maximum (tests/helpers.py)
+  * digitised rows, ZLE intervals, records: exact in BOTH modes (the north-star bar is 1 ADC count; we get 0)
 """
 import numpy as np
 import pytest
 
 from tests.helpers import (golden, make_engine, make_oracle, replay_chain_on_engine, replay_chain_on_oracle,
-                           canonical_intervals, ap_tables_from_golden)
+                           canonical_intervals, ap_tables_from_golden, with_fma, assert_currents_close)
 from wfsim_amd.config import xenonnt_test_config
 
 pytestmark = pytest.mark.gpu
@@ -24,6 +25,12 @@ def _nonempty_groups(eng):
 
 
 def _check_chain(name, config, force_dense=False, noise_offsets=False):
+    """both arithmetic modes of add_current; returns the engine of the default one (fused multiply-adds)"""
+    _check_chain_mode(name, with_fma(config, False), force_dense, noise_offsets)
+    return _check_chain_mode(name, with_fma(config, True), force_dense, noise_offsets)
+
+
+def _check_chain_mode(name, config, force_dense=False, noise_offsets=False):
     d = golden(name)
     eng = make_engine(config)
     counts = replay_chain_on_engine(eng, d, config, force_dense=force_dense)
@@ -45,6 +52,9 @@ def _check_chain(name, config, force_dense=False, noise_offsets=False):
         for j, k in enumerate(order):
             cur = p['current'][p['cur_off'][k]:p['cur_off'][k] + p['right'][k] - p['left'][k] + 1]
             ref = d['pl_current'][d['pl_cur_off'][j]:d['pl_cur_off'][j + 1]]
+            if config['fused_multiply_add']:
+                assert_currents_close(cur, ref, f'tile {j}')
+                continue
             assert np.array_equal(cur, ref), f'tile {j}: max diff {np.abs(cur - ref).max()}'
     # ---- digitise windows
     g, keep = _nonempty_groups(eng)

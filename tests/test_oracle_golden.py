@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from oracle import oracle as O
-from tests.helpers import golden, make_oracle, replay_chain_on_oracle, host_tables, ap_tables_from_golden
+from tests.helpers import (golden, make_oracle, replay_chain_on_oracle, host_tables, ap_tables_from_golden, with_fma,
+                           assert_currents_close)
 from wfsim_amd.config import xenonnt_test_config
 
 
@@ -44,16 +45,44 @@ def test_add_current_bit_exact():
             assert np.array_equal(np.around(cur * 5.8e-4), np.around(ref * 5.8e-4))
 
 
-def _check_chain(name, config, ap=None):
+def test_add_current_fused():
+    """the same vectors with fused multiply-adds (wfs_config.fma): within FMA_CURRENT_TOL_ULP of the reference's currents, the
+    per-pulse rounded ADC values equal"""
+    g = golden('add_current.npz')
+    T = golden('tables.npz')['templates']
+    worst = 0.0
+    for i in range(int(g['n'])):
+        cur = O.Oracle.add_current(g[f't{i}'], g[f'g{i}'], int(g[f'left{i}']), 10, T, len(g[f'cur{i}']), fma=True)
+        ref = g[f'cur{i}']
+        assert_currents_close(cur, ref, f'case {i}')
+        worst = max(worst, np.abs(cur - ref).max() / np.spacing(np.abs(ref).max()))
+        assert np.array_equal(np.around(cur * 5.8e-4), np.around(ref * 5.8e-4))
+    assert worst > 0          # (the two forms do differ: the switch reaches the arithmetic)
+
+
+def _check_chain(name, config, ap=None, noise_override=False):
+    """The golden chain `name` on the oracle in both arithmetic modes: the reference's separately rounded product and sum (currents
+    bit-exact; the session of this mode is returned) and fused multiply-adds (the default of the HIP path: currents within
+    FMA_CURRENT_TOL_ULP of the reference, digitised rows and ZLE tuples EQUAL)."""
     d = golden(name)
-    orc = make_oracle(config, ap)
-    r = replay_chain_on_oracle(orc, d)
-    assert np.array_equal(r['pl_ch'], d['pl_ch'])
-    assert np.array_equal(r['pl_left'], d['pl_left'])
-    assert np.array_equal(r['pl_right'], d['pl_right'])
-    assert np.array_equal(r['pl_nph'], d['pl_photons'])
-    if 'pl_current' in d:
-        assert np.array_equal(r['cur'], d['pl_current'])
+    for fma in (True, False):
+        orc = make_oracle(with_fma(config, fma), ap)
+        if noise_override:
+            orc.set_noise_override(d['dg_ix_rand'])
+        r = replay_chain_on_oracle(orc, d)
+        assert np.array_equal(r['pl_ch'], d['pl_ch'])
+        assert np.array_equal(r['pl_left'], d['pl_left'])
+        assert np.array_equal(r['pl_right'], d['pl_right'])
+        assert np.array_equal(r['pl_nph'], d['pl_photons'])
+        if 'pl_current' in d:
+            if fma:
+                assert_currents_close(r['cur'], d['pl_current'], name)
+            else:
+                assert np.array_equal(r['cur'], d['pl_current'])
+        if fma:
+            assert np.array_equal(r['row_data'], d['row_data'])
+            for k in ['ch', 'left', 'right', 'data_off', 'data']:
+                assert np.array_equal(r['zl_' + k], d['zle_' + k]), k
     assert np.array_equal(r['dg_left'], d['dg_left'])
     assert np.array_equal(r['dg_right'], d['dg_right'])
     assert np.array_equal(r['row_ch'], d['row_ch'])
@@ -137,11 +166,8 @@ def test_record_packing_layout():
 
 
 def test_chain_noise():
-    d = golden('chain_noise.npz')
     cfg = xenonnt_test_config(enable_noise=True, noise_data=golden('noise.npz')['noise'])
-    orc = make_oracle(cfg)
-    orc.set_noise_override(d['dg_ix_rand'])
-    r = replay_chain_on_oracle(orc, d)
+    d, r, orc = _check_chain('chain_noise.npz', cfg, noise_override=True)
     assert np.array_equal(r['row_data'], d['row_data'])
     for k in ['ch', 'left', 'right', 'data']:
         assert np.array_equal(r['zl_' + k], d['zle_' + k]), k

@@ -108,6 +108,15 @@ __device__ __forceinline__ u32 gain_code(u32 w, u64 thr_dpe, double dpe_inv)
     return g1 | (g2 << 16);
 }
 
+// One term of Pulse.add_current (pulse.py:303-318): current += template * gain.  FMA = false: numpy's two roundings (the product,
+// then the sum; the library is compiled with -ffp-contract=off, so the two stay apart) -- currents bit-exact with the reference.
+// FMA = true (wfs_config.fma): one v_fma_f64, one rounding; half the f64 issue slots of every gather loop.
+template <bool FMA> __device__ __forceinline__ double mac(double a, double b, double c)
+{
+    if constexpr (FMA) return __builtin_fma(a, b, c);
+    else { const double prod = a * b; return c + prod; }
+}
+
 // Index of the wave inside its workgroup as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes but the compiler cannot know, and
 // everything computed from it (row descriptors, base pointers, loop bounds of the wave-per-row kernels) would sit in vector
 // registers and be recomputed by the vector unit; through readfirstlane it becomes SGPR work and scalar loads.

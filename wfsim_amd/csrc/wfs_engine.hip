@@ -6,6 +6,25 @@
 #include "wfs_tilegen.h"
 #include "../../include/wfsim_amd.h"
 
+// Every pulse kernel exists in two forms: FMA = true (wfs_config.fma, one rounding per template * gain term) and FMA = false (numpy's two
+// roundings, currents bit-exact with the reference).  The handle's switch picks one at launch time.
+#define K_S2_TILE_FULL(F) k_s2_tile<true, false, F>
+#define K_S2_TILE_FULL_AP(F) k_s2_tile<true, true, F>
+#define K_S2_TILE_GEN(F) k_s2_tile<false, false, F>
+#define K_S2_TILE_GEN_AP(F) k_s2_tile<false, true, F>
+#define K_PULSE_256_RES(F) k_pulse<256, true, F>
+#define K_PULSE_128_RES(F) k_pulse<128, true, F>
+#define K_PULSE_256_WIN(F) k_pulse<256, false, F>
+#define K_PULSE_128_WIN(F) k_pulse<128, false, F>
+#define K_PULSE_GENERIC(F) k_pulse_generic<256, F>
+#define K_PULSE_SPARSE_64(F) k_pulse_sparse<64, F>
+#define K_PULSE_SPARSE_256(F) k_pulse_sparse<256, F>
+#define K_PULSE_TINY(F) k_pulse_tiny<F>
+#define K_PULSE_WAVE(F) k_pulse_wave<F>
+#define WFS_LAUNCH_F(h, KM, grid, block, lds, ...) do { \
+    if ((h)->cfg.fma) hipLaunchKernelGGL(HIP_KERNEL_NAME(KM(true)), grid, block, lds, (h)->stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(KM(false)), grid, block, lds, (h)->stream, __VA_ARGS__); } while (0)
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -431,22 +450,17 @@ try {
     if (const char *e = getenv("WFS_TAP_SPARSE_MAX")) h->tap_sparse_max = std::min(atoi(e), TAP_LIST_LEN - 1);      // tuning knob of tap_block (results do not depend on it)
     if (build_time_tables(h) != WFS_OK) { delete h; return WFS_E_HIP; }
     // the pulse kernel stages up to 1024 start bins per tile: (10 * 1024 + 220) * 8 + 1024 * 4 bytes of LDS
-    hipFuncSetAttribute((const void *)k_pulse<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_pulse<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_pulse<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_pulse<128, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+#define WFS_BIG_LDS(K, B) hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (B) * 1024)
+#define WFS_BIG_LDS_F(KM, B) do { WFS_BIG_LDS(HIP_KERNEL_NAME(KM(true)), B); WFS_BIG_LDS(HIP_KERNEL_NAME(KM(false)), B); } while (0)
+    WFS_BIG_LDS_F(K_PULSE_256_RES, 100); WFS_BIG_LDS_F(K_PULSE_128_RES, 100); WFS_BIG_LDS_F(K_PULSE_256_WIN, 100); WFS_BIG_LDS_F(K_PULSE_128_WIN, 100);
     hipFuncSetAttribute((const void *)k_photon_fill<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_tile_order_big, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_pulse_generic<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    hipFuncSetAttribute((const void *)k_s2_tile<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_s2_tile<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_s2_tile<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_s2_tile<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_pulse_sparse<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-    hipFuncSetAttribute((const void *)k_pulse_sparse<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    WFS_BIG_LDS_F(K_PULSE_GENERIC, 128);
+    WFS_BIG_LDS_F(K_S2_TILE_FULL, 100); WFS_BIG_LDS_F(K_S2_TILE_FULL_AP, 100); WFS_BIG_LDS_F(K_S2_TILE_GEN, 100); WFS_BIG_LDS_F(K_S2_TILE_GEN_AP, 100);
+    WFS_BIG_LDS_F(K_PULSE_SPARSE_64, 100); WFS_BIG_LDS_F(K_PULSE_SPARSE_256, 100);
     *out = h;
     return WFS_OK;
 } WFS_CATCH(nullptr)
@@ -1361,10 +1375,10 @@ static int run_generation(wfs_handle *h)
         f.sparse_max = h->tap_sparse_max;
         Timer t(h, "k_s2_tile");
         const dim3 grid((unsigned)h->n_fused_tiles);
-        if (h->fuse_full && ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<true, true>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
-        else if (h->fuse_full) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<true, false>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
-        else if (ap_on) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<false, true>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_s2_tile<false, false>), grid, dim3(256), lds, h->stream, d, f, tp, app, ap_lds_off);
+        if (h->fuse_full && ap_on) WFS_LAUNCH_F(h, K_S2_TILE_FULL_AP, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
+        else if (h->fuse_full) WFS_LAUNCH_F(h, K_S2_TILE_FULL, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
+        else if (ap_on) WFS_LAUNCH_F(h, K_S2_TILE_GEN_AP, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
+        else WFS_LAUNCH_F(h, K_S2_TILE_GEN, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
     }
     h->fuse_args = f;
     if (ap_on) {
@@ -1520,7 +1534,7 @@ try {
         PulseArgs pt = pa;
         pt.desc = h->tile_desc.as<TileDesc>();
         Timer t(h, "k_pulse_tiny");
-        hipLaunchKernelGGL(k_pulse_tiny, dim3(nblocks(h->n_tiny_tiles * TINY_LANES, 256)), dim3(256), 0, h->stream, d, pt, h->n_tiny_tiles);
+        WFS_LAUNCH_F(h, K_PULSE_TINY, dim3(nblocks(h->n_tiny_tiles * TINY_LANES, 256)), dim3(256), 0, d, pt, h->n_tiny_tiles);
     }
     if (h->n_wave_tiles > 0) {          // work list order: tiny | sparse | dense | wave
         PulseArgs pw = pa;
@@ -1528,7 +1542,7 @@ try {
         pw.desc = h->tile_desc.as<TileDesc>() + first;
         if (pw.cur_off) pw.cur_off += first;
         Timer t(h, "k_pulse_wave");
-        hipLaunchKernelGGL(k_pulse_wave, dim3(nblocks(h->n_wave_tiles, 4)), dim3(256), 0, h->stream, d, pw, h->n_wave_tiles);
+        WFS_LAUNCH_F(h, K_PULSE_WAVE, dim3(nblocks(h->n_wave_tiles, 4)), dim3(256), 0, d, pw, h->n_wave_tiles);
     }
     if (h->n_sparse_tiles > 0) {
         PulseArgs ps = pa;
@@ -1540,8 +1554,8 @@ try {
         size_t lds = (size_t)ps.NP * 12 + (size_t)8 * (tpb / 64) * 8 + ((size_t)d.dt * ps.W + 8) * 2 + 8 * 4 + std::max((size_t)d.dt * ps.W * 2, (size_t)1 * 260 * 8) + 16;
         lds = (lds + 15) / 16 * 16;
         Timer t(h, "k_pulse_sparse");
-        if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_sparse<64>), dim3((unsigned)h->n_sparse_tiles), dim3(64), lds, h->stream, d, ps);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_sparse<256>), dim3((unsigned)h->n_sparse_tiles), dim3(256), lds, h->stream, d, ps);
+        if (small) WFS_LAUNCH_F(h, K_PULSE_SPARSE_64, dim3((unsigned)h->n_sparse_tiles), dim3(64), lds, d, ps);
+        else WFS_LAUNCH_F(h, K_PULSE_SPARSE_256, dim3((unsigned)h->n_sparse_tiles), dim3(256), lds, d, ps);
     }
     if (h->n_dense_tiles > 0 && h->generic_geom) {        // any digitiser geometry: one kernel for every tile
         PulseArgs pd = pa;
@@ -1551,7 +1565,7 @@ try {
         lds = (lds + 15) / 16 * 16;
         if (lds > 128 * 1024) return h->fail(WFS_E_CAPACITY, "sample_duration x template length too large for the LDS tables of k_pulse_generic");
         Timer t(h, "k_pulse_generic");
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse_generic<256>), dim3((unsigned)h->n_dense_tiles), dim3(256), lds, h->stream, d, pd);
+        WFS_LAUNCH_F(h, K_PULSE_GENERIC, dim3((unsigned)h->n_dense_tiles), dim3(256), lds, d, pd);
     } else if (h->n_dense_tiles > 0) {
         PulseArgs pd = pa;
         pd.active_tiles = h->active_tiles.as<i32>() + h->n_tiny_tiles + h->n_sparse_tiles;
@@ -1575,11 +1589,11 @@ try {
         const unsigned grid = (unsigned)(h->n_dense_tiles * pd.n_win);
         Timer t(h, "k_pulse_dense");
         if (pd.n_win == 1) {
-            if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128, true>), dim3(grid), dim3(128), lds, h->stream, d, pd, tp);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256, true>), dim3(grid), dim3(256), lds, h->stream, d, pd, tp);
+            if (small) WFS_LAUNCH_F(h, K_PULSE_128_RES, dim3(grid), dim3(128), lds, d, pd, tp);
+            else WFS_LAUNCH_F(h, K_PULSE_256_RES, dim3(grid), dim3(256), lds, d, pd, tp);
         } else {
-            if (small) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<128, false>), dim3(grid), dim3(128), lds, h->stream, d, pd, tp);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pulse<256, false>), dim3(grid), dim3(256), lds, h->stream, d, pd, tp);
+            if (small) WFS_LAUNCH_F(h, K_PULSE_128_WIN, dim3(grid), dim3(128), lds, d, pd, tp);
+            else WFS_LAUNCH_F(h, K_PULSE_256_WIN, dim3(grid), dim3(256), lds, d, pd, tp);
         }
     }
 

@@ -424,6 +424,7 @@ __global__ void k_tile_desc(WfsDev d, DescArgs a)
 // The gather of one sample (pulse.py:303-318 in the H-table form): thread `tid` owns the sample whose start bins are the H rows
 // tid (tap k = 21) .. tid + 21 (tap k = 0); it adds its tlen x dt possible contributions in ascending time, separate multiply and
 // add.  The tap loop is outermost so that only the dt taps of one k are live in SGPRs.
+template <bool FMA>
 __device__ __forceinline__ double tap_gather(const double *H, const TemplateArg &tp, int tid)
 {
     constexpr int dt = WFS_DT, tlen = 22;
@@ -435,12 +436,11 @@ __device__ __forceinline__ double tap_gather(const double *H, const TemplateArg 
         const double T0 = Tk[0], T1 = Tk[1], T2 = Tk[2], T3 = Tk[3], T4 = Tk[4], T5 = Tk[5], T6 = Tk[6], T7 = Tk[7], T8 = Tk[8], T9 = Tk[9];
         const double2 *hp = (const double2 *)(Hs - k * dt);
         const double2 h0 = hp[0], h1 = hp[1], h2 = hp[2], h3 = hp[3], h4 = hp[4];
-        double prod;
-        prod = T0 * h0.x; c = c + prod;  prod = T1 * h0.y; c = c + prod;
-        prod = T2 * h1.x; c = c + prod;  prod = T3 * h1.y; c = c + prod;
-        prod = T4 * h2.x; c = c + prod;  prod = T5 * h2.y; c = c + prod;
-        prod = T6 * h3.x; c = c + prod;  prod = T7 * h3.y; c = c + prod;
-        prod = T8 * h4.x; c = c + prod;  prod = T9 * h4.y; c = c + prod;
+        c = mac<FMA>(T0, h0.x, c); c = mac<FMA>(T1, h0.y, c);
+        c = mac<FMA>(T2, h1.x, c); c = mac<FMA>(T3, h1.y, c);
+        c = mac<FMA>(T4, h2.x, c); c = mac<FMA>(T5, h2.y, c);
+        c = mac<FMA>(T6, h3.x, c); c = mac<FMA>(T7, h3.y, c);
+        c = mac<FMA>(T8, h4.x, c); c = mac<FMA>(T9, h4.y, c);
     }
     return c;
 }
@@ -464,11 +464,12 @@ __device__ __forceinline__ void tap_w2_fill(double *W2, const double *templates,
 }
 // W2 is followed by the waves' lists: [TAP_W2_LEN doubles][tpb / 64][TAP_LIST_LEN] unsigned short
 // n_cells: the cells of H that hold data (the caller may have cleared only the rows its live samples can see)
+template <bool FMA>
 __device__ __forceinline__ double tap_block(const double *H, double *W2, const TemplateArg &tp, int tid, int sparse_max, int n_cells)
 {
     constexpr int dt = WFS_DT, tlen = 22, REACH = (64 + tlen - 1) * dt, NR = (REACH + 63) / 64;
     const int lane = tid & 63;
-    if (sparse_max < 0) return tap_gather(H, tp, tid);
+    if (sparse_max < 0) return tap_gather<FMA>(H, tp, tid);
     const double *Hw = H + (tid & ~63) * dt;            // first cell of the wave's reach
     const u32 *Hhi = (const u32 *)Hw + 1;               // high words
     unsigned short *list = (unsigned short *)(W2 + TAP_W2_LEN) + (tid >> 6) * TAP_LIST_LEN;
@@ -476,7 +477,7 @@ __device__ __forceinline__ double tap_block(const double *H, double *W2, const T
     const int c_end = min(REACH, n_cells - (tid & ~63) * dt);      // cells of the reach that hold data
     {   // rounds 6 and 7 (the middle of the reach) first
         const u32 a = 6 * 64 + lane < c_end ? Hhi[2 * (6 * 64 + lane)] : 0u, b = 7 * 64 + lane < c_end ? Hhi[2 * (7 * 64 + lane)] : 0u;
-        if (__popcll(__ballot(a != 0u)) + __popcll(__ballot(b != 0u)) > (sparse_max >> 2)) return tap_gather(H, tp, tid);      // wave-uniform
+        if (__popcll(__ballot(a != 0u)) + __popcll(__ballot(b != 0u)) > (sparse_max >> 2)) return tap_gather<FMA>(H, tp, tid);      // wave-uniform
     }
     int m = 0;
 #pragma unroll 1
@@ -494,7 +495,7 @@ __device__ __forceinline__ double tap_block(const double *H, double *W2, const T
             }
         }
     }
-    if (m > sparse_max) return tap_gather(H, tp, tid);   // wave-uniform
+    if (m > sparse_max) return tap_gather<FMA>(H, tp, tid);   // wave-uniform
     if (m == 0) return 0.0;
     // lane i <- entry i (behind the last entry: a cell no sample reaches)
     const int ci = lane < m ? (int)list[lane] : 0x7fff;
@@ -514,12 +515,12 @@ __device__ __forceinline__ double tap_block(const double *H, double *W2, const T
             w[u] = W2[idx];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const double prod = w[u] * g[u]; acc = acc + prod; }
+        for (int u = 0; u < 4; u++) acc = mac<FMA>(w[u], g[u], acc);
     }
     return acc;
 }
 
-template <int TPB, bool RESIDENT>
+template <int TPB, bool RESIDENT, bool FMA>
 __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateArg tp)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         // k are live in SGPRs.
         const bool act = c0 + tid < n_live;
         if (__any(act)) {                                  // wave-uniform
-            const double c = tap_block(H, W2, tp, tid, a.sparse_max, HROWS * dt);
+            const double c = tap_block<FMA>(H, W2, tp, tid, a.sparse_max, HROWS * dt);
             if (act) {
                 const i64 sx = lead + c0 + tid;            // sample of the tile
                 if (a.currents) a.currents[a.cur_off[tidx] + sx] = c;
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
 // path of every tile when the configuration differs from the XENONnT TPC digitiser.  Same bits as the reference (add_current).
 #define WFS_MAX_DT 16
 #define WFS_MAX_TLEN 256
-template <int TPB>
+template <int TPB, bool FMA>
 __global__ __launch_bounds__(TPB) void k_pulse_generic(WfsDev d, PulseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(TPB) void k_pulse_generic(WfsDev d, PulseArgs a)
             double c = 0.0;
             for (int k = tlen - 1; k >= 0; k--) {
                 const double *hp = H + (size_t)(tid + (tlen - 1) - k) * dt;
-                for (int r = 0; r < dt; r++) { const double prod = T[r * tlen + k] * hp[r]; c = c + prod; }
+                for (int r = 0; r < dt; r++) c = mac<FMA>(T[r * tlen + k], hp[r], c);
             }
             const i64 sx = lead + c0 + tid;
             if (a.currents) a.currents[a.cur_off[blockIdx.x] + sx] = c;
@@ -889,6 +890,7 @@ __global__ __launch_bounds__(TPB) void k_pulse_generic(WfsDev d, PulseArgs a)
 // sorted by time in registers, equal-ns photons merged (first of the run carries the summed gain), and every sample in
 // reach of a photon adds templates[r][k] * gain in ascending time with a separate multiply and add: the arithmetic of
 // add_current (pulse.py:276-318), hence the same bits as the other two kernels.  Truth sums need no reduction.
+template <bool FMA>
 __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n_tiny)
 {
     constexpr int dt = WFS_DT, tlen = 22, NP = TINY_MAX_PHOTONS;
@@ -970,7 +972,7 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
 #pragma unroll
         for (int k = 0; k < NP; k++) {
             const int kk = s - lead - jb[k];
-            if (k < n && kk >= 0 && kk < tlen) { const double prod = sT[rr[k] * tlen + kk] * g[k]; cur = cur + prod; }
+            if (k < n && kk >= 0 && kk < tlen) cur = mac<FMA>(sT[rr[k] * tlen + kk], g[k], cur);
         }
         if (a.currents) a.currents[a.cur_off[idx] + s] = cur;
         const i64 adc = -(i64)rint(cur * d.c2a);                 // rawdata.py:236
@@ -987,6 +989,7 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
 // list, their (bin, ns remainder, gain) are broadcast one at a time from the lane that holds them, and every sample in
 // reach adds templates[r][k] * gain with a separate multiply and add, in ascending time: the arithmetic of add_current
 // (pulse.py:276-318), the same bits as the other kernels.
+template <bool FMA>
 __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n_wave)
 {
     constexpr int dt = WFS_DT, tlen = 22;
@@ -1092,7 +1095,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
 #pragma unroll
             for (int u = 0; u < PW_U; u++) { int kk = sp - w[u].bin; kk = kk < -1 ? -1 : (kk > tlen ? tlen : kk); tap[u] = sTz[w[u].row + kk]; }
 #pragma unroll
-            for (int u = 0; u < PW_U; u++) { const double prod = tap[u] * w[u].g; c = c + prod; }
+            for (int u = 0; u < PW_U; u++) c = mac<FMA>(tap[u], w[u].g, c);
         }
         if (sp < n_live) {
             if (a.currents) a.currents[a.cur_off[idx] + lead + sp] = c;
@@ -1112,7 +1115,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
 // contributions from the contiguous slice of that list in ascending time.  Same bits as the dense kernel.
 #define SPARSE_PPT 16      // photons per thread held in registers: tile photons <= TPB * SPARSE_PPT
 
-template <int TPB>
+template <int TPB, bool FMA>
 __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1266,10 +1269,10 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
             for (; q + 2 <= q1; q += 2) {
                 const i32 o0 = ctoff[q], o1 = ctoff[q + 1];
                 const double g0 = cg[q], g1 = cg[q + 1];
-                const double a0 = Ts[o0] * g0, b0 = Ts[o0 + 1] * g0, a1 = Ts[o1] * g1, b1 = Ts[o1 + 1] * g1;
-                cur0 = cur0 + a0; cur1 = cur1 + b0; cur0 = cur0 + a1; cur1 = cur1 + b1;
+                cur0 = mac<FMA>(Ts[o0], g0, cur0); cur1 = mac<FMA>(Ts[o0 + 1], g0, cur1);
+                cur0 = mac<FMA>(Ts[o1], g1, cur0); cur1 = mac<FMA>(Ts[o1 + 1], g1, cur1);
             }
-            if (q < q1) { const i32 o0 = ctoff[q]; const double g0 = cg[q]; const double a0 = Ts[o0] * g0, b0 = Ts[o0 + 1] * g0; cur0 = cur0 + a0; cur1 = cur1 + b0; }
+            if (q < q1) { const i32 o0 = ctoff[q]; const double g0 = cg[q]; cur0 = mac<FMA>(Ts[o0], g0, cur0); cur1 = mac<FMA>(Ts[o0 + 1], g0, cur1); }
         }
         if (a.currents) { a.currents[a.cur_off[blockIdx.x] + sa] = cur0; if (sa + 1 < L) a.currents[a.cur_off[blockIdx.x] + sa + 1] = cur1; }
         const i64 adc0 = -(i64)rint(cur0 * d.c2a), adc1 = -(i64)rint(cur1 * d.c2a);      // rawdata.py:236

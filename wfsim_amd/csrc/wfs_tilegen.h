@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_tile_counts(WfsDev d, FuseArgs f)
 // AP: PMT afterpulses of the tile's photons (same channel, the afterpulse set of the instruction): screened here, photon by photon
 // (ap_screen_mask: counter (c0, gid, q) of the parent photon q of the tile), the candidates leave for the global list that
 // k_ap_finish works through (wfs_kernels.h); their photons become ordinary tiles of the afterpulse sets.
-template <bool FULL, bool AP>
+template <bool FULL, bool AP, bool FMA>
 __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, TemplateArg tp, const ApArgs *app, int ap_lds_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256, 6) void k_s2_tile(WfsDev d, FuseArgs f, Templa
         STAMP(d, 20);
         const bool act = c0 + tid < n_live;
         if (__any(act)) {                                  // wave-uniform
-            const double c = tap_block(H, W2, tp, tid, f.sparse_max, ncell);
+            const double c = tap_block<FMA>(H, W2, tp, tid, f.sparse_max, ncell);
             if (act) tb[d.tw + lead + c0 + tid] = (i32)(-(i64)rint(c * d.c2a));        // rawdata.py:236, np.around = round half to even
         }
         STAMP(d, 21);
