@@ -208,6 +208,18 @@ int wfs_scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const d
 int wfs_scalar_map_spline(wfs_handle *h, int32_t nx, const double *tx, int32_t ny, const double *ty, int32_t kx, int32_t ky,
                           const double *c, int32_t *map_id);
 int wfs_scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out);
+/* The other shapes make_map / InterpolatingMap can take (load_resource.py:357, 383-401): array-valued maps -- n_values entries per node,
+ * values f64[nodes][n_values], WeightedNearestNeighbors on a grid or a point list -- and method 'RegularGridInterpolator' on a regular
+ * grid (wfs_scalar_map_linear: scipy's multilinear interpolation with bounds_error=False, fill_value=None, i.e. the edge cell's plane
+ * continued outside the grid; scalar or array-valued).  wfs_scalar_map_eval_array: pos f64[n][dims] -> out f64[n][n_values];
+ * n_values must be the map's (wfs_scalar_map_eval is the n_values = 1 form).  Tolerance as above (multilinear: rtol 1e-12). */
+int wfs_scalar_map_grid_array(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
+                              const double *values, int32_t n_values, int32_t *map_id);
+int wfs_scalar_map_points_array(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values,
+                                int32_t n_values, int32_t *map_id);
+int wfs_scalar_map_linear(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi,
+                          const double *values, int32_t n_values, int32_t *map_id);
+int wfs_scalar_map_eval_array(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out, int32_t n_values);
 int wfs_copy_cdf_rows(wfs_handle *h, int32_t *cdf_row, double *cdf_table, int64_t cap_rows);
 
 /* Order of the packed records of a batch: 0 (default) as the reference yields pulses (window, channel, interval,
@@ -250,9 +262,11 @@ int wfs_get_counts(wfs_handle *h, wfs_counts *out);
 
 /* Electron afterpulses need, per parent S2, the number of detected photons and the arrival times of randomly chosen ones
  * (afterpulse.py:37-47, 106-121: len(signal_pulse._photon_timings), _photon_timings[randint]).
- * off[n + 1]: first generated photon of every instruction (generation order: instruction by instruction, emitter by
- * emitter); index: photons in that numbering, t_out: their arrival times in ns (recomputed from the photon's own draws,
- * so the answer does not depend on the order inside the channel buckets).  After wfs_run (also with debug bit 2). */
+ * off[n + 1]: first generated photon of every instruction (generation order: instruction by instruction; inside an instruction of
+ * the per-electron generator emitter by emitter, inside a tile-generated one (wfs_config.tile_gen) tile by tile -- channel ascending,
+ * photon q of a tile at position q); index: photons in that numbering, t_out: their arrival times in ns (recomputed from the photon's
+ * own draws, so the answer does not depend on the order inside the channel buckets -- and, for tile-generated instructions, not on
+ * any photon having been generated: debug bit 2 without bit 4 only draws the tiles' photon numbers).  After wfs_run (also with debug bit 2). */
 int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t capacity);
 int wfs_gather_photon_times(wfs_handle *h, int64_t n, const int64_t *index, int64_t *t_out);
 

@@ -325,3 +325,23 @@ def noise_high(mask, left, right, noise_len):
     f = lib().orc_noise_high
     f.restype = C.c_int64
     return int(f(C.c_int64(len(m)), _p(m), _p(l), _p(r), C.c_int64(int(noise_len))))
+
+
+def make_oracle(config, ap_tables=None, resource=None):
+    """An oracle session for a fax config: the scalars and host tables the HIP engine gets (wfsim_amd.config / tables / resource build
+    them for both sides), the run-set switch and the delay-model tables.  Used by tests/, __graft_entry__.smoke() and bench.py's
+    cpu_baseline leg -- never by the product path."""
+    from wfsim_amd import tables as T
+    from wfsim_amd.config import kernel_params, N_ROWS
+    from wfsim_amd.delay_models import DelayModels
+    from wfsim_amd.resource import Resource
+    resource = resource or Resource(config)
+    thr_truth, thr_zle = T.thresholds(config, N_ROWS)
+    lum_x, lum_t = T.luminescence_table(config)
+    tables = dict(templates=T.pmt_current_templates(config), spe=T.spe_scaling_table(resource.spe_charge, resource.spe_pdfs),
+                  gains=np.asarray(config['gains'], dtype=np.float64), thr_truth=thr_truth, thr_zle=thr_zle,
+                  lum_x=lum_x, lum_t=lum_t, noise=getattr(resource, 'noise_data', None))
+    orc = Oracle(kernel_params(config), tables, ap_tables)
+    orc.set_save_full_truth(config.get('save_full_truth', True))
+    orc.set_delay_models(DelayModels(config, resource))
+    return orc

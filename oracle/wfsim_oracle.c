@@ -977,20 +977,20 @@ static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, doubl
 /* s2.py:73-136 S2.__call__ (luminescence 'simple') for one instruction.  Candidate electron j < amp survives with
  * probability cy (s2.py:254 Binomial as Bernoulli trials); survivors draw s2.py:280-282 arrival time and
  * s2.py:308-310 photon count; photons as one_photon(). */
-#define TILE_MAX_PHOTONS 2048
-/* Tile-local generation (RNG spec v9; device: wfs_tilegen.h).  With one secondary gain for all electrons (s2_gain_spread == 0) the
+/* Tile-local generation (RNG spec v9, v11: tiles of any size; device: wfs_tilegen.h).  With one secondary gain for all electrons (s2_gain_spread == 0) the
  * photon counts per (electron, channel) are independent Poisson(g p_ch) variates (Poisson splitting of s2.py:308 + the
  * np.random.choice of :673), so a tile (instruction, channel) holds Poisson(n_surviving g p_ch) photons, each from a uniformly
  * drawn surviving electron -- the same joint distribution, drawn tile by tile.  The rule below is evaluated identically on the device. */
 static int fuse_eligible(const orc_session *s, int type, u32 em_base, i64 amp, double sc_gain, const double *cdf)
 {
     const orc_config *c = &s->c;
-    if (!c->tile_gen || c->gain_spread != 0.0 || s->n_ins_models > 0 || !s->save_full_truth) return 0;
+    if (!c->tile_gen || c->gain_spread != 0.0 || !s->save_full_truth) return 0;
+    if (s->cur_gg >= 0) return 0;                   /* 'garfield_gas_gap' luminescence: the instruction's photons share a mean (s2.py:447-450) */
     if (type != 2 || em_base != 0u || amp <= 0 || !(sc_gain > 0)) return 0;
     double pmax = 0.0;
     for (int ch = 0; ch < c->n_tpc; ch++) { const double p = cdf[ch] - (ch ? cdf[ch - 1] : 0.0); pmax = p > pmax ? p : pmax; }
     const double lam = (double)amp * sc_gain * pmax;
-    return lam >= (double)c->tile_gen_min && lam + 8.0 * sqrt(lam) + 8.0 <= (double)TILE_MAX_PHOTONS;
+    return lam >= (double)c->tile_gen_min && lam < 1.0e9;      /* (tile counts are 32-bit; which kernel makes a tile is the device's business) */
 }
 static i64 gen_s2(orc_session *s, call_ctx *x, int type, u32 gid, u32 em_base, i64 time, i64 amp, double cy, double drift_mean, double drift_spread,
                   double sc_gain, const double *cdf)
@@ -1025,13 +1025,14 @@ static i64 gen_s2(orc_session *s, call_ctx *x, int type, u32 gid, u32 em_base, i
         }
     }
     if (fused) {
-        const orc_tab *tab = &s->tab[TAB_S2_TOTAL];
         for (int ch = 0; ch < c->n_tpc && surv.n > 0; ch++) {
+            /* the instruction's table for this channel's array when timing-model variants are set (s2.py:504-557), else all S2 terms */
+            const orc_tab *tab = s->cur_tab >= 0 ? &s->xtab[ch >= c->n_top ? s->cur_tabb : s->cur_tab] : &s->tab[TAB_S2_TOTAL];
             const double p = cdf[ch] - (ch ? cdf[ch - 1] : 0.0);
             const double lam = (double)(i32)surv.n * sc_gain * p;
             const u32 c0 = em_base + (u32)ch;
             i64 N = poisson_site(s, c0, gid, SITE_TILE_N, lam);
-            if (N > TILE_MAX_PHOTONS) N = TILE_MAX_PHOTONS;
+            if (N > 0x3fffffffLL) N = 0x3fffffffLL;
             int sc = c->n_spe_channels > ch ? ch : 0;
             const double *row = s->spe + (i64)sc * 2001;
             for (i64 q = 0; q < N; q++) {                                       /* photon q of the tile: word q & 3 of three calls */

@@ -111,3 +111,32 @@ def test_gather_batches_with_unequal_numbers_of_rounds(tmp_path, world):
     got = np.load(out)
     ref = np.concatenate([r for rank in range(world) for r in _batches_of(rank)])
     assert got.tobytes() == ref.tobytes() and np.all(np.diff(got['time']) >= 0)
+
+
+def test_shard_plan_ranges_meet_and_cover_the_run():
+    """shard_plan (no communication: every rank computes it from the same instructions): slices partition the sorted instructions at
+    cluster boundaries, run-wide ids follow the slices, chunk ranges of consecutive non-empty shards meet at first key - rext"""
+    from wfsim_amd.config import xenonnt_test_config
+    from wfsim_amd.distributed import shard_plan
+    from wfsim_amd.dtypes import instruction_dtype
+    rng = np.random.default_rng(5)
+    n = 400
+    ins = np.zeros(n, dtype=instruction_dtype)
+    ins['type'] = rng.choice([1, 2], n)
+    ins['time'] = np.cumsum(rng.choice([300, 40_000, 30_000_000], n)).astype(np.int64) + 1_000_000
+    ins['z'], ins['amp'] = -rng.uniform(1, 90, n), rng.integers(1, 500, n)
+    cfg = xenonnt_test_config(enable_electron_afterpulses=False)
+    for world in (1, 2, 3, 8):
+        p = shard_plan(cfg, ins, world)
+        b = p['bounds']
+        assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) >= 0) and len(b) == world + 1
+        assert np.array_equal(np.sort(p['order']), np.arange(n))
+        nonempty = [r for r in range(world) if b[r + 1] > b[r]]
+        assert p['starts'][nonempty[0]] is None and p['ends'][nonempty[-1]] is None
+        for a, nxt in zip(nonempty[:-1], nonempty[1:]):
+            assert p['ends'][a] == p['starts'][nxt] == int(p['key'][b[nxt]]) - int(cfg['right_raw_extension'])
+            assert p['cluster'][b[nxt]] != p['cluster'][b[nxt] - 1]                  # a cut never splits a cluster
+            assert p['key'][b[nxt]] - p['key'][b[nxt] - 1] > cfg['right_raw_extension']
+    # two calls agree (what lets the ranks plan without talking to each other)
+    q = shard_plan(cfg, ins, 3)
+    assert np.array_equal(q['bounds'], shard_plan(cfg, ins.copy(), 3)['bounds'])

@@ -102,10 +102,92 @@ def test_bench_launches_its_own_ranks():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT')}
     env['WFS_BENCH_BACKEND'] = 'gloo'
-    for extra, gather in (([], 'none'), (['--gather'], 'gloo')):       # default: every rank keeps its records (no exchange step on this path)
+    # default: the step ends with the gather of every rank's records on rank 0 (the exchange step north_star names), overlapped with the
+    # next batch; the same run also reports the rate without it.  --no-gather: only that one.
+    for extra, gather in (([], 'send/recv'), (['--no-gather'], 'none')):
         r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--instructions', '12', '--steps', '2', '--warmup', '1',
                             '--cpu-sample', '0'] + extra, capture_output=True, text=True, cwd=root, env=env, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
         assert line['config']['instructions_per_gpu'] == 12 and gather in line['config']['gather']
+        if not extra:
+            assert 'gloo send/recv to rank 0, overlapped' in line['config']['gather'] and 'gathered on rank 0' in line['metric']
+            assert line['value_no_gather'] > 0 and line['config']['gather_ms_per_step'] > 0
+            assert line['config']['gather_bytes_per_step'] == 244 * line['config']['records_per_step']
+        else:
+            assert 'value_no_gather' not in line
+
+
+def _plugin_chunks(cfg):
+    import wfsim_amd
+    from wfsim_amd import ministrax
+    return ministrax.run_plugin(wfsim_amd.RawRecordsFromFaxNT(cfg))
+
+
+def _plugin_case():
+    cfg, ins = _case()
+    ok = (np.hypot(ins['x'], ins['y']) < cfg['tpc_radius']) & (ins['z'] < 0.25) & (ins['amp'] > 0) & ~((ins['type'] == 2) & (ins['z'] < -cfg['tpc_length']))
+    return dict(cfg, chunk_size=0.05), ins[ok]        # (what check_instructions accepts, strax_interface.py:687-700)
+
+
+def _assert_sharded_chunks_equal_single(parts, single, world):
+    for kind in ('raw_records', 'raw_records_he', 'raw_records_aqmon'):
+        ref = np.concatenate([c.data for c in single[kind]])
+        got = np.concatenate([c.data for p in parts for c in p[kind]])
+        assert got.tobytes() == ref.tobytes(), kind
+    assert len(np.concatenate([c.data for c in single['raw_records']])) > 1000
+    # truth rows: the same rows (a row without photons leaves with the chunk its instruction time falls into, which a shard cut can move)
+    ref = np.concatenate([c.data for c in single['truth']])
+    got = np.concatenate([c.data for p in parts for c in p['truth']])
+    assert len(got) == len(ref) and np.sort(got, order=['event_number', 'type', 'time']).tobytes() == np.sort(ref, order=['event_number', 'type', 'time']).tobytes()
+    # the chunk streams join: every rank's chunks are contiguous, rank r + 1 starts where rank r ended, every record inside its chunk
+    chunks = [c for p in parts for c in p['raw_records']]
+    assert len(chunks) >= world and all(a.end == b.start for a, b in zip(chunks[:-1], chunks[1:]))
+    assert chunks[0].start == single['raw_records'][0].start and chunks[-1].end == single['raw_records'][-1].end
+    for c in chunks:
+        if len(c.data):
+            assert c.data['time'].min() >= c.start and c.data['time'].max() <= c.end
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_plugin_sharded_delivery_equals_single_process(world):
+    """RawRecordsFromFaxNT with config['shard'] = (rank, world): every rank emits ITS time range as its own strax chunks (no gather, no
+    collective); the chunk streams of the ranks, one after the other, hold the single-process run byte for byte.  (The ranks need no
+    communication, so they can run one after the other in this process.)"""
+    cfg, ins = _plugin_case()
+    single = _plugin_chunks(dict(cfg, instructions=ins))
+    parts = [_plugin_chunks(dict(cfg, instructions=ins, shard=(r, world))) for r in range(world)]
+    assert all(len(p['raw_records']) for p in parts)
+    _assert_sharded_chunks_equal_single(parts, single, world)
+
+
+def _plugin_worker(rank, world, port, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import pickle
+    cfg, ins = _plugin_case()
+    res = _plugin_chunks(dict(cfg, instructions=ins, shard='auto'))            # rank and world size from the process group
+    with open(out + f'.{rank}.pkl', 'wb') as f:
+        pickle.dump({k: [(c.start, c.end, c.data) for c in v] for k, v in res.items()}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plugin_sharded_delivery_two_processes(tmp_path):
+    """the same with two processes of a torch.distributed group (gloo; shard = 'auto'), sharing the test box's GPU"""
+    import pickle
+    from types import SimpleNamespace
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / 'chunks')
+    mp.spawn(_plugin_worker, args=(2, port, out), nprocs=2, join=True)
+    parts = []
+    for r in range(2):
+        with open(out + f'.{r}.pkl', 'rb') as f:
+            parts.append({k: [SimpleNamespace(start=a, end=b, data=d) for a, b, d in v] for k, v in pickle.load(f).items()})
+    cfg, ins = _plugin_case()
+    _assert_sharded_chunks_equal_single(parts, _plugin_chunks(dict(cfg, instructions=ins)), 2)

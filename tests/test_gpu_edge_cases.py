@@ -41,6 +41,13 @@ def test_very_large_tiles_dense_kernel_multi_window():
     orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows))
     assert counts['n_photons'] > 2_000_000            # deep electrons are attenuated by the 650 us lifetime
     _compare(orc, o, eng, counts, s_ins)
+    # tiles of ~5000 photons are generated tile by tile in passes and reach the dense kernel in generation order: the truth rows equal
+    # the oracle's in every column, n_pe_trigger (pulse.py:255: the first n_dpe photons of the channel slice) included
+    acc, ts = eng.truth()
+    tr = o['truth'].reshape(-1, 12)
+    for k in range(len(tr)):
+        kk = int(np.argmin(np.abs(acc[:, 0] - tr[k, 0])))
+        assert np.allclose(acc[kk], tr[k], rtol=1e-9), (k, acc[kk], tr[k])
 
 
 def test_epoch_scale_times():
@@ -180,3 +187,23 @@ def test_fewer_channels_than_lanes(n_pmts):
     ph = eng.photons()
     assert counts['n_photons'] > 5000 and ph['ch'].min() >= 0 and ph['ch'].max() < n_pmts
     assert len(np.unique(ph['ch'])) == n_pmts
+
+
+def test_generation_order_of_tiles_beyond_the_workgroup_sort():
+    """Tiles of the per-electron generator with more than 4096 photons (an S2 of 3 x 10^4 electrons with a gain spread: ~6000 photons per
+    PMT, and PMT afterpulses riding along): the bucketing leaves them in slot order; their order keys go through the segmented radix sort
+    (k_tile_order_huge).  n_pe_trigger (pulse.py:255: the triggered photons among the FIRST n_dpe of the channel slice) then equals the
+    oracle's, like every other truth column."""
+    from tests.helpers import ap_tables_from_golden
+    cfg = xenonnt_test_config(seed=47, s2_secondary_sc_gain=100.0, s2_gain_spread=2.0)
+    rows = [dict(type=2, time=MS, x=0, y=0, z=-5.0, amp=30000), dict(type=1, time=3 * MS, x=1, y=1, z=-20, amp=4000)]
+    orc, o, eng, counts, s_ins = _run_both(cfg, _instructions(rows), ap=ap_tables_from_golden())
+    ph = eng.photons()
+    per_tile = np.bincount(ph['ch'][ph['set_off'][0]:ph['set_off'][1]], minlength=494)
+    assert per_tile.max() > 4096
+    _compare(orc, o, eng, counts, s_ins)
+    acc, ts = eng.truth()
+    tr = o['truth'].reshape(-1, 12)
+    for k in range(len(tr)):
+        kk = int(np.argmin(np.abs(acc[:, 0] - tr[k, 0])))
+        assert np.allclose(acc[kk], tr[k], rtol=1e-9), (k, acc[kk], tr[k])

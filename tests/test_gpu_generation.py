@@ -129,8 +129,9 @@ def test_mixed_clusters_and_large_s2():
 
 
 def test_tiles_above_one_register_batch():
-    """an S2 of ~4x10^6 PE: ~6000 photons per PMT, more than the 2048 the resident pulse kernel keeps in registers ->
-    the dense kernel runs one workgroup per (tile, window), and a second, small S2 rides along in the same launch"""
+    """an S2 of ~4x10^6 PE: ~6000 photons per PMT, more than the 2048 a pulse workgroup keeps in registers -> its tiles are generated
+    in passes (k_s2_tile<!FULL>, photons to the photon array in generation order) and pulsed by the dense kernel, one workgroup per
+    (tile, window); a second, small S2 rides along in the same launch"""
     cfg = xenonnt_test_config(s2_secondary_sc_gain=100.0)
     rows = [dict(type=2, time=MS, x=2, y=-1, z=-12, amp=40000), dict(type=2, time=3 * MS, x=0, y=0, z=-30, amp=200),
             dict(type=1, time=5 * MS, x=0, y=0, z=-30, amp=900)]
@@ -142,7 +143,7 @@ def test_tiles_above_one_register_batch():
     tr = o['truth'].reshape(-1, 12)
     big = int(np.argmax(acc[:, 0]))
     kbig = int(np.argmax(tr[:, 0]))
-    for j in (0, 1, 2, 4, 5, 6, 7, 8, 10, 11):          # all but n_pe_trigger(_bottom): order dependent (pulse.py:255)
+    for j in range(12):          # n_pe_trigger(_bottom) too: it depends on the photon order (pulse.py:255), the tiles are in generation order
         assert np.isclose(acc[big, j], tr[kbig, j], rtol=1e-9), j
 
 
@@ -209,7 +210,7 @@ def test_pmt_afterpulses_generated_on_device():
     _compare(orc, o, eng, counts, s_ins)
 
 
-@pytest.mark.parametrize('scale,scale_uniform,modifier', [(1.0, 1.0, 1.0), (12.0, 12.0, 0.37), (4.0, 4.0, 2.5), (2.0, 60.0, 2.5), (0.0, 0.0, 1.0)])
+@pytest.mark.parametrize('scale,scale_uniform,modifier', [(1.0, 1.0, 1.0), (12.0, 12.0, 0.37), (4.0, 4.0, 2.5), (2.0, 60.0, 2.5), (0.0, 0.0, 1.0), (3.0, 3.0, 0.0)])
 def test_pmt_afterpulse_screen_never_loses_an_afterpulse(scale, scale_uniform, modifier):
     """The generator screens afterpulse candidates with an integer threshold per (element, channel, single / double PE parent)
     (RNG spec v10, ap_threshold in wfs_engine.hip) and only candidates get the reference's floating-point comparison
@@ -227,7 +228,7 @@ def test_pmt_afterpulse_screen_never_loses_an_afterpulse(scale, scale_uniform, m
     n_ap = sum(o['call_ph_off'][k + 1] - o['call_ph_off'][k] for k in range(len(o['call_kind'])) if o['call_kind'][k] == 3)
     n_par = counts['n_photons'] - n_ap
     assert n_par > 15000
-    if scale == 0.0: assert n_ap == 0
+    if scale == 0.0 or modifier == 0.0: assert n_ap == 0          # (modifier 0: rU0 / 0 = inf accepts nothing, afterpulse.py:198)
     elif scale_uniform == 60.0: assert n_ap >= n_par     # P(Uniform) * modifier = 0.48 * 2.5 > 1: one for every parent, and the others
     else: assert n_ap > 500
     _compare(orc, o, eng, counts, s_ins)
@@ -260,3 +261,106 @@ def test_noise_on_generated_path():
     keep = g['right'] >= g['left']
     assert np.array_equal(g['ix_rand'][keep], o['dg_ix_rand']) and np.all(o['dg_ix_rand'] >= 0)
     _compare(orc, o, eng, counts, s_ins)
+
+
+@pytest.mark.parametrize('n_target', [1, 63, 65, 257])
+def test_tile_reductions_with_inactive_lanes(n_target, monkeypatch):
+    """Regression test of the round-3 fault: the tile's tmin / tmax / n_dpe reductions in k_s2_tile run on DPP moves, and a
+    DPP read of a switched-off lane inside a divergent region returns the old value -- a tile whose last wave has inactive lanes then
+    got a garbage time range.  Tile-generated S2s whose brightest tile holds about 1, 63, 65 and 257 photons on ONE channel (a pattern
+    row with all light on channel 17), so that the first / second / fifth wave of the workgroup is partly empty; every launch checked
+    (WFS_CHECK_LAUNCHES=1: a faulting kernel is named on the spot); device == oracle photon by photon, records byte for byte."""
+    monkeypatch.setenv('WFS_CHECK_LAUNCHES', '1')
+    from wfsim_amd.resource import Resource
+    cfg = dict(xenonnt_test_config(s2_secondary_sc_gain=n_target / 4.0), tile_local_min_photons=0, seed=40 + n_target)
+    ins = _instructions([dict(type=2, time=MS * (i + 1), x=0, y=0, z=-5 - i, amp=4) for i in range(12)])
+    res = Resource(cfg)
+    one_channel = np.zeros(494); one_channel[17] = 1.0
+    res.s2_pattern_map = (lambda pos, **kw: np.repeat(one_channel[None, :], len(pos), axis=0))      # a plain callable: host rows
+    order, key, cluster = schedule(ins, cfg)
+    s_ins, gid = ins[order], order.astype(np.uint32)
+    ip = instruction_params(s_ins, cfg, res)
+    orc = make_oracle(cfg, resource=res)
+    orc.simulate(s_ins, gid, ip)
+    o = orc.results()
+    eng = make_engine(cfg, resource=res)
+    eng.load_instructions(s_ins, gid, cluster, key, ip)
+    counts = eng.run()
+    assert set(np.unique(o['ph_ch'])) == {17}
+    sizes = np.diff(o['call_ph_off'])
+    assert sizes.min() >= 0 and abs(np.median(sizes) - n_target) < max(8, 0.5 * n_target)
+    _compare(orc, o, eng, counts, s_ins)
+
+
+@pytest.mark.parametrize('afterpulses', [False, True])
+def test_bright_tiles_next_to_ordinary_ones(afterpulses):
+    """A position dependent hit pattern: channel 17 takes 5 % of the light, channel 300 1 %, the others share the rest -- one S2 then
+    holds tiles of ~30000, ~6000 and ~1200 photons.  Which kernel makes a tile is decided per tile (k_tile_counts): up to 2048 photons
+    photons and pulse in one workgroup, above that generation in passes + the dense pulse kernel; the Philox coordinates of photon q
+    of a tile are the same either way.  Device == oracle photon by photon (PMT afterpulses included), records byte for byte, truth rows
+    equal in every column (n_pe_trigger depends on the order inside the channel: generation order on both sides)."""
+    from tests.helpers import ap_tables_from_golden
+    from wfsim_amd.resource import Resource
+    cfg = dict(xenonnt_test_config(s2_secondary_sc_gain=100.0), tile_local_min_photons=0, seed=77)
+    ap = ap_tables_from_golden() if afterpulses else None
+    if ap is not None:
+        cfg = dict(cfg, enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap)
+    ins = _instructions([dict(type=2, time=MS, x=0, y=0, z=-8, amp=6000), dict(type=2, time=3 * MS, x=1, y=1, z=-20, amp=900),
+                         dict(type=1, time=5 * MS, x=0, y=0, z=-30, amp=2000)])
+    res = Resource(cfg)
+    p = np.full(494, (1.0 - 0.06) / 492); p[17], p[300] = 0.05, 0.01
+    res.s2_pattern_map = (lambda pos, **kw: np.repeat(p[None, :], len(pos), axis=0))
+    order, key, cluster = schedule(ins, cfg)
+    s_ins, gid = ins[order], order.astype(np.uint32)
+    ip = instruction_params(s_ins, cfg, res)
+    orc = make_oracle(cfg, ap, resource=res)
+    orc.simulate(s_ins, gid, ip)
+    o = orc.results()
+    eng = make_engine(cfg, resource=res)
+    eng.load_instructions(s_ins, gid, cluster, key, ip)
+    counts = eng.run()
+    per_channel = np.bincount(o['ph_ch'][o['call_ph_off'][0]:o['call_ph_off'][1]], minlength=494)
+    assert per_channel[17] > 20000 and 2048 < per_channel[300] < 10000 and np.median(per_channel) < 2048
+    _compare(orc, o, eng, counts, s_ins)
+    acc, ts = eng.truth()
+    tr = o['truth'].reshape(-1, 12)
+    assert len(acc) == len(tr)
+    for k in range(len(tr)):
+        kk = int(np.argmin(np.abs(acc[:, 0] - tr[k, 0])))          # (sets are matched by their photon number)
+        assert np.allclose(acc[kk], tr[k], rtol=1e-9), (k, acc[kk], tr[k])
+
+
+def test_prepass_counts_and_photon_times_of_tile_generated_instructions():
+    """The electron-afterpulse pre-pass (rawdata.py:133-145 -> afterpulse.py:49, 70-87) needs, per parent S2, its photon number and the
+    arrival times of a few picked photons.  For tile-generated instructions both come from the tiles' counters and the photons' own
+    Philox coordinates -- no photon is generated in the pre-pass (Engine.generate()): the photon offsets equal the photons per
+    instruction of the full run, and the times recomputed for EVERY index of an instruction are, as a multiset, the times of its photons
+    in the full run (tile-generated S2s with ordinary and bright tiles, a small S2 and an S1 of the per-electron generator)."""
+    from wfsim_amd.resource import Resource
+    cfg = dict(xenonnt_test_config(s2_secondary_sc_gain=80.0), seed=61)          # default tile_local_min_photons: the small S2 keeps the per-electron generator
+    ins = _instructions([dict(type=2, time=MS, x=0, y=0, z=-8, amp=3000), dict(type=2, time=3 * MS, x=1, y=1, z=-20, amp=30),
+                         dict(type=1, time=5 * MS, x=0, y=0, z=-30, amp=2000), dict(type=2, time=7 * MS, x=2, y=-1, z=-40, amp=1500)])
+    res = Resource(cfg)
+    p = np.full(494, (1.0 - 0.05) / 493); p[40] = 0.05                            # channel 40 holds bright tiles (> 2048 photons)
+    res.s2_pattern_map = (lambda pos, **kw: np.repeat(p[None, :], len(pos), axis=0))
+    order, key, cluster = schedule(ins, cfg)
+    s_ins, gid = ins[order], order.astype(np.uint32)
+    ip = instruction_params(s_ins, cfg, res)
+    eng = make_engine(cfg, resource=res)
+    eng.load_instructions(s_ins, gid, cluster, key, ip)
+    eng.run()
+    ph = eng.photons()
+    n_per_ins = np.diff(ph['set_off'])[:len(s_ins)]
+    eng.keep_photons = False                                                      # the pre-pass proper: counts only
+    eng.generate()
+    off = eng.instruction_photon_offsets()
+    assert np.array_equal(np.diff(off), n_per_ins) and n_per_ins.max() > 100000
+    for i in range(len(s_ins)):
+        t = eng.gather_photon_times(np.arange(off[i], off[i + 1]))
+        ref = ph['t'][ph['set_off'][i]:ph['set_off'][i + 1]]
+        assert np.array_equal(np.sort(t), np.sort(ref)), i
+    # channel-major order inside a tile-generated instruction: the first photons are those of channel 0
+    c0 = int(np.sum(ph['ch'][ph['set_off'][0]:ph['set_off'][1]] == 0))
+    t0 = eng.gather_photon_times(np.arange(off[0], off[0] + c0))
+    sel = ph['ch'][ph['set_off'][0]:ph['set_off'][1]] == 0
+    assert np.array_equal(np.sort(t0), np.sort(ph['t'][ph['set_off'][0]:ph['set_off'][1]][sel]))

@@ -10,35 +10,7 @@ from wfsim_amd.dtypes import instruction_dtype, optical_extra_dtype
 pytestmark = pytest.mark.gpu
 
 
-def nveto_config(**kw):
-    kw.setdefault('right_raw_extension', 2000)
-    c = xenonnt_test_config(detector='XENONnT_neutron_veto', **kw)
-    n = 120
-    c['gains'] = np.full(n, 2e6)
-    c['gains'][7] = 0.0                       # one dead PMT
-    c['n_tpc_pmts'], c['n_top_pmts'] = n, 0
-    c['channels_bottom'] = np.array([], dtype=np.int64)
-    c['channel_map'] = dict(nveto=(2000, 2119), sum_signal=800, he=(500, 752))
-    c['photon_area_distribution'] = dict(c['photon_area_distribution'], n_channels=n)
-    return c
-
-
-def optical_instructions(n, rate_ns, seed):
-    rng = np.random.default_rng(seed)
-    ins = np.zeros(n, dtype=instruction_dtype + optical_extra_dtype)
-    ins['type'] = 1
-    ins['time'] = 1_000_000 + np.cumsum(rng.exponential(rate_ns, n)).astype(np.int64)
-    nph = rng.poisson(10, n)
-    ins['_first'] = np.concatenate([[0], np.cumsum(nph)[:-1]])
-    ins['_last'] = np.cumsum(nph)
-    ins['amp'] = nph
-    ins['event_number'] = np.arange(n)
-    tot = int(nph.sum())
-    channels = rng.integers(0, 120, tot)
-    timings = rng.exponential(60, tot).astype(np.int64)
-    timings[rng.random(tot) < 0.01] = -5          # a few photons outside the accepted window
-    timings[rng.random(tot) < 0.01] = 2_000_000
-    return ins, channels, timings
+from wfsim_amd.workloads import nveto_config, optical_instructions      # noqa: E402  (the builders of BASELINE configs[4])
 
 
 def test_nveto_high_rate_against_oracle():

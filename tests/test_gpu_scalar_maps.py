@@ -86,11 +86,14 @@ def test_one_dimensional_and_named_maps():
         assert np.allclose(dm(pos, map_name=name), m(pos, map_name=name), rtol=1e-6, atol=1e-12)
     # a NaN coordinate gives NaN (the host's KD-tree refuses it outright)
     assert np.isnan(dm(np.array([[np.nan]]))[0])
-    # array-valued maps and other methods stay on the host
+    # array-valued maps and method RegularGridInterpolator are evaluated on the device too (round 4: wfs_scalar_map_*_array / _linear)
     pm = InterpolatingMap(dict(coordinate_system=[['x', [0, 1, 3]], ['y', [0, 1, 3]]], map=np.ones((3, 3, 4))))
-    assert DeviceMap(eng, pm).ids == {}
+    assert set(DeviceMap(eng, pm).ids) == {'map'} and DeviceMap(eng, pm)(np.array([[0.3, 0.4]])).shape == (1, 4)
     rg = InterpolatingMap(dict(coordinate_system=[['x', [0, 1, 3]], ['y', [0, 1, 3]]], map=np.ones((3, 3))), method='RegularGridInterpolator')
-    assert DeviceMap(eng, rg).ids == {}
+    assert set(DeviceMap(eng, rg).ids) == {'map'}
+    # what stays on the host: a RegularGridInterpolator map given as a point list (straxen falls back to nearest neighbours there)
+    pl = InterpolatingMap(dict(coordinate_system=[[0.0, 0.0], [1.0, 0.0], [0.0, 1.0], [1.0, 1.0], [0.5, 0.5]], map=np.arange(5.0)), method='RegularGridInterpolator')
+    assert DeviceMap(eng, pl).ids == {}
 
 
 def point_map_config(map_seed, **kw):
@@ -169,3 +172,46 @@ def test_rawdata_with_all_maps_on_the_device_is_batching_invariant():
         rd.max_batch_quanta = quanta
         out.append(b''.join(w['records'].tobytes() for w in rd.iter_windows(ins)))
     assert out[0] == out[1] and len(out[0]) > 0
+
+
+@pytest.mark.parametrize('dims', [1, 2, 3])
+@pytest.mark.parametrize('nv', [1, 5])
+def test_regular_grid_interpolator_maps(dims, nv):
+    """method 'RegularGridInterpolator' (load_resource.py:357, 383-401: scipy's multilinear interpolation, bounds_error=False,
+    fill_value=None -- the edge cell continued outside the grid), scalar and array valued: wfs_scalar_map_linear ==
+    itp_map.InterpolatingMap (which calls scipy) to rtol 1e-10, positions outside the grid included"""
+    from wfsim_amd.device_maps import DeviceMap
+    rng = np.random.default_rng(10 * dims + nv)
+    axes = [('x', [-50.0, 50.0, 11]), ('y', [-40.0, 60.0, 7]), ('z', [-150.0, 0.0, 9])][:dims]
+    shape = tuple(a[1][2] for a in axes)
+    values = rng.normal(1.0, 0.3, shape + ((nv,) if nv > 1 else ()))
+    host = InterpolatingMap(dict(coordinate_system=[[n, list(r)] for n, r in axes], map=values), method='RegularGridInterpolator')
+    eng = make_engine(xenonnt_test_config())
+    dev = DeviceMap(eng, host)
+    assert 'map' in dev.ids
+    pos = np.array([rng.uniform(r[0] - 20, r[1] + 20, 4000) for _, r in axes]).T
+    got, ref = dev(pos), host(pos)
+    assert got.shape == ref.shape and np.allclose(got, ref, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize('points', [False, True])
+def test_array_valued_nearest_neighbour_maps(points):
+    """array-valued WeightedNearestNeighbors maps (make_map, load_resource.py:383-401) on a grid and on a point list: every value of a
+    node is averaged with the node's weight -- wfs_scalar_map_grid_array / _points_array == the host map to rtol 1e-6"""
+    from wfsim_amd.device_maps import DeviceMap
+    rng = np.random.default_rng(3 + points)
+    gx = np.linspace(-60, 60, 13)
+    X, Y = np.meshgrid(gx, gx, indexing='ij')
+    vals = np.stack([1.0 + 0.1 * np.cos(X / 20.0), 2.0 + 0.2 * np.sin(Y / 15.0), 0.5 + 0.001 * X * Y / 10], axis=-1)
+    if points:
+        p = np.array([X.ravel(), Y.ravel()]).T + rng.uniform(-1, 1, (X.size, 2))
+        data = dict(coordinate_system=p.tolist(), map=vals.reshape(-1, 3))
+    else:
+        data = dict(coordinate_system=[['x', [-60, 60, 13]], ['y', [-60, 60, 13]]], map=vals)
+    host = InterpolatingMap(data)
+    eng = make_engine(xenonnt_test_config())
+    dev = DeviceMap(eng, host)
+    assert 'map' in dev.ids
+    pos = rng.uniform(-70, 70, (3000, 2))
+    got, ref = dev(pos), host(pos)
+    assert got.shape == ref.shape == (3000, 3) and np.allclose(got, ref, rtol=1e-6)

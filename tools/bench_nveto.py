@@ -3,7 +3,7 @@ Reports sustained instructions/s through RawDataOptical.iter_windows (host sched
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import wfsim_amd
-from tests.test_gpu_optical import nveto_config, optical_instructions
+from wfsim_amd.workloads import nveto_config, optical_instructions
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 cfg = nveto_config(seed=31)

@@ -26,9 +26,8 @@ elif which == 's1':
 else:
     n_ev = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-    from tests.helpers import ap_tables_from_golden, golden
-    cfg = xenonnt_test_config(seed=4, chunk_size=5.0, enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap_tables_from_golden(),
-                              enable_noise=True, noise_data=golden('noise.npz')['noise'])
+    from wfsim_amd.workloads import mixed_config
+    cfg = mixed_config(seed=4, chunk_size=5.0)
     rng = np.random.default_rng(4)
     ins = np.zeros(2 * n_ev, dtype=instruction_dtype)
     ins['type'] = np.tile([1, 2], n_ev)

@@ -1,6 +1,8 @@
 """Turn the output of tools/profile_round.sh (gpurun_out/<tag>/) into the committed summaries under profiles/:
 <tag>_bench.json        the bench line
-<tag>_kernel_stats.csv  rocprofv3 --kernel-trace --stats
+<tag>_kernel_stats.csv  rocprofv3 --kernel-trace --stats (every dispatch of the profiled process, the cold first batch included)
+<tag>_kernel_stats_steady.csv  the same trace without the first batch of the process: per kernel calls / average / min / max duration of the
+                        dispatches that start behind the end of the first batch (its last k_pack) -- steady-state averages
 <tag>_traffic.json      FETCH_SIZE / WRITE_SIZE per launch -> HBM bytes, keyed by the engine's timer names
 <tag>_counters.json     SQ counters per launch and what they say limits each kernel
 python tools/make_profiles.py r2"""
@@ -41,6 +43,23 @@ json.dump(bench, open(os.path.join(dst, f'{tag}_bench.json'), 'w'), indent=1)
 stats = glob.glob(os.path.join(src, 'trace', '**', '*kernel_stats.csv'), recursive=True)
 if stats:
     shutil.copy(max(stats, key=os.path.getmtime), os.path.join(dst, f'{tag}_kernel_stats.csv'))
+# steady-state averages: the kernel trace itself, first batch of the process dropped (cold caches, first-touch allocations, code loading)
+traces = glob.glob(os.path.join(src, 'trace', '**', '*kernel_trace.csv'), recursive=True)
+if traces:
+    rows = list(csv.DictReader(open(max(traces, key=os.path.getmtime))))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    last = [r for r in rows if timer_name(r['Kernel_Name']) == 'k_pack']
+    t_cut = int(last[0]['End_Timestamp']) if last else 0
+    dur = collections.defaultdict(list)
+    for r in rows:
+        if int(r['Start_Timestamp']) > t_cut:
+            dur[timer_name(r['Kernel_Name'])].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+    total = sum(sum(v) for v in dur.values()) or 1
+    with open(os.path.join(dst, f'{tag}_kernel_stats_steady.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs'])
+        for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow([k, len(v), sum(v), round(sum(v) / len(v), 1), round(100.0 * sum(v) / total, 3), min(v), max(v)])
 fetch, n_fetch = per_launch('fetch')
 write, n_write = per_launch('write')
 out = dict(note='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), python bench.py --steps 1 --warmup 0 (the full headline batch), '

@@ -1,6 +1,6 @@
 # usage (on the GPU box, via gpurun): bash tools/profile_round.sh <tag> [bench args]
 # One round's profile evidence of the default bench command (the full 1000-instruction headline batch):
-#   bench line, rocprofv3 kernel trace + stats, HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes), SQ counters (three
+#   bench line, rocprofv3 kernel trace + stats (make_profiles.py also writes steady-state averages: the first batch of the process dropped), HBM traffic (FETCH_SIZE / WRITE_SIZE, separate passes), SQ counters (three
 #   passes of <= 8 counters; TA_* passes hang rocprofv3 on this pool and are left out).  Every pass has its own timeout.
 # Raw output goes to gpurun_out/<tag>/; tools/make_profiles.py <tag> turns it into the committed summaries under profiles/.
 TAG=${1:-r2}; shift
@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --cpu-sample 0 --no-copy-ceiling $*"
 python3 $R/bench.py --steps 5 --warmup 2 $* > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 3 --warmup 1 > $OUT/trace.log 2>&1; echo "trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps 6 --warmup 2 > $OUT/trace.log 2>&1; echo "trace rc=$?"
 run() { n=$1; shift; timeout -k 10 240 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$n -- $B --steps 1 --warmup 0 > $OUT/$n.log 2>&1; echo "$n rc=$?"; }
 run fetch FETCH_SIZE &&
 run write WRITE_SIZE &&

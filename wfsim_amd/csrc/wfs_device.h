@@ -117,6 +117,12 @@ template <bool FMA> __device__ __forceinline__ double mac(double a, double b, do
     else { const double prod = a * b; return c + prod; }
 }
 
+// Wave votes straight on the lane mask: HIP's __ballot / __any / __all take an int, which costs a v_cndmask (bool -> 0 / 1) and a v_cmp per
+// vote on the vector unit; the builtin compares into the scalar mask directly.  (Votes are over the ACTIVE lanes, as the HIP ones.)
+__device__ __forceinline__ u64 ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool any64(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ __forceinline__ bool all64(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
+
 // Index of the wave inside its workgroup as a SCALAR: threadIdx.x >> 6 is the same in all 64 lanes but the compiler cannot know, and
 // everything computed from it (row descriptors, base pointers, loop bounds of the wave-per-row kernels) would sit in vector
 // registers and be recomputed by the vector unit; through readfirstlane it becomes SGPR work and scalar loads.
@@ -170,9 +176,11 @@ __device__ __forceinline__ double wave_sum(double v)
 #define STAMP(d, i) do { if (threadIdx.x == 0 && (d).stamps) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
     unsigned long long *row_ = (d).stamps + (size_t)(blockIdx.x & 4095u) * 64; \
     atomicAdd(&row_[i], t_ - st_last_); atomicAdd(&row_[(i) + 32], 1ull); st_last_ = t_; } } while (0)
+#define STAMP_WAIT() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory")      // (charges the phase with the latency of what it issued)
 #else
 #define STAMP_INIT
 #define STAMP(d, i)
+#define STAMP_WAIT()
 #endif
 
 // python-style floor division / modulo on int64 (numpy // and % on int64, pulse.py:305-306)

@@ -2,6 +2,7 @@
 // stage orchestration on one HIP stream.  gfx950 (MI355X) only.
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include "wfs_kernels.h"
 #include "wfs_tilegen.h"
 #include "../../include/wfsim_amd.h"
@@ -59,6 +60,8 @@ struct wfs_handle {
     DevBuf set_gid, opt_t, opt_item, opt_first, opt_last, opt_ch, opt_time;
     int keep_currents = 0, profiling = 0;
     bool gen_done = false;
+    bool gen_order_ready = false;          // host tables of the generation order (gen_order_tables), valid for the current generation
+    std::vector<i64> go_off, go_block0; std::vector<i32> go_fused, go_tile_count;
     GenArgs gen_args{};           // the generator's view of the batch (kept for wfs_gather_photon_times)
     int carry_has = 0; i64 carry_runmax = 0;
     // tables
@@ -108,7 +111,7 @@ struct wfs_handle {
     struct PatternMap { bool set = false; i32 dims = 0, n[3] = {1, 1, 1}, w[3] = {0, 0, 0}, n_map_ch = 0; double lo[3] = {0, 0, 0}, hgrid[3] = {1, 1, 1}; DevBuf values;
                         i64 n_points = 0; DevBuf points; } pmap[2];
     // scalar maps (kind 0: weighted nearest neighbours on a regular grid, 1: on a point list, 2: RectBivariateSpline)
-    struct ScalarMap { int kind = 0; PatternMap g; i32 nx = 0, ny = 0, kx = 0, ky = 0; DevBuf tx, ty, c; };
+    struct ScalarMap { int kind = 0; int nv = 1; PatternMap g; i32 nx = 0, ny = 0, kx = 0, ky = 0; DevBuf tx, ty, c; };      // kind 0 / 1: nearest neighbours on a grid / a point list, 2: spline, 3: multilinear grid
     std::vector<std::unique_ptr<ScalarMap>> smaps;
     DevBuf smap_pos, smap_out, smap_nb_idx, smap_nb_w, ins_aft; bool ins_aft_set = false;
     // transverse diffusion with field maps: instructions whose pattern is averaged over their electrons (k_diffuse_patterns)
@@ -117,9 +120,10 @@ struct wfs_handle {
     DevBuf map_row_ins[2], map_row_id[2], map_x, map_y, map_z, map_nb_idx[2], map_nb_w[2];
 
     // tile-local generation (wfs_tilegen.h): S2 instructions whose photons are made inside the pulse workgroup
-    DevBuf row_pmax, ins_fused, ins_nsurv, ins_bcap, ins_bcap_all, ins_boff, et32, ftiles, tbuf, row_cnt, row_tile;
+    DevBuf huge_start, huge_cbeg, huge_keys, huge_keys2, huge_vals, huge_vals2, huge_rec, huge_gain;      // ordering of tiles beyond TILE_ORDER_MAX photons
+    DevBuf row_pmax, ins_fused, ins_nsurv, ins_bcap, ins_bcap_all, ins_boff, et32, ftiles, tbuf, row_cnt, row_tile, tile_done;
     bool fuse_on = false, fuse_full = false, run_sets_given = false, any_s2 = false;
-    i64 n_fused_tiles = 0, p_fused = 0, s_raw_direct = 0;
+    i64 n_fused_tiles = 0 /* made by k_s2_tile<FULL> */, n_gen_tiles = 0 /* tile-generated, pulse by the ordinary kernels */, p_fused = 0, s_raw_direct = 0;
     int tap_sparse_max = 48;     // tap_block: occupied cells up to which a wave of the dense pulse kernels walks them (WFS_TAP_SPARSE_MAX)
     FuseArgs fuse_args{};
 
@@ -138,7 +142,8 @@ namespace {
 // the low bits and the two roundings of the divisions are.  Everything else is a candidate and gets the reference's comparison.
 static u32 ap_threshold(double prob, double modifier, bool dpe)
 {
-    if (!(modifier > 0.0) || !(prob == prob)) return 0u;           // (nothing screened: the exact comparison decides)
+    if (modifier == 0.0) return 134217728u;                        // rU0 / 0 = inf <= prob never holds (afterpulse.py:198): no photon is a candidate
+    if (!(modifier > 0.0) || !(prob == prob)) return 0u;           // (negative / NaN: nothing screened, the exact comparison decides)
     const double pm = prob * modifier * (dpe ? 2.0 : 1.0) * (1.0 + 1e-9);
     if (!(pm < 1.0)) return 0u;
     const double a = std::floor((1.0 - pm) * 134217728.0) - 2.0;
@@ -489,7 +494,7 @@ try {
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal,
-        &h->ph_idx, &h->ap_key, &h->order_list, &h->order_list2, &h->ins_sbase, &h->tile_tail, &h->tile_tailbase, &h->ins_fullsort, &h->row_pmax, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile};
+        &h->ph_idx, &h->ap_key, &h->order_list, &h->order_list2, &h->ins_sbase, &h->tile_tail, &h->tile_tailbase, &h->ins_fullsort, &h->row_pmax, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile, &h->tile_done, &h->huge_start, &h->huge_cbeg, &h->huge_keys, &h->huge_keys2, &h->huge_vals, &h->huge_vals2, &h->huge_rec, &h->huge_gain};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
     for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft, &h->ins_sigr, &h->ins_siga, &h->diff_row_ins, &h->diff_row_id, &h->diff_pre}) if (b->p) hipFree(b->p);
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
@@ -910,27 +915,44 @@ static int smap_new(wfs_handle *h, std::unique_ptr<wfs_handle::ScalarMap> m, int
     return WFS_OK;
 }
 
-int wfs_scalar_map_grid(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi, const double *values, int32_t *map_id)
-try {
+static int scalar_map_grid(wfs_handle *h, int kind, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi, const double *values, int32_t n_values, int32_t *map_id)
+{
     if (!h || !map_id || !values) return WFS_E_INVALID;
+    if (n_values < 1 || n_values > 4096) return h->fail(WFS_E_INVALID, "scalar map: 1 .. 4096 values per node");
     HIPCHK(hipSetDevice(h->device));
     std::unique_ptr<wfs_handle::ScalarMap> m(new wfs_handle::ScalarMap()); size_t nodes = 0;
-    m->kind = 0;
+    m->kind = kind; m->nv = n_values;
     TRY(map_set_grid(h, m->g, dims, 1, n_nodes, lo, hi, nodes));
-    TRY(upload(h, m->g.values, values, nodes * 8));
+    TRY(upload(h, m->g.values, values, nodes * (size_t)n_values * 8));
     return smap_new(h, std::move(m), map_id);
-} WFS_CATCH(h)
+}
 
-int wfs_scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values, int32_t *map_id)
-try {
+int wfs_scalar_map_grid(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi, const double *values, int32_t *map_id)
+try { return scalar_map_grid(h, 0, dims, n_nodes, lo, hi, values, 1, map_id); } WFS_CATCH(h)
+
+int wfs_scalar_map_grid_array(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi, const double *values, int32_t n_values, int32_t *map_id)
+try { return scalar_map_grid(h, 0, dims, n_nodes, lo, hi, values, n_values, map_id); } WFS_CATCH(h)
+
+int wfs_scalar_map_linear(wfs_handle *h, int32_t dims, const int32_t *n_nodes, const double *lo, const double *hi, const double *values, int32_t n_values, int32_t *map_id)
+try { return scalar_map_grid(h, 3, dims, n_nodes, lo, hi, values, n_values, map_id); } WFS_CATCH(h)
+
+static int scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values, int32_t n_values, int32_t *map_id)
+{
     if (!h || !map_id || !values || !points || dims < 1 || dims > 3 || n_points < 2 * dims) return h ? h->fail(WFS_E_INVALID, "wfs_scalar_map_points: 1..3 dimensions, at least 2 * dims points") : WFS_E_INVALID;
+    if (n_values < 1 || n_values > 4096) return h->fail(WFS_E_INVALID, "scalar map: 1 .. 4096 values per node");
     HIPCHK(hipSetDevice(h->device));
     std::unique_ptr<wfs_handle::ScalarMap> m(new wfs_handle::ScalarMap());
-    m->kind = 1; m->g.dims = dims; m->g.n_points = n_points;
+    m->kind = 1; m->nv = n_values; m->g.dims = dims; m->g.n_points = n_points;
     TRY(upload(h, m->g.points, points, (size_t)n_points * dims * 8));
-    TRY(upload(h, m->g.values, values, (size_t)n_points * 8));
+    TRY(upload(h, m->g.values, values, (size_t)n_points * (size_t)n_values * 8));
     return smap_new(h, std::move(m), map_id);
-} WFS_CATCH(h)
+}
+
+int wfs_scalar_map_points(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values, int32_t *map_id)
+try { return scalar_map_points(h, dims, n_points, points, values, 1, map_id); } WFS_CATCH(h)
+
+int wfs_scalar_map_points_array(wfs_handle *h, int32_t dims, int64_t n_points, const double *points, const double *values, int32_t n_values, int32_t *map_id)
+try { return scalar_map_points(h, dims, n_points, points, values, n_values, map_id); } WFS_CATCH(h)
 
 int wfs_scalar_map_spline(wfs_handle *h, int32_t nx, const double *tx, int32_t ny, const double *ty, int32_t kx, int32_t ky, const double *c, int32_t *map_id)
 try {
@@ -944,31 +966,43 @@ try {
     return smap_new(h, std::move(m), map_id);
 } WFS_CATCH(h)
 
-int wfs_scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out)
-try {
+static int scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out, int32_t n_values)
+{
     if (!h) return WFS_E_INVALID;
     if (map_id < 0 || (size_t)map_id >= h->smaps.size() || n < 0 || (n && (!pos || !out))) return h->fail(WFS_E_INVALID, "wfs_scalar_map_eval: unknown map or missing arrays");
+    const auto &sm = *h->smaps[map_id];
+    if (sm.nv != n_values) return h->fail(WFS_E_INVALID, "wfs_scalar_map_eval: the map has another number of values per node (wfs_scalar_map_eval_array)");
     if (n == 0) return WFS_OK;
     HIPCHK(hipSetDevice(h->device));
-    const auto &sm = *h->smaps[map_id];
-    const int dims = sm.kind == 2 ? 2 : sm.g.dims;
-    TRY(upload(h, h->smap_pos, pos, (size_t)n * dims * 8)); TRY(ensure(h, h->smap_out, (size_t)n * 8));
+    const int dims = sm.kind == 2 ? 2 : sm.g.dims, nv = sm.nv;
+    TRY(upload(h, h->smap_pos, pos, (size_t)n * dims * 8)); TRY(ensure(h, h->smap_out, (size_t)n * nv * 8));
     if (sm.kind == 2) {
         SplineArgs a{sm.nx, sm.ny, sm.kx, sm.ky, sm.tx.as<double>(), sm.ty.as<double>(), sm.c.as<double>(), n, h->smap_pos.as<double>(), h->smap_out.as<double>()};
         Timer t(h, "k_map_spline"); hipLaunchKernelGGL(k_map_spline, dim3(nblocks(n, 128)), dim3(128), 0, h->stream, a);
+    } else if (sm.kind == 3) {
+        LinearMapArgs a{};
+        a.dims = dims; a.nv = nv; a.values = sm.g.values.as<double>(); a.n_rows = n; a.pos = h->smap_pos.as<double>(); a.out = h->smap_out.as<double>();
+        for (int q = 0; q < 3; q++) { a.n[q] = sm.g.n[q]; a.lo[q] = sm.g.lo[q]; a.h[q] = sm.g.hgrid[q]; }
+        Timer t(h, "k_map_linear"); hipLaunchKernelGGL(k_map_linear, dim3(nblocks(n * nv, 128)), dim3(128), 0, h->stream, a);
     } else {
         TRY(ensure(h, h->smap_nb_idx, (size_t)n * MAP_K * 8)); TRY(ensure(h, h->smap_nb_w, (size_t)n * MAP_K * 8));
         MapArgs m{};
         map_args(sm.g, m);
         m.n_rows = n; m.pos = h->smap_pos.as<double>(); m.nb_idx = h->smap_nb_idx.as<i64>(); m.nb_w = h->smap_nb_w.as<double>();
         launch_neighbours(h, m);
-        { Timer t(h, "k_map_scalar"); hipLaunchKernelGGL(k_map_scalar, dim3(nblocks(n, 128)), dim3(128), 0, h->stream, m, sm.g.values.as<double>(), h->smap_out.as<double>()); }
+        { Timer t(h, "k_map_scalar"); hipLaunchKernelGGL(k_map_scalar, dim3(nblocks(n * nv, 128)), dim3(128), 0, h->stream, m, sm.g.values.as<double>(), h->smap_out.as<double>(), nv); }
     }
-    HIPCHK(hipMemcpyAsync(out, h->smap_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out, h->smap_out.p, (size_t)n * nv * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipGetLastError());
     return WFS_OK;
-} WFS_CATCH(h)
+}
+
+int wfs_scalar_map_eval(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out)
+try { return scalar_map_eval(h, map_id, n, pos, out, 1); } WFS_CATCH(h)
+
+int wfs_scalar_map_eval_array(wfs_handle *h, int32_t map_id, int64_t n, const double *pos, double *out, int32_t n_values)
+try { return scalar_map_eval(h, map_id, n, pos, out, n_values); } WFS_CATCH(h)
 
 int wfs_eval_pattern_rows(wfs_handle *h, int64_t n, const float *x, const float *y, const float *z)
 try {
@@ -1214,13 +1248,18 @@ static int run_generation(wfs_handle *h)
     // tile-local generation (wfs_tilegen.h): which instructions take it is decided before the electrons are drawn -- theirs get no
     // photon numbers.  Debug modes that need the per-photon arrays (currents, generation only) run the generation half alone.
     const bool ap_cfg = h->ap_active;
-    h->fuse_on = h->cfg.tile_gen && !h->generic_geom && h->any_s2 && !ext && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
+    h->fuse_on = h->cfg.tile_gen && !h->generic_geom && h->any_s2 && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
     (void)ap_cfg;                                // (PMT afterpulses of tile-generated photons are screened inside k_s2_tile)
     h->fuse_full = h->fuse_on && !(h->keep_currents & 5);
-    h->n_fused_tiles = 0; h->p_fused = 0;
+    h->n_fused_tiles = 0; h->n_gen_tiles = 0; h->p_fused = 0;
     FuseArgs f{};
     if (h->fuse_on) {
         f.lam_min = h->cfg.tile_gen_min; f.n_ins = N; f.nch = d.n_tpc; f.table_span = (i32)(1u << (32 - d.tab_s2.shift));
+        f.n_top = d.n_top;
+        if (ext) {       // timing-model variants: the instruction's tables (the longest one bounds every tile buffer)
+            f.tabs = g.tabs; f.ins_tab = g.ins_tab; f.ins_tabb = g.ins_tabb; f.ins_gg = g.gg_inv ? g.ins_gg : nullptr;
+            for (const AliasTab &t : h->h_tabs) if (t.cell) f.table_span = std::max(f.table_span, (i32)(1u << (32 - t.shift)));
+        }
         f.ins_type = g.ins_type; f.ins_amp = g.ins_amp; f.ins_sc = g.ins_sc; f.ins_embase = g.ins_embase; f.ins_gid = g.ins_gid; f.ins_cdfrow = g.ins_cdfrow;
         f.cdf_table = g.cdf_table; f.ins_time = g.ins_time; f.em_off = g.em_off; f.em_time = g.em_time; f.el_minmax = g.el_minmax; f.scal = g.scal;
         TRY(ensure(h, h->ins_fused, (size_t)N * 4)); TRY(ensure(h, h->ins_nsurv, (size_t)N * 4)); TRY(ensure(h, h->ins_bcap, (size_t)N * 4));
@@ -1273,14 +1312,15 @@ static int run_generation(wfs_handle *h)
         // surviving electrons compacted per instruction, tile buffers sized from their time range, photons per tile (Poisson)
         { Timer t(h, "k_fuse_electrons"); hipLaunchKernelGGL(k_fuse_electrons, dim3((unsigned)N), dim3(256), 0, h->stream, d, f); }
         TRY(scan(h, h->ins_bcap_all.as<i32>(), N, h->ins_boff, 23));
-        TRY(ensure(h, h->ftiles, (size_t)TP * sizeof(FTile)));
+        TRY(ensure(h, h->ftiles, (size_t)TP * sizeof(FTile))); TRY(ensure(h, h->tile_done, (size_t)TP * 4));
         f.ins_boff = h->ins_boff.as<i64>(); f.tile_count = h->tile_count.as<i32>(); f.tiles = h->ftiles.as<FTile>();
+        f.tile_done = h->tile_done.as<i32>(); f.full = h->fuse_full ? 1 : 0; f.n_list = TP;
         { Timer t(h, "k_tile_counts"); hipLaunchKernelGGL(k_tile_counts, dim3(nblocks(TP, 256)), dim3(256), 0, h->stream, d, f); }
     }
     TRY(scan(h, h->em_nph.as<i32>(), E, h->em_ph_off, 6));
     TRY(read_scal(h));
     const i64 P = h->h_scal[6];                 // photons of the block generator; the tiles' own photons come on top
-    if (h->fuse_on) { h->p_fused = h->h_scal[24]; h->n_fused_tiles = h->h_scal[25]; }
+    if (h->fuse_on) { h->p_fused = h->h_scal[24]; h->n_fused_tiles = h->h_scal[25]; h->n_gen_tiles = h->h_scal[28]; }
     h->n_photons = P + h->p_fused; h->n_ap_photons = 0;
     g.em_ph_off = h->em_ph_off.as<i64>(); g.n_photons = P;
     const bool ap_on = h->ap_active;
@@ -1354,7 +1394,10 @@ static int run_generation(wfs_handle *h)
     } else {
         TRY(scan_into(h, h->tile_count.as<i32>(), TP, h->tile_off.as<i64>(), 7, 0));
     }
-    if (h->fuse_on && h->n_fused_tiles > 0) {
+    // (photon counts only -- wfs_set_debug bit 2 without bit 4, the electron-afterpulse pre-pass: the tiles' photon numbers are drawn
+    // (k_tile_counts) and single photons are recomputed on request (wfs_gather_photon_times); no photon of a tile is generated)
+    const bool counts_only = (h->keep_currents & 4) && !(h->keep_currents & 16);
+    if (h->fuse_on && h->n_fused_tiles + h->n_gen_tiles > 0 && !counts_only) {
         // the tiles' photons and pulses (before the geometry: the tile time ranges come out of this kernel)
         TRY(ensure(h, h->tbuf, (size_t)h->h_scal[23] * 4 + 64));
         TRY(ensure(h, h->tile_truth, (size_t)T * 8 * 8));
@@ -1362,23 +1405,32 @@ static int run_generation(wfs_handle *h)
         f.tbuf = h->tbuf.as<i32>(); f.ph = h->ph.as<PhotonRec>(); f.keep_ph = (h->keep_currents & 16) ? 1 : 0;
         TemplateArg tp;
         for (int k = 0; k < 22; k++) for (int r = 0; r < WFS_DT; r++) tp.t[k * WFS_DT + r] = h->h_templates[r * 22 + k];
-        size_t lds = (size_t)(256 + d.tlen - 1) * d.dt * 8 + 4 * 4 * 4 + TAP_LDS_BYTES(256) + 64;
+        // H table + the waves' counters; the exact form adds the tables of tap_block (the fused form gathers every sample densely)
+        size_t lds = (size_t)(WFS_TILE_CHUNK + d.tlen - 1) * d.dt * 8 + 4 * 4 * 4 + (h->cfg.fma ? 16 : TAP_LDS_BYTES(256) + 64);
         lds = (lds + 15) / 16 * 16;
         const int ap_lds_off = (int)lds;                         // afterpulse candidates of the tile (AP variants)
         const ApArgs *app = nullptr;
         if (ap_on) {
             lds += (size_t)AP_STAGE * sizeof(ApCand);
-            TRY(ensure(h, h->ap_seg, (size_t)h->n_fused_tiles * sizeof(ApSeg))); ap.seg = h->ap_seg.as<ApSeg>(); ap.n_seg = h->n_fused_tiles;
+            TRY(ensure(h, h->ap_seg, (size_t)(h->n_fused_tiles + h->n_gen_tiles) * sizeof(ApSeg))); ap.seg = h->ap_seg.as<ApSeg>(); ap.n_seg = h->n_fused_tiles + h->n_gen_tiles;
             f.n_ptiles = TP;
             TRY(upload(h, h->ap_args_dev, &ap, sizeof ap)); app = h->ap_args_dev.as<ApArgs>();      // (`ap` outlives the copy: read_scal below)
         }
         f.sparse_max = h->tap_sparse_max;
-        Timer t(h, "k_s2_tile");
-        const dim3 grid((unsigned)h->n_fused_tiles);
-        if (h->fuse_full && ap_on) WFS_LAUNCH_F(h, K_S2_TILE_FULL_AP, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
-        else if (h->fuse_full) WFS_LAUNCH_F(h, K_S2_TILE_FULL, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
-        else if (ap_on) WFS_LAUNCH_F(h, K_S2_TILE_GEN_AP, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
-        else WFS_LAUNCH_F(h, K_S2_TILE_GEN, grid, dim3(256), lds, d, f, tp, app, ap_lds_off);
+        // tiles of up to 2048 photons: photons and pulse in one workgroup (listed from the front); brighter ones -- and every tile in the
+        // debug modes -- generation only (listed from the back), their pulses are made by the ordinary kernels below
+        if (h->n_fused_tiles > 0) {
+            Timer t(h, "k_s2_tile");
+            const dim3 grid((unsigned)h->n_fused_tiles);
+            if (ap_on) WFS_LAUNCH_F(h, K_S2_TILE_FULL_AP, grid, dim3(256), lds, d, f, tp, app, ap_lds_off, (i64)0, 1, 0);
+            else WFS_LAUNCH_F(h, K_S2_TILE_FULL, grid, dim3(256), lds, d, f, tp, app, ap_lds_off, (i64)0, 1, 0);
+        }
+        if (h->n_gen_tiles > 0) {
+            Timer t(h, "k_s2_tile_gen");
+            const dim3 grid((unsigned)h->n_gen_tiles);
+            if (ap_on) WFS_LAUNCH_F(h, K_S2_TILE_GEN_AP, grid, dim3(256), lds, d, f, tp, app, ap_lds_off, TP - 1, -1, (int)h->n_fused_tiles);
+            else WFS_LAUNCH_F(h, K_S2_TILE_GEN, grid, dim3(256), lds, d, f, tp, app, ap_lds_off, TP - 1, -1, (int)h->n_fused_tiles);
+        }
     }
     h->fuse_args = f;
     if (ap_on) {
@@ -1398,7 +1450,7 @@ static int run_generation(wfs_handle *h)
         TRY(ensure(h, h->order_list, (size_t)T * 2 * sizeof(OrderRange))); TRY(ensure(h, h->order_list2, (size_t)T * 2 * sizeof(OrderRange)));
         OrderArgs oa{T, TP, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->ph.as<PhotonRec>(), h->ph_idx.as<u32>(),
                      ap_on ? h->ph_gain.as<double>() : nullptr, P + h->p_fused, h->order_list.as<OrderRange>(), h->order_list2.as<OrderRange>(), h->scal.as<i64>(),
-                     (h->fuse_on && h->n_fused_tiles > 0) ? h->ins_fused.as<i32>() : nullptr, d.n_tpc,
+                     (h->fuse_on && h->n_fused_tiles + h->n_gen_tiles > 0) ? h->ins_fused.as<i32>() : nullptr, d.n_tpc,
                      h->tile_cursor.as<i32>(), h->tile_tailbase.as<i32>(), h->ins_fullsort.as<i32>(), h->set_ins_off.as<i64>(), h->set_ins_list.as<i32>()};
         { Timer t(h, "k_tile_order_scan"); hipLaunchKernelGGL(k_tile_order_scan, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, oa); }
         TRY(read_scal(h));
@@ -1407,6 +1459,32 @@ static int run_generation(wfs_handle *h)
         if (n_big > 0) {
             Timer t(h, "k_tile_order_big");
             hipLaunchKernelGGL(k_tile_order_big, dim3((unsigned)n_big), dim3(256), (size_t)TILE_ORDER_MAX * 24, h->stream, oa);
+        }
+        const i64 n_huge = h->h_scal[19];
+        if (n_huge > 0) {
+            // ranges beyond the workgroup sort: compact copies, one segmented radix sort over (order key, position), records to their ranks
+            std::vector<OrderRange> rg((size_t)n_huge);
+            HIPCHK(hipMemcpy(rg.data(), h->order_list2.as<OrderRange>() + (2 * T - n_huge), (size_t)n_huge * sizeof(OrderRange), hipMemcpyDeviceToHost));
+            std::sort(rg.begin(), rg.end(), [](const OrderRange &x, const OrderRange &y) { return x.start < y.start; });      // (appended with atomics: a fixed order for the offsets)
+            std::vector<i64> start((size_t)n_huge), cbeg((size_t)n_huge + 1, 0);
+            for (i64 k = 0; k < n_huge; k++) { start[(size_t)k] = rg[(size_t)k].start; cbeg[(size_t)k + 1] = cbeg[(size_t)k] + rg[(size_t)k].n; }
+            const i64 tot = cbeg[(size_t)n_huge];
+            if (tot > 0xffffffffLL) return h->fail(WFS_E_CAPACITY, "more than 2^32 photons in tiles beyond 4096 photons");
+            TRY(upload(h, h->huge_start, start.data(), start.size() * 8)); TRY(upload(h, h->huge_cbeg, cbeg.data(), cbeg.size() * 8));
+            TRY(ensure(h, h->huge_keys, (size_t)tot * 4)); TRY(ensure(h, h->huge_keys2, (size_t)tot * 4)); TRY(ensure(h, h->huge_vals, (size_t)tot * 4)); TRY(ensure(h, h->huge_vals2, (size_t)tot * 4));
+            TRY(ensure(h, h->huge_rec, (size_t)tot * 8)); TRY(ensure(h, h->huge_gain, (size_t)tot * 8));
+            HugeOrderArgs ha{n_huge, tot, h->huge_start.as<i64>(), h->huge_cbeg.as<i64>(), oa.ph, oa.ph_idx, oa.ph_gain, oa.gain_first,
+                             h->huge_keys.as<u32>(), h->huge_vals.as<u32>(), h->huge_rec.as<PhotonRec>(), h->huge_gain.as<double>()};
+            Timer t(h, "k_tile_order_huge");
+            hipLaunchKernelGGL(k_order_huge_pack, dim3(nblocks(tot, 256)), dim3(256), 0, h->stream, ha);
+            size_t bytes = 0;
+            HIPCHK(rocprim::segmented_radix_sort_pairs(nullptr, bytes, h->huge_keys.as<u32>(), h->huge_keys2.as<u32>(), h->huge_vals.as<u32>(), h->huge_vals2.as<u32>(),
+                                                       (unsigned)tot, (unsigned)n_huge, h->huge_cbeg.as<i64>(), h->huge_cbeg.as<i64>() + 1, 0u, 32u, h->stream));
+            TRY(ensure(h, h->sort_tmp, bytes));
+            HIPCHK(rocprim::segmented_radix_sort_pairs(h->sort_tmp.p, bytes, h->huge_keys.as<u32>(), h->huge_keys2.as<u32>(), h->huge_vals.as<u32>(), h->huge_vals2.as<u32>(),
+                                                       (unsigned)tot, (unsigned)n_huge, h->huge_cbeg.as<i64>(), h->huge_cbeg.as<i64>() + 1, 0u, 32u, h->stream));
+            hipLaunchKernelGGL(k_order_huge_apply, dim3(nblocks(tot, 256)), dim3(256), 0, h->stream, ha, h->huge_keys2.as<u32>(), h->huge_vals2.as<u32>(), h->ph.as<PhotonRec>(), h->ph_idx.as<u32>(),
+                               ap_on ? h->ph_gain.as<double>() : nullptr);
         }
     }
     h->gen_args = g;
@@ -1418,7 +1496,7 @@ try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded) return h->fail(WFS_E_STATE, "no batch loaded");
     if (h->dev_rows_pending && !h->injected && !h->optical) return h->fail(WFS_E_STATE, "instructions with cdf_row -1: call wfs_eval_pattern_rows before wfs_run");
-    h->ran = false; h->gen_done = false;
+    h->ran = false; h->gen_done = false; h->gen_order_ready = false;
     HIPCHK(hipSetDevice(h->device));
     for (auto &t : h->times) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     h->times.clear();
@@ -1459,7 +1537,7 @@ try {
     if (tiles_done) {
         TRY(ensure(h, h->row_cnt, (size_t)CG * d.n_tpc * 4)); TRY(ensure(h, h->row_tile, (size_t)CG * d.n_tpc * 4));
         HIPCHK(hipMemsetAsync(h->row_cnt.p, 0, (size_t)CG * d.n_tpc * 4, h->stream));
-        ga.tile_done_ins = h->ins_fused.as<i32>(); ga.n_done = h->n_ins; ga.row_cnt = h->row_cnt.as<i32>(); ga.row_tile = h->row_tile.as<i32>();
+        ga.tile_done = h->tile_done.as<i32>(); ga.n_done = h->n_psets * d.n_tpc; ga.row_cnt = h->row_cnt.as<i32>(); ga.row_tile = h->row_tile.as<i32>();
         ga.ins_bcap = h->ins_bcap.as<i32>(); ga.ins_boff = h->ins_boff.as<i64>();
     }
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 1024)), dim3(1024), 0, h->stream, d, ga); }
@@ -1620,7 +1698,7 @@ try {
     za.acc_off = h->acc_off.as<i64>(); za.raw = h->raw.as<i32>(); za.grp_left = h->grp_left.as<i64>(); za.grp_ixrand = h->grp_ixrand.as<i64>();
     za.itv_off = h->itv_off.as<i64>(); za.itv_left = h->itv_left.as<i64>(); za.itv_right = h->itv_right.as<i64>();
     za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = 110;
-    if (tiles_done) { za.tile_done_ins = ga.tile_done_ins; za.n_done = ga.n_done; za.row_cnt = ga.row_cnt; za.row_tile = ga.row_tile; za.ins_bcap = ga.ins_bcap; za.ins_boff = ga.ins_boff; za.tbuf = h->tbuf.as<i32>(); }
+    if (tiles_done) { za.tile_done = ga.tile_done; za.n_done = ga.n_done; za.row_cnt = ga.row_cnt; za.row_tile = ga.row_tile; za.ins_bcap = ga.ins_bcap; za.ins_boff = ga.ins_boff; za.tbuf = h->tbuf.as<i32>(); }
     h->row_dbg_total = 0;
     if ((h->keep_currents & 1) && h->n_active_rows > 0) {
         std::vector<i32> ar((size_t)h->n_active_rows);
@@ -1930,16 +2008,42 @@ try {
     return WFS_OK;
 } WFS_CATCH(h)
 
-int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t cap)
-try {
-    if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
-    if (h->fuse_on && h->n_fused_tiles > 0) return h->fail(WFS_E_STATE, "photons in generation order do not exist with tile-local generation (wfs_config.tile_gen = 0 for the electron-afterpulse pre-pass)");
-    const i64 N = h->n_ins;
-    if (cap < N + 1) return h->fail(WFS_E_CAPACITY, "offset buffer too small");
+// Generation order of a batch's photons as the electron-afterpulse pre-pass sees it (rawdata.py:133-145 hands the parent S2's photons to
+// afterpulse.py): instruction by instruction; the photons of an instruction of the per-electron generator in its generation order, those
+// of a tile-generated instruction tile by tile (channel ascending), photon q of a tile at position q.  Host-side tables of that order,
+// built once per generation.
+static int gen_order_tables(wfs_handle *h)
+{
+    if (h->gen_order_ready) return WFS_OK;
+    const i64 N = h->n_ins; const int nch = h->dev.n_tpc;
     std::vector<i64> emo((size_t)N + 1), epo((size_t)h->n_emitters + 1);
     HIPCHK(hipMemcpy(emo.data(), h->em_off.p, emo.size() * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(epo.data(), h->em_ph_off.p, epo.size() * 8, hipMemcpyDeviceToHost));
-    for (i64 i = 0; i <= N; i++) off[i] = epo[(size_t)emo[i]];
+    h->go_fused.assign((size_t)N, 0); h->go_tile_count.clear();
+    const bool any_fused = h->fuse_on && h->n_fused_tiles + h->n_gen_tiles > 0;
+    if (any_fused) {
+        HIPCHK(hipMemcpy(h->go_fused.data(), h->ins_fused.p, (size_t)N * 4, hipMemcpyDeviceToHost));
+        h->go_tile_count.resize((size_t)N * nch);
+        HIPCHK(hipMemcpy(h->go_tile_count.data(), h->tile_count.p, h->go_tile_count.size() * 4, hipMemcpyDeviceToHost));      // (one pulse set per instruction: tile = instruction * n_tpc + channel)
+    }
+    h->go_off.assign((size_t)N + 1, 0); h->go_block0.assign((size_t)N, 0);
+    for (i64 i = 0; i < N; i++) {
+        i64 n = epo[(size_t)emo[i + 1]] - epo[(size_t)emo[i]];           // (0 for a tile-generated instruction: its electrons carry no photon numbers)
+        h->go_block0[i] = epo[(size_t)emo[i]];
+        if (any_fused && h->go_fused[i]) for (int c = 0; c < nch; c++) n += h->go_tile_count[(size_t)i * nch + c];
+        h->go_off[i + 1] = h->go_off[i] + n;
+    }
+    h->gen_order_ready = true;
+    return WFS_OK;
+}
+
+int wfs_copy_instruction_photon_offsets(wfs_handle *h, int64_t *off, int64_t cap)
+try {
+    if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
+    const i64 N = h->n_ins;
+    if (cap < N + 1) return h->fail(WFS_E_CAPACITY, "offset buffer too small");
+    TRY(gen_order_tables(h));
+    for (i64 i = 0; i <= N; i++) off[i] = h->go_off[(size_t)i];
     return WFS_OK;
 } WFS_CATCH(h)
 
@@ -1948,12 +2052,40 @@ try {
     if (!h || !h->gen_done || h->injected || h->optical) return WFS_E_STATE;
     if (n <= 0) return WFS_OK;
     if (!index || !t_out) return h->fail(WFS_E_INVALID, "wfs_gather_photon_times: null argument");
-    for (i64 i = 0; i < n; i++) if (index[i] < 0 || index[i] >= h->n_photons) return h->fail(WFS_E_INVALID, "photon index out of range");
+    TRY(gen_order_tables(h));
+    const i64 N = h->n_ins; const int nch = h->dev.n_tpc;
+    for (i64 i = 0; i < n; i++) if (index[i] < 0 || index[i] >= h->go_off[(size_t)N]) return h->fail(WFS_E_INVALID, "photon index out of range");
     HIPCHK(hipSetDevice(h->device));
-    TRY(upload(h, h->gather_idx, index, (size_t)n * 8)); TRY(ensure(h, h->gather_out, (size_t)n * 8));
-    hipLaunchKernelGGL(k_photon_times, dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->dev, h->gen_args, n, h->gather_idx.as<i64>(), h->gather_out.as<i64>());
-    HIPCHK(hipMemcpyAsync(t_out, h->gather_out.p, (size_t)n * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
+    // requests of the per-electron generator (index in ITS photon order) and of tile-generated instructions (instruction, channel, q)
+    std::vector<i64> blk_idx, blk_pos, tile_pos; std::vector<TileTimeReq> treq;
+    for (i64 k = 0; k < n; k++) {
+        const i64 i = (i64)(std::upper_bound(h->go_off.begin(), h->go_off.end(), (i64)index[k]) - h->go_off.begin()) - 1;
+        i64 local = index[k] - h->go_off[(size_t)i];
+        if (!h->go_fused[(size_t)i]) { blk_idx.push_back(h->go_block0[(size_t)i] + local); blk_pos.push_back(k); continue; }
+        int c = 0;
+        const i32 *cnt = &h->go_tile_count[(size_t)i * nch];
+        while (c < nch - 1 && local >= cnt[c]) { local -= cnt[c]; c++; }
+        treq.push_back(TileTimeReq{(i32)i, (i32)c, (i32)local, 0}); tile_pos.push_back(k);
+    }
+    std::vector<i64> got;
+    if (!blk_idx.empty()) {
+        const i64 m = (i64)blk_idx.size();
+        TRY(upload(h, h->gather_idx, blk_idx.data(), (size_t)m * 8)); TRY(ensure(h, h->gather_out, (size_t)m * 8));
+        hipLaunchKernelGGL(k_photon_times, dim3(nblocks(m, 256)), dim3(256), 0, h->stream, h->dev, h->gen_args, m, h->gather_idx.as<i64>(), h->gather_out.as<i64>());
+        got.resize((size_t)m);
+        HIPCHK(hipMemcpyAsync(got.data(), h->gather_out.p, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (i64 k = 0; k < m; k++) t_out[blk_pos[(size_t)k]] = got[(size_t)k];
+    }
+    if (!treq.empty()) {
+        const i64 m = (i64)treq.size();
+        TRY(upload(h, h->gather_idx, treq.data(), (size_t)m * sizeof(TileTimeReq))); TRY(ensure(h, h->gather_out, (size_t)m * 8));
+        hipLaunchKernelGGL(k_tile_photon_times, dim3(nblocks(m, 256)), dim3(256), 0, h->stream, h->dev, h->fuse_args, m, h->gather_idx.as<TileTimeReq>(), h->gather_out.as<i64>());
+        got.resize((size_t)m);
+        HIPCHK(hipMemcpyAsync(got.data(), h->gather_out.p, (size_t)m * 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        for (i64 k = 0; k < m; k++) t_out[tile_pos[(size_t)k]] = got[(size_t)k];
+    }
     return WFS_OK;
 } WFS_CATCH(h)
 

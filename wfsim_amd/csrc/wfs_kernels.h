@@ -127,8 +127,8 @@ struct GeomArgs {
     i32 *sparse_tiles;   // sparse-class tiles (few photons per start bin: sorted-list kernel)
     i32 *dense_tiles;    // everything else (dense H-table kernel, windows over time)
     i32 *wave_tiles;     // medium tiles (at most 64 photons, any width: wave per tile); scal[17] = their number
-    const i32 *tile_done_ins;   // [n_done] 1: the tiles of this instruction (= pulse set) were simulated by k_s2_tile: on no work list (or nullptr)
-    i64 n_done;                 // primary pulse sets (afterpulse sets, which follow them, are never done)
+    const i32 *tile_done;       // [n_done] 1: the tile's pulse was made by k_s2_tile<FULL> (wfs_tilegen.h): on no work list (or nullptr)
+    i64 n_done;                 // primary tiles (the tiles of the afterpulse sets, which follow them, are never done)
     i32 *row_cnt, *row_tile;    // [groups * n_tpc] tiles in the row; one of them
     const i32 *ins_bcap; const i64 *ins_boff;      // tile sample buffers (wfs_tilegen.h)
     i32 force_dense;     // debug: send every tile to the dense kernel
@@ -170,7 +170,7 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
         cnt = a.tile_count[tile];
         if (!a.force_dense) cls = (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1
                                   : ((cnt <= WAVE_MAX_PHOTONS && nb <= WAVE_MAX_BINS) ? 3 : 2));
-        if (a.tile_done_ins && set < a.n_done && a.tile_done_ins[set]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
+        if (a.tile_done && tile < a.n_done && a.tile_done[tile]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
     }
     {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
         const u64 ml = __ballot(live);
@@ -318,11 +318,11 @@ __global__ void k_group_final(WfsDev d, GeomArgs a)
     a.grp_ixrand[g] = ix;
 }
 
-__device__ __forceinline__ bool row_is_direct(const i32 *done_ins, i64 n_done, const i32 *row_cnt, const i32 *row_tile, i64 ridx, int nch)
+__device__ __forceinline__ bool row_is_direct(const i32 *tile_done, i64 n_done, const i32 *row_cnt, const i32 *row_tile, i64 ridx)
 {
-    if (!done_ins || row_cnt[ridx] != 1) return false;
-    const i64 set = row_tile[ridx] / nch;
-    return set < n_done && done_ins[set] != 0;
+    if (!tile_done || row_cnt[ridx] != 1) return false;
+    const i64 tile = row_tile[ridx];
+    return tile < n_done && tile_done[tile] != 0;
 }
 
 // per (group, row slot): accumulator length and reserved ZLE interval slots; list of rows with data
@@ -344,7 +344,7 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
             i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
             cap = (i32)((len + hold) / (hold + 1));
             // a row made by ONE tile whose samples exist already (k_s2_tile) is read from the tile's buffer: no accumulators
-            const bool direct = row_is_direct(a.tile_done_ins, a.n_done, a.row_cnt, a.row_tile, g * d.n_tpc + ch, d.n_tpc);
+            const bool direct = row_is_direct(a.tile_done, a.n_done, a.row_cnt, a.row_tile, g * d.n_tpc + ch);
             if (slot < d.n_tpc) { a.acc_len[g * d.n_tpc + ch] = direct ? 0 : (i32)len; if (direct) atomicAdd(&s_direct, (i32)len); }
             if (slot < d.n_tpc && a.row_cnt && a.row_cnt[g * d.n_tpc + ch] > 1) atomicAdd(&s_shared, 1);
             rk = atomicAdd(&s_n, 1);
@@ -1343,7 +1343,7 @@ struct ZleArgs {
     struct RowDesc *desc;        // [n_active_rows] everything a row's wave needs, prepared by k_row_desc
     const u32 *rec_dest;         // record order by (time, channel): slot of record r in the output (nullptr: row order)
     u64 *rec_key; u32 *rec_val; i64 *key_base;     // k_rec_keys: sort key (sample - *key_base) << 12 | channel, and the record index; *key_base = first sample of the batch (k_row_desc)
-    const i32 *tile_done_ins, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf; i64 n_done;      // rows read from a tile buffer in place (wfs_tilegen.h)
+    const i32 *tile_done, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf; i64 n_done;      // rows read from a tile buffer in place (wfs_tilegen.h)
 };
 
 // One 64-byte descriptor per active row (thread per row: the divisions and the five dependent look-ups of a row are
@@ -1369,7 +1369,7 @@ __global__ void k_row_desc(WfsDev d, ZleArgs a)
     RowDesc q;
     q.acc_off = a.acc_off[ridx]; q.row_abs = a.row_lo[ridx] - d.tw; q.ixr = a.grp_ixrand[g]; q.itv_base = a.itv_off[idx];
     q.src = 0;
-    if (row_is_direct(a.tile_done_ins, a.n_done, a.row_cnt, a.row_tile, ridx, d.n_tpc)) {
+    if (row_is_direct(a.tile_done, a.n_done, a.row_cnt, a.row_tile, ridx)) {
         const i32 tile = a.row_tile[ridx]; const i32 ins = tile / d.n_tpc;
         q.acc_off = a.ins_boff[ins] + (i64)(tile - ins * d.n_tpc) * a.ins_bcap[ins]; q.src = 1;
     }
@@ -2438,18 +2438,50 @@ __global__ __launch_bounds__(256) void k_diffuse_patterns(WfsDev d, GenArgs a, M
 }
 
 // scalar maps (LCE, S2 correction, SE gain, longitudinal diffusion ...: s1.py:125, s2.py:170-234): the weighted average itself
-__global__ void k_map_scalar(MapArgs m, const double *values, double *out)
+// (nv values per node: array-valued maps, load_resource.py:383-401 make_map -- one thread per (position, value))
+__global__ void k_map_scalar(MapArgs m, const double *values, double *out, int nv)
 {
-    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= m.n_rows) return;
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= m.n_rows * nv) return;
+    const i64 r = t / nv; const int v = (int)(t - r * nv);
     double num = 0, den = 0;
     for (int k = 0; k < MAP_K; k++) {
         const i64 i = m.nb_idx[r * MAP_K + k];
         if (i < 0) continue;
         const double w = m.nb_w[r * MAP_K + k];
-        num += values[i] * w; den += w;
+        num += values[i * nv + v] * w; den += w;
     }
-    out[r] = den > 0 ? num / den : __builtin_nan("");
+    out[t] = den > 0 ? num / den : __builtin_nan("");
+}
+
+// scipy.interpolate.RegularGridInterpolator(method='linear', bounds_error=False, fill_value=None) -- what straxen's InterpolatingMap
+// builds for method 'RegularGridInterpolator' (load_resource.py:357, 383-401): multilinear inside the grid, the edge cell's plane
+// continued outside it.  Per axis the cell (clamped to [0, n - 2]) and the normalised distance to its lower node, then the sum over
+// the cell's 2^dims corners of value * product of weights, corners in scipy's order (itertools.product of (i, i + 1) per axis).
+struct LinearMapArgs { i32 dims, nv; i32 n[3]; double lo[3], h[3]; const double *values; i64 n_rows; const double *pos; double *out; };
+__global__ void k_map_linear(LinearMapArgs a)
+{
+    const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= a.n_rows * a.nv) return;
+    const i64 r = t / a.nv; const int v = (int)(t - r * a.nv);
+    i64 cell[3] = {0, 0, 0}; double f[3] = {0, 0, 0};
+    for (int q = 0; q < a.dims; q++) {
+        const double x = (a.pos[r * a.dims + q] - a.lo[q]) / a.h[q];
+        i64 c = (i64)floor(x);
+        c = c < 0 ? 0 : (c > a.n[q] - 2 ? a.n[q] - 2 : c);
+        cell[q] = c; f[q] = x - (double)c;
+    }
+    double sum = 0.0;
+    for (int corner = 0; corner < (1 << a.dims); corner++) {
+        double w = 1.0; i64 idx = 0;
+        for (int q = 0; q < a.dims; q++) {
+            const int up = (corner >> (a.dims - 1 - q)) & 1;
+            w *= up ? f[q] : 1.0 - f[q];
+            idx = idx * a.n[q] + cell[q] + up;
+        }
+        sum += a.values[idx * a.nv + v] * w;
+    }
+    a.out[t] = sum;
 }
 
 // scipy.interpolate.RectBivariateSpline.ev (the field-dependence and COMSOL distortion maps, load_resource.py:316, 326): FITPACK's
@@ -3067,14 +3099,17 @@ __global__ __launch_bounds__(256) void k_ap_seg(WfsDev d, GenArgs a, ApArgs ap, 
 // does), and two things depend on that order: the truth quirk that counts the triggered photons among the FIRST n_dpe of the
 // channel slice (pulse.py:255) and the order in which three or more photons of one ns are merged.  Every stored photon carries
 // its order key (ph_idx); tiles whose keys are out of order are listed (one thread per tile) and sorted: by a wave up to 64
-// photons (rank by counting smaller keys), by a workgroup in LDS up to TILE_ORDER_MAX; larger ones keep the order they have
-// (documented: n_pe_trigger is then only statistically right).  Explicit gains (afterpulses) move along.
+// photons (rank by counting smaller keys), by a workgroup in LDS up to TILE_ORDER_MAX; larger ones -- tiles of the per-electron
+// generator beyond 4096 photons: S2s of 10^5 electrons with a gain spread or inside run sets -- go on a third list and through a
+// segmented radix sort over (order key, position) pairs (k_order_huge_pack / rocPRIM / k_order_huge_apply, wfs_engine.hip).
+// Explicit gains (afterpulses) move along.
 #define TILE_ORDER_MAX 4096
 #define TILE_ORDER_INLINE 12        // ranges up to this many photons are sorted by the scanning thread itself
 struct OrderRange { i64 start; i32 n, pad; };          // photons [start, start + n) of the photon array
 struct OrderArgs { i64 n_tiles, n_ptiles; const i32 *tile_count; const i64 *tile_off; PhotonRec *ph; u32 *ph_idx; double *ph_gain; i64 gain_first;
                    OrderRange *wave_list, *big_list; i64 *scal;      // ph_gain[p - gain_first] for photons p >= gain_first (afterpulses), or nullptr;
-                                                                     // scal[30] / scal[31]: ranges on the wave list / the workgroup list
+                                                                     // scal[30] / scal[31]: ranges on the wave list / the workgroup list; ranges beyond
+                                                                     // TILE_ORDER_MAX photons: big_list[2 n_tiles - 1 - k], scal[19] of them
                    const i32 *skip_ins; i32 nch;                     // [n_ins] 1: the tiles of this instruction (tile / nch) come from k_s2_tile, already in order (or nullptr)
                    const i32 *tile_cursor, *tile_tailbase; const i32 *ins_fullsort; const i64 *set_ins_off; const i32 *set_ins_list; };
                    // primary tiles of a set whose (first) instruction is not flagged ins_fullsort: head = [0, cursor), tail = [tailbase, n)
@@ -3091,7 +3126,7 @@ __device__ __forceinline__ void order_range(const OrderArgs &a, i64 start, i32 n
     u32 prev = k[0];
     for (i32 q = 1; q < n; q++) { const u32 x = k[q]; if (x < prev) { sorted = false; break; } prev = x; }
     if (sorted) return;
-    if (n > TILE_ORDER_INLINE) { cls = n <= 64 ? 0 : (n <= TILE_ORDER_MAX ? 1 : -1); return; }
+    if (n > TILE_ORDER_INLINE) { cls = n <= 64 ? 0 : (n <= TILE_ORDER_MAX ? 1 : 2); return; }
     const bool has_gain = a.ph_gain && start >= a.gain_first;
     for (i32 i = 1; i < n; i++) {                            // insertion sort of a handful of records
         const u32 key = a.ph_idx[start + i]; const PhotonRec r = a.ph[start + i];
@@ -3108,8 +3143,8 @@ __device__ __forceinline__ void order_range(const OrderArgs &a, i64 start, i32 n
 }
 __global__ __launch_bounds__(256) void k_tile_order_scan(OrderArgs a)
 {
-    __shared__ i32 s_n[2]; __shared__ i64 s_base[2];
-    if (threadIdx.x < 2) s_n[threadIdx.x] = 0;
+    __shared__ i32 s_n[3]; __shared__ i64 s_base[3];
+    if (threadIdx.x < 3) s_n[threadIdx.x] = 0;
     __syncthreads();
     const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     OrderRange rg[2] = {{0, 0, 0}, {0, 0, 0}}; int cls[2] = {-1, -1}, rk[2] = {0, 0};
@@ -3126,9 +3161,40 @@ __global__ __launch_bounds__(256) void k_tile_order_scan(OrderArgs a)
         }
     }
     __syncthreads();
-    if (threadIdx.x < 2 && s_n[threadIdx.x]) s_base[threadIdx.x] = (i64)atomicAdd((u64 *)&a.scal[30 + threadIdx.x], (u64)s_n[threadIdx.x]);
+    if (threadIdx.x < 3 && s_n[threadIdx.x]) s_base[threadIdx.x] = (i64)atomicAdd((u64 *)&a.scal[threadIdx.x < 2 ? 30 + threadIdx.x : 19], (u64)s_n[threadIdx.x]);
     __syncthreads();
-    for (int q = 0; q < 2; q++) if (cls[q] >= 0) (cls[q] == 0 ? a.wave_list : a.big_list)[s_base[cls[q]] + rk[q]] = rg[q];
+    for (int q = 0; q < 2; q++) {
+        if (cls[q] == 0) a.wave_list[s_base[0] + rk[q]] = rg[q];
+        else if (cls[q] == 1) a.big_list[s_base[1] + rk[q]] = rg[q];
+        else if (cls[q] == 2) a.big_list[2 * a.n_tiles - 1 - (s_base[2] + rk[q])] = rg[q];
+    }
+}
+// Ranges beyond TILE_ORDER_MAX photons: their order keys, positions and records are copied to compact arrays (range k at cbeg[k]), the
+// (key, position) pairs are sorted range by range (rocPRIM's segmented radix sort), and the records move to their ranks.
+struct HugeOrderArgs { i64 n_ranges, total; const i64 *start; const i64 *cbeg; const PhotonRec *ph; const u32 *ph_idx; const double *ph_gain; i64 gain_first;
+                       u32 *keys, *vals; PhotonRec *rec; double *gain; };
+__device__ __forceinline__ i64 huge_range_of(const HugeOrderArgs &a, i64 i)
+{
+    i64 lo = 0, hi = a.n_ranges;
+    while (hi - lo > 1) { const i64 mid = (lo + hi) >> 1; if (a.cbeg[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ void k_order_huge_pack(HugeOrderArgs a)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const i64 r = huge_range_of(a, i), p = a.start[r] + (i - a.cbeg[r]);
+    a.keys[i] = a.ph_idx[p]; a.vals[i] = (u32)(i - a.cbeg[r]); a.rec[i] = a.ph[p];
+    if (a.ph_gain && p >= a.gain_first) a.gain[i] = a.ph_gain[p - a.gain_first];
+}
+__global__ void k_order_huge_apply(HugeOrderArgs a, const u32 *keys_sorted, const u32 *vals_sorted, PhotonRec *ph, u32 *ph_idx, double *ph_gain)
+{
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.total) return;
+    const i64 r = huge_range_of(a, i), p = a.start[r] + (i - a.cbeg[r]);
+    const i64 src = a.cbeg[r] + vals_sorted[i];
+    ph[p] = a.rec[src]; ph_idx[p] = keys_sorted[i];
+    if (ph_gain && p >= a.gain_first) ph_gain[p - a.gain_first] = a.gain[src];
 }
 // pass 2, one wave per listed range of at most 64 photons: rank = number of smaller keys (the keys of a range are distinct)
 __global__ __launch_bounds__(256) void k_tile_order(OrderArgs a, i64 n_list)

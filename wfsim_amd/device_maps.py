@@ -6,7 +6,9 @@ longitudinal-diffusion, field-distortion and field-dependence maps the reference
 with the calling convention of ``straxen.InterpolatingMap`` (``m(positions, map_name='map')``); everything else is handed
 through.  Eligible: InterpolatingMap objects (this package's, or a straxen one carrying the same ``data`` dict) with
 
-* method WeightedNearestNeighbors, scalar valued (or array valued with one entry), on a regular grid or a point list;
+* method WeightedNearestNeighbors, scalar or array valued (up to 4096 values per node), on a regular grid or a point list;
+* method RegularGridInterpolator on a regular grid (load_resource.py:357 builds the S1 time spline with it): scipy's multilinear
+  interpolation, the edge cell continued outside the grid; scalar or array valued;
 * method RectBivariateSpline on a 2-D regular grid (load_resource.py:316, 326) -- the knots and coefficients of scipy's own
   spline object are uploaded, so the device evaluates the very spline the host would.
 
@@ -50,7 +52,7 @@ class DeviceMap:
         if reg is None:
             return self.host(positions, map_name=map_name)
         out = self.engine.eval_scalar_map(reg[0], positions)
-        return out[:, None] if reg[1] else out
+        return out[:, None] if (reg[1] and out.ndim == 1) else out
 
     def __getattr__(self, k):               # data, method, map_names, scale_coordinates ...
         if k in ('host', 'engine', 'ids'):      # (not yet set: copy / pickle probing an empty instance)

@@ -62,6 +62,28 @@ def safe_cut_gap(config):
     return float(config['right_raw_extension']) + reach
 
 
+def shard_plan(config, instructions, world_size):
+    """Who simulates what, computed by every rank on its own from the same instructions (no communication): the scheduler's
+    order, and per rank its slice ``[bounds[r], bounds[r + 1])`` of the sorted instructions, the run-wide ids of that slice and the
+    time range its strax chunks cover.  Ranges meet at ``first key of the next shard - right_raw_extension``: every window of a
+    shard ends before it (``safe_cut_gap``; checked by the consumers), so per-rank chunk streams concatenate into one contiguous,
+    time-ordered stream (sharded delivery)."""
+    from .scheduler import schedule
+    order, key, cluster = schedule(instructions, config)
+    s_ins = instructions[order]
+    weight = np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15, s_ins['amp'] * float(config.get('s2_secondary_sc_gain', 30)))
+    b = shard_clusters(cluster, weight, world_size, key=key, min_gap=safe_cut_gap(config))
+    rext = int(config['right_raw_extension'])
+    # rank r's chunks start at starts[r] (None: before its first instruction, as a single process does) and end at ends[r] (None: behind
+    # its last window); an empty shard passes its range on to the next non-empty one
+    starts, ends = [None] * world_size, [None] * world_size
+    nonempty = [r for r in range(world_size) if b[r + 1] > b[r]]
+    for a, nxt in zip(nonempty[:-1], nonempty[1:]):
+        cut = int(key[b[nxt]]) - rext
+        ends[a], starts[nxt] = cut, cut
+    return dict(order=order, key=key, cluster=cluster, sorted_instructions=s_ins, bounds=b, starts=starts, ends=ends)
+
+
 def gather_records(records, dst=0, group=None, async_op=False):
     """Variable-length gather of packed records (uint8 tensor of n * 244 bytes per rank, on the backend's device).
 
@@ -143,15 +165,11 @@ def simulate_sharded(config, instructions, device=None, dst=0, max_batch_quanta=
     import torch.distributed as dist
     from .dtypes import raw_record_dtype
     from .rawdata import RawData
-    from .scheduler import schedule
     rank, world = dist.get_rank(), dist.get_world_size()
     device = int(os.environ.get('LOCAL_RANK', rank)) if device is None else device
     on_gpu = dist.get_backend() == 'nccl'
-    order, key, cluster = schedule(instructions, config)
-    s_ins = instructions[order]
-    weight = np.where(s_ins['type'] == 1, s_ins['amp'] * 0.15, s_ins['amp'] * float(config.get('s2_secondary_sc_gain', 30)))
-    min_gap = safe_cut_gap(config)
-    b = shard_clusters(cluster, weight, world, key=key, min_gap=min_gap)
+    plan = shard_plan(config, instructions, world)
+    order, key, s_ins, b = plan['order'], plan['key'], plan['sorted_instructions'], plan['bounds']
     mine = s_ins[b[rank]:b[rank + 1]]
     rd = RawData(config, device=device)
     # run-wide instruction ids keep the RNG streams independent of the sharding

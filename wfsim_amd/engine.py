@@ -108,7 +108,8 @@ EXPORTS = ['wfs_create', 'wfs_destroy', 'wfs_last_error', 'wfs_device_count', 'w
            'wfs_set_pattern_map', 'wfs_eval_pattern_rows', 'wfs_copy_cdf_rows', 'wfs_set_record_order', 'wfs_copy_records_range',
            'wfs_copy_records_range_async', 'wfs_wait_records', 'wfs_host_register', 'wfs_host_unregister',
            'wfs_set_gas_gap_model', 'wfs_set_instruction_gas_gap', 'wfs_set_pattern_map_points', 'wfs_set_instruction_aft',
-           'wfs_scalar_map_grid', 'wfs_scalar_map_points', 'wfs_scalar_map_spline', 'wfs_scalar_map_eval', 'wfs_set_noise_float', 'wfs_set_instruction_diffusion']
+           'wfs_scalar_map_grid', 'wfs_scalar_map_points', 'wfs_scalar_map_spline', 'wfs_scalar_map_eval', 'wfs_set_noise_float', 'wfs_set_instruction_diffusion',
+           'wfs_scalar_map_grid_array', 'wfs_scalar_map_points_array', 'wfs_scalar_map_linear', 'wfs_scalar_map_eval_array']
 
 
 def load_library():
@@ -331,30 +332,52 @@ class Engine:
             kx, ky = spl.degrees
             self._check(self.lib.wfs_scalar_map_spline(self._h, C.c_int32(len(tx)), _p(tx), C.c_int32(len(ty)), _p(ty), C.c_int32(kx), C.c_int32(ky), _p(c), C.byref(mid)))
             return mid.value, False
-        if m.method != 'WeightedNearestNeighbors' or not 1 <= m.dimensions <= 3:
+        if m.method not in ('WeightedNearestNeighbors', 'RegularGridInterpolator') or not 1 <= m.dimensions <= 3:
             return None
         v = np.asarray(m.data[name], dtype=np.float64)
         n_points = len(m.coordinate_system)
-        if v.size != n_points:
-            return None                 # array valued: the pattern maps have their own path
-        trailing = (v.ndim > 1 and v.shape[0] == n_points) or v.ndim == m.dimensions + 1
-        v = np.ascontiguousarray(v.reshape(-1))
+        if v.size % n_points or v.size // n_points > 4096:
+            return None
+        nv = v.size // n_points
+        # values per node on a trailing axis: flat layout [points, nv] or nested along the grid axes [..., nv]
+        array_valued = (v.ndim == 2 and v.shape[0] == n_points) or v.ndim == m.dimensions + 1
+        if nv > 1 and not array_valued:
+            return None
+        trailing = array_valued and nv == 1
+        v = np.ascontiguousarray(v.reshape(n_points, nv))
+        if m.method == 'RegularGridInterpolator' and m.grid is None:
+            return None                 # (straxen falls back to nearest neighbours on a point list: the WeightedNearestNeighbors path below)
         if m.grid is not None:
             nn = np.asarray([len(g) for g in m.grid], dtype=np.int32)
             lo, hi = np.asarray([g[0] for g in m.grid], dtype=np.float64), np.asarray([g[-1] for g in m.grid], dtype=np.float64)
-            self._check(self.lib.wfs_scalar_map_grid(self._h, C.c_int32(m.dimensions), _p(nn), _p(lo), _p(hi), _p(v), C.byref(mid)))
+            if m.method == 'RegularGridInterpolator':
+                self._check(self.lib.wfs_scalar_map_linear(self._h, C.c_int32(m.dimensions), _p(nn), _p(lo), _p(hi), _p(v), C.c_int32(nv), C.byref(mid)))
+            elif nv == 1:
+                self._check(self.lib.wfs_scalar_map_grid(self._h, C.c_int32(m.dimensions), _p(nn), _p(lo), _p(hi), _p(v), C.byref(mid)))
+            else:
+                self._check(self.lib.wfs_scalar_map_grid_array(self._h, C.c_int32(m.dimensions), _p(nn), _p(lo), _p(hi), _p(v), C.c_int32(nv), C.byref(mid)))
         else:
             if n_points < 2 * m.dimensions:
                 return None
             pts = np.ascontiguousarray(m.coordinate_system, dtype=np.float64)
-            self._check(self.lib.wfs_scalar_map_points(self._h, C.c_int32(m.dimensions), C.c_int64(n_points), _p(pts), _p(v), C.byref(mid)))
+            if nv == 1:
+                self._check(self.lib.wfs_scalar_map_points(self._h, C.c_int32(m.dimensions), C.c_int64(n_points), _p(pts), _p(v), C.byref(mid)))
+            else:
+                self._check(self.lib.wfs_scalar_map_points_array(self._h, C.c_int32(m.dimensions), C.c_int64(n_points), _p(pts), _p(v), C.c_int32(nv), C.byref(mid)))
+        self._smap_nv = getattr(self, '_smap_nv', {})
+        self._smap_nv[mid.value] = nv
         return mid.value, bool(trailing)
 
     def eval_scalar_map(self, map_id, positions):
         pos = np.ascontiguousarray(positions, dtype=np.float64)
         pos = pos.reshape(len(pos), -1)
-        out = np.empty(len(pos), dtype=np.float64)
-        self._check(self.lib.wfs_scalar_map_eval(self._h, C.c_int32(map_id), C.c_int64(len(pos)), _p(pos), _p(out)))
+        nv = getattr(self, '_smap_nv', {}).get(map_id, 1)
+        if nv == 1:
+            out = np.empty(len(pos), dtype=np.float64)
+            self._check(self.lib.wfs_scalar_map_eval(self._h, C.c_int32(map_id), C.c_int64(len(pos)), _p(pos), _p(out)))
+            return out
+        out = np.empty((len(pos), nv), dtype=np.float64)          # array-valued map: one row of values per position
+        self._check(self.lib.wfs_scalar_map_eval_array(self._h, C.c_int32(map_id), C.c_int64(len(pos)), _p(pos), _p(out), C.c_int32(nv)))
         return out
 
     def cdf_rows(self):

@@ -89,9 +89,11 @@ class ChunkRawRecords(object):
             pass
 
     # ------------------------------------------------------------------------------------------
-    def __call__(self, instructions, time_zero=None, **kwargs):
+    def __call__(self, instructions, time_zero=None, chunk_start=None, chunk_end=None, **kwargs):
         """Generator of chunks (strax_interface.py:368-440): dicts of record arrays + truth rows; ``chunk_time_pre`` / ``chunk_time``
-        are the bounds of the chunk just yielded."""
+        are the bounds of the chunk just yielded.  ``chunk_start`` / ``chunk_end`` (sharded delivery, distributed.shard_plan): the
+        first chunk opens exactly at ``chunk_start`` and the last one closes at ``chunk_end`` instead of before the first instruction /
+        behind the last window, so that the chunk streams of consecutive time ranges join without gap or overlap."""
         if not len(instructions):               # nothing to simulate: no chunk at all (:370-373)
             setattr(self.rawdata, 'source_finished', True)
             return
@@ -101,7 +103,7 @@ class ChunkRawRecords(object):
         self.blevel = 0
         # the first chunk opens right_raw_extension before time_zero (a falsy time_zero: before the first instruction), :378-380
         origin = time_zero if time_zero else np.min(instructions['time'])
-        self.chunk_time_pre = origin - self._rext
+        self.chunk_time_pre = origin - self._rext if chunk_start is None else int(chunk_start)
         self.chunk_time = self.chunk_time_pre + self._cksz
         self.last_digitized_right = self.current_digitized_right = 0
         self._sorted_stream = False
@@ -114,6 +116,11 @@ class ChunkRawRecords(object):
         # the last chunk ends behind the last digitised window, and is at least one sample long (:438-440)
         self.last_digitized_right = int(self.current_digitized_right)
         end_of_data = (self.last_digitized_right + 1) * dt
+        if chunk_end is not None:
+            if end_of_data > chunk_end:
+                raise RuntimeError(f'a digitise window ends at {end_of_data}, behind the end of this time range ({chunk_end}): the '
+                                   f'next range would depend on it (shard cut too tight)')
+            end_of_data = int(chunk_end)
         self.chunk_time = end_of_data if end_of_data > self.chunk_time_pre + dt else self.chunk_time_pre + dt
         yield from self.final_results()
 
@@ -504,7 +511,39 @@ class RawRecordsFromFaxNT(SimulatorPlugin):
 
     def _setup(self):
         self.sim = ChunkRawRecords(self.config, device=self.device)
-        self.sim_iter = iter(self.sim(self.instructions))
+        shard = self._shard()
+        if shard is None:
+            self.sim_iter = iter(self.sim(self.instructions))
+            return
+        # Sharded delivery (one process per GPU): this process simulates ITS contiguous time range of whole clusters and
+        # emits it as its own strax chunks -- no record leaves the rank.  The ranges are disjoint and meet exactly (shard_plan), the
+        # RNG streams are keyed by run-wide instruction ids, so the chunk streams of ranks 0 .. world - 1, one after the other, hold
+        # byte for byte the records and truth rows of a single-process run.  The reference has one feeding process
+        # (parallel = False, strax_interface.py:546); `shard` = None keeps that contract.
+        from .distributed import shard_plan
+        rank, world = shard
+        plan = shard_plan(self.config, self.instructions, world)
+        b = plan['bounds']
+        mine = plan['sorted_instructions'][b[rank]:b[rank + 1]]
+        self.sim.rawdata.global_ids = plan['order'][b[rank]:b[rank + 1]]
+        self.shard_range = (plan['starts'][rank], plan['ends'][rank])
+        self.sim_iter = iter(self.sim(mine, chunk_start=plan['starts'][rank], chunk_end=plan['ends'][rank]))
+
+    def _shard(self):
+        """(rank, world_size) of the sharded delivery, or None: config['shard'] = (rank, world) | 'auto' (the torch.distributed
+        process group, when one is initialised) | None (default)"""
+        shard = self.config.get('shard')
+        if shard is None:
+            return None
+        if shard == 'auto':
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+                return None
+            return dist.get_rank(), dist.get_world_size()
+        rank, world = (int(x) for x in shard)
+        if not 0 <= rank < world:
+            raise ValueError(f'shard = {shard!r}: rank must lie in [0, world)')
+        return (rank, world) if world > 1 else None
 
     def get_instructions(self):
         if self.config.get('instructions') is not None:           # in-memory instructions (tests, benchmarks)
