@@ -173,10 +173,10 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
         if (a.tile_done && tile < a.n_done && a.tile_done[tile]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
     }
     {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
-        const u64 ml = __ballot(live);
+        const u64 ml = ballot64(live);
         if (ml) {
             const i32 cl0 = __shfl(cl, __ffsll((long long)ml) - 1, 64);
-            if (__all(!live || cl == cl0)) {
+            if (all64(!live || cl == cl0)) {
                 i64 e = end;
                 for (int o = 32; o > 0; o >>= 1) { const i64 x = __shfl_down(e, o, 64); e = x > e ? x : e; }
                 if (lane == 0) atomicMax(&a.cl_end[cl0], e);
@@ -283,10 +283,10 @@ __global__ void k_tile_rows(WfsDev d, GeomArgs a)
     }
     // the group's range: the 494 tiles of a pulse set all aim at one address -- reduce inside the wave first when its
     // live lanes share the group (the usual case), one atomic pair per wave instead of 64
-    const u64 lm = __ballot(live);
+    const u64 lm = ballot64(live);
     if (lm == 0) return;
     const i64 g0 = __shfl(g, __ffsll((long long)lm) - 1, 64);
-    if (__all(!live || g == g0)) {
+    if (all64(!live || g == g0)) {
         for (int o = 32; o > 0; o >>= 1) {
             const i64 l2 = __shfl_xor(left, o, 64), r2 = __shfl_xor(right, o, 64);
             left = l2 < left ? l2 : left; right = r2 > right ? r2 : right;
@@ -477,7 +477,7 @@ __device__ __forceinline__ double tap_block(const double *H, double *W2, const T
     const int c_end = min(REACH, n_cells - (tid & ~63) * dt);      // cells of the reach that hold data
     {   // rounds 6 and 7 (the middle of the reach) first
         const u32 a = 6 * 64 + lane < c_end ? Hhi[2 * (6 * 64 + lane)] : 0u, b = 7 * 64 + lane < c_end ? Hhi[2 * (7 * 64 + lane)] : 0u;
-        if (__popcll(__ballot(a != 0u)) + __popcll(__ballot(b != 0u)) > (sparse_max >> 2)) return tap_gather<FMA>(H, tp, tid);      // wave-uniform
+        if (__popcll(ballot64(a != 0u)) + __popcll(ballot64(b != 0u)) > (sparse_max >> 2)) return tap_gather<FMA>(H, tp, tid);      // wave-uniform
     }
     int m = 0;
 #pragma unroll 1
@@ -487,7 +487,7 @@ __device__ __forceinline__ double tap_block(const double *H, double *W2, const T
         for (int u = 0; u < 4; u++) { const int c = (r0 + u) * 64 + lane; hw[u] = c < c_end ? Hhi[2 * c] : 0u; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const u64 mk = __ballot(hw[u] != 0u);
+            const u64 mk = ballot64(hw[u] != 0u);
             if (mk) {                                    // wave-uniform
                 const int pos = m + __popcll(mk & below);
                 if (hw[u] != 0u && pos < TAP_LIST_LEN) list[pos] = (unsigned short)((r0 + u) * 64 + lane);
@@ -658,8 +658,8 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
             const bool v = r_ns[k] >= 0;
             const int r = v ? r_ns[k] % dt : 0;
             const bool above = v && (r_gain[k] * s_cmax[r] * d.c2a > thr);
-            c_trig += (u32)__popcll(__ballot(above));
-            c_trig_dpe += (u32)__popcll(__ballot(above && tid + k * TPB < n_dpe_tile));
+            c_trig += (u32)__popcll(ballot64(above));
+            c_trig_dpe += (u32)__popcll(ballot64(above && tid + k * TPB < n_dpe_tile));
             if (v) {
                 sg += r_gain[k];
                 if (above) sgt += r_gain[k];
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(TPB) void k_pulse(WfsDev d, PulseArgs a, TemplateAr
         // reads the rows tid (tap k = 21) .. tid + 21 (tap k = 0).  The tap loop is outermost so that only the dt taps of one
         // k are live in SGPRs.
         const bool act = c0 + tid < n_live;
-        if (__any(act)) {                                  // wave-uniform
+        if (any64(act)) {                                  // wave-uniform
             const double c = tap_block<FMA>(H, W2, tp, tid, a.sparse_max, HROWS * dt);
             if (act) {
                 const i64 sx = lead + c0 + tid;            // sample of the tile
@@ -1024,9 +1024,9 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     }
     if (a.tile_truth) {        // pulse.py:229-271, photons in their order in the channel slice (= lane order)
         const bool is_dpe = v && (code >> 16) != 0;
-        const i32 n_dpe = __popcll(__ballot(is_dpe));
+        const i32 n_dpe = __popcll(ballot64(is_dpe));
         const bool above = v && (g * s_cmax[v ? ns0 % dt : 0] * d.c2a > td.thr);
-        const i32 n_trig = __popcll(__ballot(above)), n_trig_dpe = __popcll(__ballot(above && lane < n_dpe));
+        const i32 n_trig = __popcll(ballot64(above)), n_trig_dpe = __popcll(ballot64(above && lane < n_dpe));
         const double tr = v ? (double)(ns0 + td.rel0) : 0.0;
         const double sg = wave_sum(g), sgt = wave_sum(above ? g : 0.0), st = wave_sum(tr), st2 = wave_sum(tr * tr);     // (DPP: no LDS crossbar trips)
         if (lane == 0) {
@@ -1055,12 +1055,12 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     {
         const i32 prev = __shfl_up(ns, 1, 64);
         const bool head = lane == 0 || prev != ns;
-        if (__any(!head && lane < n)) {
+        if (any64(!head && lane < n)) {
             double tot = g;
             for (int step = 1; step < 64; step++) {
                 const i32 nsq = __shfl_down(ns, step, 64); const double gq = __shfl_down(g, step, 64);
                 const bool same = lane + step < n && nsq == ns;
-                if (!__any(head && same)) break;
+                if (!any64(head && same)) break;
                 if (head && same) tot += gq;
             }
             g = head ? tot : 0.0;
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     int s0 = 0;
     while (s0 < n_live) {
         // sorted photons with a start bin in [s0 - 21, s0 + 63]: a contiguous range [q_lo, q_hi) of lanes
-        const int q_lo = __popcll(__ballot(bin < s0 - (tlen - 1))), q_hi = __popcll(__ballot(bin <= s0 + 63));
+        const int q_lo = __popcll(ballot64(bin < s0 - (tlen - 1))), q_hi = __popcll(ballot64(bin <= s0 + 63));
         if (q_lo >= n) break;                                 // nothing reaches s0 or anything behind it
         if (q_hi == q_lo) { s0 = __builtin_amdgcn_readlane(bin, q_lo); continue; }      // (bin[q_lo] > s0 + 63: the next block starts at that photon)
         const int sp = s0 + lane;
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
 #pragma unroll
         for (int k = 0; k < SPARSE_PPT; k++) {
             s1[k] = 0; s2[k] = 0;
-            if (k < kmax) { s1[k] = spe_row[code[k] & 0xffffu]; if (__any((code[k] >> 16) != 0)) s2[k] = spe_row[code[k] >> 16]; }
+            if (k < kmax) { s1[k] = spe_row[code[k] & 0xffffu]; if (any64((code[k] >> 16) != 0)) s2[k] = spe_row[code[k] >> 16]; }
         }
 #pragma unroll
         for (int k = 0; k < SPARSE_PPT; k++) {
@@ -1548,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
                 u32 nib = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) { const i32 v = finish_four<NK>(d, buf[u], j, he, noisy); nib |= (i + j < len32 && (i64)v < thr) ? (1u << j) : 0u; }
-                const u64 mask = __ballot(nib != 0);
+                const u64 mask = ballot64(nib != 0);
                 if (mask == 0) continue;                        // wave-uniform
                 const i32 fpos = i + (i32)__builtin_ctz(nib | 16u), lpos = i + 31 - (i32)__builtin_clz(nib | 1u);      // first / last hit of the lane
 #pragma unroll
@@ -1601,12 +1601,12 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
             if (c0 >= len32) break;                             // wave-uniform
             const i32 i = c0 + lane;
             const bool hit = i < len32 && (i64)vv[u] < thr;
-            const u64 mask = __ballot(hit);
+            const u64 mask = ballot64(hit);
             const u64 lt = (1ull << lane) - 1ull;
             const u64 below = mask & lt;
             const i32 prev = below ? c0 + 63 - __clzll(below) : carry_last;       // last hit before this sample
             const bool start = hit && (prev < 0 || i - prev > hold32);
-            const u64 smask = __ballot(start);
+            const u64 smask = ballot64(start);
             if (start) {
                 const u64 sbelow = smask & lt;
                 const i32 k = count + __popcll(sbelow);
@@ -1974,7 +1974,7 @@ __global__ __launch_bounds__(256) void k_s2_electrons(WfsDev d, GenArgs a)
     // whole wave works on one instruction, else one per lane
     const i64 i_first = __shfl(i, 0, 64);
     bool leader = true;
-    if (__all(i == i_first)) {
+    if (all64(i == i_first)) {
         for (int o = 32; o > 0; o >>= 1) {
             st_n += __shfl_down(st_n, o, 64); st_t += __shfl_down(st_t, o, 64); st_t2 += __shfl_down(st_t2, o, 64);
             i64 mn = __shfl_down(st_min, o, 64), mx = __shfl_down(st_max, o, 64);
@@ -2415,7 +2415,7 @@ __global__ __launch_bounds__(256) void k_diffuse_patterns(WfsDev d, GenArgs a, M
             }
         }
         // slots in electron order (ballot ranks): the sums below run in a fixed order
-        const u64 mask = __ballot(ok);
+        const u64 mask = ballot64(ok);
         if ((tid & 63) == 0) s_wn[tid >> 6] = __popcll(mask);
         __syncthreads();
         int slot = __popcll(mask & ((1ull << (tid & 63)) - 1ull));
@@ -2659,7 +2659,7 @@ __global__ __launch_bounds__(64) void k_chan_alias(const double *cdf_table, int 
         const double qi = i < nch ? (cum[i] - (i ? cum[i - 1] : 0.0)) * (double)K : 0.0;
         if (valid) { q[i] = qi; cell[i] = uint2{0xffffffffu, (u32)i}; }
         const bool sm = valid && qi < 1.0, lgc = valid && !(qi < 1.0);
-        const u64 ms = __ballot(sm), ml = __ballot(lgc), below = (1ull << threadIdx.x) - 1ull;
+        const u64 ms = ballot64(sm), ml = ballot64(lgc), below = (1ull << threadIdx.x) - 1ull;
         if (sm) st_small[ns + __popcll(ms & below)] = (unsigned short)i; else if (lgc) st_large[nl + __popcll(ml & below)] = (unsigned short)i;
         ns += __popcll(ms); nl += __popcll(ml);
     }
@@ -3012,7 +3012,7 @@ struct ApRun { int head, rank, len; };
 __device__ __forceinline__ ApRun ap_run(i64 tile, int lane)
 {
     const i64 prev = __shfl_up(tile, 1, 64);
-    const u64 heads = __ballot(lane == 0 || tile != prev);
+    const u64 heads = ballot64(lane == 0 || tile != prev);
     ApRun r;
     r.head = 63 - __clzll(heads & ((2ull << lane) - 1ull));
     const u64 behind = r.head == 63 ? 0ull : heads & ~((2ull << r.head) - 1ull);
@@ -3069,7 +3069,7 @@ __global__ __launch_bounds__(256) void k_ap_seg(WfsDev d, GenArgs a, ApArgs ap, 
     i32 total = 0;
     for (i32 c = 0; c < sg.n; c += 64) {
         const i64 i = sg.base + c + lane;
-        total += __popcll(__ballot(c + lane < sg.n && i < ap.cap && ap.ap_ch[i] >= 0));
+        total += __popcll(ballot64(c + lane < sg.n && i < ap.cap && ap.ap_ch[i] >= 0));
     }
     if (total == 0) return;
     if (!PLACE) { if (lane == 0) atomicAdd(&a.tile_count[sg.tile], total); return; }
@@ -3081,7 +3081,7 @@ __global__ __launch_bounds__(256) void k_ap_seg(WfsDev d, GenArgs a, ApArgs ap, 
     for (i32 c = 0; c < sg.n; c += 64) {
         const i64 i = sg.base + c + lane;
         const bool v = c + lane < sg.n && i < ap.cap && ap.ap_ch[i] >= 0;
-        const u64 m = __ballot(v);
+        const u64 m = ballot64(v);
         if (v) {
             const i64 pos = off + done + __popcll(m & ((1ull << lane) - 1ull));
             const i32 t = ap.ap_t[i];
