@@ -49,6 +49,22 @@ def synthetic_noise(seed=5, n_samples=3000, n_channels=N_TPC):
     return np.round(rng.normal(0, 2.2, (n_samples, n_channels))).astype(np.int16)
 
 
+def synthetic_electron_afterpulses(n_bins=140, t_max=150e3, tau_bins=30.0, total=3e-3):
+    """(histogram, bin_edges) of the photo-ionisation delay: the shape load_resource.py:233 reads from a private file -- a
+    falling delay spectrum over 150 us whose integral is the probability per photon"""
+    hist = np.exp(-np.arange(n_bins) / tau_bins)
+    hist *= total / hist.sum()
+    return hist, np.linspace(0.0, t_max, n_bins + 1)
+
+
+def synthetic_garfield_table(seed=4242, n_x=11, n_samples=4000):
+    """dict(t[n_x, n_samples], x[n_x]): sampled luminescence delays per distance to the anode wire, the layout of the garfield
+    file of load_resource.py:293-309 (the file itself is private)"""
+    rng = np.random.default_rng(seed)
+    x = np.linspace(-0.25, 0.25, n_x)
+    return dict(t=np.stack([rng.gamma(3.0 + 8 * abs(v), 60.0, n_samples) + 900 for v in x]), x=x)
+
+
 def synthetic_pmt_positions(n_tpc=N_TPC, n_top=N_TOP):
     """a made-up PMT layout: sunflower rings of 48 cm radius, top array first"""
     def rings(n):
@@ -142,12 +158,17 @@ def optical_instructions(n, rate_ns, seed):
 
 
 # ---------------------------------------------------------------------------------------------- configurations
-def bench_config(seed, pmt_afterpulses=False, **overrides):
+def bench_config(seed, pmt_afterpulses=False, reference_defaults=False, **overrides):
     """configs[2]: E[PE] = 10^4 e- * survival * sc_gain 100 = ~10^6 PE per instruction; dummy maps, noise and
-    afterpulses off (pmt_afterpulses: the side measurement with synthetic afterpulse tables)"""
+    afterpulses off (pmt_afterpulses: the side measurement with synthetic afterpulse tables; reference_defaults: the side measurement
+    with electron afterpulses on, the reference's default (rawdata.py:194), and the garfield luminescence model XENONnT's fax config
+    selects -- both on synthetic tables)"""
     kw = dict(s2_secondary_sc_gain=100.0, seed=seed)
     if pmt_afterpulses:
         kw.update(enable_pmt_afterpulses=True, uniform_to_pmt_ap=synthetic_afterpulse_tables())
+    if reference_defaults:
+        kw.update(enable_electron_afterpulses=True, uniform_to_ele_ap=synthetic_electron_afterpulses(),
+                  s2_luminescence_model='garfield', s2_luminescence=synthetic_garfield_table())
     kw.update(overrides)
     return xenonnt_test_config(**kw)
 
