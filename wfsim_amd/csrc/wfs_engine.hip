@@ -59,6 +59,8 @@ struct wfs_handle {
     bool tables_set = false, batch_loaded = false, injected = false, optical = false, ran = false;
     DevBuf set_gid, opt_t, opt_item, opt_first, opt_last, opt_ch, opt_time;
     int keep_currents = 0, profiling = 0;
+    i32 res_env = -1;                // WFS_ROW_RESIDENT=0/1 overrides the config switch (A/B runs)
+    i32 res_max_len = 2048;          // longest resident row (k_row_pulse: 4 bytes of LDS per sample and wave); WFS_RES_MAX_LEN overrides
     bool gen_done = false;
     bool gen_order_ready = false;          // host tables of the generation order (gen_order_tables), valid for the current generation
     std::vector<i64> go_off, go_block0; std::vector<i32> go_fused, go_tile_count;
@@ -88,7 +90,9 @@ struct wfs_handle {
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
-    i64 h_scal[32] = {0};
+    i64 h_scal[64] = {0};
+    DevBuf row_bad, fin_len, res_cnt, fin_off, res_toff, res_desc, fin, res_long, res_rows;      // resident rows (k_row_pulse)
+    i64 n_front_rows = 0, n_res_rows = 0, n_short_rows = 0, n_res_tiles = 0, max_res_len = 0, s_fin = 0, s_res = 0; bool res_on = false;
     i64 n_active_tiles = 0, n_tiny_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, n_wave_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
     i64 cur_total = 0, row_dbg_total = 0;
     std::vector<KernelTime> times;
@@ -445,7 +449,7 @@ try {
     h->own_stream = true;
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->rec_copied[0], hipEventDisableTiming) != hipSuccess
         || hipEventCreateWithFlags(&h->rec_copied[1], hipEventDisableTiming) != hipSuccess) { delete h; return WFS_E_HIP; }
-    if (hipMalloc(&h->scal.p, 256) != hipSuccess) { delete h; return WFS_E_HIP; }
+    if (hipMalloc(&h->scal.p, 512) != hipSuccess) { delete h; return WFS_E_HIP; }
     h->scal.cap = 256;
 #ifdef WFS_STAMPS
     if (hipMalloc(&h->stamps.p, 4096 * 64 * 8) != hipSuccess) { delete h; return WFS_E_HIP; }
@@ -464,6 +468,12 @@ try {
     hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_tile_order_big, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     WFS_BIG_LDS_F(K_PULSE_GENERIC, 128);
+#define K_ROW_PULSE_0(F) k_row_pulse<0, F>
+#define K_ROW_PULSE_1(F) k_row_pulse<1, F>
+#define K_ROW_PULSE_2(F) k_row_pulse<2, F>
+    WFS_BIG_LDS_F(K_ROW_PULSE_0, 128); WFS_BIG_LDS_F(K_ROW_PULSE_1, 128); WFS_BIG_LDS_F(K_ROW_PULSE_2, 128);
+    if (const char *e = getenv("WFS_ROW_RESIDENT")) h->res_env = atoi(e) != 0;
+    if (const char *e = getenv("WFS_RES_MAX_LEN")) h->res_max_len = std::max(0, std::min(atoi(e), 7168));      // tuning knob (results do not depend on it)
     WFS_BIG_LDS_F(K_S2_TILE_FULL, 100); WFS_BIG_LDS_F(K_S2_TILE_FULL_AP, 100); WFS_BIG_LDS_F(K_S2_TILE_GEN, 100); WFS_BIG_LDS_F(K_S2_TILE_GEN_AP, 100);
     WFS_BIG_LDS_F(K_PULSE_SPARSE_64, 100); WFS_BIG_LDS_F(K_PULSE_SPARSE_256, 100);
     *out = h;
@@ -1190,7 +1200,7 @@ try {
     TRY(ensure(h, h->tile_count, (size_t)T * 4)); TRY(ensure(h, h->tile_cursor, (size_t)T * 4)); TRY(ensure(h, h->tile_off, (size_t)(T + 1) * 8));
     TRY(ensure(h, h->opt_t, (size_t)n_ph * 4)); TRY(ensure(h, h->opt_item, (size_t)n_ph * 4));
     HIPCHK(hipMemsetAsync(h->tile_count.p, 0, (size_t)T * 4, h->stream)); HIPCHK(hipMemsetAsync(h->tile_cursor.p, 0, (size_t)T * 4, h->stream));
-    HIPCHK(hipMemsetAsync(h->scal.p, 0, 256, h->stream));
+    HIPCHK(hipMemsetAsync(h->scal.p, 0, 512, h->stream));
     OptLoadArgs oa{n, h->opt_first.as<i32>(), h->opt_last.as<i32>(), h->opt_ch.as<i32>(), h->opt_time.as<i64>(), cutoff, h->t_gains.as<double>(),
                    h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->tile_cursor.as<i32>(), h->opt_t.as<i32>(), h->opt_item.as<u32>(), h->scal.as<i64>()};
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_optical_bucket<false>), dim3(nblocks(n, 256)), dim3(256), 0, h->stream, h->dev, oa);
@@ -1502,7 +1512,7 @@ try {
     h->times.clear();
     const WfsDev &d = h->dev;
     const i64 T = h->n_tiles, S = h->n_sets, C = h->n_clusters;
-    HIPCHK(hipMemsetAsync(h->scal.p, 0, 256, h->stream));
+    HIPCHK(hipMemsetAsync(h->scal.p, 0, 512, h->stream));
     if (h->optical) {
         OpticalArgs oa{T, h->tile_count.as<i32>(), h->tile_off.as<i64>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_gid.as<u32>(),
                        h->opt_t.as<i32>(), h->opt_item.as<u32>(), h->ph.as<PhotonRec>(), h->scal.as<i64>()};
@@ -1534,11 +1544,26 @@ try {
     ga.active_rows = h->active_rows.as<i32>(); ga.scal = h->scal.as<i64>(); ga.active_tiles = h->active_tiles.as<i32>(); ga.sparse_tiles = h->sparse_tiles.as<i32>(); ga.dense_tiles = h->dense_tiles.as<i32>(); ga.wave_tiles = h->wave_tiles.as<i32>(); ga.force_dense = ((h->keep_currents & 2) || h->generic_geom) ? 1 : 0; ga.init_has = h->carry_has; ga.init_runmax = h->carry_runmax;
     ga.noise_override = h->n_noise_override ? h->noise_override.as<i64>() : nullptr; ga.n_noise_override = h->n_noise_override;
     const bool tiles_done = !h->injected && !h->optical && h->fuse_full && h->n_fused_tiles > 0;      // pulses made by k_s2_tile (wfs_tilegen.h)
-    if (tiles_done) {
+    // resident rows (k_row_pulse): the usual digitiser geometry, a hold-off of at least a chunk and a noise table the fast row loads
+    // can walk (as the fast path of k_zle), no HE rows, no debug copies of currents or rows
+    h->res_on = (h->res_env >= 0 ? h->res_env != 0 : h->cfg.row_resident != 0) && !(h->keep_currents & 3) && !h->generic_geom && !d.he_rows && 2 * (i64)d.tw + 1 >= 63
+                && (!d.enable_noise || d.noise_len >= NOISE_MIN_FAST);
+    if (tiles_done || h->res_on) {
         TRY(ensure(h, h->row_cnt, (size_t)CG * d.n_tpc * 4)); TRY(ensure(h, h->row_tile, (size_t)CG * d.n_tpc * 4));
         HIPCHK(hipMemsetAsync(h->row_cnt.p, 0, (size_t)CG * d.n_tpc * 4, h->stream));
-        ga.tile_done = h->tile_done.as<i32>(); ga.n_done = h->n_psets * d.n_tpc; ga.row_cnt = h->row_cnt.as<i32>(); ga.row_tile = h->row_tile.as<i32>();
+        ga.row_cnt = h->row_cnt.as<i32>(); ga.row_tile = h->row_tile.as<i32>();
+    }
+    if (tiles_done) {
+        ga.tile_done = h->tile_done.as<i32>(); ga.n_done = h->n_psets * d.n_tpc;
         ga.ins_bcap = h->ins_bcap.as<i32>(); ga.ins_boff = h->ins_boff.as<i64>();
+    }
+    if (h->res_on) {
+        const size_t nr = (size_t)CG * d.n_tpc;
+        TRY(ensure(h, h->row_bad, nr * 4)); TRY(ensure(h, h->fin_len, nr * 4)); TRY(ensure(h, h->res_cnt, nr * 4));
+        HIPCHK(hipMemsetAsync(h->row_bad.p, 0, nr * 4, h->stream)); HIPCHK(hipMemsetAsync(h->fin_len.p, 0, nr * 4, h->stream)); HIPCHK(hipMemsetAsync(h->res_cnt.p, 0, nr * 4, h->stream));
+        ga.res_on = 1; ga.res_max_len = h->res_max_len; ga.row_bad = h->row_bad.as<i32>(); ga.fin_len = h->fin_len.as<i32>(); ga.res_cnt = h->res_cnt.as<i32>();
+        ga.rows_cap = CG * d.row_slots;
+        TRY(ensure(h, h->res_long, nr * 4)); ga.res_long = h->res_long.as<i32>();
     }
     { Timer t(h, "k_tile_geom"); hipLaunchKernelGGL(k_tile_geom, dim3(nblocks(T, 1024)), dim3(1024), 0, h->stream, d, ga); }
     { Timer t(h, "k_groups"); hipLaunchKernelGGL(k_groups, dim3(1), dim3(GROUPS_TPB), 0, h->stream, d, ga); }
@@ -1547,11 +1572,29 @@ try {
     { Timer t(h, "k_row_len"); hipLaunchKernelGGL(k_row_len, dim3(nblocks(CG * d.row_slots, 1024)), dim3(1024), 0, h->stream, d, ga); }
     TRY(scan(h, h->acc_len.as<i32>(), CG * d.n_tpc, h->acc_off, 8));
     TRY(scan(h, h->itv_cap.as<i32>(), CG * d.row_slots, h->itv_off, 9));
+    if (h->res_on) {
+        TRY(scan(h, h->fin_len.as<i32>(), CG * d.n_tpc, h->fin_off, 34)); TRY(scan(h, h->res_cnt.as<i32>(), CG * d.n_tpc, h->res_toff, 35));
+        // rows are known: tiles onto their row's list or the work list of their class (descriptor slots for every tile: no host
+        // round trip for the number of resident ones)
+        TRY(ensure(h, h->res_desc, (size_t)std::max<i64>(T, 1) * sizeof(TileDesc)));
+        ga.res_toff = h->res_toff.as<i64>(); ga.res_desc = h->res_desc.as<TileDesc>();
+        DescArgs da{}; da.tile_off = h->tile_off.as<i64>(); da.set_mode = h->set_mode.as<i32>();
+        TRY(ensure(h, h->tile_truth, (size_t)T * 8 * 8));
+        PulseArgs pt{}; pt.ph = h->ph.as<PhotonRec>(); pt.tile_truth = h->tile_truth.as<double>();
+        pt.ph_gain = (!h->injected && h->ap_active) ? h->ph_gain.as<double>() - h->n_photons : h->ph_gain.as<double>();
+        Timer t(h, "k_tile_assign"); hipLaunchKernelGGL(k_tile_assign, dim3(nblocks(T, 256)), dim3(256), 0, h->stream, d, ga, da, pt);
+    }
     TRY(read_scal(h));
     if (h->h_scal[1] == 1) return h->fail(WFS_E_CAPACITY, "Pulse cache too long (digitise window of 10^6 samples or more, rawdata.py:219)");
     if (h->h_scal[1] == 2) return h->fail(WFS_E_CAPACITY, "photon time further than 2^31 ns from its instruction");
     if (h->h_scal[1] == 3) return h->fail(WFS_E_STATE, "internal: a tile of k_s2_tile did not fit its sample buffer");
-    h->n_groups = h->h_scal[0]; h->n_active_rows = h->h_scal[2]; h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5]; h->max_tile_dense = h->h_scal[15];
+    h->n_front_rows = h->h_scal[2]; h->n_short_rows = h->res_on ? h->h_scal[32] : 0; h->n_res_rows = h->res_on ? h->h_scal[32] + h->h_scal[37] : 0; h->max_res_len = h->h_scal[33]; h->s_fin = h->res_on ? h->h_scal[34] : 0;
+    h->n_res_tiles = h->res_on ? h->h_scal[35] : 0; h->s_res = h->res_on ? h->h_scal[36] : 0;
+    h->n_groups = h->h_scal[0]; h->n_active_rows = h->n_front_rows + h->n_res_rows;
+    if (h->res_on && getenv("WFS_RES_STATS"))
+        fprintf(stderr, "resident rows: %lld short + %lld long of %lld rows, %lld tiles of %lld listed + resident, longest %lld samples, %lld finished samples, accumulators %lld samples\n",
+                (long long)h->n_short_rows, (long long)(h->n_res_rows - h->n_short_rows), (long long)h->n_active_rows, (long long)h->n_res_tiles,
+                (long long)(h->n_res_tiles + h->h_scal[16] + h->h_scal[3] + h->h_scal[11] + h->h_scal[17]), (long long)h->max_res_len, (long long)h->s_fin, (long long)h->h_scal[8]); h->n_sparse_tiles = h->h_scal[3]; h->max_nb = h->h_scal[4]; h->max_tile = h->h_scal[5]; h->max_tile_dense = h->h_scal[15];
     h->n_dense_tiles = h->h_scal[11]; h->max_nb_dense = h->h_scal[12]; h->n_tiny_tiles = h->h_scal[16];
     h->n_wave_tiles = h->h_scal[17];
     h->n_active_tiles = h->n_tiny_tiles + h->n_sparse_tiles + h->n_dense_tiles + h->n_wave_tiles;
@@ -1681,13 +1724,6 @@ try {
         hipLaunchKernelGGL(k_tile_add, dim3((unsigned)h->n_fused_tiles), dim3(256), 0, h->stream, d, h->fuse_args, ta);
     }
 
-    {   // truth accumulators of every pulse set from the per-tile partial sums
-        TruthArgs ta{S, h->tile_count.as<i32>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_t0.as<i64>(), h->tile_truth.as<double>(),
-                     h->truth.as<double>(), h->tminmax.as<i64>()};
-        Timer t(h, "k_truth_reduce");
-        hipLaunchKernelGGL(k_truth_reduce, dim3(nblocks(S, 4)), dim3(256), 0, h->stream, d, ta);
-    }
-
     // ---- ZLE + records
     const i64 RS = CG * d.row_slots;
     TRY(ensure(h, h->itv_left, (size_t)h->n_itv_slots * 8 + 16)); TRY(ensure(h, h->itv_right, (size_t)h->n_itv_slots * 8 + 16));      // (+16: k_pack reads the first two slots of a row whatever its capacity)
@@ -1699,6 +1735,13 @@ try {
     za.itv_off = h->itv_off.as<i64>(); za.itv_left = h->itv_left.as<i64>(); za.itv_right = h->itv_right.as<i64>();
     za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = 110;
     if (tiles_done) { za.tile_done = ga.tile_done; za.n_done = ga.n_done; za.row_cnt = ga.row_cnt; za.row_tile = ga.row_tile; za.ins_bcap = ga.ins_bcap; za.ins_boff = ga.ins_boff; za.tbuf = h->tbuf.as<i32>(); }
+    za.n_front = h->n_front_rows; za.rows_cap = CG * d.row_slots;
+    if (h->n_res_rows > 0) {
+        TRY(ensure(h, h->fin, (size_t)h->s_fin * 2 + 16));
+        TRY(ensure(h, h->res_rows, (size_t)h->n_res_rows * sizeof(ResRow)));
+        za.res_toff = h->res_toff.as<i64>(); za.fin_off = h->fin_off.as<i64>(); za.fin = h->fin.as<int16_t>();
+        za.n_short = h->n_short_rows; za.res_long = h->res_long.as<i32>(); za.res_rows = h->res_rows.as<ResRow>();
+    }
     h->row_dbg_total = 0;
     if ((h->keep_currents & 1) && h->n_active_rows > 0) {
         std::vector<i32> ar((size_t)h->n_active_rows);
@@ -1724,9 +1767,32 @@ try {
         hipLaunchKernelGGL(k_fill_i64, dim3(1), dim3(64), 0, h->stream, h->scal.as<i64>() + 29, (i64)1, I64_MIN);
     }
     if (h->n_active_rows > 0) { Timer t(h, "k_row_desc"); hipLaunchKernelGGL(k_row_desc, dim3(nblocks(h->n_active_rows, 256)), dim3(256), 0, h->stream, d, za); }
-    const int noise_kind = !d.enable_noise ? 0 : (d.noise_f ? 2 : 1);      // (a template parameter of the two row kernels: no branch between their loads)
-    if (h->n_active_rows > 0) {
-        Timer t(h, "k_zle"); const dim3 grid(nblocks(h->n_active_rows, 4));
+    const int noise_kind = !d.enable_noise ? 0 : (d.noise_f ? 2 : 1);      // (a template parameter of the row kernels: no branch between their loads)
+    if (h->n_res_rows > 0) {        // resident rows: pulses, finished samples and intervals by one wave per row
+        PulseArgs pr = pa;
+        pr.desc = h->res_desc.as<TileDesc>(); pr.currents = nullptr; pr.cur_off = nullptr;
+        // two launches: the rows of at most RES_SHORT_LEN samples at full occupancy, the longer ones with LDS for the longest of them
+        Timer t(h, "k_row_pulse");
+#define WFS_ROW_PULSE(NK) do { if (h->cfg.fma) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_pulse<NK, true>), grid, dim3(256), lds, h->stream, d, pr, za, first, n_rows, region); \
+                               else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_pulse<NK, false>), grid, dim3(256), lds, h->stream, d, pr, za, first, n_rows, region); } while (0)
+        for (int part = 0; part < 2; part++) {
+            const i64 first = part == 0 ? 0 : h->n_short_rows, n_rows = part == 0 ? h->n_short_rows : h->n_res_rows - h->n_short_rows;
+            if (n_rows <= 0) continue;
+            const i32 region = part == 0 ? RES_SHORT_LEN : (i32)((h->max_res_len + 255) / 256 * 256);
+            const size_t lds = ROW_LDS_FIXED + (size_t)4 * region * 4;
+            const dim3 grid(nblocks(n_rows, 4));
+            if (noise_kind == 0) WFS_ROW_PULSE(0); else if (noise_kind == 1) WFS_ROW_PULSE(1); else WFS_ROW_PULSE(2);
+        }
+    }
+    {   // truth accumulators of every pulse set from the per-tile partial sums
+        TruthArgs ta{S, h->tile_count.as<i32>(), h->tile_tmin.as<i32>(), h->tile_tmax.as<i32>(), h->set_t0.as<i64>(), h->tile_truth.as<double>(),
+                     h->truth.as<double>(), h->tminmax.as<i64>()};
+        Timer t(h, "k_truth_reduce");
+        hipLaunchKernelGGL(k_truth_reduce, dim3(nblocks(S, 4)), dim3(256), 0, h->stream, d, ta);
+    }
+
+    if (h->n_front_rows > 0) {
+        Timer t(h, "k_zle"); const dim3 grid(nblocks(h->n_front_rows, 4));
         if (noise_kind == 0) hipLaunchKernelGGL(k_zle<0>, grid, dim3(256), 0, h->stream, d, za);
         else if (noise_kind == 1) hipLaunchKernelGGL(k_zle<1>, grid, dim3(256), 0, h->stream, d, za);
         else hipLaunchKernelGGL(k_zle<2>, grid, dim3(256), 0, h->stream, d, za);
@@ -1782,8 +1848,8 @@ try {
     wfs_counts c{};
     c.n_instructions = h->n_ins; c.n_pulse_sets = h->n_sets; c.n_emitters = h->n_emitters; c.n_photons = h->n_photons + ((!h->injected && h->ap_active) ? h->n_ap_photons : 0);
     const bool tiles_done = !h->injected && !h->optical && h->fuse_full && h->n_fused_tiles > 0;
-    c.n_tiles = h->n_active_tiles + (tiles_done ? h->n_fused_tiles : 0); c.n_groups = h->n_groups; c.n_rows = h->n_active_rows;
-    c.n_raw_samples = h->s_raw + (tiles_done ? h->s_raw_direct : 0);
+    c.n_tiles = h->n_active_tiles + (tiles_done ? h->n_fused_tiles : 0) + h->n_res_tiles; c.n_groups = h->n_groups; c.n_rows = h->n_active_rows;
+    c.n_raw_samples = h->s_raw + (tiles_done ? h->s_raw_direct : 0) + h->s_res;
     c.n_records = h->n_records;
     c.n_intervals = h->h_scal[20]; c.n_pe = h->h_scal[21];          // reduced on the device at the end of wfs_run (k_counts)
     *out = c; h->counts = c;

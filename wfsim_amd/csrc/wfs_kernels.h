@@ -10,6 +10,7 @@
 //   intervals   = ZLE output per row, reserved slots; records = 244-byte strax raw_records
 #pragma once
 #include "wfs_device.h"
+#include <cstddef>
 
 #define I64_MAX 0x7fffffffffffffffLL
 #define I64_MIN (-I64_MAX - 1)
@@ -131,6 +132,15 @@ struct GeomArgs {
     i64 n_done;                 // primary tiles (the tiles of the afterpulse sets, which follow them, are never done)
     i32 *row_cnt, *row_tile;    // [groups * n_tpc] tiles in the row; one of them
     const i32 *ins_bcap; const i64 *ins_boff;      // tile sample buffers (wfs_tilegen.h)
+    // resident rows (k_row_pulse): rows no longer than res_max_len whose tiles all fit a wave are made, finished and zero-suppressed by
+    // ONE wave in LDS; their tiles are on no work list but in a per-row list (res_toff: row -> first entry of res_desc)
+    i32 res_on, res_max_len;
+    i32 *row_bad;               // [groups * n_tpc] 1: the row holds a tile that needs one of the tile kernels
+    i32 *fin_len, *res_cnt;     // [groups * n_tpc] finished int16 samples reserved for a resident row (a multiple of 4) / its tiles
+    const i64 *res_toff;        // exclusive scan of res_cnt
+    struct TileDesc *res_desc;  // [resident tiles] descriptors in row order (k_tile_assign)
+    i64 rows_cap;               // capacity of active_rows: resident rows of at most RES_SHORT_LEN samples are appended from its end backwards,
+    i32 *res_long;              // the longer ones to this list (two launches of k_row_pulse: its LDS goes with the longest row)
     i32 force_dense;     // debug: send every tile to the dense kernel
     i32 init_has; i64 init_runmax;      // last_pulse_end_time carried in from earlier batches
     const i64 *noise_override; i64 n_noise_override;
@@ -143,6 +153,7 @@ struct GeomArgs {
 #define TINY_LANES 16              // lanes that share the samples of one tiny tile (k_pulse_tiny)
 #define WAVE_MAX_PHOTONS 64        // medium tiles: photons fit the lanes of one wave (any width): k_pulse_wave
 #define WAVE_MAX_BINS 16384
+#define RES_SHORT_LEN 768          // resident rows up to this length: 4 waves x 3 KB of LDS per workgroup, eight workgroups per CU
 
 __device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i32 tmax, i64 &left, i64 &right, i64 &bin0, i64 &nb)
 {
@@ -154,42 +165,14 @@ __device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i
     right = bin1 + d.store_after + d.samples_after;
 }
 
-// per tile: end time of its pulse -> cluster (rawdata.py:188-190); work lists of non-empty tiles.
-// List appends and the two maxima are aggregated per wave (one atomic per wave instead of one per tile).
-__global__ void k_tile_geom(WfsDev d, GeomArgs a)
+// work lists and maxima: aggregated per workgroup in LDS, then one global atomic per workgroup and counter
+// (76k wave-level atomics on one cache line cost ~3 ms; the counters all live in the same line of scal[])
+__device__ __forceinline__ void tile_list_append(const GeomArgs &a, bool listed, int cls, i64 nb, i32 cnt, i64 tile)
 {
-    const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool live = tile < a.n_tiles && a.tile_count[tile] > 0;
-    int cls = 2; i64 nb = 0; i32 cnt = 0; i32 cl = -1; i64 end = I64_MIN;      // class 0 tiny, 1 sparse, 2 dense, 3 wave (medium)
-    if (live) {
-        const i64 set = tile / d.n_tpc;
-        i64 left, right, bin0;
-        tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
-        cl = a.set_cluster[set]; end = right * d.dt;
-        cnt = a.tile_count[tile];
-        if (!a.force_dense) cls = (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1
-                                  : ((cnt <= WAVE_MAX_PHOTONS && nb <= WAVE_MAX_BINS) ? 3 : 2));
-        if (a.tile_done && tile < a.n_done && a.tile_done[tile]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
-    }
-    {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
-        const u64 ml = ballot64(live);
-        if (ml) {
-            const i32 cl0 = __shfl(cl, __ffsll((long long)ml) - 1, 64);
-            if (all64(!live || cl == cl0)) {
-                i64 e = end;
-                for (int o = 32; o > 0; o >>= 1) { const i64 x = __shfl_down(e, o, 64); e = x > e ? x : e; }
-                if (lane == 0) atomicMax(&a.cl_end[cl0], e);
-            } else if (live) atomicMax(&a.cl_end[cl], end);
-        }
-    }
-    // work lists and maxima: aggregated per workgroup in LDS, then one global atomic per workgroup and counter
-    // (76k wave-level atomics on one cache line cost ~3 ms; the counters all live in the same line of scal[])
     __shared__ i32 s_n[4]; __shared__ i64 s_b[4], s_mx[4];
     if (threadIdx.x == 0) { s_n[0] = 0; s_n[1] = 0; s_n[2] = 0; s_n[3] = 0; s_mx[0] = 0; s_mx[1] = 0; s_mx[2] = 0; s_mx[3] = 0; }
     __syncthreads();
     i32 rk = 0;
-    const bool listed = live && cls >= 0;
     if (listed) {
         rk = atomicAdd(&s_n[cls], 1);
         if (cls == 1) { atomicMax(&s_mx[0], nb); atomicMax(&s_mx[1], (i64)cnt); } else if (cls == 2) { atomicMax(&s_mx[2], nb); atomicMax(&s_mx[3], (i64)cnt); }
@@ -207,6 +190,44 @@ __global__ void k_tile_geom(WfsDev d, GeomArgs a)
     }
     __syncthreads();
     if (listed) (cls == 0 ? a.active_tiles : (cls == 1 ? a.sparse_tiles : (cls == 2 ? a.dense_tiles : a.wave_tiles)))[s_b[cls] + rk] = (i32)tile;
+}
+
+__device__ __forceinline__ int tile_class(const GeomArgs &a, i32 cnt, i64 nb)      // 0 tiny, 1 sparse, 2 dense, 3 wave (medium)
+{
+    if (a.force_dense) return 2;
+    return (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) ? 0 : ((cnt <= SPARSE_MAX_PHOTONS && nb <= SPARSE_MAX_BINS) ? 1
+           : ((cnt <= WAVE_MAX_PHOTONS && nb <= WAVE_MAX_BINS) ? 3 : 2));
+}
+
+// per tile: end time of its pulse -> cluster (rawdata.py:188-190); work lists of non-empty tiles.
+// List appends and the two maxima are aggregated per wave (one atomic per wave instead of one per tile).
+__global__ void k_tile_geom(WfsDev d, GeomArgs a)
+{
+    const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const bool live = tile < a.n_tiles && a.tile_count[tile] > 0;
+    int cls = 2; i64 nb = 0; i32 cnt = 0; i32 cl = -1; i64 end = I64_MIN;      // class 0 tiny, 1 sparse, 2 dense, 3 wave (medium)
+    if (live) {
+        const i64 set = tile / d.n_tpc;
+        i64 left, right, bin0;
+        tile_bounds(d, a.set_t0[set], a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+        cl = a.set_cluster[set]; end = right * d.dt;
+        cnt = a.tile_count[tile];
+        cls = tile_class(a, cnt, nb);
+        if (a.tile_done && tile < a.n_done && a.tile_done[tile]) cls = -1;      // its pulse exists already (k_s2_tile): no work list
+    }
+    {   // cluster end time: the live lanes of a wave usually belong to one cluster -> one atomic for the wave
+        const u64 ml = ballot64(live);
+        if (ml) {
+            const i32 cl0 = __shfl(cl, __ffsll((long long)ml) - 1, 64);
+            if (all64(!live || cl == cl0)) {
+                i64 e = end;
+                for (int o = 32; o > 0; o >>= 1) { const i64 x = __shfl_down(e, o, 64); e = x > e ? x : e; }
+                if (lane == 0) atomicMax(&a.cl_end[cl0], e);
+            } else if (live) atomicMax(&a.cl_end[cl], end);
+        }
+    }
+    if (!a.res_on) tile_list_append(a, live && cls >= 0, cls, nb, cnt, tile);      // (resident rows on: k_tile_assign makes the lists, once the rows are known)
 }
 
 // Digitise groups.  The cache is digitised before cluster k when min(instruction key of k) - last_pulse_end_time > rext
@@ -280,6 +301,10 @@ __global__ void k_tile_rows(WfsDev d, GeomArgs a)
         g = a.cl_group[a.set_cluster[set]];
         atomicMin(&a.row_lo[g * d.n_tpc + ch], left); atomicMax(&a.row_hi[g * d.n_tpc + ch], right);
         if (a.row_cnt) { atomicAdd(&a.row_cnt[g * d.n_tpc + ch], 1); a.row_tile[g * d.n_tpc + ch] = (i32)tile; }      // (row_tile: only read when the row has ONE tile)
+        if (a.res_on) {         // a tile of more than a wave's photons, or one whose pulse exists already, keeps its row off the resident path
+            const bool done = a.tile_done && tile < a.n_done && a.tile_done[tile];
+            if (done || a.tile_count[tile] > WAVE_MAX_PHOTONS || nb > WAVE_MAX_BINS) a.row_bad[g * d.n_tpc + ch] = 1;
+        }
     }
     // the group's range: the 494 tiles of a pulse set all aim at one address -- reduce inside the wave first when its
     // live lanes share the group (the usual case), one atomic pair per wave instead of 64
@@ -329,12 +354,12 @@ __device__ __forceinline__ bool row_is_direct(const i32 *tile_done, i64 n_done, 
 // (appended with one global atomic per workgroup)
 __global__ void k_row_len(WfsDev d, GeomArgs a)
 {
-    __shared__ i32 s_n, s_direct, s_shared; __shared__ i64 s_base;
-    if (threadIdx.x == 0) { s_n = 0; s_direct = 0; s_shared = 0; }
+    __shared__ i32 s_n, s_nres, s_nlong, s_direct, s_shared, s_maxres, s_reslen; __shared__ i64 s_base, s_rbase, s_lbase;
+    if (threadIdx.x == 0) { s_n = 0; s_nres = 0; s_nlong = 0; s_direct = 0; s_shared = 0; s_maxres = 0; s_reslen = 0; }
     __syncthreads();
     const i64 idx = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     const i64 n = a.scal[0] * d.row_slots;
-    i32 cap = 0, rk = -1;
+    i32 cap = 0, rk = -1; bool resident = false, longrow = false;
     if (idx < n) {
         const i64 g = idx / d.row_slots; const i32 slot = (i32)(idx - g * d.row_slots);
         const i32 ch = slot < d.n_tpc ? slot : slot - d.n_tpc;         // HE slot -> its top channel
@@ -345,17 +370,30 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
             cap = (i32)((len + hold) / (hold + 1));
             // a row made by ONE tile whose samples exist already (k_s2_tile) is read from the tile's buffer: no accumulators
             const bool direct = row_is_direct(a.tile_done, a.n_done, a.row_cnt, a.row_tile, g * d.n_tpc + ch);
-            if (slot < d.n_tpc) { a.acc_len[g * d.n_tpc + ch] = direct ? 0 : (i32)len; if (direct) atomicAdd(&s_direct, (i32)len); }
-            if (slot < d.n_tpc && a.row_cnt && a.row_cnt[g * d.n_tpc + ch] > 1) atomicAdd(&s_shared, 1);
-            rk = atomicAdd(&s_n, 1);
+            // a short row of small tiles is made in LDS by one wave (k_row_pulse): no accumulators either, 16-bit finished samples instead
+            resident = a.res_on && !direct && len <= a.res_max_len && !a.row_bad[g * d.n_tpc + ch];
+            if (slot < d.n_tpc) {
+                a.acc_len[g * d.n_tpc + ch] = (direct || resident) ? 0 : (i32)len; if (direct) atomicAdd(&s_direct, (i32)len);
+                if (a.res_on) { a.fin_len[g * d.n_tpc + ch] = resident ? (i32)((len + 3) & ~(i64)3) : 0; a.res_cnt[g * d.n_tpc + ch] = resident ? a.row_cnt[g * d.n_tpc + ch] : 0; }
+                if (resident) { atomicMax(&s_maxres, (i32)len); atomicAdd(&s_reslen, (i32)len); longrow = len > RES_SHORT_LEN; }
+            }
+            if (slot < d.n_tpc && !resident && a.row_cnt && a.row_cnt[g * d.n_tpc + ch] > 1) atomicAdd(&s_shared, 1);
+            rk = atomicAdd(resident ? (longrow ? &s_nlong : &s_nres) : &s_n, 1);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0 && s_n) s_base = (i64)atomicAdd((u64 *)&a.scal[2], (u64)s_n);
+    if (threadIdx.x == 0 && s_nres) s_rbase = (i64)atomicAdd((u64 *)&a.scal[32], (u64)s_nres);
+    if (threadIdx.x == 0 && s_nlong) s_lbase = (i64)atomicAdd((u64 *)&a.scal[37], (u64)s_nlong);
+    if (threadIdx.x == 0 && s_reslen) { atomicMax(&a.scal[33], (i64)s_maxres); atomicAdd((u64 *)&a.scal[36], (u64)s_reslen); }
     if (threadIdx.x == 0 && s_direct) atomicAdd((u64 *)&a.scal[26], (u64)s_direct);      // samples of the rows read in place
     if (threadIdx.x == 0 && s_shared) atomicAdd((u64 *)&a.scal[27], (u64)s_shared);      // rows made by several tiles (k_tile_add is needed)
     __syncthreads();
-    if (rk >= 0) a.active_rows[s_base + rk] = (i32)idx;
+    if (rk >= 0) {
+        if (!resident) a.active_rows[s_base + rk] = (i32)idx;
+        else if (!longrow) a.active_rows[a.rows_cap - 1 - (s_rbase + rk)] = (i32)idx;
+        else a.res_long[s_lbase + rk] = (i32)idx;
+    }
     if (idx < a.n_gslots * d.row_slots) a.itv_cap[idx] = cap;
 }
 
@@ -377,7 +415,7 @@ struct TileDesc {
     i64 rel0;             // ns of the tile's first start bin relative to the set's t0
     double G, thr;        // PMT gain, truth threshold of the channel
     i32 n, nb, L, tile;   // photons, start bins, samples, tile id
-    i32 ch, mode, pad0, pad1;
+    i32 ch, mode;
 };
 
 struct PulseArgs {
@@ -417,7 +455,7 @@ __global__ void k_tile_desc(WfsDev d, DescArgs a)
     t.off = a.tile_off[tile]; t.dst = a.acc_off[ridx] + (left - (a.row_lo[ridx] - d.tw)); t.rel0 = bin0 * d.dt - t0;
     t.G = d.gains[ch]; t.thr = d.thr_truth[ch];
     t.n = a.tile_count[tile]; t.nb = (i32)nb; t.L = (i32)(right - left + 1); t.tile = (i32)tile;
-    t.ch = ch; t.mode = a.set_mode[set]; t.pad0 = 0; t.pad1 = 0;
+    t.ch = ch; t.mode = a.set_mode[set];
     a.desc[i] = t;
 }
 
@@ -890,22 +928,14 @@ __global__ __launch_bounds__(TPB) void k_pulse_generic(WfsDev d, PulseArgs a)
 // sorted by time in registers, equal-ns photons merged (first of the run carries the summed gain), and every sample in
 // reach of a photon adds templates[r][k] * gain in ascending time with a separate multiply and add: the arithmetic of
 // add_current (pulse.py:276-318), hence the same bits as the other two kernels.  Truth sums need no reduction.
-template <bool FMA>
-__global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n_tiny)
+// The pulse of a tile of at most TINY_MAX_PHOTONS photons (see k_pulse_tiny) in two steps.  tiny_tile_prepare: the photons sorted by
+// time, runs of equal ns merged, start bin and ns remainder of each, the samples they reach -- and the tile's truth sums (sub == 0).
+// tiny_tile_samples: lane `sub` of LANES takes the samples s_first + sub, + LANES, ...; tap(r, k) = templates[r][k], sink(s, adc)
+// receives the non-zero ADC counts.
+struct TinyPrep { int jb[TINY_MAX_PHOTONS], rr[TINY_MAX_PHOTONS]; double g[TINY_MAX_PHOTONS]; int n, s_first, s_last; };
+__device__ __forceinline__ TinyPrep tiny_tile_prepare(const WfsDev &d, const PulseArgs &a, const TileDesc &td, int sub, const double *s_cmax)
 {
     constexpr int dt = WFS_DT, tlen = 22, NP = TINY_MAX_PHOTONS;
-    __shared__ double sT[dt * tlen];                      // templates[r][k]
-    __shared__ double s_cmax[dt];
-    for (int i = threadIdx.x; i < dt * tlen; i += blockDim.x) sT[i] = d.templates[i];
-    if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
-    __syncthreads();
-    // TINY_LANES lanes per tile: all of them load, sort and merge the tile's (at most 4) photons -- the same registers in each, no
-    // exchange -- and share the tile's samples, lane j taking s_first + j, + TINY_LANES, ...: the adds of a tile land in runs of 64
-    // bytes instead of 64 rows per instruction, and a wave's loop is as long as its longest tile divided by TINY_LANES.
-    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    const i64 idx = gtid / TINY_LANES; const int sub = (int)(gtid % TINY_LANES);
-    if (idx >= n_tiny) return;
-    const TileDesc td = a.desc[idx];
     const int n = td.n, L = td.L;
     const int lead = d.store_before + d.samples_before;
     const double G = td.G;
@@ -960,24 +990,106 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
     int jb[NP], rr[NP];
 #pragma unroll
     for (int k = 0; k < NP; k++) { jb[k] = (k < n) ? ns[k] / dt : 0x3fffffff; rr[k] = (k < n) ? ns[k] - jb[k] * dt : 0; }
-    i32 *dst = a.raw + td.dst;
     // samples in reach of a photon: start bin j touches samples j + lead .. j + lead + tlen - 1
     const int s_first = a.currents ? 0 : jb[0] + lead;
     int jmax = 0;
 #pragma unroll
     for (int k = 0; k < NP; k++) if (k < n) jmax = jb[k] > jmax ? jb[k] : jmax;
     const int s_last = a.currents ? L - 1 : (jmax + lead + tlen - 1 < L - 1 ? jmax + lead + tlen - 1 : L - 1);
-    for (int s = s_first + sub; s <= s_last; s += TINY_LANES) {
+    TinyPrep q; q.n = n; q.s_first = s_first; q.s_last = s_last;
+#pragma unroll
+    for (int k = 0; k < NP; k++) { q.jb[k] = jb[k]; q.rr[k] = rr[k]; q.g[k] = g[k]; }
+    return q;
+}
+
+template <bool FMA, int LANES, class Tap, class Sink>
+__device__ __forceinline__ void tiny_tile_samples(const WfsDev &d, const PulseArgs &a, const TinyPrep &q, i64 idx, int sub, Tap tap, Sink sink)
+{
+    constexpr int tlen = 22, NP = TINY_MAX_PHOTONS;
+    const int lead = d.store_before + d.samples_before;
+    for (int s = q.s_first + sub; s <= q.s_last; s += LANES) {
         double cur = 0.0;
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-            const int kk = s - lead - jb[k];
-            if (k < n && kk >= 0 && kk < tlen) cur = mac<FMA>(sT[rr[k] * tlen + kk], g[k], cur);
+            const int kk = s - lead - q.jb[k];
+            if (k < q.n && kk >= 0 && kk < tlen) cur = mac<FMA>(tap(q.rr[k], kk), q.g[k], cur);
         }
         if (a.currents) a.currents[a.cur_off[idx] + s] = cur;
         const i64 adc = -(i64)rint(cur * d.c2a);                 // rawdata.py:236
-        if (adc != 0) atomicAdd(&dst[s], (i32)adc);
+        if (adc != 0) sink(s, (i32)adc);
     }
+}
+
+template <bool FMA, int LANES, class Tap, class Sink>
+__device__ __forceinline__ void tiny_tile_pulse(const WfsDev &d, const PulseArgs &a, const TileDesc &td, i64 idx, int sub, const double *s_cmax, Tap tap, Sink sink)
+{
+    const TinyPrep q = tiny_tile_prepare(d, a, td, sub, s_cmax);
+    tiny_tile_samples<FMA, LANES>(d, a, q, idx, sub, tap, sink);
+}
+
+// A prepared tiny tile of a resident row (k_tile_assign -> k_row_pulse), in the 64 bytes of a TileDesc; n_neg = -photons sits where
+// TileDesc::n does and tells the two apart.
+struct __attribute__((aligned(64))) TinyDesc { double g[TINY_MAX_PHOTONS]; i32 dst, s_first, n_neg, s_last; u32 jr[TINY_MAX_PHOTONS]; };      // jr = start bin << 4 | ns remainder
+static_assert(sizeof(TinyDesc) == 64 && sizeof(TileDesc) == 64 && offsetof(TinyDesc, n_neg) == offsetof(TileDesc, n), "descriptor layouts");
+
+// Resident rows on: every live tile goes either into its row's list (descriptor written here, dst relative to the row's first
+// sample) or onto the work list of its class -- the choice k_tile_geom cannot make, because rows exist only after k_groups.
+__global__ void k_tile_assign(WfsDev d, GeomArgs a, DescArgs da, PulseArgs pa)
+{
+    const i64 tile = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = tile < a.n_tiles && a.tile_count[tile] > 0;
+    int cls = 2; i64 nb = 0; i32 cnt = 0; bool listed = false;
+    if (live) {
+        const i64 set = tile / d.n_tpc; const i32 ch = (i32)(tile - set * d.n_tpc);
+        const i64 t0 = a.set_t0[set];
+        i64 left, right, bin0;
+        tile_bounds(d, t0, a.tile_tmin[tile], a.tile_tmax[tile], left, right, bin0, nb);
+        cnt = a.tile_count[tile];
+        const i64 ridx = (i64)a.cl_group[a.set_cluster[set]] * d.n_tpc + ch;
+        const i64 first = a.res_toff[ridx];
+        if (a.res_toff[ridx + 1] > first) {
+            const i32 k = atomicSub(&a.res_cnt[ridx], 1) - 1;          // (the scan has consumed the counts: they serve as the rows' cursors)
+            TileDesc t;
+            t.off = da.tile_off[tile]; t.dst = left - (a.row_lo[ridx] - d.tw); t.rel0 = bin0 * d.dt - t0;
+            t.G = d.gains[ch]; t.thr = d.thr_truth[ch];
+            t.n = cnt; t.nb = (i32)nb; t.L = (i32)(right - left + 1); t.tile = (i32)tile;
+            t.ch = ch; t.mode = da.set_mode[set];
+            if (cnt <= TINY_MAX_PHOTONS && nb <= 4 * TINY_MAX_BINS) {
+                // a handful of photons: everything that does not depend on the sample is done here, one LANE per tile (sorted and merged
+                // photons, their start bins, the tile's truth sums) -- in k_row_pulse a whole wave would do it for one tile
+                const TinyPrep q = tiny_tile_prepare(d, pa, t, 0, d.current_max);
+                TinyDesc y;
+                y.dst = (i32)t.dst; y.s_first = q.s_first; y.s_last = q.s_last; y.n_neg = -q.n;
+#pragma unroll
+                for (int j = 0; j < TINY_MAX_PHOTONS; j++) { y.g[j] = q.g[j]; y.jr[j] = ((u32)q.jb[j] << 4) | (u32)q.rr[j]; }
+                *(TinyDesc *)&a.res_desc[first + k] = y;
+            } else a.res_desc[first + k] = t;
+        } else {
+            cls = tile_class(a, cnt, nb);
+            listed = !(a.tile_done && tile < a.n_done && a.tile_done[tile]);
+        }
+    }
+    tile_list_append(a, listed, cls, nb, cnt, tile);
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n_tiny)
+{
+    constexpr int dt = WFS_DT, tlen = 22, NP = TINY_MAX_PHOTONS;
+    __shared__ double sT[dt * tlen];                      // templates[r][k]
+    __shared__ double s_cmax[dt];
+    for (int i = threadIdx.x; i < dt * tlen; i += blockDim.x) sT[i] = d.templates[i];
+    if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
+    __syncthreads();
+    // TINY_LANES lanes per tile: all of them load, sort and merge the tile's (at most 4) photons -- the same registers in each, no
+    // exchange -- and share the tile's samples, lane j taking s_first + j, + TINY_LANES, ...: the adds of a tile land in runs of 64
+    // bytes instead of 64 rows per instruction, and a wave's loop is as long as its longest tile divided by TINY_LANES.
+    const i64 gtid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 idx = gtid / TINY_LANES; const int sub = (int)(gtid % TINY_LANES);
+    if (idx >= n_tiny) return;
+    const TileDesc td = a.desc[idx];
+    i32 *dst = a.raw + td.dst;
+    tiny_tile_pulse<FMA, TINY_LANES>(d, a, td, idx, sub, s_cmax, [&](int r_, int k_) { return sT[r_ * tlen + k_]; }, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });
 }
 
 // Medium tiles: at most 64 photons over any number of start bins -- the tiles of a small S2 (a few hundred to a few thousand
@@ -989,23 +1101,23 @@ __global__ __launch_bounds__(256) void k_pulse_tiny(WfsDev d, PulseArgs a, i64 n
 // list, their (bin, ns remainder, gain) are broadcast one at a time from the lane that holds them, and every sample in
 // reach adds templates[r][k] * gain with a separate multiply and add, in ascending time: the arithmetic of add_current
 // (pulse.py:276-318), the same bits as the other kernels.
-template <bool FMA>
-__global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n_wave)
+struct __attribute__((aligned(16))) WavePhoton { i32 bin, row; double g; };       // start bin, first tap of its template row in sTz, merged gain
+#define PW_U 2
+#define WAVE_TZ_LEN (WFS_DT * (22 + 2))
+__device__ __forceinline__ void wave_tables_fill(const WfsDev &d, double *sTz, double *s_cmax)      // (every thread of the workgroup; a barrier follows)
 {
     constexpr int dt = WFS_DT, tlen = 22;
-    __shared__ double sTz[dt * (tlen + 2)];               // templates[r][k] with a zero tap in front of and behind every row
-    __shared__ double s_cmax[dt];
-    struct __attribute__((aligned(16))) WavePhoton { i32 bin, row; double g; };       // start bin, first tap of its template row in sTz, merged gain
-    constexpr int PW_U = 2;
-    __shared__ WavePhoton s_ph[4][64 + PW_U];             // the sorted, merged photons of each wave's tile, pad entries that reach nothing behind them
     for (int i = threadIdx.x; i < dt * (tlen + 2); i += blockDim.x) { const int r = i / (tlen + 2), k = i - r * (tlen + 2) - 1; sTz[i] = (k >= 0 && k < tlen) ? d.templates[r * tlen + k] : 0.0; }
     if (threadIdx.x < dt) s_cmax[threadIdx.x] = d.current_max[threadIdx.x];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const i64 idx = (i64)blockIdx.x * 4 + wave_in_block();       // (an SGPR: the tile descriptor stays scalar)
-    WavePhoton *wph = s_ph[wave_in_block()];
-    if (idx >= n_wave) return;                            // wave-uniform
-    const TileDesc td = a.desc[idx];
+}
+
+// The pulse of one tile made by one wave (see k_pulse_wave): sink(s, adc) receives the rounded, non-zero ADC counts of the tile's
+// sample s, every lane a different sample.
+template <bool FMA, class Sink>
+__device__ __forceinline__ void wave_tile_pulse(const WfsDev &d, const PulseArgs &a, const TileDesc &td, i64 idx, WavePhoton *wph, const double *sTz,
+                                                const double *s_cmax, int lane, Sink sink)
+{
+    constexpr int dt = WFS_DT, tlen = 22;
     const int n = td.n, L = td.L;
     const int lead = d.store_before + d.samples_before;
     const bool v = lane < n;
@@ -1075,7 +1187,6 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     // reach a sample not yet written (a photon of the thin tail of an S2 is alone in its 22 samples; whole blocks between the
     // photons are skipped).  Inside a block every sample walks the photons in reach, in ascending time; sTz has a zero tap on
     // either side of every template row, so a photon out of a sample's reach adds +0.0, which changes nothing (no exec masking).
-    i32 *dst = a.raw + td.dst;
     const int n_live = td.nb + tlen - 1;
     if (a.currents) for (int s = lane; s < L; s += 64) a.currents[a.cur_off[idx] + s] = 0.0;
     int s0 = 0;
@@ -1102,10 +1213,28 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
             const double x = rint(c * d.c2a);                  // rawdata.py:236
             // (|x| < 2^31 unless a current is absurd: the one-instruction conversion; the general one otherwise, same value)
             const i32 adc = fabs(x) < 2147483648.0 ? -(i32)x : (i32)(-(i64)x);
-            if (adc != 0) atomicAdd(&dst[lead + sp], adc);
+            if (adc != 0) sink(lead + sp, adc);
         }
         s0 += 64;
     }
+}
+
+template <bool FMA>
+__global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n_wave)
+{
+    constexpr int dt = WFS_DT, tlen = 22;
+    __shared__ double sTz[WAVE_TZ_LEN];                   // templates[r][k] with a zero tap in front of and behind every row
+    __shared__ double s_cmax[dt];
+    __shared__ WavePhoton s_ph[4][64 + PW_U];             // the sorted, merged photons of each wave's tile, pad entries that reach nothing behind them
+    wave_tables_fill(d, sTz, s_cmax);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const i64 idx = (i64)blockIdx.x * 4 + wave_in_block();       // (an SGPR: the tile descriptor stays scalar)
+    WavePhoton *wph = s_ph[wave_in_block()];
+    if (idx >= n_wave) return;                            // wave-uniform
+    const TileDesc td = a.desc[idx];
+    i32 *dst = a.raw + td.dst;
+    wave_tile_pulse<FMA>(d, a, td, idx, wph, sTz, s_cmax, lane, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });
 }
 
 // Sparse form of the same computation, for tiles with few photons per start bin (every S1, S2s up to ~10^6 PE):
@@ -1344,6 +1473,8 @@ struct ZleArgs {
     const u32 *rec_dest;         // record order by (time, channel): slot of record r in the output (nullptr: row order)
     u64 *rec_key; u32 *rec_val; i64 *key_base;     // k_rec_keys: sort key (sample - *key_base) << 12 | channel, and the record index; *key_base = first sample of the batch (k_row_desc)
     const i32 *tile_done, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf; i64 n_done;      // rows read from a tile buffer in place (wfs_tilegen.h)
+    // resident rows (k_row_pulse): the rows behind the first n_front of the row list; their finished 16-bit samples
+    i64 n_front, n_short, rows_cap; const i64 *res_toff, *fin_off; int16_t *fin; const i32 *res_long; struct ResRow *res_rows;
 };
 
 // One 64-byte descriptor per active row (thread per row: the divisions and the five dependent look-ups of a row are
@@ -1355,20 +1486,29 @@ struct __attribute__((aligned(64))) RowDesc {
     i64 itv_base;                // first interval slot of the row
     i64 thr;                     // ZLE threshold of the channel
     i64 idx;                     // row slot (group * row_slots + slot): index of itv_n / row_nrec / rec_off
-    i32 len, channel, he, src;   // src 1: acc_off points into the tile buffers (a row made by one k_s2_tile tile)
+    i32 len, channel, he, src;   // src 1: acc_off points into the tile buffers (a row made by one k_s2_tile tile); 2: into the finished
+                                 // 16-bit samples of the resident rows (k_row_pulse)
 };
+
+struct __attribute__((aligned(16))) ResRow { i64 t0; i32 n, pad; };       // a resident row's tiles: res_desc[t0 .. t0 + n)
 
 __global__ void k_row_desc(WfsDev d, ZleArgs a)
 {
     const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.n_active_rows) return;
-    const i64 idx = a.active_rows[r];
+    // row list order: accumulator rows | short resident rows (from the end of active_rows backwards, k_row_len) | long resident rows
+    const i64 idx = r < a.n_front ? a.active_rows[r] : (r < a.n_front + a.n_short ? a.active_rows[a.rows_cap - 1 - (r - a.n_front)] : a.res_long[r - a.n_front - a.n_short]);
     const i64 g = idx / d.row_slots; const i32 slot = (i32)(idx - g * d.row_slots);
     const bool he = slot >= d.n_tpc; const i32 acc_ch = he ? slot - d.n_tpc : slot, channel = he ? d.he_first + acc_ch : slot;
     const i64 ridx = g * d.n_tpc + acc_ch;
     RowDesc q;
     q.acc_off = a.acc_off[ridx]; q.row_abs = a.row_lo[ridx] - d.tw; q.ixr = a.grp_ixrand[g]; q.itv_base = a.itv_off[idx];
     q.src = 0;
+    if (r >= a.n_front) {
+        q.acc_off = a.fin_off[ridx]; q.src = 2;
+        const i64 t0 = a.res_toff[ridx];
+        a.res_rows[r - a.n_front] = ResRow{t0, (i32)(a.res_toff[ridx + 1] - t0), 0};
+    }
     if (row_is_direct(a.tile_done, a.n_done, a.row_cnt, a.row_tile, ridx)) {
         const i32 tile = a.row_tile[ridx]; const i32 ins = tile / d.n_tpc;
         q.acc_off = a.ins_boff[ins] + (i64)(tile - ins * d.n_tpc) * a.ins_bcap[ins]; q.src = 1;
@@ -1463,6 +1603,56 @@ __device__ __forceinline__ i32 finish_four(const WfsDev &d, const Raw4<NK> &s, i
     return v < 0 ? 0 : (i32)v;
 }
 
+// The interval bookkeeping of a row whose hold-off is at least a chunk of 64 samples: two hits of one chunk are never more than the
+// hold-off apart, so only the FIRST hit of a chunk can open an interval -- scalar work on the ballot of the lanes' hit nibbles.
+// Closed intervals wait in lane (k mod 64) and leave in one store (flush / finish).  A store inside a loop of loads -- even one that
+// is almost never executed -- may be outstanding together with loads, the two kinds retire out of order, and the compiler then waits
+// for EVERYTHING at the top of the loop; the flush of a row with more than 64 intervals drains the counter itself.
+struct ZleFast {
+    i32 s_last = -1, s_left = -1, s_count = 0, s_nrec = 0, my_l = 0, my_r = 0;
+    // close interval k = [rawl, rawr] (first / last hit): window, clip, even landing (rawdata.py:302-308); returns the records it needs
+    __device__ __forceinline__ i32 close(const WfsDev &d, const ZleArgs &a, int lane, i64 base, i64 row_abs, i32 len32, i32 k, i32 rawl, i32 rawr)
+    {
+        i32 l = rawl - d.tw, rr = rawr + d.tw;
+        l = l < 0 ? 0 : (l > len32 - 1 ? len32 - 1 : l); rr = rr < 0 ? 0 : (rr > len32 - 1 ? len32 - 1 : rr);
+        l = (l + 1) / 2 * 2; rr = rr / 2 * 2;                  // ceil(l/2)*2, floor(r/2)*2 for non-negative ints
+        const int slot = k & 63;
+        if (lane == slot) { my_l = l; my_r = rr; }
+        if (slot == 63) {
+            a.itv_left[base + (k - 63) + lane] = row_abs + my_l; a.itv_right[base + (k - 63) + lane] = row_abs + my_r;      // absolute sample indices (rawdata.py:311)
+            __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
+        }
+        const i32 plen = rr - l + 1;
+        return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
+    }
+    // 256 samples: lane q holds the hits of samples i .. i + 3 (i = block start + 4 q) as a nibble; 16 lanes are a chunk of 64 samples,
+    // whose first and last hit come from the ballot of the non-empty nibbles and two readlanes
+    __device__ __forceinline__ void block(const WfsDev &d, const ZleArgs &a, int lane, i64 base, i64 row_abs, i32 len32, i32 hold32, u32 nib, i32 i)
+    {
+        const u64 mask = ballot64(nib != 0);
+        if (mask == 0) return;                              // wave-uniform
+        const i32 fpos = i + (i32)__builtin_ctz(nib | 16u), lpos = i + 31 - (i32)__builtin_clz(nib | 1u);      // first / last hit of the lane
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const u32 m = (u32)(mask >> (16 * c)) & 0xffffu;
+            if (m == 0) continue;
+            const i32 first = __builtin_amdgcn_readlane(fpos, 16 * c + (i32)__builtin_ctz(m));
+            const i32 last = __builtin_amdgcn_readlane(lpos, 16 * c + 31 - (i32)__builtin_clz(m));
+            if (s_last < 0 || first - s_last > hold32) {
+                if (s_count > 0) s_nrec += close(d, a, lane, base, row_abs, len32, s_count - 1, s_left, s_last);
+                s_left = first; s_count++;
+            }
+            s_last = last;
+        }
+    }
+    __device__ __forceinline__ void finish(const WfsDev &d, const ZleArgs &a, int lane, i64 base, i64 row_abs, i32 len32, i64 idx)
+    {
+        if (s_count > 0) s_nrec += close(d, a, lane, base, row_abs, len32, s_count - 1, s_left, s_last);
+        if (lane < (s_count & 63)) { const i64 k0 = base + (s_count & ~63); a.itv_left[k0 + lane] = row_abs + my_l; a.itv_right[k0 + lane] = row_abs + my_r; }
+        if (lane == 0) { a.itv_n[idx] = s_count; a.row_nrec[idx] = s_nrec; }
+    }
+};
+
 // one wave per row: find_intervals_below_threshold (utils.py:13-58) in its parallel form: consecutive
 // hit samples a < b belong to one interval iff b - a <= max(holdoff, 1); then the window of rawdata.py:302-308.
 template <int NK>
@@ -1470,7 +1660,7 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
 {
     const int lane = threadIdx.x & 63;
     const i64 r = (i64)blockIdx.x * 4 + wave_in_block();         // (an SGPR: the descriptor and everything derived from it stay scalar)
-    if (r >= a.n_active_rows) return;
+    if (r >= a.n_front) return;                             // (the rows behind n_front are resident: k_row_pulse has made their intervals)
     const RowDesc q = a.desc[r];
     const i64 idx = q.idx; const i32 channel = q.channel; const bool he = q.he != 0;
     const i64 len = q.len;
@@ -1500,31 +1690,12 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     const i64 noise_off = noisy ? (i64)channel * d.noise_stride : 0; const u32 nixr = noisy ? (u32)ixr : 0u;
     const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
     if (hold32 >= 63 && fast_loads && !a.row_dbg) {
-        // The usual geometry (hold-off of at least a chunk): two hits of one chunk are never more than the hold-off apart, so only
-        // the FIRST hit of a chunk can open an interval -- the whole interval bookkeeping is scalar work on the ballot mask, and
+        // The usual geometry (hold-off of at least a chunk): the interval bookkeeping is scalar work on the ballot mask (ZleFast), and
         // the vector unit is left with load, finish and compare.
         constexpr int G = 4;
-        i32 s_last = -1, s_left = -1, s_count = 0, s_nrec = 0;
-        // Closed intervals wait in lane (k mod 64) and leave in one store behind the loop.  A store inside the loop -- even one that is
-        // almost never executed -- may be outstanding together with loads, the two kinds retire out of order, and the compiler then
-        // waits for EVERYTHING at the top of the loop; the flush of a row with more than 64 intervals drains the counter itself.
-        i32 my_l = 0, my_r = 0;
-        auto close_scalar = [&](i32 k, i32 rawl, i32 rawr) -> i32 {
-            i32 l = rawl - d.tw, rr = rawr + d.tw;
-            l = l < 0 ? 0 : (l > len32 - 1 ? len32 - 1 : l); rr = rr < 0 ? 0 : (rr > len32 - 1 ? len32 - 1 : rr);
-            l = (l + 1) / 2 * 2; rr = rr / 2 * 2;
-            const int slot = k & 63;
-            if (lane == slot) { my_l = l; my_r = rr; }
-            if (slot == 63) {
-                a.itv_left[base + (k - 63) + lane] = row_abs + my_l; a.itv_right[base + (k - 63) + lane] = row_abs + my_r;
-                __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
-            }
-            const i32 plen = rr - l + 1;
-            return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
-        };
+        ZleFast z;
         // A lane takes FOUR consecutive samples (one 16-byte load of the row, one 8-byte load of the noise): a wave instruction moves
-        // 1 KB of the row, and the hits of a lane are a nibble.  16 lanes are a chunk of 64 samples; its first and last hit come from
-        // the ballot of the non-empty nibbles and two readlanes.
+        // 1 KB of the row, and the hits of a lane are a nibble.
         // G such loads per trip: 1024 samples, most rows in one trip (6 KB in flight per wave; a second register set filled ahead
         // bought nothing -- the register allocator reuses the first set's registers for addresses and waits for its loads anyway).
         // Loads are unconditional (lanes past the end of the row read its first samples): behind a branch the compiler drains the
@@ -1548,27 +1719,11 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
                 u32 nib = 0;
 #pragma unroll
                 for (int j = 0; j < 4; j++) { const i32 v = finish_four<NK>(d, buf[u], j, he, noisy); nib |= (i + j < len32 && (i64)v < thr) ? (1u << j) : 0u; }
-                const u64 mask = ballot64(nib != 0);
-                if (mask == 0) continue;                        // wave-uniform
-                const i32 fpos = i + (i32)__builtin_ctz(nib | 16u), lpos = i + 31 - (i32)__builtin_clz(nib | 1u);      // first / last hit of the lane
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const u32 m = (u32)(mask >> (16 * c)) & 0xffffu;
-                    if (m == 0) continue;
-                    const i32 first = __builtin_amdgcn_readlane(fpos, 16 * c + (i32)__builtin_ctz(m));
-                    const i32 last = __builtin_amdgcn_readlane(lpos, 16 * c + 31 - (i32)__builtin_clz(m));
-                    if (s_last < 0 || first - s_last > hold32) {
-                        if (s_count > 0) s_nrec += close_scalar(s_count - 1, s_left, s_last);
-                        s_left = first; s_count++;
-                    }
-                    s_last = last;
-                }
+                z.block(d, a, lane, base, row_abs, len32, hold32, nib, i);
             }
         };
         for (i32 g0 = 0; g0 < len32; g0 += 256 * G) { fetch(A, g0); look(A, g0); }
-        if (s_count > 0) s_nrec += close_scalar(s_count - 1, s_left, s_last);
-        if (lane < (s_count & 63)) { const i64 k0 = base + (s_count & ~63); a.itv_left[k0 + lane] = row_abs + my_l; a.itv_right[k0 + lane] = row_abs + my_r; }
-        if (lane == 0) { a.itv_n[idx] = s_count; a.row_nrec[idx] = s_nrec; }
+        z.finish(d, a, lane, base, row_abs, len32, idx);
         return;
     }
     // chunks of 64 samples; the loads of ZLE_GROUP chunks are issued together (one dependent load per chunk leaves the wave
@@ -1621,6 +1776,78 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
     if (lane == 0 && count > 0) nrec += close_interval(count - 1, open_left, carry_last);
     for (int o = 32; o > 0; o >>= 1) nrec += __shfl_down(nrec, o, 64);
     if (lane == 0) { a.itv_n[idx] = count; a.row_nrec[idx] = nrec; }
+}
+
+// Resident rows: ONE wave makes a whole (window, channel) row -- zeroes it in LDS, adds the rounded pulses of the row's tiles
+// (wave_tile_pulse: the arithmetic of k_pulse_wave; integer sums, so the order of the tiles does not matter), finishes the samples
+// (noise, baseline, clamp: rawdata.py:398-458), runs the zero-length encoding on them and writes them ONCE, as 16-bit samples.
+// Against the accumulator path (memset 4 B + atomics + 6 B read by k_zle + 6 B read by k_pack per sample) a row costs 2 B of noise
+// read and 2 B written here and 2 B read by k_pack.  rawdata.py:231-239 (per-pulse rounding into the row), :302-311 (intervals).
+#define ROW_LDS_FIXED ((WAVE_TZ_LEN + 16) * 8 + 4 * (64 + PW_U) * 16)
+template <int NK, bool FMA>
+__global__ __launch_bounds__(256) void k_row_pulse(WfsDev d, PulseArgs a, ZleArgs z, i64 first, i64 n_res, i32 region)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char row_lds[];
+    double *sTz = (double *)row_lds; double *s_cmax = sTz + WAVE_TZ_LEN;
+    WavePhoton *s_ph = (WavePhoton *)(s_cmax + 16);
+    i32 *s_acc = (i32 *)(s_ph + 4 * (64 + PW_U));
+    wave_tables_fill(d, sTz, s_cmax);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = wave_in_block();
+    const i64 r = (i64)blockIdx.x * 4 + w;
+    if (r >= n_res) return;                               // wave-uniform; no barrier below
+    const RowDesc q = z.desc[z.n_front + first + r];
+    const ResRow rr = z.res_rows[first + r];
+    i32 *acc = s_acc + (size_t)w * region;
+    WavePhoton *wph = s_ph + w * (64 + PW_U);
+    const i32 len32 = q.len;
+    for (i32 i = 4 * lane; i < ((len32 + 255) & ~255); i += 256) *(int4 *)(acc + i) = make_int4(0, 0, 0, 0);
+    // ---- the row's tiles (no HE rows on this path: row slot == row index)
+    const i64 t1 = rr.t0 + rr.n;
+    TileDesc nxt = a.desc[rr.t0];                         // (a resident row has at least one tile)
+    for (i64 t = rr.t0; t < t1; t++) {
+        const TileDesc td = nxt;
+        if (t + 1 < t1) nxt = a.desc[t + 1];             // on its way while this tile is made
+        if (td.n < 0) {                                   // a prepared tiny tile (k_tile_assign): the samples its photons reach, nothing else
+            TinyDesc y; __builtin_memcpy(&y, &td, 64);
+            TinyPrep q; q.n = -y.n_neg; q.s_first = y.s_first; q.s_last = y.s_last;
+#pragma unroll
+            for (int j = 0; j < TINY_MAX_PHOTONS; j++) { q.g[j] = y.g[j]; q.jb[j] = (int)(y.jr[j] >> 4); q.rr[j] = (int)(y.jr[j] & 15u); }
+            i32 *dst = acc + y.dst;
+            tiny_tile_samples<FMA, 64>(d, a, q, t, lane, [&](int r_, int k_) { return sTz[r_ * (22 + 2) + 1 + k_]; }, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });
+        } else {
+            i32 *dst = acc + td.dst;
+            wave_tile_pulse<FMA>(d, a, td, t, wph, sTz, s_cmax, lane, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });      // (ds_add_u32: every lane its own sample)
+        }
+    }
+    // ---- finish, zero-length encoding, 16-bit samples
+    const i64 thr = q.thr; const i64 base = q.itv_base, row_abs = q.row_abs, idx = q.idx;
+    i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
+    const i32 hold32 = (i32)hold;
+    const bool noisy = NK != 0 && q.channel < d.noise_channels;
+    const i64 noise_off = noisy ? (i64)q.channel * d.noise_stride : 0;
+    const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
+    u32 nrun = noisy ? (u32)q.ixr : 0u;
+    int16_t *fin = z.fin + q.acc_off;
+    const i32 fin_len = (len32 + 3) & ~3;
+    ZleFast zf;
+    for (i32 b0 = 0; b0 < len32; b0 += 256) {
+        const i32 i = b0 + 4 * lane;
+        Raw4<NK> s4;
+        *(int4 *)s4.acc = *(const int4 *)(acc + i);
+        if constexpr (NK != 0) {
+            u32 in = nrun + 4u * (u32)lane;
+            in = in >= (u32)d.noise_len ? in - (u32)d.noise_len : in;
+            if constexpr (NK == 2) __builtin_memcpy(s4.nzf, (const double *)noise_row + in, 32); else __builtin_memcpy(s4.nz, (const int16_t *)noise_row + in, 8);
+            nrun += 256u; nrun = nrun >= (u32)d.noise_len ? nrun - (u32)d.noise_len : nrun;
+        }
+        u32 nib = 0; u32 v16[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const i32 v = finish_four<NK>(d, s4, j, false, noisy); nib |= (i + j < len32 && (i64)v < thr) ? (1u << j) : 0u; v16[j] = (u32)(uint16_t)v; }
+        if (i < fin_len) *(uint2 *)(fin + i) = make_uint2(v16[0] | (v16[1] << 16), v16[2] | (v16[3] << 16));
+        zf.block(d, z, lane, base, row_abs, len32, hold32, nib, i);
+    }
+    zf.finish(d, z, lane, base, row_abs, len32, idx);
 }
 
 // Records ordered by (time, channel) as strax.sort_by_time leaves them (strax_interface.py:453): one key per record; the
@@ -1677,6 +1904,51 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const u32 w3 = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
     constexpr int PACK_U = 4;
     i64 rec = a.rec_off[idx];
+    if (q.src == 2) {       // a resident row: its finished 16-bit samples exist (k_row_pulse), two of them are a dword of the record
+        const int16_t *fin = a.fin + q.acc_off;
+        const i32 last = ((len32 + 3) & ~3) - 2;
+        for (i32 k = 0; k < count; k++) {
+            const i64 left = a.itv_left[base + k]; const i32 plen = (i32)(a.itv_right[base + k] - left + 1);
+            if (plen <= 0) continue;
+            const i32 need = (plen + spr - 1) / spr;
+            const i32 off = (i32)(left - row_abs);                 // even (rawdata.py:305-306), and the row starts on a multiple of four samples of fin
+            for (int q0 = 0; q0 < rec_dwords; q0 += 64) {
+                const int qd = q0 + lane;
+                const int s0 = (qd - 6) * 2;
+                for (i32 f0 = 0; f0 < need; f0 += PACK_U) {
+                    u32 two[PACK_U];
+#pragma unroll
+                    for (int u = 0; u < PACK_U; u++) {
+                        const i32 f = f0 + u;
+                        if (f >= need) break;                       // wave-uniform
+                        i32 i0 = off + spr * f + (s0 < 0 ? 0 : s0);
+                        i0 = i0 > last ? last : i0;                 // (lanes past the row read a valid pair and drop it)
+                        two[u] = *(const u32 *)(fin + i0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < PACK_U; u++) {
+                        const i32 f = f0 + u;
+                        if (f >= need) break;
+                        if (rec + f >= a.rec_capacity) break;
+                        u32 *out = (u32 *)(a.records + (a.rec_dest ? (i64)a.rec_dest[rec + f] : rec + f) * rec_bytes);
+                        const i64 time = (i64)d.dt * (left + spr * f);
+                        const i32 length = (plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f;
+                        u32 w;
+                        if (qd >= 6) w = (s0 < length ? two[u] & 0xffffu : 0u) | (s0 + 1 < length ? two[u] & 0xffff0000u : 0u);
+                        else if (qd == 0) w = (u32)(u64)time;
+                        else if (qd == 1) w = (u32)((u64)time >> 32);
+                        else if (qd == 2) w = (u32)length;
+                        else if (qd == 3) w = w3;
+                        else if (qd == 4) w = (u32)plen;
+                        else w = (u32)(uint16_t)f;
+                        if (qd < rec_dwords) out[qd] = w;
+                    }
+                }
+            }
+            rec += need;
+        }
+        return;
+    }
     for (i32 k = 0; k < count; k++) {
         const i64 left = a.itv_left[base + k]; const i32 plen = (i32)(a.itv_right[base + k] - left + 1);
         if (plen <= 0) continue;

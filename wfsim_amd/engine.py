@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get('WFSIM_AMD_LIB') or os.path.join(HERE, 'libwfsim_amd.s
 
 _I32 = ['dt', 'samples_before', 'samples_after', 'store_before', 'store_after', 'tlen', 'trigger_window', 'baseline',
         'n_rows', 'n_tpc', 'n_top', 'he_first', 'he_factor', 'sum_channel', 'last_bottom', 'detector_nt', 'enable_noise',
-        's1_simple', 's2_time_model', 'enable_pmt_ap', 'tile_gen', 'tile_gen_min', 'fma', 'pad0']
+        's1_simple', 's2_time_model', 'enable_pmt_ap', 'tile_gen', 'tile_gen_min', 'fma', 'row_resident']
 _F64 = ['c2a', 'tts_mean', 'tts_sigma', 'p_dpe', 's1_decay_time', 's1_decay_spread', 'sf_gas', 't1_gas', 't3_gas',
         's2_time_spread', 'trap_time', 'gain_spread', 'pmt_ap_modifier', 'pmt_ap_t_modifier', 'rext', 'drift_velocity']
 
