@@ -28,8 +28,9 @@ def _random_case(seed):
         kw.update(enable_pmt_afterpulses=True, uniform_to_pmt_ap=ap)
     if rng.random() < 0.3:
         kw.update(enable_noise=True, noise_data=golden('noise.npz')['noise'])
-    if np.random.default_rng(seed + 77).random() < 0.25:      # (its own stream: the cases of the earlier rounds keep their draws)
-        kw['row_resident'] = False
+    u = np.random.default_rng(seed + 77).random()             # (its own stream: the cases of the earlier rounds keep their draws)
+    if u < 0.5:                                                # resident rows forced on / off for a quarter of the cases each, else the batch decides
+        kw['row_resident'] = u < 0.25
     cfg = xenonnt_test_config(**kw)
     n = int(rng.integers(3, 60))
     ins = np.zeros(n, dtype=instruction_dtype)

@@ -103,3 +103,14 @@ def test_optical_instructions_same_records_either_way():
         c = eng.run()
         out.append((eng.records().tobytes(), c['n_records'], c['n_pe']))
     assert out[0] == out[1] and out[0][1] > 100
+
+
+@pytest.mark.parametrize('seg', [256, 512, 1024])
+def test_rows_longer_than_the_lds_of_a_wave_are_made_in_segments(monkeypatch, seg):
+    """WFS_RES_MAX_LEN shrinks the segment: most rows of a mixed batch then take several, with pulses across the seams"""
+    ins = W.mixed_batch(120)
+    ref, _, _ = _run(W.mixed_config(seed=21, row_resident=False), ins)
+    monkeypatch.setenv('WFS_RES_MAX_LEN', str(seg))
+    eng, counts, _ = _run(W.mixed_config(seed=21, row_resident=True), ins)
+    assert eng.records().tobytes() == ref.records().tobytes()
+    assert _truth_bytes(eng) == _truth_bytes(ref)

@@ -119,7 +119,7 @@ def kernel_params(config):
         s2_time_model=s2_time_model,
         enable_pmt_ap=int(afterpulse_switches(c)['pmt']),
         tile_gen=int(tile_local_generation(c)), tile_gen_min=int(c.get('tile_local_min_photons', 64)),
-        fma=int(bool(c.get('fused_multiply_add', True))), row_resident=int(bool(c.get('row_resident', True))),
+        fma=int(bool(c.get('fused_multiply_add', True))), row_resident=(2 if c.get('row_resident', 'auto') == 'auto' else int(bool(c.get('row_resident')))),
         c2a=float(current_2_adc(c)),
         tts_mean=float(c['pmt_transit_time_mean']),
         tts_sigma=float(c['pmt_transit_time_spread'] / 2.35482),          # pulse.py:52-56

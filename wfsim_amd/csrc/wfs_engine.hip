@@ -91,7 +91,8 @@ struct wfs_handle {
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
     i64 h_scal[64] = {0};
-    DevBuf row_bad, fin_len, res_cnt, fin_off, res_toff, res_desc, fin, res_long, res_rows;      // resident rows (k_row_pulse)
+    DevBuf pack_desc;
+    DevBuf row_bad, fin_len, res_cnt, fin_off, res_toff, res_desc, fin, res_long, res_rows, res_first;      // resident rows (k_row_pulse)
     i64 n_front_rows = 0, n_res_rows = 0, n_short_rows = 0, n_res_tiles = 0, max_res_len = 0, s_fin = 0, s_res = 0; bool res_on = false;
     i64 n_active_tiles = 0, n_tiny_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, n_wave_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
     i64 cur_total = 0, row_dbg_total = 0;
@@ -468,12 +469,12 @@ try {
     hipFuncSetAttribute((const void *)k_photon_fill<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     hipFuncSetAttribute((const void *)k_tile_order_big, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
     WFS_BIG_LDS_F(K_PULSE_GENERIC, 128);
-#define K_ROW_PULSE_0(F) k_row_pulse<0, F>
-#define K_ROW_PULSE_1(F) k_row_pulse<1, F>
-#define K_ROW_PULSE_2(F) k_row_pulse<2, F>
+#define K_ROW_PULSE_0(F) k_row_pulse<0, F, true>
+#define K_ROW_PULSE_1(F) k_row_pulse<1, F, true>
+#define K_ROW_PULSE_2(F) k_row_pulse<2, F, true>
     WFS_BIG_LDS_F(K_ROW_PULSE_0, 128); WFS_BIG_LDS_F(K_ROW_PULSE_1, 128); WFS_BIG_LDS_F(K_ROW_PULSE_2, 128);
-    if (const char *e = getenv("WFS_ROW_RESIDENT")) h->res_env = atoi(e) != 0;
-    if (const char *e = getenv("WFS_RES_MAX_LEN")) h->res_max_len = std::max(0, std::min(atoi(e), 7168));      // tuning knob (results do not depend on it)
+    if (const char *e = getenv("WFS_ROW_RESIDENT")) h->res_env = atoi(e);          // 0 / 1 / 2 as the config switch (A/B runs)
+    if (const char *e = getenv("WFS_RES_MAX_LEN")) h->res_max_len = std::max(256, std::min(atoi(e), 7168)) / 256 * 256;      // tuning knob (results do not depend on it)
     WFS_BIG_LDS_F(K_S2_TILE_FULL, 100); WFS_BIG_LDS_F(K_S2_TILE_FULL_AP, 100); WFS_BIG_LDS_F(K_S2_TILE_GEN, 100); WFS_BIG_LDS_F(K_S2_TILE_GEN_AP, 100);
     WFS_BIG_LDS_F(K_PULSE_SPARSE_64, 100); WFS_BIG_LDS_F(K_PULSE_SPARSE_256, 100);
     *out = h;
@@ -1546,7 +1547,13 @@ try {
     const bool tiles_done = !h->injected && !h->optical && h->fuse_full && h->n_fused_tiles > 0;      // pulses made by k_s2_tile (wfs_tilegen.h)
     // resident rows (k_row_pulse): the usual digitiser geometry, a hold-off of at least a chunk and a noise table the fast row loads
     // can walk (as the fast path of k_zle), no HE rows, no debug copies of currents or rows
-    h->res_on = (h->res_env >= 0 ? h->res_env != 0 : h->cfg.row_resident != 0) && !(h->keep_currents & 3) && !h->generic_geom && !d.he_rows && 2 * (i64)d.tw + 1 >= 63
+    // 2 (auto, the default): on when the batch holds at least two photons per (pulse set, channel) slot -- rows that collect several
+    // pulses are where the accumulators cost (memset, atomics, two more reads); a batch of sparse S1 or nVeto hits is as fast through
+    // them, and the resident path's extra pass over the tiles does not pay there
+    const i64 p_all = h->n_photons + ((!h->injected && !h->optical && h->ap_active) ? h->n_ap_photons : 0);
+    const bool res_auto = T > 0 && p_all >= 2 * T;
+    const int res_mode = h->res_env >= 0 ? h->res_env : h->cfg.row_resident;
+    h->res_on = (res_mode == 2 ? res_auto : res_mode != 0) && !(h->keep_currents & 3) && !h->generic_geom && !d.he_rows && 2 * (i64)d.tw + 1 >= 63
                 && (!d.enable_noise || d.noise_len >= NOISE_MIN_FAST);
     if (tiles_done || h->res_on) {
         TRY(ensure(h, h->row_cnt, (size_t)CG * d.n_tpc * 4)); TRY(ensure(h, h->row_tile, (size_t)CG * d.n_tpc * 4));
@@ -1738,7 +1745,8 @@ try {
     za.n_front = h->n_front_rows; za.rows_cap = CG * d.row_slots;
     if (h->n_res_rows > 0) {
         TRY(ensure(h, h->fin, (size_t)h->s_fin * 2 + 16));
-        TRY(ensure(h, h->res_rows, (size_t)h->n_res_rows * sizeof(ResRow)));
+        TRY(ensure(h, h->res_rows, (size_t)h->n_res_rows * sizeof(ResRow))); TRY(ensure(h, h->res_first, (size_t)h->n_res_rows * sizeof(TileDesc)));
+        za.res_desc = h->res_desc.as<TileDesc>(); za.res_first = h->res_first.as<TileDesc>();
         za.res_toff = h->res_toff.as<i64>(); za.fin_off = h->fin_off.as<i64>(); za.fin = h->fin.as<int16_t>();
         za.n_short = h->n_short_rows; za.res_long = h->res_long.as<i32>(); za.res_rows = h->res_rows.as<ResRow>();
     }
@@ -1773,12 +1781,13 @@ try {
         pr.desc = h->res_desc.as<TileDesc>(); pr.currents = nullptr; pr.cur_off = nullptr;
         // two launches: the rows of at most RES_SHORT_LEN samples at full occupancy, the longer ones with LDS for the longest of them
         Timer t(h, "k_row_pulse");
-#define WFS_ROW_PULSE(NK) do { if (h->cfg.fma) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_pulse<NK, true>), grid, dim3(256), lds, h->stream, d, pr, za, first, n_rows, region); \
-                               else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_pulse<NK, false>), grid, dim3(256), lds, h->stream, d, pr, za, first, n_rows, region); } while (0)
+#define WFS_ROW_PULSE2(NK, F) do { if (part == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_pulse<NK, F, false>), grid, dim3(256), lds, h->stream, d, pr, za, first, n_rows, region); \
+                                   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_row_pulse<NK, F, true>), grid, dim3(256), lds, h->stream, d, pr, za, first, n_rows, region); } while (0)
+#define WFS_ROW_PULSE(NK) do { if (h->cfg.fma) WFS_ROW_PULSE2(NK, true); else WFS_ROW_PULSE2(NK, false); } while (0)
         for (int part = 0; part < 2; part++) {
             const i64 first = part == 0 ? 0 : h->n_short_rows, n_rows = part == 0 ? h->n_short_rows : h->n_res_rows - h->n_short_rows;
             if (n_rows <= 0) continue;
-            const i32 region = part == 0 ? RES_SHORT_LEN : (i32)((h->max_res_len + 255) / 256 * 256);
+            const i32 region = part == 0 ? RES_SHORT_LEN : (i32)((std::min<i64>(h->max_res_len, h->res_max_len) + 255) / 256 * 256);
             const size_t lds = ROW_LDS_FIXED + (size_t)4 * region * 4;
             const dim3 grid(nblocks(n_rows, 4));
             if (noise_kind == 0) WFS_ROW_PULSE(0); else if (noise_kind == 1) WFS_ROW_PULSE(1); else WFS_ROW_PULSE(2);
@@ -1824,10 +1833,18 @@ try {
         za.rec_dest = h->rec_dest.as<u32>();
     }
     if (h->n_active_rows > 0 && h->n_records > 0) {
-        Timer t(h, "k_pack"); const dim3 grid(nblocks(h->n_active_rows, 4));
+        TRY(ensure(h, h->pack_desc, (size_t)h->n_active_rows * sizeof(PackDesc))); za.pdesc = h->pack_desc.as<PackDesc>();
+        { Timer t(h, "k_pack_desc"); hipLaunchKernelGGL(k_pack_desc, dim3(nblocks(h->n_active_rows, 256)), dim3(256), 0, h->stream, za); }
+        if (h->n_res_rows > 0) {
+            PackResArgs pr{h->pack_desc.as<PackDesc>() + h->n_front_rows, h->fin.as<int16_t>(), za.itv_left, za.itv_right, za.records, za.rec_dest, za.rec_capacity, h->n_res_rows, za.spr, (i32)d.dt};
+            Timer t(h, "k_pack_res"); hipLaunchKernelGGL(k_pack_res, dim3(nblocks(h->n_res_rows, 4)), dim3(256), 0, h->stream, pr);
+        }
+        if (h->n_front_rows > 0) {
+        Timer t(h, "k_pack"); const dim3 grid(nblocks(h->n_front_rows, 4));
         if (noise_kind == 0) hipLaunchKernelGGL(k_pack<0>, grid, dim3(256), 0, h->stream, d, za);
         else if (noise_kind == 1) hipLaunchKernelGGL(k_pack<1>, grid, dim3(256), 0, h->stream, d, za);
         else hipLaunchKernelGGL(k_pack<2>, grid, dim3(256), 0, h->stream, d, za);
+        }
     }
     {   // totals of wfs_get_counts: afterpulse sets carry no truth (rawdata.py:322-323)
         const i64 n_prim = (!h->injected && h->ap_active) ? h->n_psets : h->n_sets;

@@ -153,6 +153,7 @@ struct GeomArgs {
 #define TINY_LANES 16              // lanes that share the samples of one tiny tile (k_pulse_tiny)
 #define WAVE_MAX_PHOTONS 64        // medium tiles: photons fit the lanes of one wave (any width): k_pulse_wave
 #define WAVE_MAX_BINS 16384
+#define RES_MAX_TILE_VISITS 256      // a resident row longer than the LDS of its wave: tiles x segments it may cost
 #define RES_SHORT_LEN 768          // resident rows up to this length: 4 waves x 3 KB of LDS per workgroup, eight workgroups per CU
 
 __device__ __forceinline__ void tile_bounds(const WfsDev &d, i64 t0, i32 tmin, i32 tmax, i64 &left, i64 &right, i64 &bin0, i64 &nb)
@@ -371,7 +372,9 @@ __global__ void k_row_len(WfsDev d, GeomArgs a)
             // a row made by ONE tile whose samples exist already (k_s2_tile) is read from the tile's buffer: no accumulators
             const bool direct = row_is_direct(a.tile_done, a.n_done, a.row_cnt, a.row_tile, g * d.n_tpc + ch);
             // a short row of small tiles is made in LDS by one wave (k_row_pulse): no accumulators either, 16-bit finished samples instead
-            resident = a.res_on && !direct && len <= a.res_max_len && !a.row_bad[g * d.n_tpc + ch];
+            // (a row longer than res_max_len samples is made in segments of that length, its tiles looked at once per segment)
+            resident = a.res_on && !direct && !a.row_bad[g * d.n_tpc + ch]
+                       && (len <= a.res_max_len || (i64)a.row_cnt[g * d.n_tpc + ch] * ((len + a.res_max_len - 1) / a.res_max_len) <= RES_MAX_TILE_VISITS);
             if (slot < d.n_tpc) {
                 a.acc_len[g * d.n_tpc + ch] = (direct || resident) ? 0 : (i32)len; if (direct) atomicAdd(&s_direct, (i32)len);
                 if (a.res_on) { a.fin_len[g * d.n_tpc + ch] = resident ? (i32)((len + 3) & ~(i64)3) : 0; a.res_cnt[g * d.n_tpc + ch] = resident ? a.row_cnt[g * d.n_tpc + ch] : 0; }
@@ -1002,7 +1005,7 @@ __device__ __forceinline__ TinyPrep tiny_tile_prepare(const WfsDev &d, const Pul
     return q;
 }
 
-template <bool FMA, int LANES, class Tap, class Sink>
+template <bool FMA, int LANES, bool CUR, class Tap, class Sink>
 __device__ __forceinline__ void tiny_tile_samples(const WfsDev &d, const PulseArgs &a, const TinyPrep &q, i64 idx, int sub, Tap tap, Sink sink)
 {
     constexpr int tlen = 22, NP = TINY_MAX_PHOTONS;
@@ -1014,7 +1017,7 @@ __device__ __forceinline__ void tiny_tile_samples(const WfsDev &d, const PulseAr
             const int kk = s - lead - q.jb[k];
             if (k < q.n && kk >= 0 && kk < tlen) cur = mac<FMA>(tap(q.rr[k], kk), q.g[k], cur);
         }
-        if (a.currents) a.currents[a.cur_off[idx] + s] = cur;
+        if (CUR && a.currents) a.currents[a.cur_off[idx] + s] = cur;
         const i64 adc = -(i64)rint(cur * d.c2a);                 // rawdata.py:236
         if (adc != 0) sink(s, (i32)adc);
     }
@@ -1024,7 +1027,7 @@ template <bool FMA, int LANES, class Tap, class Sink>
 __device__ __forceinline__ void tiny_tile_pulse(const WfsDev &d, const PulseArgs &a, const TileDesc &td, i64 idx, int sub, const double *s_cmax, Tap tap, Sink sink)
 {
     const TinyPrep q = tiny_tile_prepare(d, a, td, sub, s_cmax);
-    tiny_tile_samples<FMA, LANES>(d, a, q, idx, sub, tap, sink);
+    tiny_tile_samples<FMA, LANES, true>(d, a, q, idx, sub, tap, sink);
 }
 
 // A prepared tiny tile of a resident row (k_tile_assign -> k_row_pulse), in the 64 bytes of a TileDesc; n_neg = -photons sits where
@@ -1113,7 +1116,7 @@ __device__ __forceinline__ void wave_tables_fill(const WfsDev &d, double *sTz, d
 
 // The pulse of one tile made by one wave (see k_pulse_wave): sink(s, adc) receives the rounded, non-zero ADC counts of the tile's
 // sample s, every lane a different sample.
-template <bool FMA, class Sink>
+template <bool FMA, bool CUR, class Sink>
 __device__ __forceinline__ void wave_tile_pulse(const WfsDev &d, const PulseArgs &a, const TileDesc &td, i64 idx, WavePhoton *wph, const double *sTz,
                                                 const double *s_cmax, int lane, Sink sink)
 {
@@ -1188,7 +1191,7 @@ __device__ __forceinline__ void wave_tile_pulse(const WfsDev &d, const PulseArgs
     // photons are skipped).  Inside a block every sample walks the photons in reach, in ascending time; sTz has a zero tap on
     // either side of every template row, so a photon out of a sample's reach adds +0.0, which changes nothing (no exec masking).
     const int n_live = td.nb + tlen - 1;
-    if (a.currents) for (int s = lane; s < L; s += 64) a.currents[a.cur_off[idx] + s] = 0.0;
+    if (CUR && a.currents) for (int s = lane; s < L; s += 64) a.currents[a.cur_off[idx] + s] = 0.0;
     int s0 = 0;
     while (s0 < n_live) {
         // sorted photons with a start bin in [s0 - 21, s0 + 63]: a contiguous range [q_lo, q_hi) of lanes
@@ -1209,7 +1212,7 @@ __device__ __forceinline__ void wave_tile_pulse(const WfsDev &d, const PulseArgs
             for (int u = 0; u < PW_U; u++) c = mac<FMA>(tap[u], w[u].g, c);
         }
         if (sp < n_live) {
-            if (a.currents) a.currents[a.cur_off[idx] + lead + sp] = c;
+            if (CUR && a.currents) a.currents[a.cur_off[idx] + lead + sp] = c;
             const double x = rint(c * d.c2a);                  // rawdata.py:236
             // (|x| < 2^31 unless a current is absurd: the one-instruction conversion; the general one otherwise, same value)
             const i32 adc = fabs(x) < 2147483648.0 ? -(i32)x : (i32)(-(i64)x);
@@ -1234,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_pulse_wave(WfsDev d, PulseArgs a, i64 n
     if (idx >= n_wave) return;                            // wave-uniform
     const TileDesc td = a.desc[idx];
     i32 *dst = a.raw + td.dst;
-    wave_tile_pulse<FMA>(d, a, td, idx, wph, sTz, s_cmax, lane, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });
+    wave_tile_pulse<FMA, true>(d, a, td, idx, wph, sTz, s_cmax, lane, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });
 }
 
 // Sparse form of the same computation, for tiles with few photons per start bin (every S1, S2s up to ~10^6 PE):
@@ -1475,6 +1478,8 @@ struct ZleArgs {
     const i32 *tile_done, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf; i64 n_done;      // rows read from a tile buffer in place (wfs_tilegen.h)
     // resident rows (k_row_pulse): the rows behind the first n_front of the row list; their finished 16-bit samples
     i64 n_front, n_short, rows_cap; const i64 *res_toff, *fin_off; int16_t *fin; const i32 *res_long; struct ResRow *res_rows;
+    const struct TileDesc *res_desc; struct TileDesc *res_first;      // [resident rows] a copy of the row's first tile descriptor: loaded WITH the row's, not behind it
+    struct PackDesc *pdesc;      // [n_active_rows] what k_pack needs of a row, in one scalar load (k_pack_desc)
 };
 
 // One 64-byte descriptor per active row (thread per row: the divisions and the five dependent look-ups of a row are
@@ -1508,6 +1513,7 @@ __global__ void k_row_desc(WfsDev d, ZleArgs a)
         q.acc_off = a.fin_off[ridx]; q.src = 2;
         const i64 t0 = a.res_toff[ridx];
         a.res_rows[r - a.n_front] = ResRow{t0, (i32)(a.res_toff[ridx + 1] - t0), 0};
+        a.res_first[r - a.n_front] = a.res_desc[t0];
     }
     if (row_is_direct(a.tile_done, a.n_done, a.row_cnt, a.row_tile, ridx)) {
         const i32 tile = a.row_tile[ridx]; const i32 ins = tile / d.n_tpc;
@@ -1784,7 +1790,7 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
 // Against the accumulator path (memset 4 B + atomics + 6 B read by k_zle + 6 B read by k_pack per sample) a row costs 2 B of noise
 // read and 2 B written here and 2 B read by k_pack.  rawdata.py:231-239 (per-pulse rounding into the row), :302-311 (intervals).
 #define ROW_LDS_FIXED ((WAVE_TZ_LEN + 16) * 8 + 4 * (64 + PW_U) * 16)
-template <int NK, bool FMA>
+template <int NK, bool FMA, bool SEG>
 __global__ __launch_bounds__(256) void k_row_pulse(WfsDev d, PulseArgs a, ZleArgs z, i64 first, i64 n_res, i32 region)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char row_lds[];
@@ -1801,51 +1807,81 @@ __global__ __launch_bounds__(256) void k_row_pulse(WfsDev d, PulseArgs a, ZleArg
     i32 *acc = s_acc + (size_t)w * region;
     WavePhoton *wph = s_ph + w * (64 + PW_U);
     const i32 len32 = q.len;
-    for (i32 i = 4 * lane; i < ((len32 + 255) & ~255); i += 256) *(int4 *)(acc + i) = make_int4(0, 0, 0, 0);
-    // ---- the row's tiles (no HE rows on this path: row slot == row index)
-    const i64 t1 = rr.t0 + rr.n;
-    TileDesc nxt = a.desc[rr.t0];                         // (a resident row has at least one tile)
-    for (i64 t = rr.t0; t < t1; t++) {
-        const TileDesc td = nxt;
-        if (t + 1 < t1) nxt = a.desc[t + 1];             // on its way while this tile is made
-        if (td.n < 0) {                                   // a prepared tiny tile (k_tile_assign): the samples its photons reach, nothing else
-            TinyDesc y; __builtin_memcpy(&y, &td, 64);
-            TinyPrep q; q.n = -y.n_neg; q.s_first = y.s_first; q.s_last = y.s_last;
-#pragma unroll
-            for (int j = 0; j < TINY_MAX_PHOTONS; j++) { q.g[j] = y.g[j]; q.jb[j] = (int)(y.jr[j] >> 4); q.rr[j] = (int)(y.jr[j] & 15u); }
-            i32 *dst = acc + y.dst;
-            tiny_tile_samples<FMA, 64>(d, a, q, t, lane, [&](int r_, int k_) { return sTz[r_ * (22 + 2) + 1 + k_]; }, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });
-        } else {
-            i32 *dst = acc + td.dst;
-            wave_tile_pulse<FMA>(d, a, td, t, wph, sTz, s_cmax, lane, [&](int s_, i32 adc) { atomicAdd(&dst[s_], adc); });      // (ds_add_u32: every lane its own sample)
-        }
-    }
-    // ---- finish, zero-length encoding, 16-bit samples
     const i64 thr = q.thr; const i64 base = q.itv_base, row_abs = q.row_abs, idx = q.idx;
+    const i32 thr32 = thr > 0x7fffffffLL ? 0x7fffffff : (thr < -0x7fffffffLL ? -0x7fffffff : (i32)thr);      // (finished samples are 0 .. 2^31 - 1: the comparison is the same)
     i64 hold = 2 * (i64)d.tw + 1; if (hold < 1) hold = 1;
     const i32 hold32 = (i32)hold;
     const bool noisy = NK != 0 && q.channel < d.noise_channels;
     const i64 noise_off = noisy ? (i64)q.channel * d.noise_stride : 0;
     const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
-    u32 nrun = noisy ? (u32)q.ixr : 0u;
+    u32 nrun = noisy ? (u32)q.ixr : 0u;                    // noise index of the next block's first sample (rawdata.py:433-434)
     int16_t *fin = z.fin + q.acc_off;
     const i32 fin_len = (len32 + 3) & ~3;
-    ZleFast zf;
-    for (i32 b0 = 0; b0 < len32; b0 += 256) {
-        const i32 i = b0 + 4 * lane;
-        Raw4<NK> s4;
-        *(int4 *)s4.acc = *(const int4 *)(acc + i);
+    auto load_noise = [&](Raw4<NK> &o) {
         if constexpr (NK != 0) {
             u32 in = nrun + 4u * (u32)lane;
             in = in >= (u32)d.noise_len ? in - (u32)d.noise_len : in;
-            if constexpr (NK == 2) __builtin_memcpy(s4.nzf, (const double *)noise_row + in, 32); else __builtin_memcpy(s4.nz, (const int16_t *)noise_row + in, 8);
+            if constexpr (NK == 2) __builtin_memcpy(o.nzf, (const double *)noise_row + in, 32); else __builtin_memcpy(o.nz, (const int16_t *)noise_row + in, 8);
             nrun += 256u; nrun = nrun >= (u32)d.noise_len ? nrun - (u32)d.noise_len : nrun;
         }
-        u32 nib = 0; u32 v16[4];
+    };
+    Raw4<NK> s4;
+    load_noise(s4);                                       // the first block's noise: on its way under the pulses
+    const i64 t1 = rr.t0 + rr.n;
+    ZleFast zf;
+    // A row longer than the wave's LDS (SEG) is made segment by segment: the tiles that reach into the segment are made again for it,
+    // their samples outside it dropped; the interval bookkeeping and the noise index run on across the segments.
+    for (i32 seg0 = 0; seg0 < len32; seg0 += region) {
+        const i32 seg_len = SEG ? (len32 - seg0 < region ? len32 - seg0 : region) : len32;
+        for (i32 i = 4 * lane; i < ((seg_len + 255) & ~255); i += 256) *(int4 *)(acc + i) = make_int4(0, 0, 0, 0);
+        // ---- the row's tiles (no HE rows on this path: row slot == row index)
+        TileDesc td = z.res_first[first + r];              // (most rows hold one tile: its descriptor arrives with the row's)
+        for (i64 t = rr.t0; t < t1; t++) {
+            if (t > rr.t0) td = a.desc[t];
+            if (td.n < 0) {                               // a prepared tiny tile (k_tile_assign): the samples its photons reach, nothing else
+                TinyDesc y; __builtin_memcpy(&y, &td, 64);
+                if (SEG && (y.dst + y.s_last < seg0 || y.dst + y.s_first >= seg0 + seg_len)) continue;
+                TinyPrep p; p.n = -y.n_neg; p.s_first = y.s_first; p.s_last = y.s_last;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { const i32 v = finish_four<NK>(d, s4, j, false, noisy); nib |= (i + j < len32 && (i64)v < thr) ? (1u << j) : 0u; v16[j] = (u32)(uint16_t)v; }
-        if (i < fin_len) *(uint2 *)(fin + i) = make_uint2(v16[0] | (v16[1] << 16), v16[2] | (v16[3] << 16));
-        zf.block(d, z, lane, base, row_abs, len32, hold32, nib, i);
+                for (int j = 0; j < TINY_MAX_PHOTONS; j++) { p.g[j] = y.g[j]; p.jb[j] = (int)(y.jr[j] >> 4); p.rr[j] = (int)(y.jr[j] & 15u); }
+                const i32 o = y.dst - seg0;
+                tiny_tile_samples<FMA, 64, false>(d, a, p, t, lane, [&](int r_, int k_) { return sTz[r_ * (22 + 2) + 1 + k_]; },
+                                                  [&](int s_, i32 adc) { if (!SEG || (u32)(o + s_) < (u32)seg_len) atomicAdd(&acc[o + s_], adc); });
+            } else {
+                if (SEG && (td.dst + td.L <= seg0 || td.dst >= seg0 + seg_len)) continue;
+                const i32 o = (i32)td.dst - seg0;
+                wave_tile_pulse<FMA, false>(d, a, td, t, wph, sTz, s_cmax, lane,
+                                            [&](int s_, i32 adc) { if (!SEG || (u32)(o + s_) < (u32)seg_len) atomicAdd(&acc[o + s_], adc); });      // (ds_add_u32: every lane its own sample)
+            }
+        }
+        // ---- finish, zero-length encoding, 16-bit samples
+        for (i32 b0 = 0; b0 < seg_len; b0 += 256) {
+            const i32 i = seg0 + b0 + 4 * lane;           // the lane's first sample in the row
+            Raw4<NK> nxt = s4;
+            if (i - 4 * lane + 256 < len32) load_noise(nxt);      // the next block's noise on its way under this block's arithmetic
+            *(int4 *)s4.acc = *(const int4 *)(acc + b0 + 4 * lane);
+            u32 nib = 0; u32 v16[4];
+            if constexpr (NK == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const i32 v = finish_four<NK>(d, s4, j, false, noisy); nib |= (i + j < len32 && (i64)v < thr) ? (1u << j) : 0u; v16[j] = (u32)(uint16_t)v; }
+            } else {
+                // integer noise: 32-bit arithmetic with a saturating add -- the values of finish_four for every accumulator that is not within
+                // 2^16 of overflowing an int32 (a row of a 14-bit digitiser is some 10^5 times smaller)
+                const i32 live = len32 - i;                  // samples of the lane inside the row
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    i32 add = d.baseline;
+                    if constexpr (NK == 1) add += noisy ? (i32)s4.nz[j] : 0;
+                    i32 v = __builtin_elementwise_add_sat(s4.acc[j], add);
+                    v = v < 0 ? 0 : v;
+                    nib |= (j < live && v < thr32) ? (1u << j) : 0u; v16[j] = (u32)v;
+                }
+            }
+            if (i < fin_len) *(uint2 *)(fin + i) = make_uint2(__builtin_amdgcn_perm(v16[1], v16[0], 0x05040100u), __builtin_amdgcn_perm(v16[3], v16[2], 0x05040100u));
+            zf.block(d, z, lane, base, row_abs, len32, hold32, nib, i);
+            s4 = nxt;
+        }
+        if (!SEG) break;
     }
     zf.finish(d, z, lane, base, row_abs, len32, idx);
 }
@@ -1876,6 +1912,76 @@ __global__ __launch_bounds__(256) void k_rec_keys(WfsDev d, ZleArgs a)
 }
 __global__ void k_invert_perm(const u32 *val, u32 *dest, i64 n) { const i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (p < n) dest[val[p]] = (u32)p; }
 
+// One 64-byte descriptor per active row for k_pack, made once the record offsets are known (thread per row): the row's place, its
+// first record, its first interval.  With ~10^7 short rows a wave of k_pack spent most of its life in the chain row descriptor ->
+// interval count and record offset -> interval bounds -> samples; now it is descriptor -> samples.
+struct __attribute__((aligned(64))) PackDesc {
+    i64 acc_off, rec, row_abs, left0, ixr, itv_base;
+    i32 plen0, count, channel, len_he_src;       // len | he << 20 | src << 21 (a row is shorter than 10^6 samples)
+};
+__global__ void k_pack_desc(ZleArgs a)
+{
+    const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.n_active_rows) return;
+    const RowDesc q = a.desc[r];
+    PackDesc p;
+    p.acc_off = q.acc_off; p.rec = a.rec_off[q.idx]; p.row_abs = q.row_abs; p.ixr = q.ixr; p.itv_base = q.itv_base;
+    p.count = a.itv_n[q.idx]; p.channel = q.channel; p.len_he_src = q.len | (q.he << 20) | (q.src << 21);
+    p.left0 = 0; p.plen0 = 0;
+    if (p.count > 0) { p.left0 = a.itv_left[q.itv_base]; p.plen0 = (i32)(a.itv_right[q.itv_base] - p.left0 + 1); }
+    a.pdesc[r] = p;
+}
+
+// The records of the resident rows: their finished 16-bit samples exist (k_row_pulse), two of them are a dword of a record.  A kernel
+// of its own with the few arguments it needs: in the general k_pack the scalar unit (one per CU) was the bottleneck -- ~350 scalar
+// instructions per row for address arithmetic, spilled descriptors and the branches around four unrolled records.  Here the loads of
+// up to four records are unconditional (indices clamped into the row), the header dwords are selected, not branched to, and the
+// stores are predicated per lane.
+struct PackResArgs { const PackDesc *pdesc; const int16_t *fin; const i64 *itv_left, *itv_right; uint8_t *records; const u32 *rec_dest; i64 rec_capacity, n_rows; i32 spr, dt; };
+__global__ __launch_bounds__(256) void k_pack_res(PackResArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const i64 r = (i64)blockIdx.x * 4 + wave_in_block();
+    if (r >= a.n_rows) return;
+    const PackDesc q = a.pdesc[r];
+    if (q.count == 0) return;
+    const int16_t *fin = a.fin + q.acc_off;
+    const i32 last = (((q.len_he_src & 0xfffff) + 3) & ~3) - 2;
+    const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
+    const i64 rec_bytes = 24 + 2 * (i64)spr;
+    const u32 w3 = ((u32)(uint16_t)a.dt) | ((u32)(uint16_t)q.channel << 16);
+    i64 rec = q.rec;
+    for (i32 k = 0; k < q.count; k++) {
+        const i64 left = k == 0 ? q.left0 : a.itv_left[q.itv_base + k]; const i32 plen = k == 0 ? q.plen0 : (i32)(a.itv_right[q.itv_base + k] - left + 1);
+        if (plen <= 0) continue;
+        const i32 need = (plen + spr - 1) / spr;
+        const i32 off = (i32)(left - q.row_abs);                   // even (rawdata.py:305-306), and the row starts on a multiple of four samples of fin
+        for (int q0 = 0; q0 < rec_dwords; q0 += 64) {              // (one pass unless a record is longer than 64 dwords)
+            const int qd = q0 + lane;
+            const int s0 = (qd - 6) * 2;                            // first of the lane's two samples (lanes of the header: negative)
+            const i32 lane_off = off + (s0 < 0 ? 0 : s0);
+            for (i32 f0 = 0; f0 < need; f0 += 4) {
+                u32 two[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { i32 i0 = lane_off + spr * (f0 + u); i0 = i0 > last ? last : i0; two[u] = *(const u32 *)(fin + i0); }      // (past the row: a valid pair, dropped)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const i32 f = f0 + u;
+                    const i64 slot = a.rec_dest ? (i64)a.rec_dest[rec + (f < need ? f : 0)] : rec + f;
+                    u32 *out = (u32 *)(a.records + slot * rec_bytes);
+                    const i64 time = (i64)a.dt * (left + spr * f);
+                    const i32 rest = plen - spr * f, length = rest < spr ? rest : spr;
+                    u32 w = (s0 < length ? two[u] & 0xffffu : 0u) | (s0 + 1 < length ? two[u] & 0xffff0000u : 0u);
+                    w = qd == 0 ? (u32)(u64)time : w; w = qd == 1 ? (u32)((u64)time >> 32) : w; w = qd == 2 ? (u32)length : w;
+                    w = qd == 3 ? w3 : w; w = qd == 4 ? (u32)plen : w; w = qd == 5 ? (u32)(uint16_t)f : w;          // record_i; baseline = 0
+                    if (f < need && qd < rec_dwords && rec + f < a.rec_capacity) out[qd] = w;
+                }
+            }
+        }
+        rec += need;
+    }
+}
+
 // one wave per row: write its intervals as strax raw_records (strax_interface.py:425-435).  A record is 24 bytes of header and
 // samples_per_record int16: lane q writes dword q of the record (61 dwords with 110 samples: three idle lanes, no division by the
 // record length anywhere), PACK_U records in flight so that the loads of one do not wait behind the stores of the one before.
@@ -1884,17 +1990,16 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
 {
     const int lane = threadIdx.x & 63;
     const i64 r = (i64)blockIdx.x * 4 + wave_in_block();
-    if (r >= a.n_active_rows) return;
-    const RowDesc q = a.desc[r];
-    const i64 idx = q.idx;
-    const i32 count = a.itv_n[idx];
+    if (r >= a.n_front) return;                             // (the rows behind n_front: k_pack_res)
+    const PackDesc q = a.pdesc[r];
+    const i32 count = q.count;
     if (count == 0) return;
-    const i32 channel = q.channel; const bool he = q.he != 0;
-    const i32 *acc = (q.src ? a.tbuf : a.raw) + q.acc_off;
+    const i32 channel = q.channel; const bool he = ((q.len_he_src >> 20) & 1) != 0; const int src = q.len_he_src >> 21;
+    const i32 *acc = (src ? a.tbuf : a.raw) + q.acc_off;
     const i64 row_abs = q.row_abs;
     const i64 ixr = q.ixr;
     const i64 base = q.itv_base;
-    const i32 len32 = q.len;
+    const i32 len32 = q.len_he_src & 0xfffff;
     const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
     const i64 rec_bytes = 24 + 2 * (i64)spr;
     const bool noisy = NK != 0 && channel < d.noise_channels;
@@ -1903,54 +2008,9 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const void *noise_row = NK == 2 ? (const void *)(d.noise_f + noise_off) : (const void *)(d.noise + noise_off);
     const u32 w3 = ((u32)(uint16_t)d.dt) | ((u32)(uint16_t)channel << 16);
     constexpr int PACK_U = 4;
-    i64 rec = a.rec_off[idx];
-    if (q.src == 2) {       // a resident row: its finished 16-bit samples exist (k_row_pulse), two of them are a dword of the record
-        const int16_t *fin = a.fin + q.acc_off;
-        const i32 last = ((len32 + 3) & ~3) - 2;
-        for (i32 k = 0; k < count; k++) {
-            const i64 left = a.itv_left[base + k]; const i32 plen = (i32)(a.itv_right[base + k] - left + 1);
-            if (plen <= 0) continue;
-            const i32 need = (plen + spr - 1) / spr;
-            const i32 off = (i32)(left - row_abs);                 // even (rawdata.py:305-306), and the row starts on a multiple of four samples of fin
-            for (int q0 = 0; q0 < rec_dwords; q0 += 64) {
-                const int qd = q0 + lane;
-                const int s0 = (qd - 6) * 2;
-                for (i32 f0 = 0; f0 < need; f0 += PACK_U) {
-                    u32 two[PACK_U];
-#pragma unroll
-                    for (int u = 0; u < PACK_U; u++) {
-                        const i32 f = f0 + u;
-                        if (f >= need) break;                       // wave-uniform
-                        i32 i0 = off + spr * f + (s0 < 0 ? 0 : s0);
-                        i0 = i0 > last ? last : i0;                 // (lanes past the row read a valid pair and drop it)
-                        two[u] = *(const u32 *)(fin + i0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < PACK_U; u++) {
-                        const i32 f = f0 + u;
-                        if (f >= need) break;
-                        if (rec + f >= a.rec_capacity) break;
-                        u32 *out = (u32 *)(a.records + (a.rec_dest ? (i64)a.rec_dest[rec + f] : rec + f) * rec_bytes);
-                        const i64 time = (i64)d.dt * (left + spr * f);
-                        const i32 length = (plen < spr * (f + 1) ? plen : spr * (f + 1)) - spr * f;
-                        u32 w;
-                        if (qd >= 6) w = (s0 < length ? two[u] & 0xffffu : 0u) | (s0 + 1 < length ? two[u] & 0xffff0000u : 0u);
-                        else if (qd == 0) w = (u32)(u64)time;
-                        else if (qd == 1) w = (u32)((u64)time >> 32);
-                        else if (qd == 2) w = (u32)length;
-                        else if (qd == 3) w = w3;
-                        else if (qd == 4) w = (u32)plen;
-                        else w = (u32)(uint16_t)f;
-                        if (qd < rec_dwords) out[qd] = w;
-                    }
-                }
-            }
-            rec += need;
-        }
-        return;
-    }
+    i64 rec = q.rec;
     for (i32 k = 0; k < count; k++) {
-        const i64 left = a.itv_left[base + k]; const i32 plen = (i32)(a.itv_right[base + k] - left + 1);
+        const i64 left = k == 0 ? q.left0 : a.itv_left[base + k]; const i32 plen = k == 0 ? q.plen0 : (i32)(a.itv_right[base + k] - left + 1);
         if (plen <= 0) continue;
         const i32 need = (plen + spr - 1) / spr;
         const i32 off = (i32)(left - row_abs);                     // first sample of the interval inside the row
