@@ -127,6 +127,11 @@ int wfs_set_ap_element(wfs_handle *h, int32_t element, int32_t n_bins_delay, int
  *                                           Pulse call (rawdata.py:108-127; save_full_truth=False groups S1s within 100 ns
  *                                           and S2s within 2 mm).  Sets are numbered 0..n_run_sets-1; their instructions
  *                                           share cluster and type.  NULL: one set per instruction (the default).
+ *                                           A set number may stay unused (its truth row is empty).  With n_run_sets = n
+ *                                           and every set numbered by its FIRST instruction, an S2 that is alone in its
+ *                                           set takes the tile-local generator like an S2 of a batch without run sets
+ *                                           (electron afterpulses on: the primaries, next to the shared calls of the
+ *                                           secondaries); with any other numbering no instruction does.
  *   em_base u32 (or NULL)                   offset of the instruction's emitter ids in the Philox counters: an electron-
  *                                           afterpulse instruction carries its parent's gid and (k + 1) << 20 for the k-th
  *                                           secondary of that parent (streams independent of batching / sharding) */

@@ -1207,7 +1207,9 @@ void orc_simulate_scheduled(orc_session *s, i64 n, const int8_t *type, const i64
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
                 set_cur(s, i);
                 if (type[i] == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
-                else gen_s2(s, &x, -1 /* explicit run sets: never tile by tile (the device: run_sets_given) */, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+                /* an instruction that shares its Pulse call is never generated tile by tile; one that is alone in its call follows the
+                 * usual rule (the device: k_fuse_decide, set i = {instruction i}) */
+                else gen_s2(s, &x, e - k == 1 ? type[i] : -1, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
             }
             finish_call(s, type[k] == 6 ? 5 : type[k], run_set[k], &x);
             k = e;

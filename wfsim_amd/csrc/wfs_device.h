@@ -190,6 +190,7 @@ __host__ __device__ __forceinline__ i64 floormod(i64 a, i64 b) { i64 m = a % b; 
 // A lane of k_zle reads 4 consecutive noise samples from any start below noise_len: every channel row of the device copy is
 // followed by its own first NOISE_PAD samples, so the read never meets the wrap (rawdata.py:433-434 indexes modulo noise_len).
 constexpr int NOISE_PAD = 4;
+constexpr int WFS_SPR = 110;                   // samples per strax record (strax DEFAULT_RECORD_LENGTH; a compile-time constant: the divisions by it are in every row kernel)
 constexpr int NOISE_MIN_FAST = 512;            // shortest noise table of the fast row kernels (a block of 256 samples wraps at most once)
 
 // Everything a kernel needs, passed by value (fits the kernarg segment).

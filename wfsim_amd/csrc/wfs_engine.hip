@@ -127,7 +127,7 @@ struct wfs_handle {
     // tile-local generation (wfs_tilegen.h): S2 instructions whose photons are made inside the pulse workgroup
     DevBuf huge_start, huge_cbeg, huge_keys, huge_keys2, huge_vals, huge_vals2, huge_rec, huge_gain;      // ordering of tiles beyond TILE_ORDER_MAX photons
     DevBuf row_pmax, ins_fused, ins_nsurv, ins_bcap, ins_bcap_all, ins_boff, et32, ftiles, tbuf, row_cnt, row_tile, tile_done;
-    bool fuse_on = false, fuse_full = false, run_sets_given = false, any_s2 = false;
+    bool fuse_on = false, fuse_full = false, run_sets_given = false, sets_aligned = true, any_s2 = false;
     i64 n_fused_tiles = 0 /* made by k_s2_tile<FULL> */, n_gen_tiles = 0 /* tile-generated, pulse by the ordinary kernels */, p_fused = 0, s_raw_direct = 0;
     int tap_sparse_max = 48;     // tap_block: occupied cells up to which a wave of the dense pulse kernels walks them (WFS_TAP_SPARSE_MAX)
     FuseArgs fuse_args{};
@@ -718,7 +718,9 @@ try {
     } else for (i64 i = 0; i < n; i++) ins_set[i] = (i32)i;
     std::vector<i64> set_off((size_t)PS + 1, 0); std::vector<i32> set_list((size_t)n);        // set -> its instructions (CSR)
     for (i64 i = 0; i < n; i++) set_off[ins_set[i] + 1]++;
-    for (i64 q = 0; q < PS; q++) { if (set_off[q + 1] == 0) return h->fail(WFS_E_INVALID, "empty run set"); set_off[q + 1] += set_off[q]; }
+    // (a run set may be empty: a caller that numbers the sets by their first instruction -- what lets single-instruction sets take the
+    // tile-local generator next to the shared Pulse calls of electron afterpulses -- leaves the numbers of the other members unused)
+    for (i64 q = 0; q < PS; q++) set_off[q + 1] += set_off[q];
     { std::vector<i64> cur(set_off.begin(), set_off.end() - 1); for (i64 i = 0; i < n; i++) set_list[cur[ins_set[i]]++] = (i32)i; }
     for (i64 q = 0; q < PS; q++)
         for (i64 k = set_off[q] + 1; k < set_off[q + 1]; k++)
@@ -729,6 +731,8 @@ try {
     const i64 S = h->ap_active ? 2 * PS : PS;
     h->any_ptrs = any_ptrs;
     h->run_sets_given = run_set != nullptr;
+    h->sets_aligned = PS == n;                     // every set carries the index of its first instruction
+    for (i64 q = 0; q < PS && h->sets_aligned; q++) if (set_off[q + 1] > set_off[q] && set_list[set_off[q]] != (i32)q) h->sets_aligned = false;
     h->any_s2 = false; for (i64 i = 0; i < n; i++) if (type[i] == 2) { h->any_s2 = true; break; }
     h->n_ins = n; h->n_psets = PS; h->n_sets = S; h->n_emitters = em_off[n]; h->n_tiles = S * h->cfg.n_tpc;
     h->h_rs_off = set_off; h->h_rs_list = set_list;
@@ -766,9 +770,11 @@ try {
         std::vector<i32> sc((size_t)S), sm((size_t)S, 0); std::vector<i64> st((size_t)S);
         for (i64 q = 0; q < S; q++) {
             const i64 ps = q % PS;
+            sm[q] = q >= PS ? 1 : 0;
+            if (set_off[ps + 1] == set_off[ps]) { sc[q] = 0; st[q] = 0; continue; }      // an unused set number: no instructions, no photons, no tiles
             i64 t0 = time[set_list[set_off[ps]]];
             for (i64 k = set_off[ps]; k < set_off[ps + 1]; k++) t0 = std::min<i64>(t0, time[set_list[k]]);
-            sc[q] = cluster[set_list[set_off[ps]]]; st[q] = t0; sm[q] = q >= PS ? 1 : 0;
+            sc[q] = cluster[set_list[set_off[ps]]]; st[q] = t0;
         }
         TRY(upload(h, h->ins_set, ins_set.data(), (size_t)n * 4)); TRY(upload(h, h->set_ins_off, set_off.data(), set_off.size() * 8));
         TRY(upload(h, h->set_ins_list, set_list.data(), (size_t)n * 4));
@@ -1259,13 +1265,14 @@ static int run_generation(wfs_handle *h)
     // tile-local generation (wfs_tilegen.h): which instructions take it is decided before the electrons are drawn -- theirs get no
     // photon numbers.  Debug modes that need the per-photon arrays (currents, generation only) run the generation half alone.
     const bool ap_cfg = h->ap_active;
-    h->fuse_on = h->cfg.tile_gen && !h->generic_geom && h->any_s2 && d.gain_spread == 0.0 && !h->run_sets_given && h->n_diff_rows == 0;
+    h->fuse_on = h->cfg.tile_gen && !h->generic_geom && h->any_s2 && d.gain_spread == 0.0 && (!h->run_sets_given || h->sets_aligned) && h->n_diff_rows == 0;
     (void)ap_cfg;                                // (PMT afterpulses of tile-generated photons are screened inside k_s2_tile)
     h->fuse_full = h->fuse_on && !(h->keep_currents & 5);
     h->n_fused_tiles = 0; h->n_gen_tiles = 0; h->p_fused = 0;
     FuseArgs f{};
     if (h->fuse_on) {
         f.lam_min = h->cfg.tile_gen_min; f.n_ins = N; f.nch = d.n_tpc; f.table_span = (i32)(1u << (32 - d.tab_s2.shift));
+        f.set_ins_off = h->run_sets_given ? h->set_ins_off.as<i64>() : nullptr;
         f.n_top = d.n_top;
         if (ext) {       // timing-model variants: the instruction's tables (the longest one bounds every tile buffer)
             f.tabs = g.tabs; f.ins_tab = g.ins_tab; f.ins_tabb = g.ins_tabb; f.ins_gg = g.gg_inv ? g.ins_gg : nullptr;
@@ -1740,7 +1747,7 @@ try {
     za.active_rows = h->active_rows.as<i32>(); za.n_active_rows = h->n_active_rows; za.row_lo = h->row_lo.as<i64>(); za.row_hi = h->row_hi.as<i64>();
     za.acc_off = h->acc_off.as<i64>(); za.raw = h->raw.as<i32>(); za.grp_left = h->grp_left.as<i64>(); za.grp_ixrand = h->grp_ixrand.as<i64>();
     za.itv_off = h->itv_off.as<i64>(); za.itv_left = h->itv_left.as<i64>(); za.itv_right = h->itv_right.as<i64>();
-    za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = 110;
+    za.itv_n = h->itv_n.as<i32>(); za.row_nrec = h->row_nrec.as<i32>(); za.spr = WFS_SPR;
     if (tiles_done) { za.tile_done = ga.tile_done; za.n_done = ga.n_done; za.row_cnt = ga.row_cnt; za.row_tile = ga.row_tile; za.ins_bcap = ga.ins_bcap; za.ins_boff = ga.ins_boff; za.tbuf = h->tbuf.as<i32>(); }
     za.n_front = h->n_front_rows; za.rows_cap = CG * d.row_slots;
     if (h->n_res_rows > 0) {
@@ -2224,7 +2231,7 @@ try {
     HIPCHK(hipMemcpy(t0.data(), h->ins_time.p, t0.size() * 8, hipMemcpyDeviceToHost));
     for (i64 q = 0; q < PS; q++) {
         // moments of the electrons of all instructions of the run set (rawdata.py:334-341), about the first instruction's time
-        const i64 ref = t0[h->h_rs_list[h->h_rs_off[q]]];
+        const i64 ref = h->h_rs_off[q + 1] > h->h_rs_off[q] ? t0[h->h_rs_list[h->h_rs_off[q]]] : 0;      // (an unused set number: no instructions, zero electrons)
         double n = 0, s1 = 0, s2 = 0; i64 lo = I64_MAX, hi = I64_MIN;
         for (i64 k = h->h_rs_off[q]; k < h->h_rs_off[q + 1]; k++) {
             const i64 i = h->h_rs_list[k];

@@ -1629,7 +1629,7 @@ struct ZleFast {
             __builtin_amdgcn_s_waitcnt(0x0F70);             // vmcnt(0)
         }
         const i32 plen = rr - l + 1;
-        return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
+        return plen > 0 ? (plen + WFS_SPR - 1) / WFS_SPR : 0;
     }
     // 256 samples: lane q holds the hits of samples i .. i + 3 (i = block start + 4 q) as a nibble; 16 lanes are a chunk of 64 samples,
     // whose first and last hit come from the ballot of the non-empty nibbles and two readlanes
@@ -1684,7 +1684,7 @@ __global__ __launch_bounds__(256) void k_zle(WfsDev d, ZleArgs a)
         l = (l + 1) / 2 * 2; rr = rr / 2 * 2;                  // ceil(l/2)*2, floor(r/2)*2 for non-negative ints
         a.itv_left[base + k] = row_abs + l; a.itv_right[base + k] = row_abs + rr;
         const i32 plen = (i32)(rr - l + 1);                     // a row is shorter than 10^6 samples (k_group_final)
-        return plen > 0 ? (plen + a.spr - 1) / a.spr : 0;
+        return plen > 0 ? (plen + WFS_SPR - 1) / WFS_SPR : 0;
     };
     i32 carry_last = -1, open_left = -1; i32 count = 0, nrec = 0;      // (a row is shorter than 10^6 samples: 32-bit indices)
     const i32 len32 = (i32)len, hold32 = (i32)hold;
@@ -1901,10 +1901,10 @@ __global__ __launch_bounds__(256) void k_rec_keys(WfsDev d, ZleArgs a)
     for (i32 k = 0; k < count; k++) {
         const i64 left = a.itv_left[q.itv_base + k]; const i32 plen = (i32)(a.itv_right[q.itv_base + k] - left + 1);
         if (plen <= 0) continue;
-        const i32 need = (plen + a.spr - 1) / a.spr;
+        const i32 need = (plen + WFS_SPR - 1) / WFS_SPR;
         for (i32 f = lane; f < need; f += 64) {
             if (rec + f >= a.rec_capacity) break;
-            a.rec_key[rec + f] = ((u64)(left + (i64)a.spr * f - key_base) << 12) | (u64)(u32)q.channel;
+            a.rec_key[rec + f] = ((u64)(left + (i64)WFS_SPR * f - key_base) << 12) | (u64)(u32)q.channel;
             a.rec_val[rec + f] = (u32)(rec + f);
         }
         rec += need;
@@ -1947,7 +1947,7 @@ __global__ __launch_bounds__(256) void k_pack_res(PackResArgs a)
     if (q.count == 0) return;
     const int16_t *fin = a.fin + q.acc_off;
     const i32 last = (((q.len_he_src & 0xfffff) + 3) & ~3) - 2;
-    const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
+    constexpr int spr = WFS_SPR; constexpr int rec_dwords = (24 + 2 * spr) / 4;
     const i64 rec_bytes = 24 + 2 * (i64)spr;
     const u32 w3 = ((u32)(uint16_t)a.dt) | ((u32)(uint16_t)q.channel << 16);
     i64 rec = q.rec;
@@ -2000,7 +2000,7 @@ __global__ __launch_bounds__(256) void k_pack(WfsDev d, ZleArgs a)
     const i64 ixr = q.ixr;
     const i64 base = q.itv_base;
     const i32 len32 = q.len_he_src & 0xfffff;
-    const int spr = a.spr, rec_dwords = (24 + 2 * spr) / 4;
+    constexpr int spr = WFS_SPR; constexpr int rec_dwords = (24 + 2 * spr) / 4;
     const i64 rec_bytes = 24 + 2 * (i64)spr;
     const bool noisy = NK != 0 && channel < d.noise_channels;
     const bool fast_loads = NK == 0 || (d.noise_len >= NOISE_MIN_FAST && spr <= NOISE_MIN_FAST / 2);       // (as in k_zle: a scalar noise start per record)

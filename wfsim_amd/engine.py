@@ -296,9 +296,19 @@ class Engine:
         rs = _arr(run_set, np.int32) if run_set is not None else None
         self._n_loaded = n
         self._n_run_sets = (int(rs.max()) + 1 if len(rs) else 0) if rs is not None else n
+        # Run sets go to the library numbered by their FIRST instruction (the numbers of the other members stay unused): a set of one
+        # instruction then carries that instruction's index, which is what lets it take the tile-local generator (wfs_tilegen.h) next to
+        # the shared Pulse calls of electron afterpulses.  _set_rows: the library's row of every set of the caller, for the outputs below.
+        self._set_rows = None
+        if rs is not None and len(rs):
+            first = np.full(self._n_run_sets, n, dtype=np.int64)
+            np.minimum.at(first, rs, np.arange(n))
+            if np.all(first < n) and np.all(np.diff(first) > 0):        # (every set used, numbered in order of first appearance)
+                self._set_rows = first
+                rs = _arr(first[rs], np.int32)
         eb = _arr(em_base, np.uint32) if em_base is not None else None       # (a local: the converted copy must outlive the call)
         self._check(self.lib.wfs_load_instructions(self._h, C.c_int64(n), *[_p(x) for x in a], C.c_int32(a[-1].shape[0]),
-                                                   _p(rs), C.c_int64(int(rs.max()) + 1 if rs is not None and len(rs) else 0), _p(eb)))
+                                                   _p(rs), C.c_int64((n if self._set_rows is not None else int(rs.max()) + 1) if rs is not None and len(rs) else 0), _p(eb)))
         if np.any(a[10] < 0):           # rows from the device pattern maps
             aft = ip.get('aft_factor')
             if aft is not None:
@@ -404,6 +414,10 @@ class Engine:
         c = WfsCounts()
         self._check(self.lib.wfs_get_counts(self._h, C.byref(c)))
         self.counts = {n: getattr(c, n) for n, _ in WfsCounts._fields_}
+        self._lib_sets = self.counts['n_pulse_sets']            # the library's pulse-set rows (run sets numbered by their first instruction leave gaps)
+        rows = self._caller_sets(self._lib_sets)
+        if rows is not None:
+            self.counts['n_pulse_sets'] = len(rows)
         return self.counts
 
     def set_debug(self, on=True, force_dense=False, generate_only=False, check_launches=None):
@@ -510,6 +524,11 @@ class Engine:
         s, ch = np.zeros(n, np.int32), np.zeros(n, np.int32)
         left, right, nph, off = (np.zeros(n, np.int64) for _ in range(4))
         self._check(self.lib.wfs_copy_pulses(self._h, _p(s), _p(ch), _p(left), _p(right), _p(nph), _p(off), C.c_int64(n)))
+        rows = self._caller_sets(self._lib_sets)
+        if rows is not None:                        # the library's set numbers -> the caller's
+            inv = np.full(self._lib_sets, -1, dtype=np.int32)
+            inv[rows] = np.arange(len(rows), dtype=np.int32)
+            s = inv[s]
         out = dict(set=s, channel=ch, left=left, right=right, n_photons=nph, cur_off=off)
         if currents:
             total = int((right - left + 1).sum())
@@ -528,26 +547,40 @@ class Engine:
         self._check(self.lib.wfs_copy_row_data(self._h, _p(data), C.c_int64(total)))
         return dict(group=g, channel=ch, left=left, right=right, data_off=off, data=data)
 
+    def _caller_sets(self, s):
+        """rows of the library's pulse sets that belong to the caller's run sets (None: all of them, in order): primaries, then -- when the
+        library made PMT-afterpulse sets, a second block of the same size -- theirs"""
+        rows = getattr(self, '_set_rows', None)
+        if rows is None or not self.counts['n_instructions']:
+            return None
+        n = self.counts['n_instructions']
+        return rows if s == n else np.concatenate([rows, n + rows])
+
     def photons(self):
-        n, s = self.counts['n_photons'], self.counts['n_pulse_sets']
+        n, s = self.counts['n_photons'], self._lib_sets
         off = np.zeros(s + 1, np.int64)
         t, ch, gain, dpe = np.zeros(n, np.int64), np.zeros(n, np.int16), np.zeros(n, np.float64), np.zeros(n, np.uint8)
         self._check(self.lib.wfs_copy_photons(self._h, _p(off), _p(t), _p(ch), _p(gain), _p(dpe), C.c_int64(n)))
+        rows = self._caller_sets(s)
+        if rows is not None:                        # (the unused set numbers hold no photons: dropping them keeps the offsets contiguous)
+            off = np.append(off[rows], off[-1])
         return dict(set_off=off, t=t, ch=ch, gain=gain, dpe=dpe)
 
     def truth(self):
-        s = self.counts['n_pulse_sets']
+        s = self._lib_sets
         acc, ts = np.zeros((s, 12)), np.zeros((s, 5))
         self._check(self.lib.wfs_copy_truth(self._h, _p(acc), _p(ts), C.c_int64(s)))
-        return acc, ts
+        rows = self._caller_sets(s)
+        return (acc, ts) if rows is None else (acc[rows], ts[rows])
 
     def truth_per_pmt(self):
         """[pulse set][channel][n_photon, n_pe, n_photon_trigger, n_pe_trigger, raw_area, raw_area_trigger] (pulse.py:259-271)"""
-        s = self.counts['n_pulse_sets']
+        s = self._lib_sets
         acc = np.zeros((s, int(self.params['n_tpc']), 6))
         if s:
             self._check(self.lib.wfs_copy_truth_per_pmt(self._h, _p(acc), C.c_int64(s)))
-        return acc
+        rows = self._caller_sets(s)
+        return acc if rows is None else acc[rows]
 
     def set_noise_offsets(self, ix_rand):
         a = _arr(ix_rand, np.int64)
@@ -565,12 +598,15 @@ class Engine:
     def electron_stats(self):
         """per run set (= per instruction unless run sets were given): n, mean, min, max, std of the electron times"""
         n = getattr(self, '_n_run_sets', None)
+        rows = getattr(self, '_set_rows', None)
         if n is None or self.counts['n_instructions'] == 0:
+            n, rows = self.counts['n_instructions'], None
+        if rows is not None:
             n = self.counts['n_instructions']
         es = np.zeros((n, 5))
         if n:
             self._check(self.lib.wfs_copy_electron_stats(self._h, _p(es), C.c_int64(n)))
-        return es
+        return es if rows is None else es[rows]
 
     def kernel_times(self):
         names = C.create_string_buffer(4096)
