@@ -364,3 +364,36 @@ def test_prepass_counts_and_photon_times_of_tile_generated_instructions():
     t0 = eng.gather_photon_times(np.arange(off[0], off[0] + c0))
     sel = ph['ch'][ph['set_off'][0]:ph['set_off'][1]] == 0
     assert np.array_equal(np.sort(t0), np.sort(ph['t'][ph['set_off'][0]:ph['set_off'][1]][sel]))
+
+
+def test_tile_generation_next_to_the_shared_calls_of_electron_afterpulses():
+    """enable_electron_afterpulses (the reference's default, rawdata.py:194): the secondaries of a cluster share one Pulse call, so the
+    batch carries run sets -- numbered by their first instruction (engine.load_instructions), which keeps every primary S2 that is alone
+    in its call on the tile-local generator.  The tile kernel runs, and records equal the oracle's (whose rule is the same)."""
+    import wfsim_amd
+    from wfsim_amd.scheduler import feedback_schedule
+    edges = np.linspace(0, 150e3, 141)
+    hist = np.exp(-np.arange(140) / 30.0); hist *= 3e-4 / hist.sum()
+    cfg = xenonnt_test_config(enable_electron_afterpulses=True, uniform_to_ele_ap=(hist, edges), seed=77, s2_secondary_sc_gain=100.0)
+    n = 6
+    ins = np.zeros(n, dtype=instruction_dtype)
+    ins['type'] = [2, 1, 2, 2, 1, 2]
+    ins['time'] = 1_000_000 * (1 + np.arange(n))
+    ins['x'], ins['y'], ins['z'] = [0, 3, -8, 12, 0, 5], [1, 0, 4, -6, 9, -2], [-10, -30, -55, -70, -20, -90]
+    ins['amp'] = [3000, 800, 9000, 500, 3000, 2000]
+    ins['recoil'], ins['event_number'] = 7, np.arange(n)
+    rd = wfsim_amd.RawData(cfg)
+    rd.engine.set_profiling(True)
+    windows = list(rd.iter_windows(ins))
+    assert 'k_s2_tile' in rd.engine.kernel_times()
+    rec = np.concatenate([w['records'] for w in windows])
+    sec, sec_gid, sec_base, sec_parent = rd.electron_afterpulse_instructions(ins, np.arange(n), with_parent=True)
+    assert len(sec) > 10
+    allins = np.concatenate([ins, sec]); gids = np.concatenate([np.arange(n), sec_gid])
+    base = np.concatenate([np.zeros(n, np.uint32), sec_base]); parent = np.concatenate([np.full(n, -1), sec_parent])
+    order, key, cluster, rs = feedback_schedule(allins, parent, cfg)
+    s_ins = allins[order]
+    assert len(np.unique(rs)) < len(rs)                      # at least one shared call
+    orc = make_oracle(cfg)
+    orc.simulate_scheduled(s_ins, gids[order].astype(np.uint32), instruction_params(s_ins, cfg, Resource(cfg)), base[order], cluster, key, rs)
+    assert rec.tobytes() == orc.pack_records().tobytes()
