@@ -144,3 +144,40 @@ def test_photon_times_match_the_reference_draws():
     assert _ks(v, c, t) < _ks_limit(20000, n_e, 2.5)
     m, s = _moments(v, c)
     assert abs(t.mean() - m) < 6 * s / np.sqrt(n_e) and abs(t.std() / s - 1) < 0.03
+
+
+def test_scheduled_runs_apply_the_rule_to_instructions_alone_in_their_call():
+    """RNG spec v12: with run sets given (electron afterpulses: orc_simulate_scheduled) an S2 that is alone in its Pulse call is
+    generated tile by tile like an S2 of a plain run; one that shares its call keeps the per-electron generator."""
+    from wfsim_amd.scheduler import schedule
+    cfg, ins = _s2(4, 400, s2_secondary_sc_gain=60.0, seed=11)
+    res = Resource(cfg)
+    order, key, cluster = schedule(ins, cfg)
+    s_ins = ins[order]
+    gid = order.astype(np.uint32)
+    ip = instruction_params(s_ins, cfg, res)
+    plain = make_oracle(cfg); plain.simulate(s_ins, gid, ip)
+    sched = make_oracle(cfg); sched.simulate_scheduled(s_ins, gid, ip, np.zeros(len(ins), np.uint32), cluster, key, np.arange(len(ins)))
+    a, b = plain.results(), sched.results()
+    assert np.array_equal(a['ph_t'], b['ph_t']) and plain.pack_records().tobytes() == sched.pack_records().tobytes()
+    off = make_oracle(dict(cfg, tile_local_generation=False)); off.simulate(s_ins, gid, ip)
+    assert not np.array_equal(a['ph_t'], off.results()['ph_t'])            # (the tile path was really taken)
+    # two S2s 200 ns apart in ONE call: the per-electron generator for both, whatever the switch
+    cfg2, ins2 = _s2(2, 400, s2_secondary_sc_gain=60.0, seed=11)
+    ins2['time'] = [MS, MS + 200]
+    o2, k2, c2 = schedule(ins2, cfg2)
+    ip2 = instruction_params(ins2[o2], cfg2, Resource(cfg2))
+    out = []
+    for c in (cfg2, dict(cfg2, tile_local_generation=False)):
+        orc = make_oracle(c)
+        orc.simulate_scheduled(ins2[o2], o2.astype(np.uint32), ip2, np.zeros(2, np.uint32), c2, k2, np.zeros(2, np.int32))
+        out.append(orc.results()['ph_t'])
+    assert np.array_equal(out[0], out[1])
+
+
+def test_run_sets_are_numbered_by_their_first_instruction():
+    from wfsim_amd.engine import first_instruction_of_sets
+    assert np.array_equal(first_instruction_of_sets([0, 1, 1, 2, 1, 3], 4), [0, 1, 3, 5])
+    assert np.array_equal(first_instruction_of_sets(np.arange(5), 5), np.arange(5))
+    assert first_instruction_of_sets([1, 0, 2], 3) is None                  # not in order of first appearance
+    assert first_instruction_of_sets([0, 2, 2], 3) is None                  # a set number without instructions

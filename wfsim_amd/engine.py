@@ -151,6 +151,18 @@ def _arr(a, dtype):
     return np.ascontiguousarray(a, dtype=dtype)
 
 
+def first_instruction_of_sets(run_set, n_sets):
+    """index of the first instruction of every run set -- the number the library knows the set by (include/wfsim_amd.h,
+    wfs_load_instructions) -- or None when a set number is unused or the sets are not numbered in order of first appearance"""
+    run_set = np.asarray(run_set)
+    n = len(run_set)
+    first = np.full(n_sets, n, dtype=np.int64)
+    np.minimum.at(first, run_set, np.arange(n))
+    if np.all(first < n) and np.all(np.diff(first) > 0):
+        return first
+    return None
+
+
 class Engine:
     """One GPU, one stream, one fax configuration."""
 
@@ -301,9 +313,8 @@ class Engine:
         # the shared Pulse calls of electron afterpulses.  _set_rows: the library's row of every set of the caller, for the outputs below.
         self._set_rows = None
         if rs is not None and len(rs):
-            first = np.full(self._n_run_sets, n, dtype=np.int64)
-            np.minimum.at(first, rs, np.arange(n))
-            if np.all(first < n) and np.all(np.diff(first) > 0):        # (every set used, numbered in order of first appearance)
+            first = first_instruction_of_sets(rs, self._n_run_sets)
+            if first is not None:
                 self._set_rows = first
                 rs = _arr(first[rs], np.int32)
         eb = _arr(em_base, np.uint32) if em_base is not None else None       # (a local: the converted copy must outlive the call)
