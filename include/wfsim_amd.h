@@ -70,8 +70,8 @@ typedef struct wfs_config {
                                   reference's, ADC samples / ZLE / records equal unless a current lands within that distance of a
                                   rounding tie (tolerance of the path: 1 ADC count).  0: the reference's two roundings, currents
                                   bit-exact                                                                   */
-    int32_t row_resident;      /* config 'row_resident'.  1: a (window, channel) row no longer than 2048 samples whose pulses all
-                                  hold at most 64 photons is made, finished and zero-suppressed by one wave in LDS (k_row_pulse);
+    int32_t row_resident;      /* config 'row_resident'.  1: a (window, channel) row whose pulses all
+                                  hold at most 64 photons is made (in segments of 1024 samples), finished and zero-suppressed by one wave in LDS (k_row_pulse);
                                   0: every row through the integer accumulators in HBM; 2 ('auto', the default): 1 for a batch with
                                   at least two photons per (pulse set, channel) slot, else 0.  Same records either way.          */
     double c2a;                /* current_2_adc                                     pulse.py:33-35   */

@@ -60,7 +60,7 @@ struct wfs_handle {
     DevBuf set_gid, opt_t, opt_item, opt_first, opt_last, opt_ch, opt_time;
     int keep_currents = 0, profiling = 0;
     i32 res_env = -1;                // WFS_ROW_RESIDENT=0/1 overrides the config switch (A/B runs)
-    i32 res_max_len = 2048;          // longest resident row (k_row_pulse: 4 bytes of LDS per sample and wave); WFS_RES_MAX_LEN overrides
+    i32 res_max_len = 1024;          // segment of a resident row (k_row_pulse: 4 bytes of LDS per sample and wave; longer rows take several); WFS_RES_MAX_LEN overrides
     bool gen_done = false;
     bool gen_order_ready = false;          // host tables of the generation order (gen_order_tables), valid for the current generation
     std::vector<i64> go_off, go_block0; std::vector<i32> go_fused, go_tile_count;
