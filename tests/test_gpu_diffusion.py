@@ -22,10 +22,23 @@ def diffusion_config(**kw):
                       enable_field_dependencies=dict(diffusion_transverse_map=True), **kw)
 
 
-@pytest.mark.parametrize('aft', [False, True])
-def test_rows_averaged_over_the_electrons(aft):
+def _as_point_list(cfg, seed=7):
+    """the S2 pattern map of the configuration as a jittered point list (an irregular coordinate system): the device finds every
+    electron's neighbours through its cell index (points_nearest_2d)"""
+    from wfsim_amd.itp_map import InterpolatingMap
+    m = InterpolatingMap(cfg['s2_pattern_map'])
+    pts = m.coordinate_system + np.random.default_rng(seed).uniform(-0.8, 0.8, m.coordinate_system.shape)
+    cfg['s2_pattern_map'] = dict(coordinate_system=pts.tolist(), map=np.asarray(cfg['s2_pattern_map']['map']).reshape(len(pts), -1))
+    return cfg
+
+
+@pytest.mark.parametrize('aft,points', [(False, False), (True, False), (False, True), (True, True)])
+def test_rows_averaged_over_the_electrons(aft, points):
     cfg = diffusion_config(**(dict(s2_aft_sigma=0.06) if aft else {}))
+    if points:
+        cfg = _as_point_list(cfg)
     res = Resource(cfg)
+    assert (res.s2_pattern_map.grid is None) == points
     eng = make_engine(cfg, resource=res)
     ins = instructions(60, 5)
     ins['amp'][ins['type'] == 2] = np.random.default_rng(2).choice([3, 40, 900, 5000], int(np.sum(ins['type'] == 2)))

@@ -114,7 +114,8 @@ struct wfs_handle {
     DevBuf gg_inv, ins_gg, ins_ggw, ins_ggsum; i32 gg_n = 0, gg_L = 0; bool ins_gg_set = false;       // 'garfield_gas_gap' luminescence
     // pattern maps evaluated on the device
     struct PatternMap { bool set = false; i32 dims = 0, n[3] = {1, 1, 1}, w[3] = {0, 0, 0}, n_map_ch = 0; double lo[3] = {0, 0, 0}, hgrid[3] = {1, 1, 1}; DevBuf values;
-                        i64 n_points = 0; DevBuf points; } pmap[2];
+                        i64 n_points = 0; DevBuf points;
+                        DevBuf cell_start, cell_pts; i32 cnx = 0, cny = 0; double cell_lo[2] = {0, 0}, cell_h = 1; } pmap[2];       // 2-D point lists: cell index (transverse diffusion)
     // scalar maps (kind 0: weighted nearest neighbours on a regular grid, 1: on a point list, 2: RectBivariateSpline)
     struct ScalarMap { int kind = 0; int nv = 1; PatternMap g; i32 nx = 0, ny = 0, kx = 0, ky = 0; DevBuf tx, ty, c; };      // kind 0 / 1: nearest neighbours on a grid / a point list, 2: spline, 3: multilinear grid
     std::vector<std::unique_ptr<ScalarMap>> smaps;
@@ -836,6 +837,8 @@ static void map_args(const wfs_handle::PatternMap &pm, MapArgs &m)
     m.dims = pm.dims; for (int q = 0; q < 3; q++) { m.n[q] = pm.n[q]; m.w[q] = pm.w[q]; m.lo[q] = pm.lo[q]; m.h[q] = pm.hgrid[q]; }
     m.n_points = pm.n_points; m.points = pm.n_points ? pm.points.as<double>() : nullptr;
     m.values = pm.values.as<float>(); m.n_map_ch = pm.n_map_ch;
+    m.cell_start = pm.cnx ? pm.cell_start.as<i32>() : nullptr; m.cell_pts = pm.cnx ? pm.cell_pts.as<i32>() : nullptr;
+    m.cnx = pm.cnx; m.cny = pm.cny; m.cell_lo[0] = pm.cell_lo[0]; m.cell_lo[1] = pm.cell_lo[1]; m.cell_h = pm.cell_h;
 }
 
 static void launch_neighbours(wfs_handle *h, const MapArgs &m)
@@ -874,6 +877,25 @@ try {
     m.dims = dims; m.n_points = n_points; m.n_map_ch = n_map_channels;
     TRY(upload(h, m.points, points, (size_t)n_points * dims * 8));
     TRY(upload(h, m.values, values, (size_t)n_points * (size_t)n_map_channels * 4));
+    m.cnx = m.cny = 0;
+    if (dims == 2) {
+        // cell index for the per-electron searches of the transverse diffusion (k_diffuse_patterns): square cells of about two points
+        double lo[2] = {points[0], points[1]}, hi[2] = {points[0], points[1]};
+        for (i64 q = 0; q < n_points; q++) for (int a = 0; a < 2; a++) { lo[a] = std::min(lo[a], points[2 * q + a]); hi[a] = std::max(hi[a], points[2 * q + a]); }
+        const double span = std::max(std::max(hi[0] - lo[0], hi[1] - lo[1]), 1e-9);
+        const double ch = span / std::max<double>(1.0, std::ceil(std::sqrt((double)n_points / 2.0)));
+        const i32 cnx = (i32)std::floor((hi[0] - lo[0]) / ch) + 1, cny = (i32)std::floor((hi[1] - lo[1]) / ch) + 1;
+        std::vector<i32> start((size_t)cnx * cny + 1, 0), pts((size_t)n_points), cell((size_t)n_points);
+        for (i64 q = 0; q < n_points; q++) {
+            i32 cx = (i32)std::floor((points[2 * q] - lo[0]) / ch), cy = (i32)std::floor((points[2 * q + 1] - lo[1]) / ch);
+            cx = std::min(std::max(cx, 0), cnx - 1); cy = std::min(std::max(cy, 0), cny - 1);
+            cell[(size_t)q] = cx * cny + cy; start[(size_t)cell[(size_t)q] + 1]++;
+        }
+        for (size_t c = 0; c + 1 < start.size(); c++) start[c + 1] += start[c];
+        { std::vector<i32> cur(start.begin(), start.end() - 1); for (i64 q = 0; q < n_points; q++) pts[(size_t)cur[(size_t)cell[(size_t)q]]++] = (i32)q; }      // (ascending point index inside a cell)
+        TRY(upload(h, m.cell_start, start.data(), start.size() * 4)); TRY(upload(h, m.cell_pts, pts.data(), pts.size() * 4));
+        m.cnx = cnx; m.cny = cny; m.cell_lo[0] = lo[0]; m.cell_lo[1] = lo[1]; m.cell_h = ch;
+    }
     HIPCHK(hipStreamSynchronize(h->stream));
     m.set = true;
     return WFS_OK;
@@ -896,13 +918,13 @@ try {
 // diffusion_constant_transverse with enable_field_dependencies['diffusion_transverse_map'] (S2.s2_pattern_map_diffuse, s2.py:560-613):
 // sigma_r[i], sigma_a[i] = sqrt(2 D t) of instruction i along / across the radius (cm; NaN: not this path).  The pattern of such an
 // instruction is averaged over its surviving electrons inside wfs_run (k_diffuse_patterns), not by wfs_eval_pattern_rows.
-// Needs the S2 pattern map on the device as a regular grid and the instruction loaded with cdf_row = -1.
+// Needs the S2 pattern map on the device (a 2-D regular grid or point list) and the instruction loaded with cdf_row = -1.
 int wfs_set_instruction_diffusion(wfs_handle *h, int64_t n, const double *sigma_r, const double *sigma_a, double tpc_radius)
 try {
     if (!h) return WFS_E_INVALID;
     if (!h->batch_loaded || h->injected || h->optical || n != h->n_ins || !sigma_r || !sigma_a) return h->fail(WFS_E_STATE, "wfs_set_instruction_diffusion follows wfs_load_instructions of the same batch");
     const auto &pm = h->pmap[1];
-    if (!pm.set || pm.n_points || pm.dims != 2) return h->fail(WFS_E_STATE, "wfs_set_instruction_diffusion needs a regular-grid S2 pattern map on the device (wfs_set_pattern_map)");
+    if (!pm.set || pm.dims != 2 || (pm.n_points && !pm.cnx)) return h->fail(WFS_E_STATE, "wfs_set_instruction_diffusion needs a two-dimensional S2 pattern map on the device (wfs_set_pattern_map / wfs_set_pattern_map_points)");
     HIPCHK(hipSetDevice(h->device));
     h->ins_diff.assign((size_t)n, 0);
     std::vector<char> is_dev((size_t)n, 0);

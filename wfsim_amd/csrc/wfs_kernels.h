@@ -2597,6 +2597,8 @@ struct MapArgs {
     i32 dims, n[3], w[3];          // regular grid: nodes per axis; half-width of the candidate block per axis
     double lo[3], h[3];            // first node and spacing per axis
     i64 n_points; const double *points;    // point-list map (an irregular coordinate system): [n_points][dims]; else nullptr
+    // 2-D point lists: a uniform cell index over the points (cell (i, j) = cell_start[i * cny + j] .. of cell_pts, ascending point index)
+    const i32 *cell_start, *cell_pts; i32 cnx, cny; double cell_lo[2], cell_h;
     const float *values;           // [nodes][n_map_ch]
     i32 n_map_ch;                  // channels stored in the map; channels beyond get weight 1 (s2.py:648-650: top-only maps)
     i64 n_rows;                    // positions to evaluate
@@ -2657,6 +2659,39 @@ __device__ __forceinline__ void grid_nearest(const MapArgs &m, const double *pos
     }
 }
 
+// The same for a 2-D point list, through the cell index: rings of cells around the position's cell until the K-th neighbour found is
+// closer than anything in the rings not yet visited can be (a cell at Chebyshev distance k lies at least (k - 1) cell widths away);
+// equal distances: the lower point index, as the brute-force search of k_map_neighbours_points.
+__device__ __forceinline__ void points_nearest_2d(const MapArgs &m, const double *pos, double *bd, i64 *bi)
+{
+    constexpr int K = 4;
+    for (int k = 0; k < MAP_K; k++) { bd[k] = 1e300; bi[k] = -1; }
+    i32 cx = (i32)floor((pos[0] - m.cell_lo[0]) / m.cell_h), cy = (i32)floor((pos[1] - m.cell_lo[1]) / m.cell_h);
+    cx = cx < 0 ? 0 : (cx > m.cnx - 1 ? m.cnx - 1 : cx); cy = cy < 0 ? 0 : (cy > m.cny - 1 ? m.cny - 1 : cy);
+    const i32 rmax = m.cnx > m.cny ? m.cnx : m.cny;
+    for (i32 r = 0; r <= rmax; r++) {
+        for (i32 i = cx - r; i <= cx + r; i++) {
+            if (i < 0 || i >= m.cnx) continue;
+            const bool whole = i == cx - r || i == cx + r;          // the ring's two full columns; in between only its top and bottom cell
+            for (i32 j = cy - r; j <= cy + r; j += (whole || r == 0) ? 1 : 2 * r) {
+                if (j < 0 || j >= m.cny) continue;
+                const i64 cell = (i64)i * m.cny + j;
+                for (i32 q = m.cell_start[cell]; q < m.cell_start[cell + 1]; q++) {
+                    const i64 p = m.cell_pts[q];
+                    const double dx = pos[0] - m.points[2 * p], dy = pos[1] - m.points[2 * p + 1];
+                    const double d2 = dx * dx + dy * dy;
+                    if (!(d2 < bd[K - 1] || (d2 == bd[K - 1] && p < bi[K - 1]))) continue;
+                    int t = K - 1;
+                    while (t > 0 && (d2 < bd[t - 1] || (d2 == bd[t - 1] && p < bi[t - 1]))) { bd[t] = bd[t - 1]; bi[t] = bi[t - 1]; t--; }
+                    bd[t] = d2; bi[t] = p;
+                }
+            }
+        }
+        const double reach = (double)r * m.cell_h;
+        if (bi[K - 1] >= 0 && bd[K - 1] < reach * reach) break;
+    }
+}
+
 __global__ void k_map_neighbours(MapArgs m)
 {
     const i64 r = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2711,7 +2746,7 @@ __global__ __launch_bounds__(256) void k_map_neighbours_points(MapArgs m)
 // Transverse diffusion with field maps (S2.s2_pattern_map_diffuse, s2.py:560-613): the pattern of an instruction is the average
 // of the pattern map over its SURVIVING electrons' positions, each displaced by N(0, sigma_r) along the radius and N(0, sigma_a)
 // across it; electrons that end outside tpc_radius do not count.  One workgroup per instruction, after k_s2_electrons: batches of
-// 256 electrons -- a thread displaces one electron and finds its 4 grid neighbours (LDS), then the threads, one or two
+// 256 electrons -- a thread displaces one electron and finds its 4 neighbours (grid nodes, or the points of a point-list map through its cell index), then the threads, one or two
 // channels each, add the 256 weighted patterns in electron order (a fixed order: reproducible sums).  An instruction without an
 // electron inside gets no pattern: its electrons make no photons (the reference's NaN pattern sends them to channel -1).
 struct DiffArgs { i64 n_rows; const i32 *row_ins; const double *sig_r, *sig_a; double r2max; double *pre; };
@@ -2741,7 +2776,7 @@ __global__ __launch_bounds__(256) void k_diffuse_patterns(WfsDev d, GenArgs a, M
             ok = pos[0] * pos[0] + pos[1] * pos[1] <= q.r2max;
             if (ok) {
                 double bd[MAP_K];
-                grid_nearest(m, pos, bd, bi);
+                if (m.points) points_nearest_2d(m, pos, bd, bi); else grid_nearest(m, pos, bd, bi);
                 ws = 0;
                 for (int k = 0; k < 4; k++) { const double dist = sqrt(bd[k]); w[k] = bi[k] >= 0 ? 1.0 / (dist < 1e-6 ? 1e-6 : dist) : 0.0; ws += w[k]; }
             }

@@ -239,7 +239,7 @@ def instruction_params(instructions, config, resource, gids=None, device_maps=()
                                and config.get('enable_field_dependencies', {}).get('diffusion_transverse_map', False))
             if transverse_maps:
                 if 's2' not in device_maps:
-                    raise NotImplementedError('diffusion_transverse_map (s2.py:575-579) needs the S2 pattern map on the device (regular grid)')
+                    raise NotImplementedError('diffusion_transverse_map (s2.py:575-579) needs the S2 pattern map on the device (a two-dimensional WeightedNearestNeighbors map: regular grid or point list)')
                 z_obs = s2_observed_positions(ins, config, resource)[0] if config.get('field_distortion_model', 'none') in ('inverse_fdc', 'comsol') else ins['z']
                 diff_sigma[0][idx], diff_sigma[1][idx] = s2_transverse_sigmas(z_obs, np.asarray(xy_obs, dtype=np.float64), config, resource)
             elif config.get('diffusion_constant_transverse', 0) > 0:
