@@ -137,6 +137,32 @@ template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
     const int lo = dpp_mov<CTRL>((int)(u32)b), hi = dpp_mov<CTRL>((int)(u32)((u64)b >> 32));
     return __longlong_as_double((long long)(((u64)(u32)hi << 32) | (u32)lo));
 }
+// lane ^ J of the wave without a trip through the LDS crossbar where the hardware has a permute for it: quad permutes (J = 1, 2) and the
+// rotation of a 16-lane row by 8 are DPP moves on the vector unit, J = 4 / 16 swizzles (LDS unit, no address register), J = 32 the
+// generic shuffle.  All 64 lanes must be active (the callers sit in wave-uniform code).
+template <int J> __device__ __forceinline__ u32 lane_xor(u32 v)
+{
+    if constexpr (J == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);          // quad_perm [1, 0, 3, 2]
+    else if constexpr (J == 2) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);     // quad_perm [2, 3, 0, 1]
+    else if constexpr (J == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);    // row_ror:8
+    else if constexpr (J == 4) return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                       // bit mode: and 0x1f, xor 4
+    else if constexpr (J == 16) return (u32)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                      // bit mode: and 0x1f, xor 16
+    else return (u32)__shfl_xor((int)v, J, 64);
+}
+// one compare-exchange step of a bitonic network on keys held one per lane (ascending over the wave)
+template <int K, int J> __device__ __forceinline__ u32 bitonic_step(u32 key, int lane)
+{
+    const u32 other = lane_xor<J>(key);
+    const bool up = (lane & K) == 0, low = (lane & J) == 0;
+    return (low == up) ? (key < other ? key : other) : (key > other ? key : other);
+}
+template <int K, int J = (K >> 1)> __device__ __forceinline__ u32 bitonic_merge(u32 key, int lane)
+{
+    key = bitonic_step<K, J>(key, lane);
+    if constexpr (J > 1) return bitonic_merge<K, (J >> 1)>(key, lane);
+    else return key;
+}
+
 // (every DPP move is made ONCE, by all lanes, before its value is used: inside a divergent region a DPP read of a switched-off
 // lane returns the old value instead)
 #define WFS_DPP_STEPS(T, COMBINE) \

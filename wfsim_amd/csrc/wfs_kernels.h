@@ -1153,16 +1153,9 @@ __device__ __forceinline__ void wave_tile_pulse(const WfsDev &d, const PulseArgs
     u32 key = ((u32)ns0 << 6) | (u32)lane;
     // (the photons sit in lanes 0 .. n - 1 and every other lane holds a larger key: with n <= 32 (16) the merges of 64 (32) lanes have
     // nothing to do -- the lower half is sorted ascending after the stages before them, which is all that is read)
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-        if ((k >> 1) >= n && k > 16) break;                  // wave-uniform
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const u32 other = (u32)__shfl_xor((int)key, j, 64);
-            const bool up = (lane & k) == 0, low = (lane & j) == 0;
-            key = (low == up) ? (key < other ? key : other) : (key > other ? key : other);
-        }
-    }
+    // (the exchanges with lane ^ 1, 2, 8 are DPP moves, ^ 4, 16 swizzles: 19 of the 21 steps without an LDS address, wfs_device.h)
+    key = bitonic_merge<2>(key, lane); key = bitonic_merge<4>(key, lane); key = bitonic_merge<8>(key, lane); key = bitonic_merge<16>(key, lane);
+    if (n > 16) { key = bitonic_merge<32>(key, lane); if (n > 32) key = bitonic_merge<64>(key, lane); }      // wave-uniform
     const int src = (int)(key & 63u);
     i32 ns = (i32)(key >> 6);
     g = __shfl(g, src, 64);
