@@ -73,7 +73,7 @@ typedef struct wfs_config {
     int32_t row_resident;      /* config 'row_resident'.  1: a (window, channel) row whose pulses all
                                   hold at most 64 photons is made (in segments of 1024 samples), finished and zero-suppressed by one wave in LDS (k_row_pulse);
                                   0: every row through the integer accumulators in HBM; 2 ('auto', the default): 1 for a batch with
-                                  at least two photons per (pulse set, channel) slot, else 0.  Same records either way.          */
+                                  at least two photons in the photon array per (pulse set, channel) slot, else 0.  Same records either way.          */
     double c2a;                /* current_2_adc                                     pulse.py:33-35   */
     double tts_mean, tts_sigma;/* pmt_transit_time_mean, spread/2.35482             pulse.py:53-56   */
     double p_dpe;              /* p_double_pe_emision                               pulse.py:76      */

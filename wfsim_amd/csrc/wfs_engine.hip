@@ -1579,7 +1579,8 @@ try {
     // 2 (auto, the default): on when the batch holds at least two photons per (pulse set, channel) slot -- rows that collect several
     // pulses are where the accumulators cost (memset, atomics, two more reads); a batch of sparse S1 or nVeto hits is as fast through
     // them, and the resident path's extra pass over the tiles does not pay there
-    const i64 p_all = h->n_photons + ((!h->injected && !h->optical && h->ap_active) ? h->n_ap_photons : 0);
+    // (photons in the photon array: the tiles k_s2_tile made in one go hold theirs in their sample buffers and can never be resident)
+    const i64 p_all = h->n_photons - ((!h->injected && !h->optical && h->fuse_full) ? h->p_fused : 0) + ((!h->injected && !h->optical && h->ap_active) ? h->n_ap_photons : 0);
     const bool res_auto = T > 0 && p_all >= 2 * T;
     const int res_mode = h->res_env >= 0 ? h->res_env : h->cfg.row_resident;
     h->res_on = (res_mode == 2 ? res_auto : res_mode != 0) && !(h->keep_currents & 3) && !h->generic_geom && !d.he_rows && 2 * (i64)d.tw + 1 >= 63
