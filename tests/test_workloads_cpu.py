@@ -30,3 +30,22 @@ def test_synthetic_s2_pattern_map_is_a_probability_pattern():
     top = p[..., :W.N_TOP].sum(axis=-1)
     assert np.allclose(top, 0.75, atol=1e-5)
     assert 0.02 < p[30, 30].max() < 0.15          # the PMT above the event: a few percent of the light
+
+
+def test_reference_default_switches_of_the_side_bench():
+    """bench_config(reference_defaults=True): electron afterpulses on (rawdata.py:194) with a delay histogram whose integral is the
+    probability per photon, garfield luminescence with the fixture's table layout; the Resource and the kernel parameters accept both"""
+    from wfsim_amd.config import kernel_params
+    from wfsim_amd.resource import Resource
+    hist, edges = W.synthetic_electron_afterpulses()
+    assert len(edges) == len(hist) + 1 and np.isclose(hist.sum(), 3e-3) and np.all(np.diff(hist) < 0) and edges[-1] == 150e3
+    assert np.isclose(W.synthetic_electron_afterpulses(total=3e-5)[0].sum(), 3e-5)
+    g = W.synthetic_garfield_table()
+    d = golden('dists_models.npz')
+    assert np.array_equal(g['t'], d['garfield_t']) and np.array_equal(g['x'], d['garfield_x'])
+    cfg = W.bench_config(3, reference_defaults=True)
+    assert cfg['enable_electron_afterpulses'] and cfg['s2_luminescence_model'] == 'garfield'
+    res = Resource(cfg)
+    assert res.s2_luminescence['t'].shape == (11, 4000) and np.isclose(np.sum(res.uniform_to_ele_ap.histogram), 3e-3)
+    assert kernel_params(cfg)['tile_gen'] == 1 and kernel_params(cfg)['row_resident'] == 2
+    assert kernel_params(dict(cfg, row_resident=False))['row_resident'] == 0 and kernel_params(dict(cfg, row_resident=True))['row_resident'] == 1

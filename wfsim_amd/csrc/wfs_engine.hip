@@ -92,7 +92,7 @@ struct wfs_handle {
     wfs_counts counts{};
     i64 h_scal[64] = {0};
     DevBuf pack_desc;
-    DevBuf row_bad, fin_len, res_cnt, fin_off, res_toff, res_desc, fin, res_long, res_rows, res_first;      // resident rows (k_row_pulse)
+    DevBuf row_bad, fin_len, res_cnt, fin_off, res_toff, res_desc, fin, res_long, res_rows;      // resident rows (k_row_pulse)
     i64 n_front_rows = 0, n_res_rows = 0, n_short_rows = 0, n_res_tiles = 0, max_res_len = 0, s_fin = 0, s_res = 0; bool res_on = false;
     i64 n_active_tiles = 0, n_tiny_tiles = 0, n_sparse_tiles = 0, n_dense_tiles = 0, n_wave_tiles = 0, max_nb_dense = 0, n_active_rows = 0, n_groups = 0, s_raw = 0, n_itv_slots = 0, n_records = 0, max_nb = 0, max_tile = 0, max_tile_dense = 0;
     i64 cur_total = 0, row_dbg_total = 0;
@@ -1775,8 +1775,7 @@ try {
     za.n_front = h->n_front_rows; za.rows_cap = CG * d.row_slots;
     if (h->n_res_rows > 0) {
         TRY(ensure(h, h->fin, (size_t)h->s_fin * 2 + 16));
-        TRY(ensure(h, h->res_rows, (size_t)h->n_res_rows * sizeof(ResRow))); TRY(ensure(h, h->res_first, (size_t)h->n_res_rows * sizeof(TileDesc)));
-        za.res_desc = h->res_desc.as<TileDesc>(); za.res_first = h->res_first.as<TileDesc>();
+        TRY(ensure(h, h->res_rows, (size_t)h->n_res_rows * sizeof(ResRow)));
         za.res_toff = h->res_toff.as<i64>(); za.fin_off = h->fin_off.as<i64>(); za.fin = h->fin.as<int16_t>();
         za.n_short = h->n_short_rows; za.res_long = h->res_long.as<i32>(); za.res_rows = h->res_rows.as<ResRow>();
     }

@@ -1471,7 +1471,6 @@ struct ZleArgs {
     const i32 *tile_done, *row_cnt, *row_tile; const i32 *ins_bcap; const i64 *ins_boff; const i32 *tbuf; i64 n_done;      // rows read from a tile buffer in place (wfs_tilegen.h)
     // resident rows (k_row_pulse): the rows behind the first n_front of the row list; their finished 16-bit samples
     i64 n_front, n_short, rows_cap; const i64 *res_toff, *fin_off; int16_t *fin; const i32 *res_long; struct ResRow *res_rows;
-    const struct TileDesc *res_desc; struct TileDesc *res_first;      // [resident rows] a copy of the row's first tile descriptor: loaded WITH the row's, not behind it
     struct PackDesc *pdesc;      // [n_active_rows] what k_pack needs of a row, in one scalar load (k_pack_desc)
 };
 
@@ -1506,7 +1505,6 @@ __global__ void k_row_desc(WfsDev d, ZleArgs a)
         q.acc_off = a.fin_off[ridx]; q.src = 2;
         const i64 t0 = a.res_toff[ridx];
         a.res_rows[r - a.n_front] = ResRow{t0, (i32)(a.res_toff[ridx + 1] - t0), 0};
-        a.res_first[r - a.n_front] = a.res_desc[t0];
     }
     if (row_is_direct(a.tile_done, a.n_done, a.row_cnt, a.row_tile, ridx)) {
         const i32 tile = a.row_tile[ridx]; const i32 ins = tile / d.n_tpc;
@@ -1828,7 +1826,7 @@ __global__ __launch_bounds__(256) void k_row_pulse(WfsDev d, PulseArgs a, ZleArg
         const i32 seg_len = SEG ? (len32 - seg0 < region ? len32 - seg0 : region) : len32;
         for (i32 i = 4 * lane; i < ((seg_len + 255) & ~255); i += 256) *(int4 *)(acc + i) = make_int4(0, 0, 0, 0);
         // ---- the row's tiles (no HE rows on this path: row slot == row index)
-        TileDesc td = z.res_first[first + r];              // (most rows hold one tile: its descriptor arrives with the row's)
+        TileDesc td = a.desc[rr.t0];
         for (i64 t = rr.t0; t < t1; t++) {
             if (t > rr.t0) td = a.desc[t];
             if (td.n < 0) {                               // a prepared tiny tile (k_tile_assign): the samples its photons reach, nothing else
