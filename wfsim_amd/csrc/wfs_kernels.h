@@ -1057,7 +1057,7 @@ __global__ void k_tile_assign(WfsDev d, GeomArgs a, DescArgs da, PulseArgs pa)
             t.G = d.gains[ch]; t.thr = d.thr_truth[ch];
             t.n = cnt; t.nb = (i32)nb; t.L = (i32)(right - left + 1); t.tile = (i32)tile;
             t.ch = ch; t.mode = da.set_mode[set];
-            if (cnt <= TINY_MAX_PHOTONS && nb <= 4 * TINY_MAX_BINS) {
+            if (cnt <= TINY_MAX_PHOTONS && nb <= TINY_MAX_BINS) {       // (the tiny class of the work lists: the same tiles, the same order of their truth sums)
                 // a handful of photons: everything that does not depend on the sample is done here, one LANE per tile (sorted and merged
                 // photons, their start bins, the tile's truth sums) -- in k_row_pulse a whole wave would do it for one tile
                 const TinyPrep q = tiny_tile_prepare(d, pa, t, 0, d.current_max);
@@ -1406,8 +1406,10 @@ __global__ __launch_bounds__(TPB) void k_pulse_sparse(WfsDev d, PulseArgs a)
     }
 
     if (a.tile_truth) {
+        // (wave_sum: the order of wave_tile_pulse -- a tile of this class holds at most 32 photons, photon p in lane p of the first wave,
+        // so its f64 truth sums are the same bits whether this kernel, k_pulse_wave or k_row_pulse made the tile)
 #pragma unroll
-        for (int q = 0; q < 8; q++) for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 64);
+        for (int q = 0; q < 8; q++) acc[q] = wave_sum(acc[q]);
         if (lane == 0) for (int q = 0; q < 8; q++) red[wid * 8 + q] = acc[q];
         __syncthreads();
         if (tid < 8) { double sum = 0; for (int w = 0; w < TPB / 64; w++) sum += red[w * 8 + tid]; a.tile_truth[tile * 8 + tid] = sum; }
