@@ -262,6 +262,10 @@ int wfs_set_window_carry(wfs_handle *h, int32_t has_pulse, int64_t last_pulse_en
  * stream except for the size read-backs between stages. */
 int wfs_run(wfs_handle *h);
 
+/* n_pulse_sets: rows of the per-set outputs (wfs_copy_truth, wfs_copy_truth_per_pmt, wfs_copy_electron_stats; set offsets of
+ * wfs_copy_photons) = n_run_sets as given to wfs_load_instructions, unused set numbers included (their rows are empty), twice that with
+ * PMT afterpulses (the afterpulse set of set q is n_run_sets + q).  n_raw_samples: samples of every digitised row, whichever way it was
+ * made (accumulators, tile buffer read in place, resident row). */
 typedef struct wfs_counts {
     int64_t n_instructions, n_pulse_sets, n_emitters, n_photons /* primary + PMT afterpulse */, n_pe, n_tiles, n_groups, n_rows,
             n_raw_samples, n_intervals, n_records;
