@@ -984,7 +984,7 @@ static i64 gen_s1(orc_session *s, call_ctx *x, u32 gid, i64 time, i64 amp, doubl
 static int fuse_eligible(const orc_session *s, int type, u32 em_base, i64 amp, double sc_gain, const double *cdf)
 {
     const orc_config *c = &s->c;
-    if (!c->tile_gen || c->gain_spread != 0.0 || !s->save_full_truth) return 0;
+    if (!c->tile_gen || c->gain_spread != 0.0) return 0;      /* (save_full_truth off: the callers pass type -1 for an instruction that shares its Pulse call) */
     if (s->cur_gg >= 0) return 0;                   /* 'garfield_gas_gap' luminescence: the instruction's photons share a mean (s2.py:447-450) */
     if (type != 2 || em_base != 0u || amp <= 0 || !(sc_gain > 0)) return 0;
     double pmax = 0.0;
@@ -1165,11 +1165,17 @@ void orc_simulate(orc_session *s, i64 n, const int8_t *type, const i64 *time, co
             call_ctx x; memset(&x, 0, sizeof x); int open = 0; i64 last_key = 0;
             for (i64 k = a; k < b; k++) {
                 i64 i = ord[k].i; if (type[i] != ptype) continue;
-                if (open && ptype <= 2 && (s->save_full_truth || ord[k].t - last_key > gap)) { finish_call(s, ptype, runset++, &x); open = 0; }
+                const int starts = !open || (ptype <= 2 && (s->save_full_truth || ord[k].t - last_key > gap));      /* this instruction opens a Pulse call */
+                if (open && starts) { finish_call(s, ptype, runset++, &x); open = 0; }
+                /* alone in its call (the tile-local generator's condition, as on the device: k_fuse_decide): it opens one and the next
+                 * instruction of its type in the cluster, if any, opens another */
+                int alone = starts && ptype == 2;
+                if (alone && !s->save_full_truth)
+                    for (i64 q = k + 1; q < b; q++) if (type[ord[q].i] == ptype) { alone = ord[q].t - ord[k].t > gap; break; }
                 const double *cdf = cdf_table + (i64)cdf_row[i] * c->n_tpc;
                 set_cur(s, i);
                 if (ptype == 1) gen_s1(s, &x, gid[i], time[i], amp[i], p_hit[i], cdf);
-                else gen_s2(s, &x, ptype, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
+                else gen_s2(s, &x, alone ? ptype : -1, gid[i], em_base ? em_base[i] : 0u, time[i], amp[i], p_hit[i], drift_mean[i], drift_spread[i], sc_gain[i], cdf);
                 open = 1; last_key = ord[k].t;
             }
             if (open) finish_call(s, ptype == 6 ? 5 : ptype, runset++, &x);      /* call kinds: 1 S1, 2 S2, 3 PMT afterpulse, 4 PI electrons, 5 gate electrons */

@@ -397,3 +397,32 @@ def test_tile_generation_next_to_the_shared_calls_of_electron_afterpulses():
     orc = make_oracle(cfg)
     orc.simulate_scheduled(s_ins, gids[order].astype(np.uint32), instruction_params(s_ins, cfg, Resource(cfg)), base[order], cluster, key, rs)
     assert rec.tobytes() == orc.pack_records().tobytes()
+
+
+def test_tile_generation_with_grouped_pulse_calls():
+    """save_full_truth=False: two S2s 300 ns apart share a Pulse call (per-electron generator), the S2s on their own take the tile kernel;
+    photons, records and truth rows equal the oracle's"""
+    from wfsim_amd.scheduler import run_sets
+    cfg = xenonnt_test_config(save_full_truth=False, s2_secondary_sc_gain=100.0, seed=31)
+    ins = np.zeros(5, dtype=instruction_dtype)
+    ins['type'], ins['amp'], ins['z'], ins['recoil'] = 2, [4000, 3000, 6000, 2500, 2500], -10.0, 7
+    ins['time'] = [1_000_000, 1_000_300, 3_000_000, 5_000_000, 5_000_150]
+    ins['event_number'] = np.arange(5)
+    res = Resource(cfg)
+    order, key, cluster = schedule(ins, cfg)
+    s_ins, gid = ins[order], order.astype(np.uint32)
+    ip = instruction_params(s_ins, cfg, res)
+    rs, n_sets = run_sets(s_ins, key, cluster, cfg)
+    assert n_sets == 3
+    eng = make_engine(cfg)
+    eng.set_profiling(True)
+    eng.load_instructions(s_ins, gid, cluster, key, ip, run_set=rs)
+    counts = eng.run()
+    assert 'k_s2_tile' in eng.kernel_times() and 'k_photon_fill' in eng.kernel_times() and counts['n_pulse_sets'] == 3
+    orc = make_oracle(cfg)
+    orc.simulate(s_ins, gid, ip)
+    o = orc.results()
+    assert counts['n_photons'] == len(o['ph_t'])
+    assert eng.records().tobytes() == orc.pack_records().tobytes()
+    acc, ts = eng.truth()
+    assert acc.shape[0] == 3 and acc[:, 0].sum() == counts['n_photons']          # one truth row per Pulse call, every photon in one of them

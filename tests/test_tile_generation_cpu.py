@@ -35,8 +35,8 @@ def _simulate(cfg, ins):
 
 def test_switch_and_eligibility_rule():
     assert kernel_params(xenonnt_test_config())['tile_gen'] == 1
-    for off in (dict(tile_local_generation=False), dict(save_full_truth=False)):
-        assert kernel_params(xenonnt_test_config(**off))['tile_gen'] == 0
+    assert kernel_params(xenonnt_test_config(tile_local_generation=False))['tile_gen'] == 0
+    assert kernel_params(xenonnt_test_config(save_full_truth=False))['tile_gen'] == 1        # (per instruction: alone in its Pulse call or not)
     assert kernel_params(xenonnt_test_config(enable_electron_afterpulses=True))['tile_gen'] == 1       # (the pre-pass is served from the tiles' counters)
     # with and without the switch the photons differ (other streams) but not their number on average; since RNG spec v11 a tile of any
     # size is generated tile by tile (the device makes tiles above the 2048 photon registers of a workgroup in passes): a bright S2 too
@@ -179,5 +179,22 @@ def test_run_sets_are_numbered_by_their_first_instruction():
     from wfsim_amd.engine import first_instruction_of_sets
     assert np.array_equal(first_instruction_of_sets([0, 1, 1, 2, 1, 3], 4), [0, 1, 3, 5])
     assert np.array_equal(first_instruction_of_sets(np.arange(5), 5), np.arange(5))
-    assert first_instruction_of_sets([1, 0, 2], 3) is None                  # not in order of first appearance
+    assert np.array_equal(first_instruction_of_sets([1, 0, 2], 3), [1, 0, 2])  # any numbering of used sets (S1 calls before S2 calls)
     assert first_instruction_of_sets([0, 2, 2], 3) is None                  # a set number without instructions
+
+
+def test_grouped_pulse_calls_keep_the_per_electron_generator_their_neighbours_do_not():
+    """save_full_truth=False (rawdata.py:106-127): S2s whose keys are at most int(0.2 / v) ns apart share a Pulse call and are generated
+    electron by electron; an S2 alone in its call takes the tile path -- the same photons as with save_full_truth=True"""
+    cfg, ins = _s2(5, 400, s2_secondary_sc_gain=60.0, seed=21)
+    ins['time'] = [MS, MS + 300, 3 * MS, 5 * MS, 5 * MS + 200]          # two pairs and one S2 on its own (the third)
+    grouped = _simulate(dict(cfg, save_full_truth=False), ins)
+    grouped_off = _simulate(dict(cfg, save_full_truth=False, tile_local_generation=False), ins)
+    single = _simulate(cfg, ins)
+    single_off = _simulate(dict(cfg, tile_local_generation=False), ins)
+    def of(res, t0, t1):
+        t = res['ph_t']; return np.sort(t[(t >= t0) & (t < t1)])
+    lo, hi = 3 * MS - 100_000, 3 * MS + 900_000
+    assert np.array_equal(of(grouped, lo, hi), of(single, lo, hi)) and not np.array_equal(of(single, lo, hi), of(single_off, lo, hi))
+    for t0 in (MS, 5 * MS):                                              # the pairs: the per-electron generator, whatever the switch
+        assert np.array_equal(of(grouped, t0 - 100_000, t0 + 900_000), of(grouped_off, t0 - 100_000, t0 + 900_000))

@@ -62,9 +62,11 @@ def afterpulse_switches(config):
 def tile_local_generation(config):
     """Whether primary S2s may draw their photons tile by tile inside the pulse workgroup (RNG spec v9; switch:
     config['tile_local_generation'], default on).  Off wherever something needs the photons of an instruction electron by electron:
-    Pulse calls that cover several instructions (save_full_truth=False), the transverse-diffusion field maps (the pattern of an
-    instruction is then known only after its electrons) and any digitiser geometry other than 10 ns samples / 22-sample templates (the
-    fused kernel is specialised for it).  Electron / gate afterpulses (the reference's defaults: on / off, rawdata.py:194-200) do NOT
+    the transverse-diffusion field maps (the pattern of an instruction is then known only after its electrons) and any digitiser geometry
+    other than 10 ns samples / 22-sample templates (the fused kernel is specialised for it).  Pulse calls that cover several instructions
+    (save_full_truth=False, the shared calls of electron afterpulses) do not switch it off: an instruction that shares its call keeps the
+    per-electron generator, one that is alone in its call takes the tile path (run sets numbered by their first instruction,
+    engine.load_instructions; k_fuse_decide / the oracle's callers).  Electron / gate afterpulses (the reference's defaults: on / off, rawdata.py:194-200) do NOT
     switch it off: their pre-pass needs the photon number of every parent S2 and the arrival times of a few picked photons, which the
     tile path serves from the tiles' photon numbers and the photons' own Philox coordinates (wfs_copy_instruction_photon_offsets,
     wfs_gather_photon_times) without generating a photon.  The per-instruction conditions (s2_gain_spread == 0, default delay table)
@@ -73,7 +75,7 @@ def tile_local_generation(config):
                        and config.get('enable_field_dependencies', {}).get('diffusion_transverse_map', False))
     tpc_digitiser = (int(config.get('sample_duration', 10)) == 10
                      and int(config.get('samples_before_pulse_center', 2)) + int(config.get('samples_after_pulse_center', 20)) == 22)
-    return bool(config.get('tile_local_generation', True) and config.get('save_full_truth', True) and not transverse_maps and tpc_digitiser)
+    return bool(config.get('tile_local_generation', True) and not transverse_maps and tpc_digitiser)
 
 
 def kernel_params(config):

@@ -153,14 +153,13 @@ def _arr(a, dtype):
 
 def first_instruction_of_sets(run_set, n_sets):
     """index of the first instruction of every run set -- the number the library knows the set by (include/wfsim_amd.h,
-    wfs_load_instructions) -- or None when a set number is unused or the sets are not numbered in order of first appearance"""
+    wfs_load_instructions) -- or None when a set number is unused.  (The sets need not be numbered in order of first appearance: the
+    scheduler numbers the S1 calls of a cluster before its S2 calls, rawdata.py:102.)"""
     run_set = np.asarray(run_set)
     n = len(run_set)
     first = np.full(n_sets, n, dtype=np.int64)
     np.minimum.at(first, run_set, np.arange(n))
-    if np.all(first < n) and np.all(np.diff(first) > 0):
-        return first
-    return None
+    return first if np.all(first < n) else None
 
 
 class Engine:
@@ -573,8 +572,14 @@ class Engine:
         t, ch, gain, dpe = np.zeros(n, np.int64), np.zeros(n, np.int16), np.zeros(n, np.float64), np.zeros(n, np.uint8)
         self._check(self.lib.wfs_copy_photons(self._h, _p(off), _p(t), _p(ch), _p(gain), _p(dpe), C.c_int64(n)))
         rows = self._caller_sets(s)
-        if rows is not None:                        # (the unused set numbers hold no photons: dropping them keeps the offsets contiguous)
-            off = np.append(off[rows], off[-1])
+        if rows is not None:                        # the caller's sets, in the caller's order (the unused set numbers hold no photons)
+            lens = off[rows + 1] - off[rows]
+            if np.all(np.diff(rows) > 0):
+                off = np.append(off[rows], off[-1])
+            else:
+                new_off = np.concatenate([[0], np.cumsum(lens)])
+                idx = np.repeat(off[rows] - new_off[:-1], lens) + np.arange(int(new_off[-1]))
+                t, ch, gain, dpe, off = t[idx], ch[idx], gain[idx], dpe[idx], new_off
         return dict(set_off=off, t=t, ch=ch, gain=gain, dpe=dpe)
 
     def truth(self):
