@@ -116,15 +116,17 @@ def test_float_noise_array():
     assert out['float'] != out['truncated']
 
 
+@pytest.mark.parametrize('resident', [True, False])
 @pytest.mark.parametrize('noise_len,as_float', [(100, False), (511, True), (512, False), (700, True), (3000, False)])
-def test_rows_longer_than_the_noise_table(noise_len, as_float):
+def test_rows_longer_than_the_noise_table(noise_len, as_float, resident):
     """the noise index of a row wraps modulo the table length (rawdata.py:433-434) as often as the row is long: tables shorter
     than a block of samples take the general path of k_zle / k_pack, longer ones the scalar-start path; S1 + S2 pairs with PMT
-    afterpulses give rows of several thousand samples"""
+    afterpulses give rows of several thousand samples -- through the accumulators and as resident rows in segments (k_row_pulse: tables of
+    at least 512 samples; shorter ones keep the accumulators whatever the switch says)"""
     from tests.helpers import golden, ap_tables_from_golden
     nz = golden('noise.npz')['noise'][:noise_len]
     if as_float: nz = nz.astype(np.float64) + np.random.default_rng(5).uniform(-0.9, 0.9, nz.shape)
-    cfg = xenonnt_test_config(seed=70 + noise_len, enable_noise=True, noise_data=nz)
+    cfg = xenonnt_test_config(seed=70 + noise_len, enable_noise=True, noise_data=nz, row_resident=resident)
     rows = []
     for i in range(6):
         rows += [dict(type=1, time=MS * (i + 1), x=2, y=1, z=-40, amp=4000), dict(type=2, time=MS * (i + 1), x=2, y=1, z=-40, amp=300)]
@@ -133,8 +135,9 @@ def test_rows_longer_than_the_noise_table(noise_len, as_float):
     _compare(orc, o, eng, counts, s_ins)
 
 
+@pytest.mark.parametrize('resident', [True, False])
 @pytest.mark.parametrize('tw', [0, 10, 31, 50, 200])
-def test_trigger_windows_on_both_sides_of_the_chunk_rule(tw):
+def test_trigger_windows_on_both_sides_of_the_chunk_rule(tw, resident):
     """k_zle keeps its interval state on the scalar unit when the hold-off (2 * trigger_window + 1, rawdata.py:297-308) spans a chunk
     of 64 samples, and in vector form otherwise: windows of 0, 10 (hold-off 21), 31 (63: the first scalar case), 50 (the default) and
     200 samples, with noise, against the oracle -- with and without the debug copy of the rows (which takes the vector form too)."""
@@ -142,7 +145,7 @@ def test_trigger_windows_on_both_sides_of_the_chunk_rule(tw):
     from wfsim_amd.physics import instruction_params
     from wfsim_amd.resource import Resource
     from wfsim_amd.scheduler import schedule
-    cfg = xenonnt_test_config(seed=90 + tw, trigger_window=tw, enable_noise=True, noise_data=golden('noise.npz')['noise'])
+    cfg = xenonnt_test_config(seed=90 + tw, trigger_window=tw, enable_noise=True, noise_data=golden('noise.npz')['noise'], row_resident=resident)
     rows = [dict(type=1, time=MS * (i + 1), x=i, y=-i, z=-30, amp=3000 + 700 * i) for i in range(5)]
     rows += [dict(type=2, time=MS * (i + 1), x=i, y=-i, z=-30, amp=200 + 60 * i) for i in range(5)]
     ins = _instructions(rows)
