@@ -1143,7 +1143,8 @@ __device__ __forceinline__ void wave_tile_pulse(const WfsDev &d, const PulseArgs
         const bool above = v && (g * s_cmax[v ? ns0 % dt : 0] * d.c2a > td.thr);
         const i32 n_trig = __popcll(ballot64(above)), n_trig_dpe = __popcll(ballot64(above && lane < n_dpe));
         const double tr = v ? (double)(ns0 + td.rel0) : 0.0;
-        const double sg = wave_sum(g), sgt = wave_sum(above ? g : 0.0), st = wave_sum(tr), st2 = wave_sum(tr * tr);     // (DPP: no LDS crossbar trips)
+        // (DPP: no LDS crossbar trips; every photon above the threshold -- the usual tile -- : the triggered area IS the area, same bits)
+        const double sg = wave_sum(g), sgt = all64(!v || above) ? sg : wave_sum(above ? g : 0.0), st = wave_sum(tr), st2 = wave_sum(tr * tr);
         if (lane == 0) {
             double *o = a.tile_truth + (i64)td.tile * 8;
             o[0] = (double)n; o[1] = (double)n_dpe; o[2] = (double)n_trig; o[3] = (double)n_trig_dpe; o[4] = sg; o[5] = sgt; o[6] = st; o[7] = st2;
