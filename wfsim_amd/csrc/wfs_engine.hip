@@ -90,7 +90,7 @@ struct wfs_handle {
     // host mirrors
     std::vector<i64> h_set_off;       // injected photons: per set photon offsets (channel sorted input order)
     wfs_counts counts{};
-    i64 h_scal[64] = {0};
+    i64 *h_scal = nullptr;            // [64] host copy of scal in page-locked memory: read_scal's copy needs no staging buffer (five of them per batch)
     DevBuf pack_desc;
     DevBuf row_bad, fin_len, res_cnt, fin_off, res_toff, res_desc, fin, res_long, res_rows;      // resident rows (k_row_pulse)
     i64 n_front_rows = 0, n_res_rows = 0, n_short_rows = 0, n_res_tiles = 0, max_res_len = 0, s_fin = 0, s_res = 0; bool res_on = false;
@@ -242,7 +242,7 @@ int scan_into(wfs_handle *h, const i32 *in, i64 n, i64 *outp, int scal_slot, i64
 
 int read_scal(wfs_handle *h)
 {
-    HIPCHK(hipMemcpyAsync(h->h_scal, h->scal.p, sizeof(h->h_scal), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->h_scal, h->scal.p, 512, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (!h->launch_err.empty()) { const std::string m = h->launch_err; h->launch_err.clear(); return h->fail(WFS_E_HIP, m); }     // (wfs_set_debug bit 3)
     return WFS_OK;
@@ -452,6 +452,8 @@ try {
     if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->rec_copied[0], hipEventDisableTiming) != hipSuccess
         || hipEventCreateWithFlags(&h->rec_copied[1], hipEventDisableTiming) != hipSuccess) { delete h; return WFS_E_HIP; }
     if (hipMalloc(&h->scal.p, 512) != hipSuccess) { delete h; return WFS_E_HIP; }
+    if (hipHostMalloc((void **)&h->h_scal, 512, hipHostMallocDefault) != hipSuccess) { hipFree(h->scal.p); delete h; return WFS_E_HIP; }
+    memset(h->h_scal, 0, 512);
     h->scal.cap = 256;
 #ifdef WFS_STAMPS
     if (hipMalloc(&h->stamps.p, 4096 * 64 * 8) != hipSuccess) { delete h; return WFS_E_HIP; }
@@ -506,8 +508,11 @@ try {
         &h->grp_gid, &h->row_lo, &h->row_hi, &h->acc_len, &h->acc_off, &h->itv_cap, &h->itv_off, &h->active_rows, &h->raw, &h->itv_left,
         &h->itv_right, &h->itv_n, &h->row_nrec, &h->rec_off, &h->records_ab[0], &h->records_ab[1], &h->truth, &h->tminmax, &h->tile_truth, &h->tile_desc, &h->gather_idx, &h->gather_out, &h->currents, &h->cur_len, &h->cur_off,
         &h->row_dbg, &h->row_dbg_len, &h->row_dbg_off, &h->scan_tmp, &h->scal,
-        &h->ph_idx, &h->ap_key, &h->order_list, &h->order_list2, &h->ins_sbase, &h->tile_tail, &h->tile_tailbase, &h->ins_fullsort, &h->row_pmax, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile, &h->tile_done, &h->huge_start, &h->huge_cbeg, &h->huge_keys, &h->huge_keys2, &h->huge_vals, &h->huge_vals2, &h->huge_rec, &h->huge_gain};
+        &h->ph_idx, &h->ap_key, &h->order_list, &h->order_list2, &h->ins_sbase, &h->tile_tail, &h->tile_tailbase, &h->ins_fullsort, &h->row_pmax, &h->ins_fused, &h->ins_nsurv, &h->ins_bcap, &h->ins_bcap_all, &h->ins_boff, &h->et32, &h->ftiles, &h->tbuf, &h->row_cnt, &h->row_tile, &h->tile_done, &h->huge_start, &h->huge_cbeg, &h->huge_keys, &h->huge_keys2, &h->huge_vals, &h->huge_vals2, &h->huge_rec, &h->huge_gain,
+        &h->pack_desc, &h->row_bad, &h->fin_len, &h->res_cnt, &h->fin_off, &h->res_toff, &h->res_desc, &h->fin, &h->res_long, &h->res_rows,
+        &h->pmap[0].cell_start, &h->pmap[0].cell_pts, &h->pmap[1].cell_start, &h->pmap[1].cell_pts};
     for (DevBuf *b : all) if (b->p) hipFree(b->p);
+    if (h->h_scal) hipHostFree(h->h_scal);
     for (DevBuf *b : {&h->pmap[0].points, &h->pmap[1].points, &h->smap_pos, &h->smap_out, &h->smap_nb_idx, &h->smap_nb_w, &h->ins_aft, &h->ins_sigr, &h->ins_siga, &h->diff_row_ins, &h->diff_row_id, &h->diff_pre}) if (b->p) hipFree(b->p);
     for (auto &m : h->smaps) for (DevBuf *b : {&m->g.values, &m->g.points, &m->tx, &m->ty, &m->c}) if (b->p) hipFree(b->p);
     for (int q = 0; q < 6; q++) if (h->tt_alias[q].p) hipFree(h->tt_alias[q].p);
@@ -1259,12 +1264,7 @@ static int run_generation(wfs_handle *h)
     TRY(ensure(h, h->em_time, (size_t)E * 8)); TRY(ensure(h, h->em_nph, (size_t)E * 4)); TRY(ensure(h, h->em_ins, (size_t)E * 4));
     TRY(ensure(h, h->el_stat, (size_t)N * 32)); TRY(ensure(h, h->el_minmax, (size_t)N * 16));
     HIPCHK(hipMemsetAsync(h->el_stat.p, 0, (size_t)N * 32, h->stream));
-    {
-        std::vector<i64> mm((size_t)N * 2);
-        for (i64 i = 0; i < N; i++) { mm[2 * i] = I64_MAX; mm[2 * i + 1] = I64_MIN; }
-        HIPCHK(hipMemcpyAsync(h->el_minmax.p, mm.data(), mm.size() * 8, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-    }
+    hipLaunchKernelGGL(k_fill_minmax, dim3(nblocks(2 * N, 256)), dim3(256), 0, h->stream, h->el_minmax.as<i64>(), 2 * N);      // (min, max) pairs: (I64_MAX, I64_MIN)
     GenArgs g{};
     g.n_ins = N; g.n_psets = h->n_psets; g.n_emitters = E;
     g.ins_embase = h->ins_embase.as<u32>(); g.ins_set = h->ins_set.as<i32>(); g.set_ins_off = h->set_ins_off.as<i64>(); g.set_ins_list = h->set_ins_list.as<i32>(); g.set_t0 = h->set_t0.as<i64>();

@@ -18,6 +18,7 @@
 // ------------------------------------------------------------------------------------------------ fills
 __global__ void k_fill_i64(i64 *p, i64 n, i64 v) { i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 __global__ void k_fill_i32(i32 *p, i64 n, i32 v) { i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+__global__ void k_fill_minmax(i64 *p, i64 n) { i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (i & 1) ? I64_MIN : I64_MAX; }
 
 // totals for wfs_get_counts, reduced on the device (copying itv_n back cost 300 MB per 10^5-cluster batch):
 // scal[20] = sum of itv_n (ZLE intervals), scal[21] = sum of the per-set n_pe (truth[s][1], integral doubles)
